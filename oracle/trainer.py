@@ -1,0 +1,203 @@
+"""Oracle restatement of the hot methods of reference ``trainer.py`` (fp32 CPU).
+
+Follows trainer.py:268-319 (process_batch), :321-365 (predict_poses, "pairs" +
+"separate_resnet" branch), :425-474 (generate_images_pred), :476-488
+(compute_reprojection_loss), :490-596 (compute_losses) and the step in
+:237-248.  The tie-break noise (trainer.py:549-552) is an explicit *input*
+(``noise[scale]`` of shape [B,2,H,W]) so runs are reproducible; pass ``None`` to
+draw it from torch's global generator exactly like the reference does.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from . import layers as L
+from . import networks as N
+
+
+def default_opt(**over):
+    """Subset of options.py defaults the hot path reads (options.py:34-79,239-330)."""
+    o = dict(height=192, width=640, scales=[0, 1, 2, 3], frame_ids=[0, -1, 1], min_depth=0.1, max_depth=100.0,
+             disparity_smoothness=1e-3, no_ssim=False, disable_automasking=False, avg_reprojection=False,
+             v1_multiscale=False, trainer_siloss="true", trainer_siloss_all_scale=True, gdc_loss_threshold=2.0,
+             si_var=0.3, beam_encoder=True, num_layers=18, learning_rate=1e-4, batch_size=12,
+             scheduler_step_size=10)
+    o.update(over)
+    return SimpleNamespace(**o)
+
+
+def derived_hparams(batch_size, learning_rate=1e-4, scheduler_step_size=10, vram_gib=288.0):
+    """trainer.py:28-41 — epochs, accumulate_step, lr, StepLR step, micro-batch."""
+    accumulate = 2 if vram_gib < 15 else 1
+    if batch_size > 8:
+        accumulate *= 2
+    return SimpleNamespace(num_epochs=(8 * 17) // batch_size, accumulate_step=accumulate,
+                           learning_rate=learning_rate * (batch_size / 8),
+                           scheduler_step_size=int(scheduler_step_size * (8 / batch_size)),
+                           micro_batch=int(batch_size / accumulate))
+
+
+def build_models(opt, seed=0):
+    """trainer.py:66-104 — the six default networks (weights_init=scratch)."""
+    torch.manual_seed(seed)
+    m = {}
+    m["encoder"] = N.ResnetEncoder(opt.num_layers, False)
+    m["beam_encoder"] = N.ResnetEncoder(opt.num_layers, False, beam_encoder=True)
+    m["beam_encoder_pose"] = N.ResnetEncoder(opt.num_layers, False, num_input_images=2, beam_encoder=True)
+    m["depth"] = N.DepthDecoder(m["encoder"].num_ch_enc, opt.scales)
+    m["pose_encoder"] = N.ResnetEncoder(opt.num_layers, False, num_input_images=2)
+    m["pose"] = N.PoseDecoder(m["pose_encoder"].num_ch_enc, num_input_features=1, num_frames_to_predict_for=2)
+    return m
+
+
+def predict_poses(opt, models, inputs):
+    """trainer.py:321-365."""
+    out = {}
+    for f in opt.frame_ids[1:]:
+        order = (f, 0) if f < 0 else (0, f)          # always temporal order
+        rgb = torch.cat([inputs[("color_aug", i, 0)] for i in order], 1)
+        pose_in = [models["pose_encoder"](rgb)]
+        if opt.beam_encoder:
+            lidar = torch.cat([inputs[("2channel", i, 0)] for i in order], 1)
+            beam_in = [models["beam_encoder_pose"](lidar)]
+            axisangle, translation = models["pose"](pose_in, beam_inputs=beam_in)
+        else:
+            axisangle, translation = models["pose"](pose_in)
+        out[("axisangle", 0, f)] = axisangle
+        out[("translation", 0, f)] = translation
+        out[("cam_T_cam", 0, f)] = L.transformation_from_parameters(axisangle[:, 0], translation[:, 0],
+                                                                    invert=(f < 0))
+    return out
+
+
+def generate_images_pred(opt, inputs, outputs):
+    """trainer.py:425-474 (non-stereo, non-posecnn path)."""
+    for s in opt.scales:
+        disp = outputs[("disp", s)]
+        if opt.v1_multiscale:
+            src_s = s
+        else:
+            disp = F.interpolate(disp, [opt.height, opt.width], mode="bilinear", align_corners=False)
+            src_s = 0
+        _, depth = L.disp_to_depth(disp, opt.min_depth, opt.max_depth)
+        outputs[("depth", 0, s)] = depth
+        h, w = depth.shape[2:]
+        for f in opt.frame_ids[1:]:
+            T = outputs[("cam_T_cam", 0, f)]
+            pts = L.backproject_depth(depth, inputs[("inv_K", src_s)])
+            grid = L.project_3d(pts, inputs[("K", src_s)], T, h, w)
+            outputs[("sample", f, s)] = grid
+            outputs[("color", f, s)] = F.grid_sample(inputs[("color", f, src_s)], grid, padding_mode="border",
+                                                     align_corners=False)
+            if not opt.disable_automasking:
+                outputs[("color_identity", f, s)] = inputs[("color", f, src_s)]
+
+
+def reprojection_loss(opt, pred, target):
+    """trainer.py:476-488."""
+    l1 = (target - pred).abs().mean(1, True)
+    if opt.no_ssim:
+        return l1
+    return 0.85 * L.ssim(pred, target).mean(1, True) + 0.15 * l1
+
+
+def si_log_loss(opt, disp, beam):
+    """trainer.py:577-589 — masked scale-invariant log loss vs the 4-beam LiDAR."""
+    disp = F.interpolate(disp, [opt.height, opt.width], mode="bilinear", align_corners=False)
+    _, depth = L.disp_to_depth(disp, opt.min_depth, opt.max_depth)
+    beam_depth = beam * 100.0
+    depth = depth * 26.0
+    mask = ((beam_depth > 1) & (depth < 80) & (depth > 1) & ((depth - beam_depth).abs() < opt.gdc_loss_threshold)).detach()
+    d = torch.log(depth[mask]) - torch.log(beam_depth[mask])
+    return torch.sqrt((d ** 2).mean() - opt.si_var * (d.mean() ** 2)) * 0.1
+
+
+def compute_losses(opt, inputs, outputs, noise=None):
+    """trainer.py:490-596 (automask / min-reprojection default path)."""
+    losses = {}
+    total = 0
+    for s in opt.scales:
+        src_s = s if opt.v1_multiscale else 0
+        disp = outputs[("disp", s)]
+        color = inputs[("color", 0, s)]
+        target = inputs[("color", 0, src_s)]
+        reproj = torch.cat([reprojection_loss(opt, outputs[("color", f, s)], target) for f in opt.frame_ids[1:]], 1)
+        if opt.avg_reprojection:
+            reproj = reproj.mean(1, keepdim=True)
+        loss = 0
+        if not opt.disable_automasking:
+            ident = torch.cat([reprojection_loss(opt, inputs[("color", f, src_s)], target)
+                               for f in opt.frame_ids[1:]], 1)
+            if opt.avg_reprojection:
+                ident = ident.mean(1, keepdim=True)
+            eps = torch.randn(ident.shape) if noise is None else noise[s]
+            ident = ident + eps * 0.00001
+            combined = torch.cat((ident, reproj), dim=1)
+        else:
+            combined = reproj
+        if combined.shape[1] == 1:
+            to_opt = combined
+        else:
+            to_opt, idxs = torch.min(combined, dim=1)
+        if not opt.disable_automasking:
+            outputs["identity_selection/{}".format(s)] = (idxs > ident.shape[1] - 1).float()
+        loss = loss + to_opt.mean()
+        mean_disp = disp.mean(2, True).mean(3, True)
+        norm_disp = disp / (mean_disp + 1e-7)
+        loss = loss + opt.disparity_smoothness * L.get_smooth_loss(norm_disp, color) / (2 ** s)
+        total = total + loss
+        losses["loss/{}".format(s)] = loss
+        if opt.trainer_siloss == "true" and (opt.trainer_siloss_all_scale or s == 0):
+            si = si_log_loss(opt, disp, inputs["4beam"])
+            total = total + si
+            losses["loss/si_loss{}".format(s)] = si
+    losses["loss"] = total / len(opt.scales)
+    return losses
+
+
+def process_batch(opt, models, inputs, noise=None):
+    """trainer.py:268-319 (default flags: separate_resnet pose net, beam_encoder)."""
+    feats = models["encoder"](inputs[("color_aug", 0, 0)])
+    if opt.beam_encoder:
+        outputs = models["depth"](feats, beam_features=models["beam_encoder"](inputs["2channel"]))
+    else:
+        outputs = models["depth"](feats)
+    outputs = dict(outputs)
+    outputs.update(predict_poses(opt, models, inputs))
+    generate_images_pred(opt, inputs, outputs)
+    return outputs, compute_losses(opt, inputs, outputs, noise)
+
+
+def trainable_parameters(models):
+    """trainer.py:71-127 order: encoder, beam_encoder, beam_encoder_pose, depth, pose_encoder, pose."""
+    params = []
+    for k in ["encoder", "beam_encoder", "beam_encoder_pose", "depth", "pose_encoder", "pose"]:
+        if k in models:
+            params += list(models[k].parameters())
+    return params
+
+
+class OracleTrainer:
+    """Minimal harness = trainer.py:129-131 (Adam + StepLR) + :237-248 (accumulate/step)."""
+
+    def __init__(self, opt, seed=0, models=None):
+        self.opt = opt
+        self.hp = derived_hparams(opt.batch_size, opt.learning_rate, opt.scheduler_step_size)
+        self.models = models if models is not None else build_models(opt, seed)
+        for m in self.models.values():
+            m.train()
+        self.optimizer = torch.optim.Adam(trainable_parameters(self.models), self.hp.learning_rate)
+        self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, max(self.hp.scheduler_step_size, 1), 0.1)
+        self.optimizer.zero_grad()
+        self.batch_idx = 0
+
+    def micro_step(self, inputs, noise=None):
+        outputs, losses = process_batch(self.opt, self.models, inputs, noise)
+        loss = losses["loss"] / self.hp.accumulate_step
+        loss.backward()
+        if (self.batch_idx + 1) % self.hp.accumulate_step == 0:
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+        self.batch_idx += 1
+        return outputs, losses

@@ -1,0 +1,68 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, GOLD):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests are skipped (not failed) when no device is present, e.g. a plain ``pytest tests``."""
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(GOLD, name + ".npz")))
+        return cache[name]
+
+    return load
+
+
+def assert_close(actual, expected, rtol=1e-4, atol=1e-6, what=""):
+    """rtol is the north-star 1e-4 relative bound; atol guards values that are ~0."""
+    a = np.asarray(actual, dtype=np.float64)
+    e = np.asarray(expected, dtype=np.float64)
+    assert a.shape == e.shape, "%s: shape %s vs %s" % (what, a.shape, e.shape)
+    err = np.abs(a - e)
+    tol = atol + rtol * np.abs(e)
+    bad = err > tol
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError("%s: %d/%d out of tolerance; worst at %s: got %.9g want %.9g (|d|=%.3g, max|e|=%.3g)"
+                             % (what, bad.sum(), bad.size, i, a[i], e[i], err[i], np.abs(e).max()))
+
+
+def check_grad_compact(gold, key, actual, rtol=1e-4, atol=1e-6):
+    """Counterpart of make_golden.put_grad."""
+    a = np.asarray(actual)
+    if key in gold:
+        assert_close(a, gold[key], rtol, atol, key)
+        return
+    scale = float(gold[key + "@l2"])
+    assert_close(a.reshape(-1)[::97], gold[key + "@s97"], rtol, atol + 1e-6 * scale, key + "@s97")
+    assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - scale) <= 1e-4 * scale + 1e-7, key + "@l2"
+    assert abs(a.astype(np.float64).sum() - float(gold[key + "@sum"])) <= 1e-4 * scale + 1e-6, key + "@sum"

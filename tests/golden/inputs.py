@@ -1,0 +1,115 @@
+"""Deterministic synthetic inputs shared by ``make_golden.py`` (which feeds them to the imported
+reference) and by the tests (which feed them to the oracle / the HIP path).  numpy MT19937 streams
+are stable across numpy versions, so inputs are regenerated from a seed instead of being stored.
+"""
+import numpy as np
+import torch
+
+K_NORM = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+
+
+def _box3(a):
+    p = np.pad(a, [(0, 0)] * (a.ndim - 2) + [(1, 1), (1, 1)], mode="edge")
+    out = np.zeros_like(a)
+    H, W = a.shape[-2:]
+    for dy in range(3):
+        for dx in range(3):
+            out += p[..., dy:dy + H, dx:dx + W]
+    return out / 9.0
+
+
+def smooth_image(rng, B, C, H, W):
+    a = rng.rand(B, C, H, W).astype(np.float32)
+    return _box3(_box3(a)).astype(np.float32)
+
+
+def intrinsics(B, H, W, scale):
+    """kitti_dataset.py:36-39 + mono_dataset.py:166-175 — K scaled to (W,H)/2^scale, inv via pinv."""
+    K = K_NORM.copy()
+    K[0, :] *= W // (2 ** scale)
+    K[1, :] *= H // (2 ** scale)
+    inv_K = np.linalg.pinv(K)
+    return (torch.from_numpy(np.repeat(K[None], B, 0).copy()),
+            torch.from_numpy(np.repeat(inv_K[None], B, 0).astype(np.float32).copy()))
+
+
+def lidar_4beam(rng, B, H, W, density=3):
+    """4 scan rows in the lower half, every ``density``-th column, depth U[5,65] m, stored /100."""
+    beam = np.zeros((B, 1, H, W), dtype=np.float32)
+    rows = [int(H * f) for f in (0.52, 0.625, 0.73, 0.835)]
+    for b in range(B):
+        for r in rows:
+            cols = np.arange(2 + (b + r) % density, W - 2, density)
+            beam[b, 0, r, cols] = rng.uniform(5.0, 65.0, size=cols.shape).astype(np.float32) / 100.0
+    return beam
+
+
+def batch_inputs(seed, B, H, W, num_scales=4, frame_ids=(0, -1, 1)):
+    """Dict with the schema of mono_dataset.py:109-228 (tensor entries only)."""
+    rng = np.random.RandomState(seed)
+    base = smooth_image(rng, B, 3, H, W + 8)
+    inputs = {}
+    for f in frame_ids:
+        shift = 4 + 2 * f
+        img = base[..., shift:shift + W] + 0.01 * rng.randn(B, 3, H, W).astype(np.float32)
+        img = np.clip(img, 0, 1).astype(np.float32)
+        for s in range(num_scales):
+            t = torch.from_numpy(img.copy())
+            if s > 0:
+                t = torch.nn.functional.avg_pool2d(t, 2 ** s)
+            inputs[("color", f, s)] = t
+            inputs[("color_aug", f, s)] = t.clone()
+    for s in range(num_scales):
+        inputs[("K", s)], inputs[("inv_K", s)] = intrinsics(B, H, W, s)
+    inputs["4beam"] = torch.from_numpy(lidar_4beam(rng, B, H, W))
+    return inputs, rng
+
+
+def disp_pyramid(rng, B, H, W, num_scales=4):
+    """Sigmoid-range disparity maps chosen so depth*26 overlaps the LiDAR range (SI-loss mask non-empty)."""
+    out = {}
+    for s in range(num_scales):
+        h, w = H // 2 ** s, W // 2 ** s
+        d = smooth_image(rng, B, 1, h, w)
+        out[("disp", s)] = torch.from_numpy((0.03 + 0.10 * d).astype(np.float32))
+    return out
+
+
+def small_poses(rng, B):
+    """(axisangle[B,1,3], translation[B,1,3]) of KITTI-like magnitude."""
+    aa = (0.02 * rng.randn(B, 1, 3)).astype(np.float32)
+    tr = (0.05 * rng.randn(B, 1, 3)).astype(np.float32)
+    tr[..., 2] += 0.1
+    return torch.from_numpy(aa), torch.from_numpy(tr)
+
+
+def feature_pyramids(rng, B, H, W, ch):
+    """Two ReLU-like 5-level feature pyramids (RGB encoder / beam encoder stand-ins) for an HxW input."""
+    feats, beams = [], []
+    for i, c in enumerate(ch):
+        h, w = H // 2 ** (i + 1), W // 2 ** (i + 1)
+        feats.append(torch.from_numpy(np.maximum(rng.randn(B, c, h, w), 0).astype(np.float32)))
+        beams.append(torch.from_numpy(np.maximum(rng.randn(B, c, h, w), 0).astype(np.float32)))
+    return feats, beams
+
+
+def fill_params(module, seed):
+    """Overwrite every parameter/buffer of ``module`` (state-dict order) with seeded numpy values:
+    weights ~ N(0, 2/fan_in), biases ~ N(0, 0.01), BN weight ~ U[0.5,1.5], running_var ~ U[0.5,1.5]."""
+    rng = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, t in module.state_dict().items():
+            if name.endswith("num_batches_tracked"):
+                continue
+            shape = tuple(t.shape)
+            if t.dim() >= 2:
+                fan_in = int(np.prod(shape[1:]))
+                v = rng.randn(*shape) * np.sqrt(2.0 / fan_in)
+            elif name.endswith("running_var") or (name.endswith("weight") and t.dim() == 1):
+                v = rng.uniform(0.5, 1.5, size=shape)
+            elif name.endswith("running_mean"):
+                v = rng.randn(*shape) * 0.1
+            else:
+                v = rng.randn(*shape) * 0.01
+            t.copy_(torch.from_numpy(v.astype(np.float32)))
+    return module

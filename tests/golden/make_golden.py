@@ -1,0 +1,311 @@
+#!/usr/bin/env python
+"""Generate golden vectors by IMPORTING AND RUNNING THE REFERENCE in the build container.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+
+Runs only where /root/reference exists (never on the GPU box).  The reference has no tests or
+known-answer vectors of its own, so these outputs *are* the pin for ``oracle/``.
+Only arithmetic-free third-party imports are stubbed (tensorboardX, wandb, cv2, skimage,
+torchvision — the latter only so that ``import networks``/``import trainer`` succeed; no torchvision
+arithmetic is used by anything captured here).  Inputs come from ``inputs.py`` (seeded numpy) and
+are NOT stored, except small ones; outputs and autograd gradients are.
+"""
+import ast
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("FD_REFERENCE", "/root/reference")
+sys.path.insert(0, HERE)
+import inputs as gin  # noqa: E402
+
+
+def _stub_modules():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("tensorboardX", SummaryWriter=object)
+    mod("wandb")
+    mod("cv2")
+    sk = mod("skimage")
+    sk.transform = mod("skimage.transform")
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms")
+
+    class _ResNetPlaceholder(nn.Module):
+        pass
+
+    res = mod("torchvision.models.resnet", BasicBlock=object, Bottleneck=object, model_urls={})
+    tv.models = mod("torchvision.models", ResNet=_ResNetPlaceholder, resnet=res)
+    for n in ("resnet18", "resnet34", "resnet50", "resnet101", "resnet152"):
+        setattr(tv.models, n, None)
+
+
+def load_reference():
+    _stub_modules()
+    sys.path.insert(0, REF)
+    sys.argv = ["trainer.py", "--no_cuda"]
+    torch.Tensor.cuda = lambda self, *a, **k: self      # trainer.py:551-552 hard-codes .cuda()
+    import layers as ref_layers
+    import trainer as ref_trainer
+
+    def by_path(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    dd = by_path("ref_depth_decoder", "networks/depth_decoder.py")
+    pd = by_path("ref_pose_decoder", "networks/pose_decoder.py")
+    pc = by_path("ref_pose_cnn", "networks/pose_cnn.py")
+    src = open(os.path.join(REF, "gen2channel.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "get_4beam_2channel"][0]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "gen2channel.py", "exec"), ns)
+    return ref_layers, ref_trainer, dd, pd, pc, ns["get_4beam_2channel"]
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-28s %8.1f KiB  (%d arrays)" % (name + ".npz", os.path.getsize(path) / 1024, len(arrays)))
+
+
+def put_grad(out, key, g):
+    """Small gradients are stored whole; large ones as (sum, L2, every-97th-element sample)."""
+    a = npy(g)
+    if a.size <= 20000:
+        out[key] = a
+    else:
+        out[key + "@sum"] = np.array(a.astype(np.float64).sum())
+        out[key + "@l2"] = np.array(np.sqrt((a.astype(np.float64) ** 2).sum()))
+        out[key + "@s97"] = a.reshape(-1)[::97].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+def gold_layers(RL):
+    B, H, W = 2, 32, 64
+    inp, rng = gin.batch_inputs(101, B, H, W)
+    out = {}
+    disp = gin.disp_pyramid(rng, B, H, W)[("disp", 0)].requires_grad_(True)
+    sd, depth = RL.disp_to_depth(disp, 0.1, 100.0)
+    out["d2d_scaled"], out["d2d_depth"] = npy(sd), npy(depth)
+
+    aa, tr = gin.small_poses(rng, B)
+    aa.requires_grad_(True), tr.requires_grad_(True)
+    cot_T = torch.from_numpy(rng.randn(B, 4, 4).astype(np.float32))
+    for inv in (False, True):
+        M = RL.transformation_from_parameters(aa, tr, invert=inv)
+        g = torch.autograd.grad((M * cot_T).sum(), [aa, tr])
+        tag = "inv" if inv else "fwd"
+        out["T_" + tag], out["T_%s_gaa" % tag], out["T_%s_gtr" % tag] = npy(M), npy(g[0]), npy(g[1])
+    out["T_cot"] = npy(cot_T)
+
+    K, inv_K = inp[("K", 0)], inp[("inv_K", 0)]
+    T = RL.transformation_from_parameters(aa, tr, invert=False).detach().requires_grad_(True)
+    bp, pj = RL.BackprojectDepth(B, H, W), RL.Project3D(B, H, W)
+    depth_in = depth.detach().clone().requires_grad_(True)
+    pts = bp(depth_in, inv_K)
+    grid = pj(pts, K, T)
+    cot_g = torch.from_numpy(rng.randn(B, H, W, 2).astype(np.float32))
+    g = torch.autograd.grad((grid * cot_g).sum(), [depth_in, T])
+    out.update(bp_points=npy(pts), pj_grid=npy(grid), pj_cot=npy(cot_g), pj_gdepth=npy(g[0]), pj_gT=npy(g[1]))
+    out["pj_T"] = npy(T)
+
+    x = inp[("color", 0, 0)].clone().requires_grad_(True)
+    y = inp[("color", 1, 0)].clone().requires_grad_(True)
+    s = RL.SSIM()(x, y)
+    cot_s = torch.from_numpy(rng.rand(B, 3, H, W).astype(np.float32))
+    g = torch.autograd.grad((s * cot_s).sum(), [x, y])
+    out.update(ssim=npy(s), ssim_cot=npy(cot_s), ssim_gx=npy(g[0]), ssim_gy=npy(g[1]))
+
+    d = disp.detach().clone().requires_grad_(True)
+    sm = RL.get_smooth_loss(d, inp[("color", 0, 0)])
+    out["smooth"], out["smooth_gdisp"] = npy(sm), npy(torch.autograd.grad(sm, d)[0])
+
+    torch.manual_seed(7)
+    cb = RL.ConvBlock(5, 7)
+    c3 = RL.Conv3x3(5, 1, use_refl=False)
+    xin = torch.from_numpy(rng.randn(B, 5, H, W).astype(np.float32)).requires_grad_(True)
+    yo = cb(xin)
+    cot_c = torch.from_numpy(rng.randn(*yo.shape).astype(np.float32))
+    g = torch.autograd.grad((yo * cot_c).sum(), [xin, cb.conv.conv.weight, cb.conv.conv.bias])
+    out.update(cb_x=npy(xin), cb_w=npy(cb.conv.conv.weight), cb_b=npy(cb.conv.conv.bias), cb_y=npy(yo),
+               cb_cot=npy(cot_c), cb_gx=npy(g[0]), cb_gw=npy(g[1]), cb_gb=npy(g[2]))
+    out.update(c3_w=npy(c3.conv.weight), c3_b=npy(c3.conv.bias), c3_y=npy(c3(xin)))
+    out["up_y"] = npy(RL.upsample(xin))
+
+    cxy = RL.Cat_xy(B, H, W)(depth.detach().clone(), inv_K)
+    out["catxy"] = npy(cxy)
+
+    gt = torch.from_numpy(rng.uniform(1, 80, size=5000).astype(np.float32))
+    pr = torch.from_numpy(rng.uniform(1, 80, size=5000).astype(np.float32))
+    out["errs_gt"], out["errs_pred"] = npy(gt), npy(pr)
+    out["errs"] = np.array([float(v) for v in RL.compute_depth_errors(gt, pr)], dtype=np.float64)
+    save("layers_b2_32x64", **out)
+
+
+def gold_decoders(DD, PD, PC):
+    B, H, W = 2, 64, 96
+    rng = np.random.RandomState(202)
+    ch = np.array([64, 64, 128, 256, 512])
+    feats, beams = gin.feature_pyramids(rng, B, H, W, ch)
+    for t in feats + beams:
+        t.requires_grad_(True)
+    out = {}
+
+    dec = DD.DepthDecoder(ch)
+    gin.fill_params(dec, 11)
+    o = dec(feats, beam_features=beams)
+    cots = {s: torch.from_numpy(rng.randn(*o[("disp", s)].shape).astype(np.float32)) for s in range(4)}
+    loss = sum((o[("disp", s)] * cots[s]).sum() for s in range(4))
+    params = list(dec.parameters())
+    g = torch.autograd.grad(loss, feats + beams + params)
+    for s in range(4):
+        out["dec_disp%d" % s], out["dec_cot%d" % s] = npy(o[("disp", s)]), npy(cots[s])
+    for i in range(5):
+        put_grad(out, "dec_gfeat%d" % i, g[i])
+        put_grad(out, "dec_gbeam%d" % i, g[5 + i])
+    for (k, _), gv in zip(dec.named_parameters(), g[10:]):
+        put_grad(out, "dec_g/" + k.replace(".", "/"), gv)
+    # no-beam forward as well (depth_decoder.py:71-72,79-80)
+    o2 = dec([f.detach() for f in feats])
+    out["dec_nobeam_disp0"] = npy(o2[("disp", 0)])
+
+    pose = PD.PoseDecoder(ch, num_input_features=1, num_frames_to_predict_for=2)
+    gin.fill_params(pose, 12)
+    f4 = feats[4].detach().clone().requires_grad_(True)
+    b4 = beams[4].detach().clone().requires_grad_(True)
+    aa, tr = pose([[None, None, None, None, f4]], beam_inputs=[[None, None, None, None, b4]])
+    cot_a = torch.from_numpy(rng.randn(*aa.shape).astype(np.float32))
+    cot_t = torch.from_numpy(rng.randn(*tr.shape).astype(np.float32))
+    g = torch.autograd.grad((aa * cot_a).sum() + (tr * cot_t).sum(), [f4, b4] + list(pose.parameters()))
+    out.update(pose_aa=npy(aa), pose_tr=npy(tr), pose_cot_a=npy(cot_a), pose_cot_t=npy(cot_t),
+               pose_gf4=npy(g[0]), pose_gb4=npy(g[1]))
+    for (k, _), gv in zip(pose.named_parameters(), g[2:]):
+        put_grad(out, "pose_g/" + k.replace(".", "/"), gv)
+
+    pcnn = PC.PoseCNN(2)
+    gin.fill_params(pcnn, 13)
+    xin = torch.from_numpy(np.random.RandomState(213).rand(B, 6, H, W).astype(np.float32))
+    a2, t2 = pcnn(xin)
+    out.update(posecnn_aa=npy(a2), posecnn_tr=npy(t2))
+    save("decoders_b2_64x96", **out)
+
+    # refiner variant of the decoder (road/catxy/deep + depth_maps + tanh; depth_decoder.py:39-42,81-90)
+    dec2 = DD.DepthDecoder(ch, road=True, catxy=True, deep=True)
+    gin.fill_params(dec2, 14)
+    out2 = {}
+    rng2 = np.random.RandomState(214)
+    dm = {("disp", s): torch.from_numpy(rng2.rand(B, 6, H // 2 ** s, W // 2 ** s).astype(np.float32)) for s in range(4)}
+    o3 = dec2([f.detach() for f in feats], beam_features=[b.detach() for b in beams], depth_maps=dm, tanh=True)
+    for s in range(4):
+        out2["disp%d" % s] = npy(o3[("disp", s)])
+    out2["num_params"] = np.array(sum(p.numel() for p in dec2.parameters()))
+    save("decoder_refine_b2_64x96", **out2)
+
+
+def _trainer_self(RL, RT, opt_over, B, H, W):
+    from types import SimpleNamespace
+    import copy
+    opt = copy.deepcopy(RT.opts)
+    opt.height, opt.width = H, W
+    for k, v in opt_over.items():
+        setattr(opt, k, v)
+    ns = SimpleNamespace(opt=opt, batch_size=B, num_scales=len(opt.scales), ssim=RL.SSIM(),
+                         backproject_depth={}, project_3d={})
+    for s in opt.scales:
+        ns.backproject_depth[s] = RL.BackprojectDepth(B, H // 2 ** s, W // 2 ** s)
+        ns.project_3d[s] = RL.Project3D(B, H // 2 ** s, W // 2 ** s)
+    ns.compute_reprojection_loss = lambda pred, target: RT.Trainer.compute_reprojection_loss(ns, pred, target)
+    return ns
+
+
+def gold_losses(RL, RT, name, seed, B, H, W, full_arrays, opt_over=None):
+    ns = _trainer_self(RL, RT, opt_over or {}, B, H, W)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp = gin.disp_pyramid(rng, B, H, W)
+    outputs, leaves = {}, []
+    for s in range(4):
+        outputs[("disp", s)] = disp[("disp", s)].clone().requires_grad_(True)
+        leaves.append(outputs[("disp", s)])
+    Ts = {}
+    for f in (-1, 1):
+        aa, tr = gin.small_poses(rng, B)
+        Ts[f] = RL.transformation_from_parameters(aa, tr, invert=(f < 0)).detach().requires_grad_(True)
+        outputs[("cam_T_cam", 0, f)] = Ts[f]
+        leaves.append(Ts[f])
+    RT.Trainer.generate_images_pred(ns, inp, outputs, ns.opt.frame_ids)
+    noise_seed = 1000 + seed
+    torch.manual_seed(noise_seed)
+    losses = RT.Trainer.compute_losses(ns, inp, outputs)
+    torch.manual_seed(noise_seed)
+    noise = [torch.randn(B, 2, H, W) for _ in ns.opt.scales]
+    grads = torch.autograd.grad(losses["loss"], leaves)
+    out = {"noise_seed": np.array(noise_seed)}
+    for k, v in losses.items():
+        out["L/" + k.replace("/", "_")] = np.array(float(v.detach()), dtype=np.float64)
+    for s in range(4):
+        out["g_disp%d" % s] = npy(grads[s])
+        if "identity_selection/%d" % s in outputs:
+            out["idsel%d" % s] = npy(outputs["identity_selection/%d" % s]).astype(np.uint8)
+        if full_arrays:
+            out["noise%d" % s] = npy(noise[s])
+            out["depth%d" % s] = npy(outputs[("depth", 0, s)])
+            for f in (-1, 1):
+                out["sample%d_%d" % (f, s)] = npy(outputs[("sample", f, s)])
+                out["color%d_%d" % (f, s)] = npy(outputs[("color", f, s)])
+        else:   # full-size case: keep a strided subsample only
+            out["depth%d_sub" % s] = npy(outputs[("depth", 0, s)])[:, :, ::16, ::16]
+            for f in (-1, 1):
+                out["color%d_%d_sub" % (f, s)] = npy(outputs[("color", f, s)])[:, :, ::16, ::16]
+    out["g_T-1"], out["g_T1"] = npy(grads[4]), npy(grads[5])
+    out["T-1"], out["T1"] = npy(Ts[-1]), npy(Ts[1])
+    # first few noise values so the test can prove it regenerated the same stream
+    out["noise_head"] = npy(noise[0]).reshape(-1)[:16]
+    save(name, **out)
+
+
+def gold_scatter(get2ch):
+    rng = np.random.RandomState(303)
+    beams = gin.lidar_4beam(rng, 2, 192, 640)[:, 0]
+    third = np.zeros((192, 640), dtype=np.float32)            # dense clump: exercises equal-confidence averaging
+    third[100:112, 300:330] = rng.uniform(0.05, 0.65, size=(12, 30)).astype(np.float32)
+    third[80, 2] = 0.3
+    third[189, 637] = 0.4
+    third[76, 100:110:2] = 0.25
+    maps = [beams[0], beams[1], third]
+    out = {}
+    for i, m in enumerate(maps):
+        d, c = get2ch(m.astype(np.float64))   # the reference feeds float64 numpy (gen2channel.py:49-51)
+        out["beam%d" % i], out["depth%d" % i], out["conf%d" % i] = m, npy(d), npy(c)
+    save("scatter_192x640", **out)
+
+
+def main():
+    torch.set_num_threads(8)
+    RL, RT, DD, PD, PC, get2ch = load_reference()
+    gold_layers(RL)
+    gold_decoders(DD, PD, PC)
+    gold_losses(RL, RT, "losses_b2_64x96", 404, 2, 64, 96, full_arrays=True)
+    gold_losses(RL, RT, "losses_b1_192x640", 505, 1, 192, 640, full_arrays=False)
+    gold_losses(RL, RT, "losses_nossim_noautomask_b2_64x96", 606, 2, 64, 96, full_arrays=False,
+                opt_over=dict(no_ssim=True, disable_automasking=True))
+    gold_scatter(get2ch)
+
+
+if __name__ == "__main__":
+    main()

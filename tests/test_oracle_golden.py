@@ -1,0 +1,257 @@
+"""Pin the CPU oracle against golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from conftest import assert_close, check_grad_compact
+from oracle import layers as OL
+from oracle import networks as ON
+from oracle import scatter as OS
+from oracle import trainer as OT
+
+# The oracle uses the same torch CPU primitives as the reference => expect (near) bit equality.
+TIGHT = dict(rtol=1e-6, atol=1e-7)
+
+
+def npy(t):
+    return t.detach().numpy()
+
+
+def test_layers_against_reference(golden):
+    g = golden("layers_b2_32x64")
+    B, H, W = 2, 32, 64
+    inp, rng = gin.batch_inputs(101, B, H, W)
+    disp = gin.disp_pyramid(rng, B, H, W)[("disp", 0)].requires_grad_(True)
+    sd, depth = OL.disp_to_depth(disp, 0.1, 100.0)
+    assert_close(npy(sd), g["d2d_scaled"], what="scaled_disp", **TIGHT)
+    assert_close(npy(depth), g["d2d_depth"], what="depth", **TIGHT)
+
+    aa, tr = gin.small_poses(rng, B)
+    aa.requires_grad_(True), tr.requires_grad_(True)
+    cot_T = torch.from_numpy(rng.randn(B, 4, 4).astype(np.float32))
+    assert_close(npy(cot_T), g["T_cot"], **TIGHT)
+    for inv in (False, True):
+        tag = "inv" if inv else "fwd"
+        M = OL.transformation_from_parameters(aa, tr, invert=inv)
+        ga, gt = torch.autograd.grad((M * cot_T).sum(), [aa, tr])
+        assert_close(npy(M), g["T_" + tag], what="T_" + tag, **TIGHT)
+        assert_close(npy(ga), g["T_%s_gaa" % tag], rtol=1e-5, atol=1e-6, what="gaa")
+        assert_close(npy(gt), g["T_%s_gtr" % tag], rtol=1e-5, atol=1e-6, what="gtr")
+
+    K, inv_K = inp[("K", 0)], inp[("inv_K", 0)]
+    T = torch.from_numpy(g["pj_T"]).requires_grad_(True)
+    depth_in = depth.detach().clone().requires_grad_(True)
+    pts = OL.backproject_depth(depth_in, inv_K)
+    grid = OL.project_3d(pts, K, T, H, W)
+    cot_g = torch.from_numpy(rng.randn(B, H, W, 2).astype(np.float32))
+    gd, gT = torch.autograd.grad((grid * cot_g).sum(), [depth_in, T])
+    assert_close(npy(pts), g["bp_points"], what="backproject", **TIGHT)
+    assert_close(npy(grid), g["pj_grid"], what="project grid", rtol=1e-6, atol=1e-6)
+    assert_close(npy(gd), g["pj_gdepth"], rtol=1e-5, atol=1e-6, what="g depth")
+    assert_close(npy(gT), g["pj_gT"], rtol=1e-4, atol=1e-4, what="g T")
+
+    x = inp[("color", 0, 0)].clone().requires_grad_(True)
+    y = inp[("color", 1, 0)].clone().requires_grad_(True)
+    s = OL.ssim(x, y)
+    cot_s = torch.from_numpy(rng.rand(B, 3, H, W).astype(np.float32))
+    gx, gy = torch.autograd.grad((s * cot_s).sum(), [x, y])
+    assert_close(npy(s), g["ssim"], what="ssim", **TIGHT)
+    assert_close(npy(gx), g["ssim_gx"], rtol=1e-5, atol=1e-6, what="ssim gx")
+    assert_close(npy(gy), g["ssim_gy"], rtol=1e-5, atol=1e-6, what="ssim gy")
+
+    d = disp.detach().clone().requires_grad_(True)
+    sm = OL.get_smooth_loss(d, inp[("color", 0, 0)])
+    assert_close(npy(sm), g["smooth"], what="smooth", **TIGHT)
+    assert_close(npy(torch.autograd.grad(sm, d)[0]), g["smooth_gdisp"], rtol=1e-5, atol=1e-8, what="smooth grad")
+
+    xin = torch.from_numpy(g["cb_x"]).requires_grad_(True)
+    w = torch.from_numpy(g["cb_w"]).requires_grad_(True)
+    b = torch.from_numpy(g["cb_b"]).requires_grad_(True)
+    yo = OL.conv_block(xin, w, b)
+    gxx, gw, gb = torch.autograd.grad((yo * torch.from_numpy(g["cb_cot"])).sum(), [xin, w, b])
+    assert_close(npy(yo), g["cb_y"], rtol=1e-5, atol=1e-6, what="ConvBlock")
+    assert_close(npy(gxx), g["cb_gx"], rtol=1e-5, atol=1e-5, what="ConvBlock gx")
+    assert_close(npy(gw), g["cb_gw"], rtol=1e-4, atol=1e-4, what="ConvBlock gw")
+    assert_close(npy(gb), g["cb_gb"], rtol=1e-4, atol=1e-4, what="ConvBlock gb")
+    y3 = OL.conv3x3(xin, torch.from_numpy(g["c3_w"]), torch.from_numpy(g["c3_b"]), use_refl=False)
+    assert_close(npy(y3), g["c3_y"], rtol=1e-5, atol=1e-6, what="Conv3x3 zero pad")
+    assert_close(npy(OL.upsample(xin)), g["up_y"], what="upsample", **TIGHT)
+    assert_close(npy(OL.cat_xy(depth.detach(), inv_K)), g["catxy"], rtol=1e-6, atol=1e-6, what="Cat_xy")
+
+    errs = OL.compute_depth_errors(torch.from_numpy(g["errs_gt"]), torch.from_numpy(g["errs_pred"]))
+    assert_close([float(v) for v in errs], g["errs"], rtol=1e-6, atol=0, what="depth errors")
+
+
+def _decoder_setup():
+    B, H, W = 2, 64, 96
+    rng = np.random.RandomState(202)
+    ch = np.array([64, 64, 128, 256, 512])
+    feats, beams = gin.feature_pyramids(rng, B, H, W, ch)
+    return B, H, W, rng, ch, feats, beams
+
+
+def test_depth_and_pose_decoders_against_reference(golden):
+    g = golden("decoders_b2_64x96")
+    B, H, W, rng, ch, feats, beams = _decoder_setup()
+    for t in feats + beams:
+        t.requires_grad_(True)
+    dec = gin.fill_params(ON.DepthDecoder(ch), 11)
+    o = dec(feats, beam_features=beams)
+    cots = {s: torch.from_numpy(rng.randn(*o[("disp", s)].shape).astype(np.float32)) for s in range(4)}
+    for s in range(4):
+        assert_close(npy(cots[s]), g["dec_cot%d" % s], **TIGHT)
+        assert_close(npy(o[("disp", s)]), g["dec_disp%d" % s], rtol=1e-5, atol=1e-6, what="disp%d" % s)
+    loss = sum((o[("disp", s)] * cots[s]).sum() for s in range(4))
+    grads = torch.autograd.grad(loss, feats + beams + list(dec.parameters()))
+    for i in range(5):
+        check_grad_compact(g, "dec_gfeat%d" % i, npy(grads[i]), rtol=1e-4, atol=1e-5)
+        check_grad_compact(g, "dec_gbeam%d" % i, npy(grads[5 + i]), rtol=1e-4, atol=1e-5)
+    for (k, _), gv in zip(dec.named_parameters(), grads[10:]):
+        check_grad_compact(g, "dec_g/" + k.replace(".", "/"), npy(gv), rtol=1e-4, atol=1e-4)
+    o2 = dec([f.detach() for f in feats])
+    assert_close(npy(o2[("disp", 0)]), g["dec_nobeam_disp0"], rtol=1e-5, atol=1e-6, what="no-beam disp0")
+
+    pose = gin.fill_params(ON.PoseDecoder(ch, num_input_features=1, num_frames_to_predict_for=2), 12)
+    f4 = feats[4].detach().clone().requires_grad_(True)
+    b4 = beams[4].detach().clone().requires_grad_(True)
+    aa, tr = pose([[None] * 4 + [f4]], beam_inputs=[[None] * 4 + [b4]])
+    assert_close(npy(aa), g["pose_aa"], rtol=1e-5, atol=1e-8, what="axisangle")
+    assert_close(npy(tr), g["pose_tr"], rtol=1e-5, atol=1e-8, what="translation")
+    gr = torch.autograd.grad((aa * torch.from_numpy(g["pose_cot_a"])).sum() + (tr * torch.from_numpy(g["pose_cot_t"])).sum(),
+                             [f4, b4] + list(pose.parameters()))
+    assert_close(npy(gr[0]), g["pose_gf4"], rtol=1e-4, atol=1e-7, what="pose g f4")
+    for (k, _), gv in zip(pose.named_parameters(), gr[2:]):
+        check_grad_compact(g, "pose_g/" + k.replace(".", "/"), npy(gv), rtol=1e-4, atol=1e-6)
+
+    pcnn = gin.fill_params(ON.PoseCNN(2), 13)
+    xin = torch.from_numpy(np.random.RandomState(213).rand(B, 6, H, W).astype(np.float32))
+    a2, t2 = pcnn(xin)
+    assert_close(npy(a2), g["posecnn_aa"], rtol=1e-5, atol=1e-8, what="posecnn aa")
+    assert_close(npy(t2), g["posecnn_tr"], rtol=1e-5, atol=1e-8, what="posecnn tr")
+
+
+def test_refine_decoder_variant_against_reference(golden):
+    g = golden("decoder_refine_b2_64x96")
+    B, H, W, rng, ch, feats, beams = _decoder_setup()
+    dec2 = gin.fill_params(ON.DepthDecoder(ch, road=True, catxy=True, deep=True), 14)
+    assert sum(p.numel() for p in dec2.parameters()) == int(g["num_params"]) == 9547052
+    rng2 = np.random.RandomState(214)
+    dm = {("disp", s): torch.from_numpy(rng2.rand(B, 6, H // 2 ** s, W // 2 ** s).astype(np.float32)) for s in range(4)}
+    o = dec2(feats, beam_features=beams, depth_maps=dm, tanh=True)
+    for s in range(4):
+        assert_close(npy(o[("disp", s)]), g["disp%d" % s], rtol=1e-5, atol=1e-6, what="refine disp%d" % s)
+
+
+def _loss_case(g, seed, B, H, W, **opt_over):
+    opt = OT.default_opt(height=H, width=W, **opt_over)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp = gin.disp_pyramid(rng, B, H, W)
+    outputs, leaves = {}, []
+    for s in range(4):
+        outputs[("disp", s)] = disp[("disp", s)].clone().requires_grad_(True)
+        leaves.append(outputs[("disp", s)])
+    for f in (-1, 1):
+        aa, tr = gin.small_poses(rng, B)
+        T = OL.transformation_from_parameters(aa, tr, invert=(f < 0)).detach().requires_grad_(True)
+        assert_close(npy(T), g["T%d" % f], what="T", **TIGHT)
+        outputs[("cam_T_cam", 0, f)] = T
+        leaves.append(T)
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = [torch.randn(B, 2, H, W) for _ in range(4)]
+    assert_close(npy(noise[0]).reshape(-1)[:16], g["noise_head"], what="noise stream", **TIGHT)
+    OT.generate_images_pred(opt, inp, outputs)
+    losses = OT.compute_losses(opt, inp, outputs, noise)
+    grads = torch.autograd.grad(losses["loss"], leaves)
+    return opt, outputs, losses, grads
+
+
+@pytest.mark.parametrize("name,seed,B,H,W", [("losses_b2_64x96", 404, 2, 64, 96), ("losses_b1_192x640", 505, 1, 192, 640)])
+def test_loss_path_against_reference(golden, name, seed, B, H, W):
+    g = golden(name)
+    opt, outputs, losses, grads = _loss_case(g, seed, B, H, W)
+    for k, v in losses.items():
+        assert_close(float(v), g["L/" + k.replace("/", "_")], rtol=1e-6, atol=1e-8, what=k)
+    for s in range(4):
+        assert_close(npy(grads[s]), g["g_disp%d" % s], rtol=1e-5, atol=1e-9, what="g disp%d" % s)
+        assert (npy(outputs["identity_selection/%d" % s]).astype(np.uint8) == g["idsel%d" % s]).all()
+        if "depth%d" % s in g:
+            assert_close(npy(outputs[("depth", 0, s)]), g["depth%d" % s], what="depth", **TIGHT)
+            for f in (-1, 1):
+                assert_close(npy(outputs[("sample", f, s)]), g["sample%d_%d" % (f, s)], rtol=1e-6, atol=1e-6, what="sample")
+                assert_close(npy(outputs[("color", f, s)]), g["color%d_%d" % (f, s)], rtol=1e-5, atol=1e-6, what="color")
+        else:
+            assert_close(npy(outputs[("depth", 0, s)])[:, :, ::16, ::16], g["depth%d_sub" % s], what="depth", **TIGHT)
+    assert_close(npy(grads[4]), g["g_T-1"], rtol=1e-4, atol=1e-6, what="g T-1")
+    assert_close(npy(grads[5]), g["g_T1"], rtol=1e-4, atol=1e-6, what="g T+1")
+
+
+def test_loss_path_flags_no_ssim_no_automask(golden):
+    g = golden("losses_nossim_noautomask_b2_64x96")
+    opt, outputs, losses, grads = _loss_case(g, 606, 2, 64, 96, no_ssim=True, disable_automasking=True)
+    for k, v in losses.items():
+        assert_close(float(v), g["L/" + k.replace("/", "_")], rtol=1e-6, atol=1e-8, what=k)
+    for s in range(4):
+        assert_close(npy(grads[s]), g["g_disp%d" % s], rtol=1e-5, atol=1e-9, what="g disp%d" % s)
+
+
+def test_scatter_c_oracle_bit_exact_vs_reference(golden):
+    g = golden("scatter_192x640")
+    for i in range(3):
+        d, c = OS.scatter_2channel_c(g["beam%d" % i])
+        assert np.array_equal(c, g["conf%d" % i]), "confidence map %d" % i
+        assert np.array_equal(d, g["depth%d" % i]), "expanded depth %d: max diff %g" % (i, np.abs(d - g["depth%d" % i]).max())
+        d2, c2 = OS.scatter_2channel_np(g["beam%d" % i])
+        assert np.array_equal(c2, c)
+        assert np.array_equal(d2, d), "numpy formulation differs from sequential C by %g" % np.abs(d2 - d).max()
+
+
+def test_scatter_edge_cases():
+    empty = np.zeros((192, 640), np.float32)
+    d, c = OS.scatter_2channel_c(empty)
+    assert not d.any() and not c.any()
+    outside = empty.copy()
+    outside[10, 10] = 0.5          # outside the ROI: ignored (gen2channel.py:64-65)
+    outside[190, 300] = 0.5
+    outside[100, 1] = 0.5
+    d, c = OS.scatter_2channel_c(outside)
+    assert not d.any() and not c.any()
+    one = empty.copy()
+    one[100, 100] = 0.25
+    d, c = OS.scatter_2channel_c(one)
+    assert c[100, 100] == 1 and c[99, 100] == 0.5 and c[101, 100] == 0.5
+    assert c[100, 99] == 0 and c[100, 101] == 0            # never purely horizontal
+    third = np.float32(1.0 / 3.0)
+    for rr, cc in [(98, 100), (102, 100), (99, 99), (99, 101), (101, 99), (101, 101)]:
+        assert c[rr, cc] == third and d[rr, cc] == np.float32(0.25)
+    assert (c > 0).sum() == 9
+
+
+def test_resnet_trunk_structure():
+    """'parity unpinned' piece: structural pins only — key names, shapes, param counts."""
+    enc = ON.ResnetEncoder(18, False)
+    keys = list(enc.state_dict().keys())
+    assert keys[0] == "encoder.conv1.weight" and "encoder.layer2.0.downsample.1.running_var" in keys
+    assert "encoder.fc.weight" in keys
+    n = lambda m: sum(p.numel() for k, p in m.named_parameters() if ".fc." not in k)
+    assert n(ON.ResnetEncoder(18, False)) == 11176512
+    assert n(ON.ResnetEncoder(18, False, beam_encoder=True)) == 11173376
+    assert n(ON.ResnetEncoder(18, False, num_input_images=2)) == 11185920
+    assert n(ON.ResnetEncoder(18, False, num_input_images=2, beam_encoder=True)) == 11179648
+    dec = ON.DepthDecoder(enc.num_ch_enc)
+    assert sum(p.numel() for p in dec.parameters()) == 3152724
+    pose = ON.PoseDecoder(enc.num_ch_enc, 1, 2)
+    assert sum(p.numel() for p in pose.parameters()) == 1314572
+    e50 = ON.ResnetEncoder(50, False)
+    assert list(e50.num_ch_enc) == [64, 256, 512, 1024, 2048]
+    feats = enc(torch.rand(1, 3, 64, 96))
+    assert [tuple(f.shape[1:]) for f in feats] == [(64, 32, 48), (64, 16, 24), (128, 8, 12), (256, 4, 6), (512, 2, 3)]
+
+
+def test_derived_hparams_match_reference_rules():
+    hp = OT.derived_hparams(12)
+    assert (hp.accumulate_step, hp.micro_batch, hp.scheduler_step_size, hp.num_epochs) == (2, 6, 6, 11)
+    assert abs(hp.learning_rate - 1.5e-4) < 1e-12
+    hp = OT.derived_hparams(5)
+    assert (hp.accumulate_step, hp.micro_batch) == (1, 5)
