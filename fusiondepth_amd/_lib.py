@@ -1,0 +1,124 @@
+"""ctypes binding of ``libfdhip.so`` (C ABI declared in ``include/fdhip.h``).
+
+There is no CPU fallback: every op in this package goes through this library and raises if it is not
+built (``python -m fusiondepth_amd.build``) or if a tensor is not a contiguous float32 CUDA tensor.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdhip.so")
+ABI_VERSION = 1
+
+_P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
+_KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}
+
+
+class PhotoCfg(ctypes.Structure):
+    """Mirror of ``fd_photo_cfg``."""
+    _fields_ = [("min_depth", _D), ("max_depth", _D),
+                ("B", _I), ("H", _I), ("W", _I), ("Hs", _I), ("Ws", _I), ("NF", _I),
+                ("use_ssim", _I), ("avg_reprojection", _I),
+                ("si_depth_scale", _F), ("si_beam_scale", _F), ("si_threshold", _F), ("si_var", _F), ("eps", _F)]
+
+
+# name -> (argument kinds, restype kind)  ('p' pointer, 'i' int, 'l' long, 'f' float, 'd' double)
+SIGNATURES = {
+    "fd_abi_version": ("", "i"),
+    "fd_supported_arch": ("", "s"),
+    "fd_last_error": ("", "s"),
+    "fd_disp_to_depth_fwd": ("ppplddp", "i"),
+    "fd_disp_to_depth_bwd": ("pppplddp", "i"),
+    "fd_pose_matrix_fwd": ("pppiip", "i"),
+    "fd_pose_matrix_bwd": ("pppppiip", "i"),
+    "fd_proj_matrix_fwd": ("ppplip", "i"),
+    "fd_proj_matrix_bwd": ("pplpip", "i"),
+    "fd_backproject_fwd": ("pppiiip", "i"),
+    "fd_backproject_bwd": ("pppiiip", "i"),
+    "fd_project3d_fwd": ("ppppiiifp", "i"),
+    "fd_project3d_bwd_ws_floats": ("iii", "l"),
+    "fd_project3d_bwd": ("pppppppiiifp", "i"),
+    "fd_cat_xy_fwd": ("pppiiip", "i"),
+    "fd_bilinear_up_fwd": ("ppiiiiip", "i"),
+    "fd_bilinear_up_bwd": ("ppiiiiip", "i"),
+    "fd_ssim_fwd": ("pppiiiip", "i"),
+    "fd_ssim_bwd": ("pppppiiiip", "i"),
+    "fd_reproj_loss_map": ("pppliiiip", "i"),
+    "fd_photo_ws_floats": ("iii", "l"),
+    "fd_photo_fwd": ("p" * 16, "i"),
+    "fd_photo_bwd_ws_floats": ("iii", "l"),
+    "fd_photo_bwd": ("pppppppp" "i" "pppppp", "i"),
+    "fd_smooth_ws_floats": ("iii", "l"),
+    "fd_smooth_fwd": ("ppppiiiip", "i"),
+    "fd_smooth_bwd": ("pppppiiiip", "i"),
+    "fd_scatter_2channel": ("ppiiiiiiiip", "i"),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise if the library is missing or mismatched."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libfdhip.so is not built (%s missing). Run `python -m fusiondepth_amd.build` "
+                               "(or __graft_entry__.build()). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in SIGNATURES.items():
+            fn = getattr(lib, name)           # AttributeError if the symbol is not exported
+            fn.argtypes = [_KIND[k] for k in args]
+            fn.restype = ctypes.c_char_p if res == "s" else _KIND[res]
+        if lib.fd_abi_version() != ABI_VERSION:
+            raise RuntimeError("libfdhip ABI %d != expected %d; rebuild" % (lib.fd_abi_version(), ABI_VERSION))
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().fd_last_error().decode()
+
+
+def call(name, *args):
+    """Invoke an ``int``-returning entry point and raise RuntimeError on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (status %d): %s" % (name, rc, lib.fd_last_error().decode()))
+
+
+def query(name, *args):
+    """Invoke a size-query entry point."""
+    return getattr(load(), name)(*args)
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32 (or uint8) CUDA tensor; ``None`` -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("fusiondepth_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    if t.dtype not in (torch.float32, torch.uint8):
+        raise RuntimeError("tensor must be float32 (or uint8 for masks), got %s" % t.dtype)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def f32(t):
+    """Contiguous float32 view/copy (plumbing only)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

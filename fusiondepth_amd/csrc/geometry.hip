@@ -1,0 +1,461 @@
+// Geometry kernels of the hot path (reference layers.py:11-226) + library bookkeeping.
+// All memory-bound, 1 thread per element / per batch item; written for wave64.
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void fd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" int fd_abi_version(void) { return FD_ABI_VERSION; }
+extern "C" const char* fd_supported_arch(void) { return "gfx950"; }
+extern "C" const char* fd_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// disp_to_depth  (layers.py:11-20)
+__global__ void k_d2d_fwd(const float* __restrict__ disp, float* __restrict__ scaled, float* __restrict__ depth, long n,
+                          float lo, float span) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float s = lo + span * disp[i];
+        if (scaled) scaled[i] = s;
+        if (depth) depth[i] = 1.0f / s;
+    }
+}
+__global__ void k_d2d_bwd(const float* __restrict__ disp, const float* __restrict__ gs, const float* __restrict__ gd,
+                          float* __restrict__ out, long n, float lo, float span) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float s = lo + span * disp[i];
+        float g = 0.f;
+        if (gs) g += gs[i];
+        if (gd) g -= gd[i] / (s * s);
+        out[i] = g * span;
+    }
+}
+static inline int ew_grid(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+extern "C" int fd_disp_to_depth_fwd(const float* disp, float* scaled, float* depth, long n, double min_depth,
+                                    double max_depth, void* stream) {
+    FD_REQUIRE(disp && n >= 0, "fd_disp_to_depth_fwd: bad args");
+    if (n == 0) return 0;
+    float lo = (float)(1.0 / max_depth);
+    float span = (float)(1.0 / min_depth - 1.0 / max_depth);
+    hipLaunchKernelGGL(k_d2d_fwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, disp, scaled, depth, n, lo, span);
+    FD_LAUNCH_CHECK("fd_disp_to_depth_fwd");
+    return 0;
+}
+extern "C" int fd_disp_to_depth_bwd(const float* disp, const float* g_scaled, const float* g_depth, float* d_disp,
+                                    long n, double min_depth, double max_depth, void* stream) {
+    FD_REQUIRE(disp && d_disp && n >= 0, "fd_disp_to_depth_bwd: bad args");
+    if (n == 0) return 0;
+    float lo = (float)(1.0 / max_depth);
+    float span = (float)(1.0 / min_depth - 1.0 / max_depth);
+    hipLaunchKernelGGL(k_d2d_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, disp, g_scaled, g_depth, d_disp,
+                       n, lo, span);
+    FD_LAUNCH_CHECK("fd_disp_to_depth_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pose vector -> 4x4 (layers.py:23-97).  One thread per batch item.
+struct Rodrigues {
+    float x, y, z, ca, sa, C, th, inv;  // axis, cos, sin, 1-cos, angle, 1/(angle+1e-7)
+    float R[3][3];
+};
+__device__ __forceinline__ Rodrigues fd_rodrigues(float vx, float vy, float vz) {
+    Rodrigues r;
+    r.th = sqrtf(vx * vx + vy * vy + vz * vz);
+    r.inv = 1.0f / (r.th + 1e-7f);
+    r.x = vx * r.inv; r.y = vy * r.inv; r.z = vz * r.inv;
+    r.ca = cosf(r.th); r.sa = sinf(r.th); r.C = 1.0f - r.ca;
+    float xs = r.x * r.sa, ys = r.y * r.sa, zs = r.z * r.sa;
+    float xC = r.x * r.C, yC = r.y * r.C, zC = r.z * r.C;
+    float xyC = r.x * yC, yzC = r.y * zC, zxC = r.z * xC;
+    r.R[0][0] = r.x * xC + r.ca; r.R[0][1] = xyC - zs;          r.R[0][2] = zxC + ys;
+    r.R[1][0] = xyC + zs;        r.R[1][1] = r.y * yC + r.ca;   r.R[1][2] = yzC - xs;
+    r.R[2][0] = zxC - ys;        r.R[2][1] = yzC + xs;          r.R[2][2] = r.z * zC + r.ca;
+    return r;
+}
+__global__ void k_pose_fwd(const float* __restrict__ aa, const float* __restrict__ tr, float* __restrict__ T, int B,
+                           int invert) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    Rodrigues r = fd_rodrigues(aa[b * 3 + 0], aa[b * 3 + 1], aa[b * 3 + 2]);
+    float t[3] = {tr[b * 3 + 0], tr[b * 3 + 1], tr[b * 3 + 2]};
+    float* M = T + b * 16;
+    if (!invert) {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) M[i * 4 + j] = r.R[i][j];
+            M[i * 4 + 3] = t[i];
+        }
+    } else {  // R^T * T(-t): rotation R^T, translation column sum_j R^T[i][j] * (-t_j)
+        for (int i = 0; i < 3; ++i) {
+            float acc = 0.f;
+            for (int j = 0; j < 3; ++j) {
+                M[i * 4 + j] = r.R[j][i];
+                acc += r.R[j][i] * (-t[j]);
+            }
+            M[i * 4 + 3] = acc;
+        }
+    }
+    M[12] = 0.f; M[13] = 0.f; M[14] = 0.f; M[15] = 1.f;
+}
+__global__ void k_pose_bwd(const float* __restrict__ aa, const float* __restrict__ tr, const float* __restrict__ gT,
+                           float* __restrict__ g_aa, float* __restrict__ g_tr, int B, int invert) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float vx = aa[b * 3 + 0], vy = aa[b * 3 + 1], vz = aa[b * 3 + 2];
+    Rodrigues r = fd_rodrigues(vx, vy, vz);
+    float t[3] = {tr[b * 3 + 0], tr[b * 3 + 1], tr[b * 3 + 2]};
+    const float* G = gT + b * 16;
+    float dR[3][3], dt[3];
+    if (!invert) {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) dR[i][j] = G[i * 4 + j];
+            dt[i] = G[i * 4 + 3];
+        }
+    } else {
+        // M[i][j] = R[j][i];  M[i][3] = -sum_j R[j][i] t_j
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.f;
+            for (int i = 0; i < 3; ++i) {
+                dR[j][i] = G[i * 4 + j] - G[i * 4 + 3] * t[j];
+                acc -= G[i * 4 + 3] * r.R[j][i];
+            }
+            dt[j] = acc;
+        }
+    }
+    float x = r.x, y = r.y, z = r.z, C = r.C, sa = r.sa, ca = r.ca;
+    float s01 = dR[0][1] + dR[1][0], s02 = dR[0][2] + dR[2][0], s12 = dR[1][2] + dR[2][1];
+    float dx = dR[0][0] * 2.f * x * C + s01 * y * C + s02 * z * C + (dR[2][1] - dR[1][2]) * sa;
+    float dy = dR[1][1] * 2.f * y * C + s01 * x * C + s12 * z * C + (dR[0][2] - dR[2][0]) * sa;
+    float dz = dR[2][2] * 2.f * z * C + s02 * x * C + s12 * y * C + (dR[1][0] - dR[0][1]) * sa;
+    float dC = dR[0][0] * x * x + dR[1][1] * y * y + dR[2][2] * z * z + s01 * x * y + s02 * z * x + s12 * y * z;
+    float dca = dR[0][0] + dR[1][1] + dR[2][2] - dC;
+    float dsa = -z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1];
+    float dth = -sa * dca + ca * dsa;
+    // axis = v * inv, inv = 1/(th + 1e-7)
+    dth -= (dx * vx + dy * vy + dz * vz) * r.inv * r.inv;
+    float k = r.th > 0.f ? dth / r.th : 0.f;  // d||v||/dv = v/||v|| (0 at the origin, as torch.norm)
+    g_aa[b * 3 + 0] = dx * r.inv + k * vx;
+    g_aa[b * 3 + 1] = dy * r.inv + k * vy;
+    g_aa[b * 3 + 2] = dz * r.inv + k * vz;
+    g_tr[b * 3 + 0] = dt[0]; g_tr[b * 3 + 1] = dt[1]; g_tr[b * 3 + 2] = dt[2];
+}
+extern "C" int fd_pose_matrix_fwd(const float* axisangle, const float* translation, float* T, int B, int invert,
+                                  void* stream) {
+    FD_REQUIRE(axisangle && translation && T && B > 0, "fd_pose_matrix_fwd: bad args");
+    hipLaunchKernelGGL(k_pose_fwd, dim3(fd_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, axisangle, translation, T, B,
+                       invert);
+    FD_LAUNCH_CHECK("fd_pose_matrix_fwd");
+    return 0;
+}
+extern "C" int fd_pose_matrix_bwd(const float* axisangle, const float* translation, const float* gT, float* g_axisangle,
+                                  float* g_translation, int B, int invert, void* stream) {
+    FD_REQUIRE(axisangle && translation && gT && g_axisangle && g_translation && B > 0, "fd_pose_matrix_bwd: bad args");
+    hipLaunchKernelGGL(k_pose_bwd, dim3(fd_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, axisangle, translation, gT,
+                       g_axisangle, g_translation, B, invert);
+    FD_LAUNCH_CHECK("fd_pose_matrix_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// P = (K @ T)[:3]   (layers.py:217)
+__global__ void k_projmat_fwd(const float* __restrict__ K, const float* __restrict__ T, float* __restrict__ P,
+                              long pstride, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 12) return;
+    int b = i / 12, e = i % 12, r = e / 4, c = e % 4;
+    const float* k = K + b * 16 + r * 4;
+    const float* t = T + b * 16 + c;
+    float acc = 0.f;
+    for (int j = 0; j < 4; ++j) acc += k[j] * t[j * 4];
+    P[b * pstride + e] = acc;
+}
+__global__ void k_projmat_bwd(const float* __restrict__ K, const float* __restrict__ gP, long pstride,
+                              float* __restrict__ gT, int B) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 16) return;
+    int b = i / 16, e = i % 16, j = e / 4, c = e % 4;
+    float acc = 0.f;
+    for (int r = 0; r < 3; ++r) acc += K[b * 16 + r * 4 + j] * gP[b * pstride + r * 4 + c];
+    gT[i] = acc;
+}
+extern "C" int fd_proj_matrix_fwd(const float* K, const float* T, float* P, long p_batch_stride, int B, void* stream) {
+    FD_REQUIRE(K && T && P && B > 0 && p_batch_stride >= 12, "fd_proj_matrix_fwd: bad args");
+    hipLaunchKernelGGL(k_projmat_fwd, dim3(fd_cdiv(B * 12, 64)), dim3(64), 0, (hipStream_t)stream, K, T, P,
+                       p_batch_stride, B);
+    FD_LAUNCH_CHECK("fd_proj_matrix_fwd");
+    return 0;
+}
+extern "C" int fd_proj_matrix_bwd(const float* K, const float* gP, long p_batch_stride, float* gT, int B, void* stream) {
+    FD_REQUIRE(K && gP && gT && B > 0 && p_batch_stride >= 12, "fd_proj_matrix_bwd: bad args");
+    hipLaunchKernelGGL(k_projmat_bwd, dim3(fd_cdiv(B * 16, 64)), dim3(64), 0, (hipStream_t)stream, K, gP,
+                       p_batch_stride, gT, B);
+    FD_LAUNCH_CHECK("fd_proj_matrix_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BackprojectDepth (layers.py:157-162)
+__global__ void k_backproject_fwd(const float* __restrict__ depth, const float* __restrict__ invK,
+                                  float* __restrict__ pts, int H, int W) {
+    const int b = blockIdx.y;
+    const long P = (long)H * W;
+    const float* k = invK + b * 16;
+    const float k00 = k[0], k01 = k[1], k02 = k[2], k10 = k[4], k11 = k[5], k12 = k[6], k20 = k[8], k21 = k[9],
+                k22 = k[10];
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        float x = (float)(p % W), y = (float)(p / W);
+        float d = depth[b * P + p];
+        float* o = pts + (long)b * 4 * P + p;
+        o[0] = d * (k00 * x + k01 * y + k02);
+        o[P] = d * (k10 * x + k11 * y + k12);
+        o[2 * P] = d * (k20 * x + k21 * y + k22);
+        o[3 * P] = 1.0f;
+    }
+}
+__global__ void k_backproject_bwd(const float* __restrict__ gpts, const float* __restrict__ invK,
+                                  float* __restrict__ gdepth, int H, int W) {
+    const int b = blockIdx.y;
+    const long P = (long)H * W;
+    const float* k = invK + b * 16;
+    const float k00 = k[0], k01 = k[1], k02 = k[2], k10 = k[4], k11 = k[5], k12 = k[6], k20 = k[8], k21 = k[9],
+                k22 = k[10];
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        float x = (float)(p % W), y = (float)(p / W);
+        const float* g = gpts + (long)b * 4 * P + p;
+        gdepth[b * P + p] = g[0] * (k00 * x + k01 * y + k02) + g[P] * (k10 * x + k11 * y + k12) +
+                            g[2 * P] * (k20 * x + k21 * y + k22);
+    }
+}
+extern "C" int fd_backproject_fwd(const float* depth, const float* inv_K, float* points, int B, int H, int W,
+                                  void* stream) {
+    FD_REQUIRE(depth && inv_K && points && B > 0 && H > 0 && W > 0, "fd_backproject_fwd: bad args");
+    dim3 grid(ew_grid((long)H * W), B);
+    hipLaunchKernelGGL(k_backproject_fwd, grid, dim3(256), 0, (hipStream_t)stream, depth, inv_K, points, H, W);
+    FD_LAUNCH_CHECK("fd_backproject_fwd");
+    return 0;
+}
+extern "C" int fd_backproject_bwd(const float* g_points, const float* inv_K, float* g_depth, int B, int H, int W,
+                                  void* stream) {
+    FD_REQUIRE(g_points && inv_K && g_depth && B > 0 && H > 0 && W > 0, "fd_backproject_bwd: bad args");
+    dim3 grid(ew_grid((long)H * W), B);
+    hipLaunchKernelGGL(k_backproject_bwd, grid, dim3(256), 0, (hipStream_t)stream, g_points, inv_K, g_depth, H, W);
+    FD_LAUNCH_CHECK("fd_backproject_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Project3D (layers.py:215-226)
+__device__ __forceinline__ void fd_load_P(const float* K, const float* T, float (&Pm)[12]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc += K[r * 4 + j] * T[j * 4 + c];
+            Pm[r * 4 + c] = acc;
+        }
+}
+__global__ void k_project_fwd(const float* __restrict__ pts, const float* __restrict__ K, const float* __restrict__ T,
+                              float* __restrict__ grid, int H, int W, float eps) {
+    const int b = blockIdx.y;
+    const long P = (long)H * W;
+    float Pm[12];
+    fd_load_P(K + b * 16, T + b * 16, Pm);
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        const float* x = pts + (long)b * 4 * P + p;
+        float X0 = x[0], X1 = x[P], X2 = x[2 * P], X3 = x[3 * P];
+        float c0 = Pm[0] * X0 + Pm[1] * X1 + Pm[2] * X2 + Pm[3] * X3;
+        float c1 = Pm[4] * X0 + Pm[5] * X1 + Pm[6] * X2 + Pm[7] * X3;
+        float c2 = Pm[8] * X0 + Pm[9] * X1 + Pm[10] * X2 + Pm[11] * X3;
+        float den = c2 + eps;
+        float u = c0 / den, v = c1 / den;
+        float2 o;
+        o.x = (u / wm1 - 0.5f) * 2.0f;
+        o.y = (v / hm1 - 0.5f) * 2.0f;
+        reinterpret_cast<float2*>(grid)[b * P + p] = o;
+    }
+}
+// backward: g_points and per-block partial sums of gP (12 values)
+__global__ void __launch_bounds__(256) k_project_bwd(const float* __restrict__ pts, const float* __restrict__ K,
+                                                     const float* __restrict__ T, const float* __restrict__ ggrid,
+                                                     float* __restrict__ gpts, float* __restrict__ part, int H, int W,
+                                                     float eps) {
+    __shared__ float red[4 * 12];
+    const int b = blockIdx.y;
+    const long P = (long)H * W;
+    float Pm[12];
+    fd_load_P(K + b * 16, T + b * 16, Pm);
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        const float* x = pts + (long)b * 4 * P + p;
+        float X[4] = {x[0], x[P], x[2 * P], x[3 * P]};
+        float c0 = Pm[0] * X[0] + Pm[1] * X[1] + Pm[2] * X[2] + Pm[3] * X[3];
+        float c1 = Pm[4] * X[0] + Pm[5] * X[1] + Pm[6] * X[2] + Pm[7] * X[3];
+        float c2 = Pm[8] * X[0] + Pm[9] * X[1] + Pm[10] * X[2] + Pm[11] * X[3];
+        float den = c2 + eps;
+        float u = c0 / den, v = c1 / den;
+        float2 g = reinterpret_cast<const float2*>(ggrid)[b * P + p];
+        float gu = g.x * 2.0f / wm1, gv = g.y * 2.0f / hm1;
+        float dc[3] = {gu / den, gv / den, -(gu * u + gv * v) / den};
+        float* go = gpts + (long)b * 4 * P + p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            go[j * P] = Pm[j] * dc[0] + Pm[4 + j] * dc[1] + Pm[8 + j] * dc[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) acc[r * 4 + j] += dc[r] * X[j];
+        }
+    }
+    float s = fd_block_sum_n<12, 4>(acc, red);
+    if (threadIdx.x < 12) part[((long)b * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = s;
+}
+__global__ void k_project_bwd_fin(const float* __restrict__ part, const float* __restrict__ K, float* __restrict__ gT,
+                                  int nblk) {
+    // one block of 64 threads per batch item: reduce gP over blocks (fixed order) then gT = K[:3]^T gP
+    __shared__ float gP[12];
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < 12) {
+        float s = 0.f;
+        for (int i = 0; i < nblk; ++i) s += part[((long)b * nblk + i) * 12 + t];
+        gP[t] = s;
+    }
+    __syncthreads();
+    if (t < 16) {
+        int j = t / 4, c = t % 4;
+        float a = 0.f;
+        for (int r = 0; r < 3; ++r) a += K[b * 16 + r * 4 + j] * gP[r * 4 + c];
+        gT[b * 16 + t] = a;
+    }
+}
+static inline int proj_blocks(int H, int W) {
+    int n = fd_cdiv((long)H * W, 256 * 4);
+    return n < 1 ? 1 : (n > 256 ? 256 : n);
+}
+extern "C" long fd_project3d_bwd_ws_floats(int B, int H, int W) { return (long)B * proj_blocks(H, W) * 12; }
+extern "C" int fd_project3d_fwd(const float* points, const float* K, const float* T, float* grid, int B, int H, int W,
+                                float eps, void* stream) {
+    FD_REQUIRE(points && K && T && grid && B > 0 && H > 1 && W > 1, "fd_project3d_fwd: bad args");
+    dim3 g(ew_grid((long)H * W), B);
+    hipLaunchKernelGGL(k_project_fwd, g, dim3(256), 0, (hipStream_t)stream, points, K, T, grid, H, W, eps);
+    FD_LAUNCH_CHECK("fd_project3d_fwd");
+    return 0;
+}
+extern "C" int fd_project3d_bwd(const float* points, const float* K, const float* T, const float* g_grid,
+                                float* g_points, float* gT, float* ws, int B, int H, int W, float eps, void* stream) {
+    FD_REQUIRE(points && K && T && g_grid && g_points && gT && ws && B > 0 && H > 1 && W > 1,
+               "fd_project3d_bwd: bad args");
+    int nb = proj_blocks(H, W);
+    hipLaunchKernelGGL(k_project_bwd, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, points, K, T, g_grid, g_points, ws,
+                       H, W, eps);
+    FD_LAUNCH_CHECK("fd_project3d_bwd");
+    hipLaunchKernelGGL(k_project_bwd_fin, dim3(B), dim3(64), 0, (hipStream_t)stream, ws, K, gT, nb);
+    FD_LAUNCH_CHECK("fd_project3d_bwd_fin");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cat_xy (layers.py:187-201)
+__global__ void k_catxy(const float* __restrict__ depth, const float* __restrict__ invK, float* __restrict__ out, int H,
+                        int W) {
+    const int b = blockIdx.y;
+    const long P = (long)H * W;
+    const float* k = invK + b * 16;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long)gridDim.x * blockDim.x) {
+        float x = (float)(p % W), y = (float)(p / W);
+        float d = depth[b * P + p];
+        float* o = out + (long)b * 3 * P + p;
+        o[0] = d * (k[0] * x + k[1] * y + k[2]) / 30.0f;
+        o[P] = d * (k[4] * x + k[5] * y + k[6]) / 2.0f;
+        o[2 * P] = (d * (k[8] * x + k[9] * y + k[10]) - 40.0f) / 40.0f;
+    }
+}
+extern "C" int fd_cat_xy_fwd(const float* depth, const float* inv_K, float* out, int B, int H, int W, void* stream) {
+    FD_REQUIRE(depth && inv_K && out && B > 0 && H > 0 && W > 0, "fd_cat_xy_fwd: bad args");
+    hipLaunchKernelGGL(k_catxy, dim3(ew_grid((long)H * W), B), dim3(256), 0, (hipStream_t)stream, depth, inv_K, out, H,
+                       W);
+    FD_LAUNCH_CHECK("fd_cat_xy_fwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=False (trainer.py:434-435)
+__global__ void k_bilinear_fwd(const float* __restrict__ x, float* __restrict__ y, int Hin, int Win, int Hout, int Wout,
+                               float sh, float sw) {
+    const int bc = blockIdx.y;
+    const long Po = (long)Hout * Wout;
+    const float* xi = x + (long)bc * Hin * Win;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < Po; p += (long)gridDim.x * blockDim.x) {
+        int oy = (int)(p / Wout), ox = (int)(p % Wout);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        fd_bilinear_src(oy, sh, Hin, y0, y1, ly);
+        fd_bilinear_src(ox, sw, Win, x0, x1, lx);
+        float hy = 1.f - ly, hx = 1.f - lx;
+        y[(long)bc * Po + p] = hy * (hx * xi[y0 * Win + x0] + lx * xi[y0 * Win + x1]) +
+                               ly * (hx * xi[y1 * Win + x0] + lx * xi[y1 * Win + x1]);
+    }
+}
+// adjoint in gather form: each input pixel collects from the output pixels whose 2x2 footprint holds it
+__global__ void k_bilinear_bwd(const float* __restrict__ gy, float* __restrict__ gx, int Hin, int Win, int Hout,
+                               int Wout, float sh, float sw) {
+    const int bc = blockIdx.y;
+    const long Pi = (long)Hin * Win;
+    const float* g = gy + (long)bc * Hout * Wout;
+    const int ry = (Hout + Hin - 1) / Hin, rx = (Wout + Win - 1) / Win;  // upsampling ratio (ceil)
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < Pi; p += (long)gridDim.x * blockDim.x) {
+        int iy = (int)(p / Win), ix = (int)(p % Win);
+        int oy_lo = (iy - 1) * ry - 1, oy_hi = (iy + 2) * ry + 1;
+        int ox_lo = (ix - 1) * rx - 1, ox_hi = (ix + 2) * rx + 1;
+        oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
+        oy_hi = oy_hi > Hout - 1 ? Hout - 1 : oy_hi; ox_hi = ox_hi > Wout - 1 ? Wout - 1 : ox_hi;
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly;
+            fd_bilinear_src(oy, sh, Hin, y0, y1, ly);
+            float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx;
+                fd_bilinear_src(ox, sw, Win, x0, x1, lx);
+                float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                if (wx != 0.f) acc += wy * wx * g[(long)oy * Wout + ox];
+            }
+        }
+        gx[(long)bc * Pi + p] = acc;
+    }
+}
+extern "C" int fd_bilinear_up_fwd(const float* x, float* y, int BC, int Hin, int Win, int Hout, int Wout, void* stream) {
+    FD_REQUIRE(x && y && BC > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "fd_bilinear_up_fwd: bad args");
+    hipLaunchKernelGGL(k_bilinear_fwd, dim3(ew_grid((long)Hout * Wout), BC), dim3(256), 0, (hipStream_t)stream, x, y, Hin,
+                       Win, Hout, Wout, (float)Hin / (float)Hout, (float)Win / (float)Wout);
+    FD_LAUNCH_CHECK("fd_bilinear_up_fwd");
+    return 0;
+}
+extern "C" int fd_bilinear_up_bwd(const float* gy, float* gx, int BC, int Hin, int Win, int Hout, int Wout,
+                                  void* stream) {
+    FD_REQUIRE(gy && gx && BC > 0 && Hin > 0 && Win > 0 && Hout >= Hin && Wout >= Win,
+               "fd_bilinear_up_bwd: bad args (only upsampling is supported)");
+    hipLaunchKernelGGL(k_bilinear_bwd, dim3(ew_grid((long)Hin * Win), BC), dim3(256), 0, (hipStream_t)stream, gy, gx, Hin,
+                       Win, Hout, Wout, (float)Hin / (float)Hout, (float)Win / (float)Wout);
+    FD_LAUNCH_CHECK("fd_bilinear_up_bwd");
+    return 0;
+}

@@ -1,0 +1,361 @@
+"""``torch.autograd.Function`` wrappers over the libfdhip C ABI (loss path and layers.py ops).
+
+Host logic only: shape checks, workspace allocation from PyTorch's caching allocator, and the
+forward/backward pairing.  All arithmetic happens in the HIP kernels; nothing here falls back to
+torch ops on the data path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, f32, ptr, query, stream
+
+PROJECT_EPS = 1e-7
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("fusiondepth_amd: tensors must live on the GPU (no CPU fallback); got %s" % t.device)
+
+
+# ------------------------------------------------------------------------------------ geometry ---
+class _DispToDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, min_depth, max_depth):
+        disp = f32(disp)
+        _need_cuda(disp)
+        scaled, depth = torch.empty_like(disp), torch.empty_like(disp)
+        call("fd_disp_to_depth_fwd", ptr(disp), ptr(scaled), ptr(depth), disp.numel(), float(min_depth),
+             float(max_depth), stream())
+        ctx.save_for_backward(disp)
+        ctx.rng = (float(min_depth), float(max_depth))
+        return scaled, depth
+
+    @staticmethod
+    def backward(ctx, g_scaled, g_depth):
+        (disp,) = ctx.saved_tensors
+        gs = f32(g_scaled) if g_scaled is not None else None
+        gd = f32(g_depth) if g_depth is not None else None
+        out = torch.empty_like(disp)
+        call("fd_disp_to_depth_bwd", ptr(disp), ptr(gs), ptr(gd), ptr(out), disp.numel(), ctx.rng[0], ctx.rng[1],
+             stream())
+        return out, None, None
+
+
+def disp_to_depth(disp, min_depth, max_depth):
+    return _DispToDepth.apply(disp, min_depth, max_depth)
+
+
+class _PoseMatrix(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        B = axisangle.shape[0]
+        aa = f32(axisangle).reshape(B, 3)
+        tr = f32(translation).reshape(B, 3)
+        _need_cuda(aa, tr)
+        T = _empty((B, 4, 4), aa)
+        call("fd_pose_matrix_fwd", ptr(aa), ptr(tr), ptr(T), B, int(bool(invert)), stream())
+        ctx.save_for_backward(aa, tr)
+        ctx.invert = int(bool(invert))
+        ctx.shapes = (axisangle.shape, translation.shape)
+        return T
+
+    @staticmethod
+    def backward(ctx, gT):
+        aa, tr = ctx.saved_tensors
+        B = aa.shape[0]
+        gT = f32(gT)
+        gaa, gtr = torch.empty_like(aa), torch.empty_like(tr)
+        call("fd_pose_matrix_bwd", ptr(aa), ptr(tr), ptr(gT), ptr(gaa), ptr(gtr), B, ctx.invert, stream())
+        return gaa.reshape(ctx.shapes[0]), gtr.reshape(ctx.shapes[1]), None
+
+
+def transformation_from_parameters(axisangle, translation, invert=False):
+    """layers.py:23-40.  axisangle / translation: [B,1,3] -> [B,4,4]."""
+    return _PoseMatrix.apply(axisangle, translation, invert)
+
+
+class _Backproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        depth, inv_K = f32(depth), f32(inv_K)
+        _need_cuda(depth, inv_K)
+        B, _, H, W = depth.shape
+        pts = _empty((B, 4, H * W), depth)
+        call("fd_backproject_fwd", ptr(depth), ptr(inv_K), ptr(pts), B, H, W, stream())
+        ctx.save_for_backward(inv_K)
+        ctx.shape = depth.shape
+        return pts
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv_K,) = ctx.saved_tensors
+        B, _, H, W = ctx.shape
+        out = _empty(ctx.shape, g)
+        call("fd_backproject_bwd", ptr(f32(g)), ptr(inv_K), ptr(out), B, H, W, stream())
+        return out, None
+
+
+def backproject_depth(depth, inv_K):
+    return _Backproject.apply(depth, inv_K)
+
+
+class _Project3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, K, T, H, W, eps):
+        points, K, T = f32(points), f32(K), f32(T)
+        _need_cuda(points, K, T)
+        B = points.shape[0]
+        grid = _empty((B, H, W, 2), points)
+        call("fd_project3d_fwd", ptr(points), ptr(K), ptr(T), ptr(grid), B, H, W, float(eps), stream())
+        ctx.save_for_backward(points, K, T)
+        ctx.dims = (B, H, W, float(eps))
+        return grid
+
+    @staticmethod
+    def backward(ctx, g):
+        points, K, T = ctx.saved_tensors
+        B, H, W, eps = ctx.dims
+        g = f32(g)
+        gpts = torch.empty_like(points)
+        gT = _empty((B, 4, 4), points)
+        ws = _empty((query("fd_project3d_bwd_ws_floats", B, H, W),), points)
+        call("fd_project3d_bwd", ptr(points), ptr(K), ptr(T), ptr(g), ptr(gpts), ptr(gT), ptr(ws), B, H, W, eps,
+             stream())
+        return gpts, None, gT, None, None, None
+
+
+def project_3d(points, K, T, height, width, eps=PROJECT_EPS):
+    return _Project3D.apply(points, K, T, height, width, eps)
+
+
+def cat_xy(depth, inv_K):
+    depth, inv_K = f32(depth.detach()), f32(inv_K)
+    _need_cuda(depth, inv_K)
+    B, _, H, W = depth.shape
+    out = _empty((B, 3, H, W), depth)
+    call("fd_cat_xy_fwd", ptr(depth), ptr(inv_K), ptr(out), B, H, W, stream())
+    return out
+
+
+class _BilinearUp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Hout, Wout):
+        x = f32(x)
+        _need_cuda(x)
+        B, C, Hin, Win = x.shape
+        y = _empty((B, C, Hout, Wout), x)
+        call("fd_bilinear_up_fwd", ptr(x), ptr(y), B * C, Hin, Win, Hout, Wout, stream())
+        ctx.dims = (B, C, Hin, Win, Hout, Wout)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, Hin, Win, Hout, Wout = ctx.dims
+        gx = _empty((B, C, Hin, Win), g)
+        call("fd_bilinear_up_bwd", ptr(f32(g)), ptr(gx), B * C, Hin, Win, Hout, Wout, stream())
+        return gx, None, None
+
+
+def bilinear_upsample(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) for upsampling."""
+    return _BilinearUp.apply(x, int(size[0]), int(size[1]))
+
+
+# ------------------------------------------------------------------------------------ SSIM etc. ---
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = f32(x), f32(y)
+        _need_cuda(x, y)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        call("fd_ssim_fwd", ptr(x), ptr(y), ptr(out), B, C, H, W, stream())
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        call("fd_ssim_bwd", ptr(x), ptr(y), ptr(f32(g)), ptr(gx), ptr(gy), B, C, H, W, stream())
+        return gx, gy
+
+
+def ssim(x, y):
+    return _SSIM.apply(x, y)
+
+
+def reprojection_loss_map(pred, target, use_ssim=True, out=None):
+    """trainer.py:476-488 without autograd (used for the identity losses): [B,3,H,W]^2 -> [B,1,H,W]."""
+    pred, target = f32(pred.detach()), f32(target.detach())
+    _need_cuda(pred, target)
+    B, C, H, W = pred.shape
+    assert C == 3
+    if out is None:
+        out = _empty((B, 1, H, W), pred)
+        stride = H * W
+    else:
+        stride = out.stride(0)
+    call("fd_reproj_loss_map", ptr(pred), ptr(target), out.data_ptr(), stride, B, H, W, int(bool(use_ssim)), stream())
+    return out
+
+
+class _SmoothLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, img, normalize):
+        disp, img = f32(disp), f32(img)
+        _need_cuda(disp, img)
+        B, _, H, W = disp.shape
+        out = _empty((1,), disp)
+        ws = _empty((query("fd_smooth_ws_floats", B, H, W),), disp)
+        call("fd_smooth_fwd", ptr(disp), ptr(img), ptr(out), ptr(ws), B, H, W, int(normalize), stream())
+        ctx.save_for_backward(disp, img)
+        ctx.normalize = int(normalize)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, img = ctx.saved_tensors
+        B, _, H, W = disp.shape
+        g = f32(g).reshape(1)
+        d = torch.empty_like(disp)
+        ws = _empty((query("fd_smooth_ws_floats", B, H, W),), disp)
+        call("fd_smooth_bwd", ptr(disp), ptr(img), ptr(g), ptr(d), ptr(ws), B, H, W, ctx.normalize, stream())
+        return d, None, None
+
+
+def get_smooth_loss(disp, img):
+    """layers.py:235-248."""
+    return _SmoothLoss.apply(disp, img, False)
+
+
+def normalized_smooth_loss(disp, img):
+    """trainer.py:569-571: get_smooth_loss(disp / (disp.mean(2,3) + 1e-7), img)."""
+    return _SmoothLoss.apply(disp, img, True)
+
+
+# ------------------------------------------------------------------------------------ LiDAR -------
+def scatter_2channel(beam, roi=(76, 190, 2, 638), expand=2):
+    """gen2channel.py:60-117 on the GPU.  beam [B,1,H,W] (or [H,W]) -> [B,2,H,W]."""
+    squeeze = beam.dim() == 2
+    if squeeze:
+        beam = beam[None, None]
+    beam = f32(beam)
+    _need_cuda(beam)
+    B, _, H, W = beam.shape
+    out = _empty((B, 2, H, W), beam)
+    call("fd_scatter_2channel", ptr(beam), ptr(out), B, H, W, roi[0], roi[1], roi[2], roi[3], expand, stream())
+    return out[0] if squeeze else out
+
+
+def scaled_roi(H, W):
+    """ROI of gen2channel.py:64-65 (rows 76..189, cols 2..637 of 192x640) scaled to another size."""
+    return (int(round(76 * H / 192)), int(round(190 * H / 192)), 2, W - 2)
+
+
+# ------------------------------------------------------------------------------------ fused loss --
+class PhotoOptions:
+    """The option subset the fused loss reads (options.py:64-71,111-125,242-330)."""
+
+    def __init__(self, min_depth=0.1, max_depth=100.0, no_ssim=False, avg_reprojection=False, si_threshold=2.0,
+                 si_var=0.3, si_depth_scale=26.0, si_beam_scale=100.0):
+        self.min_depth, self.max_depth = float(min_depth), float(max_depth)
+        self.no_ssim, self.avg_reprojection = bool(no_ssim), bool(avg_reprojection)
+        self.si_threshold, self.si_var = float(si_threshold), float(si_var)
+        self.si_depth_scale, self.si_beam_scale = float(si_depth_scale), float(si_beam_scale)
+
+
+def _photo_cfg(po, B, H, W, Hs, Ws, NF):
+    c = _lib.PhotoCfg()
+    c.min_depth, c.max_depth = po.min_depth, po.max_depth
+    c.B, c.H, c.W, c.Hs, c.Ws, c.NF = B, H, W, Hs, Ws, NF
+    c.use_ssim = 0 if po.no_ssim else 1
+    c.avg_reprojection = 1 if po.avg_reprojection else 0
+    c.si_depth_scale, c.si_beam_scale = po.si_depth_scale, po.si_beam_scale
+    c.si_threshold, c.si_var, c.eps = po.si_threshold, po.si_var, PROJECT_EPS
+    return c
+
+
+class _PhotoLoss(torch.autograd.Function):
+    """One pyramid scale of generate_images_pred + the photometric / SI part of compute_losses.
+
+    Returns (to_optimise.mean(), si_loss, sel, depth, sample, color); the last four are
+    non-differentiable by-products (``None`` unless requested)."""
+
+    @staticmethod
+    def forward(ctx, disp, T0, T1, K, inv_K, src0, src1, target, ident, noise, beam, po, materialize):
+        disp, K, inv_K, target = f32(disp), f32(K), f32(inv_K), f32(target)
+        _need_cuda(disp, K, inv_K, target, src0)
+        NF = 1 if src1 is None else 2
+        B, _, Hs, Ws = disp.shape
+        H, W = target.shape[2:]
+        srcs = [f32(src0)] + ([f32(src1)] if NF == 2 else [])
+        Ts = [f32(T0)] + ([f32(T1)] if NF == 2 else [])
+        P = _empty((B, NF, 3, 4), disp)
+        for f in range(NF):
+            call("fd_proj_matrix_fwd", ptr(K), ptr(Ts[f]), P.data_ptr() + f * 48, NF * 12, B, stream())
+        ident = f32(ident) if ident is not None else None
+        noise = f32(noise) if noise is not None else None
+        beam = f32(beam) if beam is not None else None
+        cfg = _photo_cfg(po, B, H, W, Hs, Ws, NF)
+        sel = _empty((B, H, W), disp, torch.uint8)
+        depth = _empty((B, 1, H, W), disp) if materialize else None
+        sample = _empty((NF, B, H, W, 2), disp) if materialize else None
+        color = _empty((NF, B, 3, H, W), disp) if materialize else None
+        ws = _empty((query("fd_photo_ws_floats", B, H, W),), disp)
+        out = _empty((8,), disp)
+        src_arr = (ctypes.c_void_p * 2)(ptr(srcs[0]), ptr(srcs[-1]))
+        call("fd_photo_fwd", ctypes.addressof(cfg), ptr(disp), ptr(inv_K), ptr(P), ctypes.addressof(src_arr),
+             ptr(target), ptr(ident), ptr(noise), ptr(beam), ptr(sel), ptr(depth), ptr(sample), ptr(color), ptr(ws),
+             ptr(out), stream())
+        ctx.save_for_backward(disp, K, inv_K, P, target, beam, sel, out, *srcs)
+        ctx.cfg, ctx.NF, ctx.has_ident = cfg, NF, int(ident is not None)
+        ctx.mark_non_differentiable(sel)
+        extras = [t for t in (depth, sample, color) if t is not None]
+        if extras:
+            ctx.mark_non_differentiable(*extras)
+        return out[0], out[4], sel, depth, sample, color
+
+    @staticmethod
+    def backward(ctx, g_photo, g_si, *_):
+        disp, K, inv_K, P, target, beam, sel, stats = ctx.saved_tensors[:8]
+        srcs = ctx.saved_tensors[8:]
+        cfg, NF = ctx.cfg, ctx.NF
+        B, H, W = cfg.B, cfg.H, cfg.W
+        g = _empty((2,), disp)
+        g[0] = g_photo if g_photo is not None else 0.0
+        g[1] = g_si if g_si is not None else 0.0
+        d_disp = torch.empty_like(disp)
+        gP = _empty((B, NF, 3, 4), disp)
+        ws = _empty((query("fd_photo_bwd_ws_floats", B, H, W),), disp)
+        src_arr = (ctypes.c_void_p * 2)(ptr(srcs[0]), ptr(srcs[-1]))
+        call("fd_photo_bwd", ctypes.addressof(cfg), ptr(disp), ptr(inv_K), ptr(P), ctypes.addressof(src_arr),
+             ptr(target), ptr(beam), ptr(sel), ctx.has_ident, ptr(stats), ptr(g), ptr(d_disp), ptr(gP), ptr(ws),
+             stream())
+        gTs = []
+        for f in range(2):
+            if f < NF and ctx.needs_input_grad[1 + f]:
+                gT = _empty((B, 4, 4), disp)
+                call("fd_proj_matrix_bwd", ptr(K), gP.data_ptr() + f * 48, NF * 12, ptr(gT), B, stream())
+                gTs.append(gT)
+            else:
+                gTs.append(None)
+        return (d_disp, gTs[0], gTs[1]) + (None,) * 10
+
+
+def photo_loss(disp, T_list, K, inv_K, src_list, target, ident=None, noise=None, beam=None, po=None,
+               materialize=False):
+    """Fused per-scale loss.  T_list / src_list: one or two source frames."""
+    po = po or PhotoOptions()
+    T1 = T_list[1] if len(T_list) > 1 else None
+    s1 = src_list[1] if len(src_list) > 1 else None
+    return _PhotoLoss.apply(disp, T_list[0], T1, K, inv_K, src_list[0], s1, target, ident, noise, beam, po, materialize)

@@ -1,0 +1,151 @@
+/* libfdhip — C ABI of the MI355X-native (gfx950) FusionDepth training hot path.
+ *
+ * The reference (AutoAILab/FusionDepth) has no FFI layer: its boundary is the Python module API in
+ * layers.py / networks/*.py / trainer.py, whose arithmetic is implicit ATen/cuDNN calls.  Each entry
+ * point below replaces one such call site (cited as reference file:line).  `fusiondepth_amd` binds
+ * these with ctypes (fusiondepth_amd/_lib.py); INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every tensor is float32, contiguous, NCHW unless stated; pointers are DEVICE pointers owned by
+ *     the caller (PyTorch caching allocator); the library never allocates device memory and keeps
+ *     no state besides the last-error string.  Workspaces are passed in with their size in floats.
+ *   - `stream` is a hipStream_t; every call is asynchronous and stream-ordered, no implicit sync.
+ *   - return 0 on success; a hipError_t (>0) for launch failures; -1 for bad arguments.  Never
+ *     throws/aborts.  fd_last_error() describes the last failure on the calling thread.
+ *   - reductions are deterministic (fixed trees, no float atomics).
+ */
+#ifndef FDHIP_H
+#define FDHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FD_ABI_VERSION 1
+
+int fd_abi_version(void);
+const char* fd_supported_arch(void); /* "gfx950" */
+const char* fd_last_error(void);
+
+/* ------------------------------------------------------------------ geometry (layers.py) ------- */
+
+/* layers.py:11-20 disp_to_depth.  depth and/or scaled may be NULL. */
+int fd_disp_to_depth_fwd(const float* disp, float* scaled, float* depth, long n, double min_depth, double max_depth,
+                         void* stream);
+/* d_disp = g_scaled*(max_disp-min_disp) - g_depth*(max_disp-min_disp)*depth^2 ; either g may be NULL */
+int fd_disp_to_depth_bwd(const float* disp, const float* g_scaled, const float* g_depth, float* d_disp, long n,
+                         double min_depth, double max_depth, void* stream);
+
+/* layers.py:23-97 transformation_from_parameters (+rot_from_axisangle, get_translation_matrix).
+ * axisangle, translation: [B,3]; T: [B,4,4].  invert: M = R^T * T(-t), else T(t) * R. */
+int fd_pose_matrix_fwd(const float* axisangle, const float* translation, float* T, int B, int invert, void* stream);
+int fd_pose_matrix_bwd(const float* axisangle, const float* translation, const float* gT, float* g_axisangle,
+                       float* g_translation, int B, int invert, void* stream);
+
+/* layers.py:217 `P = matmul(K, T)[:, :3, :]`.  K,T: [B,4,4]; P: [B,3,4] written at P + b*p_batch_stride. */
+int fd_proj_matrix_fwd(const float* K, const float* T, float* P, long p_batch_stride, int B, void* stream);
+/* gT[B,4,4] = K[:3,:]^T * gP */
+int fd_proj_matrix_bwd(const float* K, const float* gP, long p_batch_stride, float* gT, int B, void* stream);
+
+/* layers.py:157-162 BackprojectDepth.forward: depth[B,1,H,W], inv_K[B,4,4] -> points [B,4,H*W]. */
+int fd_backproject_fwd(const float* depth, const float* inv_K, float* points, int B, int H, int W, void* stream);
+int fd_backproject_bwd(const float* g_points, const float* inv_K, float* g_depth, int B, int H, int W, void* stream);
+
+/* layers.py:215-226 Project3D.forward: points[B,4,H*W], K, T -> grid [B,H,W,2]. */
+int fd_project3d_fwd(const float* points, const float* K, const float* T, float* grid, int B, int H, int W, float eps,
+                     void* stream);
+/* g_points [B,4,HW] (row 3 gets its true gradient too); gP partial sums need `ws` of
+ * fd_project3d_bwd_ws_floats(B,H,W) floats; gT [B,4,4]. */
+long fd_project3d_bwd_ws_floats(int B, int H, int W);
+int fd_project3d_bwd(const float* points, const float* K, const float* T, const float* g_grid, float* g_points,
+                     float* gT, float* ws, int B, int H, int W, float eps, void* stream);
+
+/* layers.py:187-201 Cat_xy.forward (refiner.py input channels). out [B,3,H,W]. */
+int fd_cat_xy_fwd(const float* depth, const float* inv_K, float* out, int B, int H, int W, void* stream);
+
+/* F.interpolate(x,[H,W],mode="bilinear",align_corners=False) (trainer.py:434-435,:579), C channels. */
+int fd_bilinear_up_fwd(const float* x, float* y, int BC, int Hin, int Win, int Hout, int Wout, void* stream);
+int fd_bilinear_up_bwd(const float* gy, float* gx, int BC, int Hin, int Win, int Hout, int Wout, void* stream);
+
+/* ------------------------------------------------------------------ photometric loss ----------- */
+
+/* layers.py:267-281 SSIM.forward -> out [B,C,H,W] = clamp((1-SSIM)/2,0,1). */
+int fd_ssim_fwd(const float* x, const float* y, float* out, int B, int C, int H, int W, void* stream);
+/* gradients of sum(out*g) w.r.t. x and y (either may be NULL). */
+int fd_ssim_bwd(const float* x, const float* y, const float* g, float* gx, float* gy, int B, int C, int H, int W,
+                void* stream);
+
+/* trainer.py:476-488 compute_reprojection_loss (3-channel images): out[b] at out + b*out_batch_stride,
+ * = 0.85*mean_c SSIM + 0.15*mean_c|t-p|  (use_ssim) or mean_c|t-p|. */
+int fd_reproj_loss_map(const float* pred, const float* target, float* out, long out_batch_stride, int B, int H, int W,
+                       int use_ssim, void* stream);
+
+/* Fused per-scale photometric + LiDAR loss, forward.  Replaces, for one scale, trainer.py:434-470
+ * (bilinear upsample of disp, disp_to_depth, BackprojectDepth, Project3D, F.grid_sample(border)) and
+ * trainer.py:509-567,577-589 (SSIM+L1 reprojection losses, identity losses + noise, per-pixel min,
+ * mean; masked scale-invariant log loss vs the 4-beam LiDAR).
+ *
+ *   disp      [B,1,Hs,Ws]   sigmoid output of the decoder at this scale
+ *   inv_K     [B,4,4]       inverse intrinsics at the sampling resolution (H,W)
+ *   P         [B,NF,3,4]    (K @ cam_T_cam_f)[:3] per source frame (fd_proj_matrix_fwd)
+ *   src       NF pointers   source colour images [B,3,H,W]
+ *   target    [B,3,H,W]
+ *   ident     [B,NI,H,W]    identity reprojection losses (NI = NF, or 1 if avg_reprojection) or NULL
+ *   noise     [B,NI,H,W]    tie-break noise (scaled by 1e-5 inside) or NULL
+ *   beam      [B,1,H,W]     4-beam LiDAR depth / 100, or NULL to skip the SI loss
+ *   sel       [B,H,W] u8    out: argmin index into cat(ident, reproj) (trainer.py:561)
+ *   depth_out/sample_out/color_out   optional materialised ("depth",0,s) [B,1,H,W],
+ *                           ("sample",f,s) [NF][B,H,W,2], ("color",f,s) [NF][B,3,H,W]  (NULL to skip)
+ *   ws        workspace of fd_photo_ws_floats(B,H,W) floats (per-block partial sums)
+ *   out       [8] floats: 0 to_optimise.mean(), 1 n_valid, 2 mean(d), 3 mean(d^2)-si_var*mean(d)^2,
+ *             4 si_loss, 5..7 reserved
+ */
+typedef struct {
+    double min_depth, max_depth; /* opt.min_depth / opt.max_depth (doubles: 1/0.1 must be exactly 10) */
+    int B, H, W, Hs, Ws, NF;
+    int use_ssim;        /* !opt.no_ssim */
+    int avg_reprojection;
+    float si_depth_scale;   /* 26.0  (trainer.py:583) */
+    float si_beam_scale;    /* 100.0 (trainer.py:581) */
+    float si_threshold;     /* opt.gdc_loss_threshold */
+    float si_var;           /* opt.si_var */
+    float eps;              /* Project3D eps 1e-7 */
+} fd_photo_cfg;
+
+long fd_photo_ws_floats(int B, int H, int W);
+int fd_photo_fwd(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
+                 const float* const* src, const float* target, const float* ident, const float* noise,
+                 const float* beam, uint8_t* sel, float* depth_out, float* sample_out, float* color_out, float* ws,
+                 float* out, void* stream);
+/* Backward of the above.  g [2] device floats: dL/d(out[0]), dL/d(out[4]).  stats = `out` of the
+ * forward; has_ident = whether the forward was given `ident` (needed to decode `sel`).
+ * d_disp [B,1,Hs,Ws]; gP [B,NF,3,4]; ws: fd_photo_bwd_ws_floats(B,H,W) floats. */
+long fd_photo_bwd_ws_floats(int B, int H, int W);
+int fd_photo_bwd(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
+                 const float* const* src, const float* target, const float* beam, const uint8_t* sel, int has_ident,
+                 const float* stats, const float* g, float* d_disp, float* gP, float* ws, void* stream);
+
+/* layers.py:235-248 get_smooth_loss on the mean-normalised disparity (trainer.py:569-571):
+ * out[0] = get_smooth_loss(disp/(mean_hw(disp)+1e-7), img).  ws: fd_smooth_ws_floats(B,H,W). */
+long fd_smooth_ws_floats(int B, int H, int W);
+int fd_smooth_fwd(const float* disp, const float* img, float* out, float* ws, int B, int H, int W, int normalize,
+                  void* stream);
+/* d_disp [B,1,H,W] = g[0] * d out[0] / d disp */
+int fd_smooth_bwd(const float* disp, const float* img, const float* g, float* d_disp, float* ws, int B, int H, int W,
+                  int normalize, void* stream);
+
+/* ------------------------------------------------------------------ sparse LiDAR --------------- */
+
+/* gen2channel.py:60-117 get_4beam_2channel, gather formulation (race-free, bit-exact vs the
+ * sequential reference): beam [B,1,H,W] -> out [B,2,H,W] (ch0 expanded depth, ch1 confidence).
+ * Donor ROI rows [r0,r1), cols [c0,c1) (76,190,2,638 for 192x640); expand = 2. */
+int fd_scatter_2channel(const float* beam, float* out, int B, int H, int W, int r0, int r1, int c0, int c1, int expand,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDHIP_H */

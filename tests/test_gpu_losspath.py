@@ -1,0 +1,329 @@
+"""GPU parity tests (run with ``-m gpu`` on the MI355X box): HIP loss-path kernels, called through the
+C ABI, against the CPU oracle on identical seeded inputs and against the committed golden vectors.
+Tolerance: the north-star 1e-4 relative bound on loss/depth tensors (tighter where cheap)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import inputs as gin
+from conftest import assert_close
+from oracle import layers as OL
+from oracle import scatter as OS
+from oracle import trainer as OT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def FD():
+    from fusiondepth_amd import functional
+    return functional
+
+
+def dev(t):
+    return t.detach().clone().cuda()
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def grads(loss, leaves):
+    return [cpu(g) for g in torch.autograd.grad(loss, leaves)]
+
+
+# ------------------------------------------------------------------------------------------------
+def test_disp_to_depth_and_pose_matrix(FD, golden):
+    g = golden("layers_b2_32x64")
+    B, H, W = 2, 32, 64
+    inp, rng = gin.batch_inputs(101, B, H, W)
+    disp = gin.disp_pyramid(rng, B, H, W)[("disp", 0)]
+    d = dev(disp).requires_grad_(True)
+    sd, depth = FD.disp_to_depth(d, 0.1, 100.0)
+    assert_close(cpu(sd), g["d2d_scaled"], rtol=1e-6, atol=0, what="scaled disp")
+    assert_close(cpu(depth), g["d2d_depth"], rtol=1e-6, atol=0, what="depth")
+    cot = torch.from_numpy(np.random.RandomState(1).randn(2, B, 1, H, W).astype(np.float32))
+    d_o = disp.clone().requires_grad_(True)
+    so, do = OL.disp_to_depth(d_o, 0.1, 100.0)
+    want = grads((so * cot[0]).sum() + (do * cot[1]).sum(), [d_o])[0]
+    got = grads((sd * dev(cot[0])).sum() + (depth * dev(cot[1])).sum(), [d])[0]
+    assert_close(got, want, rtol=1e-5, atol=1e-6, what="disp_to_depth grad")
+
+    aa, tr = gin.small_poses(rng, B)
+    cot_T = torch.from_numpy(g["T_cot"])
+    for inv in (False, True):
+        tag = "inv" if inv else "fwd"
+        a, t = dev(aa).requires_grad_(True), dev(tr).requires_grad_(True)
+        M = FD.transformation_from_parameters(a, t, invert=inv)
+        ga, gt = grads((M * dev(cot_T)).sum(), [a, t])
+        assert_close(cpu(M), g["T_" + tag], rtol=1e-5, atol=1e-7, what="T " + tag)
+        assert_close(ga, g["T_%s_gaa" % tag], rtol=1e-4, atol=1e-5, what="g axisangle " + tag)
+        assert_close(gt, g["T_%s_gtr" % tag], rtol=1e-4, atol=1e-6, what="g translation " + tag)
+    # zero rotation: norm() has a 0 sub-gradient at the origin (must not produce NaN)
+    z = torch.zeros(B, 1, 3).cuda().requires_grad_(True)
+    M = FD.transformation_from_parameters(z, dev(tr), invert=False)
+    gz = torch.autograd.grad(M.sum(), z)[0]
+    assert torch.isfinite(gz).all() and torch.isfinite(M).all()
+
+
+def test_backproject_project_against_golden(FD, golden):
+    g = golden("layers_b2_32x64")
+    B, H, W = 2, 32, 64
+    inp, rng = gin.batch_inputs(101, B, H, W)
+    K, inv_K = dev(inp[("K", 0)]), dev(inp[("inv_K", 0)])
+    depth = torch.from_numpy(g["d2d_depth"]).cuda().requires_grad_(True)
+    T = torch.from_numpy(g["pj_T"]).cuda().requires_grad_(True)
+    pts = FD.backproject_depth(depth, inv_K)
+    grid = FD.project_3d(pts, K, T, H, W)
+    gd, gT = grads((grid * torch.from_numpy(g["pj_cot"]).cuda()).sum(), [depth, T])
+    assert_close(cpu(pts), g["bp_points"], rtol=1e-5, atol=1e-6, what="backproject")
+    assert_close(cpu(grid), g["pj_grid"], rtol=1e-4, atol=1e-5, what="project grid")
+    assert_close(gd, g["pj_gdepth"], rtol=1e-4, atol=1e-5, what="g depth")
+    assert_close(gT, g["pj_gT"], rtol=1e-4, atol=1e-3, what="g T")
+    assert_close(cpu(FD.cat_xy(depth, inv_K)), g["catxy"], rtol=1e-5, atol=1e-6, what="Cat_xy")
+
+
+@pytest.mark.parametrize("hin,win,hout,wout", [(24, 80, 192, 640), (48, 160, 192, 640), (96, 320, 192, 640),
+                                               (192, 640, 192, 640), (8, 12, 64, 96), (5, 7, 10, 14)])
+def test_bilinear_upsample(FD, hin, win, hout, wout):
+    rng = np.random.RandomState(3)
+    x = torch.from_numpy(rng.rand(2, 3, hin, win).astype(np.float32))
+    cot = torch.from_numpy(rng.randn(2, 3, hout, wout).astype(np.float32))
+    xo = x.clone().requires_grad_(True)
+    yo = F.interpolate(xo, [hout, wout], mode="bilinear", align_corners=False)
+    want_g = grads((yo * cot).sum(), [xo])[0]
+    xg = dev(x).requires_grad_(True)
+    yg = FD.bilinear_upsample(xg, (hout, wout))
+    got_g = grads((yg * dev(cot)).sum(), [xg])[0]
+    assert_close(cpu(yg), cpu(yo), rtol=1e-5, atol=1e-6, what="bilinear fwd")
+    assert_close(got_g, want_g, rtol=1e-4, atol=1e-5, what="bilinear bwd")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 3, 32, 64), (1, 3, 20, 70), (1, 2, 192, 640), (1, 1, 4, 4), (1, 1, 17, 129)])
+def test_ssim_fwd_bwd(FD, golden, B, C, H, W):
+    rng = np.random.RandomState(5)
+    if (B, C, H, W) == (2, 3, 32, 64):
+        g = golden("layers_b2_32x64")
+        inp, _ = gin.batch_inputs(101, B, H, W)
+        x, y, cot = inp[("color", 0, 0)], inp[("color", 1, 0)], torch.from_numpy(g["ssim_cot"])
+    else:
+        x = torch.from_numpy(gin.smooth_image(rng, B, C, H, W))
+        y = torch.from_numpy(np.clip(x.numpy() + 0.05 * rng.randn(B, C, H, W), 0, 1).astype(np.float32))
+        cot = torch.from_numpy(rng.rand(B, C, H, W).astype(np.float32))
+    xo, yo = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    so = OL.ssim(xo, yo)
+    want = grads((so * cot).sum(), [xo, yo])
+    xg, yg = dev(x).requires_grad_(True), dev(y).requires_grad_(True)
+    sg = FD.ssim(xg, yg)
+    got = grads((sg * dev(cot)).sum(), [xg, yg])
+    assert_close(cpu(sg), cpu(so), rtol=1e-4, atol=2e-5, what="ssim fwd")
+    if (B, C, H, W) == (2, 3, 32, 64):
+        assert_close(cpu(sg), g["ssim"], rtol=1e-4, atol=2e-5, what="ssim fwd vs golden")
+        assert_close(got[0], g["ssim_gx"], rtol=1e-3, atol=2e-4, what="ssim gx vs golden")
+    scale = np.abs(want[0]).max()
+    assert_close(got[0], want[0], rtol=1e-3, atol=1e-4 * scale, what="ssim gx")
+    assert_close(got[1], want[1], rtol=1e-3, atol=1e-4 * scale, what="ssim gy")
+
+
+@pytest.mark.parametrize("use_ssim", [True, False])
+def test_reprojection_loss_map(FD, use_ssim):
+    B, H, W = 2, 40, 100
+    inp, rng = gin.batch_inputs(77, B, H, W)
+    opt = OT.default_opt(no_ssim=not use_ssim)
+    want = OT.reprojection_loss(opt, inp[("color", -1, 0)], inp[("color", 0, 0)])
+    got = FD.reprojection_loss_map(dev(inp[("color", -1, 0)]), dev(inp[("color", 0, 0)]), use_ssim)
+    assert_close(cpu(got), cpu(want), rtol=1e-4, atol=2e-5, what="reprojection loss map")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 64), (2, 24, 80), (1, 192, 640), (3, 5, 9)])
+def test_smooth_loss(FD, golden, B, H, W):
+    inp, rng = gin.batch_inputs(101 if (H, W) == (32, 64) else 9, B, H, W)
+    disp = gin.disp_pyramid(rng, B, H, W)[("disp", 0)]
+    img = inp[("color", 0, 0)]
+    for normalize in (False, True):
+        do = disp.clone().requires_grad_(True)
+        n = do / (do.mean(2, True).mean(3, True) + 1e-7) if normalize else do
+        lo = OL.get_smooth_loss(n, img)
+        want_g = grads(lo * 1.7, [do])[0]
+        dg = dev(disp).requires_grad_(True)
+        lg = FD.normalized_smooth_loss(dg, dev(img)) if normalize else FD.get_smooth_loss(dg, dev(img))
+        got_g = grads(lg * 1.7, [dg])[0]
+        assert_close(cpu(lg), cpu(lo), rtol=1e-5, atol=1e-8, what="smooth loss normalize=%s" % normalize)
+        assert_close(got_g, want_g, rtol=1e-3, atol=1e-5 * np.abs(want_g).max(), what="smooth grad normalize=%s" % normalize)
+        if (B, H, W) == (2, 32, 64) and not normalize:
+            g = golden("layers_b2_32x64")
+            assert_close(cpu(lg), g["smooth"], rtol=1e-5, atol=1e-8, what="smooth vs golden")
+
+
+def test_scatter_2channel_bit_exact(FD, golden):
+    g = golden("scatter_192x640")
+    beams = np.stack([g["beam%d" % i] for i in range(3)])[:, None]
+    out = cpu(FD.scatter_2channel(torch.from_numpy(beams).cuda()))
+    for i in range(3):
+        assert np.array_equal(out[i, 1], g["conf%d" % i]), "confidence %d differs from the reference" % i
+        assert np.array_equal(out[i, 0], g["depth%d" % i]), "depth %d: max diff %g" % (i, np.abs(out[i, 0] - g["depth%d" % i]).max())
+    # random dense/sparse maps vs the sequential C oracle, incl. empty and ROI-edge cases
+    rng = np.random.RandomState(11)
+    maps = [np.zeros((192, 640), np.float32)]
+    for dens in (0.002, 0.05, 0.5):
+        m = (rng.rand(192, 640) < dens) * rng.uniform(0.01, 0.8, size=(192, 640))
+        maps.append(m.astype(np.float32))
+    got = cpu(FD.scatter_2channel(torch.from_numpy(np.stack(maps)[:, None]).cuda()))
+    for i, m in enumerate(maps):
+        d, c = OS.scatter_2channel_c(m)
+        assert np.array_equal(got[i, 0], d) and np.array_equal(got[i, 1], c), "random map %d" % i
+    with pytest.raises(RuntimeError):
+        FD.scatter_2channel(torch.zeros(1, 1, 192, 640).cuda(), roi=(0, 190, 2, 638))
+
+
+# ------------------------------------------------------------------------------------------------
+def _oracle_photo_terms(opt, inp, disp, Ts, noise):
+    """Per scale (to_optimise.mean(), si_loss) + outputs dict, from the oracle (trainer.py:425-589)."""
+    outputs = {("disp", s): disp[s] for s in opt.scales}
+    for f, T in Ts.items():
+        outputs[("cam_T_cam", 0, f)] = T
+    OT.generate_images_pred(opt, inp, outputs)
+    terms = []
+    for s in opt.scales:
+        target = inp[("color", 0, 0)]
+        reproj = torch.cat([OT.reprojection_loss(opt, outputs[("color", f, s)], target) for f in opt.frame_ids[1:]], 1)
+        if opt.avg_reprojection:
+            reproj = reproj.mean(1, keepdim=True)
+        if not opt.disable_automasking:
+            ident = torch.cat([OT.reprojection_loss(opt, inp[("color", f, 0)], target) for f in opt.frame_ids[1:]], 1)
+            if opt.avg_reprojection:
+                ident = ident.mean(1, keepdim=True)
+            comb = torch.cat((ident + noise[s] * 0.00001, reproj), 1)
+        else:
+            comb = reproj
+        mn, idx = (comb[:, 0], torch.zeros_like(comb[:, 0], dtype=torch.long)) if comb.shape[1] == 1 else torch.min(comb, dim=1)
+        terms.append((mn.mean(), OT.si_log_loss(opt, disp[s], inp["4beam"]), idx))
+    return terms, outputs
+
+
+def _hip_photo_terms(FD, opt, inp, disp, Ts, noise, materialize=True):
+    po = FD.PhotoOptions(opt.min_depth, opt.max_depth, opt.no_ssim, opt.avg_reprojection, opt.gdc_loss_threshold, opt.si_var)
+    fids = opt.frame_ids[1:]
+    target = dev(inp[("color", 0, 0)])
+    srcs = [dev(inp[("color", f, 0)]) for f in fids]
+    ident = None
+    if not opt.disable_automasking:
+        ident = torch.cat([FD.reprojection_loss_map(s, target, not opt.no_ssim) for s in srcs], 1)
+        if opt.avg_reprojection:
+            ident = ident.mean(1, keepdim=True)
+    K, inv_K, beam = dev(inp[("K", 0)]), dev(inp[("inv_K", 0)]), dev(inp["4beam"])
+    res = []
+    for s in opt.scales:
+        nz = dev(noise[s]) if ident is not None else None
+        res.append(FD.photo_loss(disp[s], [Ts[f] for f in fids], K, inv_K, srcs, target, ident, nz, beam, po, materialize))
+    return res
+
+
+def _photo_case(FD, seed, B, H, W, **over):
+    opt = OT.default_opt(height=H, width=W, **over)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp0 = gin.disp_pyramid(rng, B, H, W)
+    poses = {f: gin.small_poses(rng, B) for f in (-1, 1)}
+    T0 = {f: OL.transformation_from_parameters(*poses[f], invert=(f < 0)) for f in (-1, 1)}
+    noise = [torch.from_numpy(np.random.RandomState(1000 + seed + s).randn(B, 1 if opt.avg_reprojection else 2, H, W)
+                              .astype(np.float32)) for s in range(4)]
+    d_o = {s: disp0[("disp", s)].clone().requires_grad_(True) for s in range(4)}
+    T_o = {f: T0[f].clone().requires_grad_(True) for f in T0}
+    terms, outs = _oracle_photo_terms(opt, inp, d_o, T_o, noise)
+    d_g = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
+    T_g = {f: dev(T0[f]).requires_grad_(True) for f in T0}
+    res = _hip_photo_terms(FD, opt, inp, d_g, T_g, noise)
+    return opt, terms, outs, res, d_o, T_o, d_g, T_g
+
+
+@pytest.mark.parametrize("seed,B,H,W,over", [
+    (404, 2, 64, 96, {}),
+    (31, 2, 48, 200, {}),                       # partial tiles in x, several tiles in y
+    (505, 1, 192, 640, {}),                     # full size
+    (606, 2, 64, 96, dict(no_ssim=True, disable_automasking=True)),
+    (707, 2, 64, 96, dict(avg_reprojection=True)),
+    (808, 1, 32, 64, dict(no_ssim=True)),
+])
+def test_fused_photo_loss_vs_oracle(FD, seed, B, H, W, over):
+    opt, terms, outs, res, d_o, T_o, d_g, T_g = _photo_case(FD, seed, B, H, W, **over)
+    fids = opt.frame_ids[1:]
+    tot_o, tot_g = 0, 0
+    for s in range(4):
+        photo, si, sel, depth, sample, color = res[s]
+        assert_close(cpu(depth), cpu(outs[("depth", 0, s)]), rtol=1e-5, atol=1e-6, what="depth s%d" % s)
+        for i, f in enumerate(fids):
+            assert_close(cpu(sample[i]), cpu(outs[("sample", f, s)]), rtol=1e-4, atol=2e-5, what="sample f%d s%d" % (f, s))
+            assert_close(cpu(color[i]), cpu(outs[("color", f, s)]), rtol=1e-4, atol=2e-5, what="color f%d s%d" % (f, s))
+        mism = (cpu(sel).astype(np.int64) != cpu(terms[s][2])).mean()
+        assert mism <= 2e-4, "argmin differs on %.4f%% of pixels at scale %d" % (100 * mism, s)
+        assert_close(cpu(photo), cpu(terms[s][0]), rtol=1e-4, atol=1e-7, what="to_optimise.mean() s%d" % s)
+        assert_close(cpu(si), cpu(terms[s][1]), rtol=1e-4, atol=1e-7, what="si_loss s%d" % s)
+        w = 1.0 + 0.25 * s          # distinct cotangents per scale / term
+        tot_o = tot_o + w * terms[s][0] + (2.0 - 0.3 * s) * terms[s][1]
+        tot_g = tot_g + w * photo + (2.0 - 0.3 * s) * si
+    want = grads(tot_o, [d_o[s] for s in range(4)] + [T_o[f] for f in fids])
+    got = grads(tot_g, [d_g[s] for s in range(4)] + [T_g[f] for f in fids])
+    for s in range(4):
+        sc = np.abs(want[s]).max()
+        assert_close(got[s], want[s], rtol=2e-3, atol=2e-4 * sc, what="d loss / d disp s%d" % s)
+        rel = np.abs(got[s] - want[s]).sum() / np.abs(want[s]).sum()
+        assert rel < 1e-4, "aggregate disp-grad error %.3g at scale %d" % (rel, s)
+    for i, f in enumerate(fids):
+        sc = np.abs(want[4 + i]).max()
+        assert_close(got[4 + i], want[4 + i], rtol=1e-3, atol=1e-4 * sc, what="d loss / d T f%d" % f)
+
+
+def test_fused_photo_loss_vs_reference_golden(FD, golden):
+    """Same inputs as tests/golden/make_golden.py::gold_losses -> compare with what the REFERENCE produced."""
+    g = golden("losses_b2_64x96")
+    B, H, W, seed = 2, 64, 96, 404
+    opt = OT.default_opt(height=H, width=W)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp0 = gin.disp_pyramid(rng, B, H, W)
+    d_g = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
+    T_g = {f: torch.from_numpy(g["T%d" % f]).cuda().requires_grad_(True) for f in (-1, 1)}
+    noise = [torch.from_numpy(g["noise%d" % s]) for s in range(4)]
+    res = _hip_photo_terms(FD, opt, inp, d_g, T_g, noise)
+    total = 0
+    for s in range(4):
+        photo, si, sel, depth, sample, color = res[s]
+        assert_close(cpu(depth), g["depth%d" % s], rtol=1e-5, atol=1e-6, what="depth")
+        for i, f in enumerate((-1, 1)):
+            assert_close(cpu(color[i]), g["color%d_%d" % (f, s)], rtol=1e-4, atol=2e-5, what="color")
+        assert ((cpu(sel) > 1).astype(np.uint8) != g["idsel%d" % s]).mean() <= 2e-4
+        smooth = FD.normalized_smooth_loss(d_g[s], dev(inp[("color", 0, s)]))
+        loss_s = photo + opt.disparity_smoothness * smooth / (2 ** s)
+        assert_close(cpu(loss_s), g["L/loss_%d" % s], rtol=1e-4, atol=1e-7, what="loss/%d" % s)
+        assert_close(cpu(si), g["L/loss_si_loss%d" % s], rtol=1e-4, atol=1e-7, what="si_loss%d" % s)
+        total = total + loss_s + si
+    total = total / 4
+    assert_close(cpu(total), g["L/loss"], rtol=1e-4, atol=1e-7, what="total loss")
+    got = grads(total, [d_g[s] for s in range(4)] + [T_g[-1], T_g[1]])
+    for s in range(4):
+        sc = np.abs(g["g_disp%d" % s]).max()
+        assert_close(got[s], g["g_disp%d" % s], rtol=2e-3, atol=2e-4 * sc, what="g disp%d vs reference" % s)
+    assert_close(got[4], g["g_T-1"], rtol=1e-3, atol=1e-4 * np.abs(g["g_T-1"]).max(), what="g T-1 vs reference")
+    assert_close(got[5], g["g_T1"], rtol=1e-3, atol=1e-4 * np.abs(g["g_T1"]).max(), what="g T+1 vs reference")
+
+
+def test_photo_loss_identity_warp_property(FD):
+    """Size-independent property at full size: T = I and source == target => the warp is the identity,
+    so the reprojection loss vanishes and every pixel picks a reprojection (not identity+noise>0... )."""
+    B, H, W = 2, 192, 640
+    inp, rng = gin.batch_inputs(1, B, H, W)
+    disp = dev(gin.disp_pyramid(rng, B, H, W)[("disp", 0)])
+    I = torch.eye(4).repeat(B, 1, 1).cuda()
+    tgt = dev(inp[("color", 0, 0)])
+    photo, si, sel, depth, sample, color = FD.photo_loss(disp, [I, I], dev(inp[("K", 0)]), dev(inp[("inv_K", 0)]),
+                                                         [tgt, tgt], tgt, None, None, None, FD.PhotoOptions(), True)
+    assert float(photo) < 1e-4
+    assert_close(cpu(color[0]), cpu(tgt), rtol=0, atol=2e-3, what="identity warp reproduces the image")
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    want = torch.stack([(xs / (W - 1) - 0.5) * 2, (ys / (H - 1) - 0.5) * 2], -1)
+    assert_close(cpu(sample[0][0]), want.numpy(), rtol=0, atol=1e-4, what="identity sampling grid")
+
+
+def test_ops_refuse_cpu_tensors(FD):
+    with pytest.raises(RuntimeError):
+        FD.ssim(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
