@@ -25,6 +25,11 @@ class PhotoCfg(ctypes.Structure):
                 ("si_depth_scale", _F), ("si_beam_scale", _F), ("si_threshold", _F), ("si_var", _F), ("eps", _F)]
 
 
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``fd_conv_desc``."""
+    _fields_ = [(n, _I) for n in ("N", "Cin", "H", "W", "Cout", "KH", "KW", "stride", "pad", "pad_mode", "act", "in_norm")]
+
+
 # name -> (argument kinds, restype kind)  ('p' pointer, 'i' int, 'l' long, 'f' float, 'd' double)
 SIGNATURES = {
     "fd_abi_version": ("", "i"),
@@ -55,6 +60,27 @@ SIGNATURES = {
     "fd_smooth_fwd": ("ppppiiiip", "i"),
     "fd_smooth_bwd": ("pppppiiiip", "i"),
     "fd_scatter_2channel": ("ppiiiiiiiip", "i"),
+    "fd_conv2d_fwd": ("pppppp", "i"),
+    "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
+    "fd_conv2d_bwd_data": ("pppppp", "i"),
+    "fd_conv2d_bwd_weight_ws_floats": ("p", "l"),
+    "fd_conv2d_bwd_weight": ("ppppppp", "i"),
+    "fd_act_bwd": ("ppplip", "i"),
+    "fd_bn_ws_floats": ("iiii", "l"),
+    "fd_bn_train_fwd": ("pppppppppp" "iiii" "ff" "ip", "i"),
+    "fd_bn_eval_fwd": ("ppppppp" "iiii" "f" "ip", "i"),
+    "fd_bn_train_bwd": ("ppppppppppp" "iiii" "ip", "i"),
+    "fd_maxpool3x3s2_fwd": ("pppiiiip", "i"),
+    "fd_maxpool3x3s2_bwd": ("pppiiiip", "i"),
+    "fd_upcat_fwd": ("ppppp" "iiiiii" "p", "i"),
+    "fd_upcat_bwd": ("pppp" "iiiiii" "p", "i"),
+    "fd_upsample2x_fwd": ("ppliip", "i"),
+    "fd_upsample2x_bwd": ("ppliip", "i"),
+    "fd_axpby": ("ppplffp", "i"),
+    "fd_spatial_mean_fwd": ("ppllfp", "i"),
+    "fd_spatial_mean_bwd": ("ppllfp", "i"),
+    "fd_depth_errors": ("pplppp", "i"),
+    "fd_adam_step": ("ppppl" "fffffff" "p", "i"),
 }
 
 _lock = threading.Lock()

@@ -1,0 +1,624 @@
+// FP32 implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, k-ordered
+// fmaf chain) — forward, data-gradient and weight-gradient for every conv of the hot path:
+//   ResNet trunk   networks/resnet_encoder.py:92-103  (7x7 s2, 3x3 s1/s2, 1x1 s1/s2; zero pad)
+//   DepthDecoder   networks/depth_decoder.py:63-96     (3x3 reflect pad + bias + ELU / sigmoid)
+//   PoseDecoder    networks/pose_decoder.py:29-51      (1x1 / 3x3 + bias + ReLU)
+//
+// One "gather GEMM" kernel does forward AND data-gradient:  D[m][p] = sum_k A[m][k] * G[k][p]
+//   A   dense row-major [M][K] matrix in HBM (weights, or a re-laid-out copy made by the prep kernels)
+//   G   never materialised: k = (c, a, b) indexes channel c and tap (a,b); p = (n, y, x) indexes a pixel of
+//       the GEMM-N domain; G[k][p] = X[n][c][y*sy+oy+a*da][x*sx+ox+b*db]  (zero or reflect outside)
+//   D   written through an affine pixel map (so stride-2 dgrad parity classes scatter into dX directly).
+// NCHW keeps pixels contiguous, so both the G loads and the D stores are coalesced along the 64 lanes.
+// Tiles: workgroup = WAVES_M x WAVES_N waves, each wave owns WM x WN accumulators of 32x32, K-chunk 16,
+// register-staged double-buffered LDS (one barrier per chunk).
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+
+struct GemmArgs {
+    const float* A; const float* X; float* Y; const float* bias;
+    int M, K;
+    int Nb, C, Hi, Wi;
+    int NY, NX;
+    int sy, oy, da, sx, ox, db;
+    int pad_mode;   // 0 zero, 1 reflect
+    long out_ns, out_cs;
+    int out_w, osy, ooy, osx, oox;
+    int act;        // 0 none, 1 relu, 2 elu, 3 sigmoid, 4 tanh
+    int in_norm;    // conv1: (x - 0.45) / 0.225 on in-bounds taps (resnet_encoder.py:94)
+    int xcd_swizzle;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    if (act == 3) return 1.0f / (1.0f + expf(-v));
+    if (act == 4) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+template <int TA, int TB, int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gather_gemm(GemmArgs g) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
+    constexpr int LDA = BM + 2, LDB = BN;
+    constexpr int RP = NT / BN;            // k rows covered per pass of the G loader
+    constexpr int NB_LOAD = BK / RP;       // G elements per thread per chunk
+    constexpr int MP = NT / BK;            // m rows covered per pass of the A loader
+    constexpr int NA_LOAD = BM / MP;
+    static_assert(NT % BN == 0 && BK % RP == 0 && BM % MP == 0, "tile/loader mismatch");
+    __shared__ float sA[2][BK * LDA];
+    __shared__ float sB[2][BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+
+    // block -> tile (optionally XCD-aware: consecutive pixel tiles stay on one XCD / one L2)
+    int bx = blockIdx.x;
+    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    const int m0 = blockIdx.y * BM;
+    const long p0 = (long)bx * BN;
+    const long plane = (long)g.NY * g.NX, Np = (long)g.Nb * plane;
+    const long chw = (long)g.Hi * g.Wi;
+
+    // ---- G loader: this thread always fetches pixel column jn, k rows kr + RP*i
+    const int jn = tid % BN;
+    const int kr = __builtin_amdgcn_readfirstlane(tid / BN);
+    const long pg = p0 + jn;
+    const bool pvalid = pg < Np;
+    int ry0 = 0, cx0 = 0;
+    long nbase = 0;
+    {
+        const long pp = pvalid ? pg : 0;
+        const int n = (int)(pp / plane);
+        const int rem = (int)(pp - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        ry0 = y * g.sy + g.oy; cx0 = x * g.sx + g.ox;
+        nbase = (long)n * g.C * chw;
+    }
+    // ---- A loader: k column ka, m rows ma + MP*i
+    const int ka = tid % BK, ma = tid / BK;
+
+    float ra[NA_LOAD], rb[NB_LOAD];
+    auto load_chunk = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) {
+            const int m = m0 + ma + MP * i, k = k0 + ka;
+            ra[i] = (m < g.M && k < g.K) ? g.A[(long)m * g.K + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) {
+            const int k = k0 + kr + RP * i;            // wave-uniform
+            const int c = k / (TA * TB), t = k - c * (TA * TB);
+            const int ta = t / TB, tb = t - ta * TB;
+            int r = ry0 + ta * g.da, cc = cx0 + tb * g.db;
+            bool ok = pvalid && k < g.K;
+            if (g.pad_mode == 1) { r = reflect_idx(r, g.Hi); cc = reflect_idx(cc, g.Wi); }
+            else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
+            float v = 0.f;
+            if (ok) {
+                v = g.X[nbase + c * chw + (long)r * g.Wi + cc];
+                if (g.in_norm) v = (v - 0.45f) / 0.225f;
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) sA[buf][ka * LDA + ma + MP * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) sB[buf][(kr + RP * i) * LDB + jn] = rb[i];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunk = (g.K + BK - 1) / BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int arow = lane >> 5, acol = lane & 31;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nchunk) load_chunk((ch + 1) * BK);
+        const float* pa = &sA[cur][arow * LDA + wave_m * 32 * WM + acol];
+        const float* pb = &sB[cur][arow * LDB + wave_n * 32 * WN + acol];
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[i] = pa[kk * 2 * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 2 * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (ch + 1 < nchunk) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias + activation, affine pixel map.  C/D layout of 32x32 MFMA:
+    //      col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const long p = p0 + wave_n * 32 * WN + j * 32 + acol;
+        if (p >= Np) continue;
+        const int n = (int)(p / plane);
+        const int rem = (int)(p - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        float* yo = g.Y + (long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                if (m < g.M) {
+                    float v = acc[i][j][r];
+                    if (g.bias) v += g.bias[m];
+                    yo[(long)m * g.out_cs] = apply_act(v, g.act);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[m][j] = sum_p dY[m][p] * G[j][p]   (j = (c,a,b) as above, p over the OUTPUT pixels
+// of the forward conv), split over the pixel axis; partial slabs are reduced in a fixed order.
+struct WgradArgs {
+    const float* dY; const float* X; float* out;   // out: dW (splits == 1) or slabs [splits][M][J]
+    int M, J;
+    int Nb, C, Hi, Wi;
+    int NY, NX;
+    int sy, oy, da, sx, ox, db;
+    int pad_mode, in_norm;
+    long dy_ns, dy_cs;      // dY[n*dy_ns + m*dy_cs + y*NX + x]
+    long pix_per_split;
+};
+
+template <int TA, int TB, int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad(WgradArgs g) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
+    constexpr int BP = 32;                       // pixels (GEMM-K) per chunk
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int RPW = NT / BP;                 // rows (m or j) covered per pass
+    constexpr int NA_LOAD = BM / RPW, NB_LOAD = BN / RPW;
+    static_assert(BM % RPW == 0 && BN % RPW == 0, "tile/loader mismatch");
+    __shared__ float sA[2][BP * LDA];
+    __shared__ float sB[2][BP * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int m0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
+    const long plane = (long)g.NY * g.NX, Np = (long)g.Nb * plane;
+    const long chw = (long)g.Hi * g.Wi;
+    const long pbeg = (long)blockIdx.z * g.pix_per_split;
+    long pend = pbeg + g.pix_per_split;
+    if (pend > Np) pend = Np;
+
+    const int pl = tid % BP, rw = tid / BP;      // pixel within chunk, first row handled
+    // per-thread tap decode of the NB_LOAD j rows it loads (fixed for the whole kernel)
+    int jc[NB_LOAD], jro[NB_LOAD], jco[NB_LOAD];
+#pragma unroll
+    for (int i = 0; i < NB_LOAD; ++i) {
+        const int j = j0 + rw + RPW * i;
+        const int c = j / (TA * TB), t = j - c * (TA * TB);
+        const int ta = t / TB, tb = t - ta * TB;
+        jc[i] = j < g.J ? c : -1;
+        jro[i] = ta * g.da; jco[i] = tb * g.db;
+    }
+
+    float ra[NA_LOAD], rb[NB_LOAD];
+    auto load_chunk = [&](long pc) __attribute__((always_inline)) {
+        const long p = pc + pl;
+        const bool pv = p < pend;
+        const long pp = pv ? p : 0;
+        const int n = (int)(pp / plane);
+        const int rem = (int)(pp - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        const float* dy = g.dY + (long)n * g.dy_ns + rem;
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) {
+            const int m = m0 + rw + RPW * i;
+            ra[i] = (pv && m < g.M) ? dy[(long)m * g.dy_cs] : 0.f;
+        }
+        const int ry0 = y * g.sy + g.oy, cx0 = x * g.sx + g.ox;
+        const float* xb = g.X + (long)n * g.C * chw;
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) {
+            int r = ry0 + jro[i], cc = cx0 + jco[i];
+            bool ok = pv && jc[i] >= 0;
+            if (g.pad_mode == 1) { r = reflect_idx(r, g.Hi); cc = reflect_idx(cc, g.Wi); }
+            else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
+            float v = 0.f;
+            if (ok) {
+                v = xb[jc[i] * chw + (long)r * g.Wi + cc];
+                if (g.in_norm) v = (v - 0.45f) / 0.225f;
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) sA[buf][pl * LDA + rw + RPW * i] = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) sB[buf][pl * LDB + rw + RPW * i] = rb[i];
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunk = (int)((pend - pbeg + BP - 1) / BP);
+    const int arow = lane >> 5, acol = lane & 31;
+    if (nchunk > 0) {
+        load_chunk(pbeg);
+        store_chunk(0);
+        __syncthreads();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int cur = ch & 1;
+            if (ch + 1 < nchunk) load_chunk(pbeg + (long)(ch + 1) * BP);
+            const float* pa = &sA[cur][arow * LDA + wave_m * 32 * WM + acol];
+            const float* pb = &sB[cur][arow * LDB + wave_n * 32 * WN + acol];
+#pragma unroll
+            for (int kk = 0; kk < BP / 2; ++kk) {
+                float av[WM], bv[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) av[i] = pa[kk * 2 * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 2 * LDB + j * 32];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (ch + 1 < nchunk) store_chunk(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    float* out = g.out + (long)blockIdx.z * g.M * g.J;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int jj = j0 + wave_n * 32 * WN + j * 32 + acol;
+        if (jj >= g.J) continue;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                if (m < g.M) out[(long)m * g.J + jj] = acc[i][j][r];
+            }
+    }
+}
+
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slabs[(long)z * n + i];
+        out[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight re-layouts for the data gradient (tiny, once per backward):
+//   stride 1:  Wt[ci][(co, a, b)] = W[co][ci][KH-1-a][KW-1-b]
+//   stride 2:  Wt[ci][(co, a, b)] = W[co][ci][kh0+2a][kw0+2b]   (taps of one output-parity class)
+__global__ void k_weight_relayout(const float* __restrict__ W, float* __restrict__ Wt, int Co, int Ci, int KH, int KW,
+                                  int TA, int TB, int kh0, int dkh, int kw0, int dkw) {
+    const long n = (long)Ci * Co * TA * TB;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i % TB);
+        const int a = (int)((i / TB) % TA);
+        const int co = (int)((i / ((long)TB * TA)) % Co);
+        const int ci = (int)(i / ((long)TB * TA * Co));
+        const int kh = kh0 + dkh * a, kw = kw0 + dkw * b;
+        Wt[i] = W[(((long)co * Ci + ci) * KH + kh) * KW + kw];
+    }
+}
+
+// Adjoint of ReflectionPad2d(1): fold the gradient on the padded grid [H+2][W+2] back onto [H][W].
+__global__ void k_reflect_fold(const float* __restrict__ gp, float* __restrict__ gx, long planes, int H, int W) {
+    const long n = planes * H * W;
+    const int Wp = W + 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const long pl = i / ((long)W * H);
+        const float* g = gp + pl * (long)(H + 2) * Wp;
+        // padded rows that map to y: y+1 always; 0 if y == 1; H+1 if y == H-2
+        int ys[3], nys = 0, xs[3], nxs = 0;
+        ys[nys++] = y + 1; if (y == 1) ys[nys++] = 0; if (y == H - 2) ys[nys++] = H + 1;
+        xs[nxs++] = x + 1; if (x == 1) xs[nxs++] = 0; if (x == W - 2) xs[nxs++] = W + 1;
+        float s = 0.f;
+        for (int a = 0; a < nys; ++a)
+            for (int b = 0; b < nxs; ++b) s += g[(long)ys[a] * Wp + xs[b]];
+        gx[i] = s;
+    }
+}
+
+// per-channel sum over (n, y, x) — bias gradient.  One workgroup per channel.
+__global__ void __launch_bounds__(256) k_channel_sum(const float* __restrict__ x, float* __restrict__ out, int Nb, int C,
+                                                     long plane) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    float v[1] = {0.f};
+    for (int n = 0; n < Nb; ++n) {
+        const float* p = x + ((long)n * C + c) * plane;
+        for (long i = threadIdx.x; i < plane; i += 256) v[0] += p[i];
+    }
+    const float s = fd_block_sum_n<1, 4>(v, red);
+    if (threadIdx.x == 0) out[c] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int TA, int TB>
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+    const long Np = (long)g.Nb * g.NY * g.NX;
+    GemmArgs a = g;
+    auto go = [&](auto kern, int BM, int BN, int nt) {
+        const int gx = fd_cdiv(Np, BN), gy = fd_cdiv(g.M, BM);
+        a.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
+        hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(nt), 0, st, a);
+    };
+    // pick the largest tile that still yields >= ~2 workgroups per CU
+    auto blocks = [&](int BM, int BN) { return (long)fd_cdiv(Np, BN) * fd_cdiv(g.M, BM); };
+    if (g.M <= 32) {
+        go(k_gather_gemm<TA, TB, 1, 4, 1, 1>, 32, 128, 256);
+    } else if (g.M >= 128 && blocks(128, 128) >= 512) {
+        go(k_gather_gemm<TA, TB, 2, 2, 2, 2>, 128, 128, 256);
+    } else if (blocks(64, 128) >= 512) {
+        go(k_gather_gemm<TA, TB, 2, 2, 1, 2>, 64, 128, 256);
+    } else {
+        go(k_gather_gemm<TA, TB, 2, 2, 1, 1>, 64, 64, 256);
+    }
+    return 0;
+}
+
+int dispatch_gemm(int TA, int TB, const GemmArgs& g, hipStream_t st) {
+    if (TA == 1 && TB == 1) return launch_gemm<1, 1>(g, st);
+    if (TA == 3 && TB == 3) return launch_gemm<3, 3>(g, st);
+    if (TA == 7 && TB == 7) return launch_gemm<7, 7>(g, st);
+    if (TA == 5 && TB == 5) return launch_gemm<5, 5>(g, st);
+    if (TA == 1 && TB == 2) return launch_gemm<1, 2>(g, st);
+    if (TA == 2 && TB == 1) return launch_gemm<2, 1>(g, st);
+    if (TA == 2 && TB == 2) return launch_gemm<2, 2>(g, st);
+    if (TA == 3 && TB == 4) return launch_gemm<3, 4>(g, st);
+    if (TA == 4 && TB == 3) return launch_gemm<4, 3>(g, st);
+    if (TA == 4 && TB == 4) return launch_gemm<4, 4>(g, st);
+    if (TA == 2 && TB == 3) return launch_gemm<2, 3>(g, st);
+    if (TA == 3 && TB == 2) return launch_gemm<3, 2>(g, st);
+    fd_set_error("conv: unsupported tap shape %dx%d", TA, TB);
+    return -1;
+}
+
+template <int TA, int TB>
+int launch_wgrad(const WgradArgs& g, int splits, hipStream_t st) {
+    if (g.M <= 32 || g.J <= 64) {
+        dim3 grid(fd_cdiv(g.J, 64), fd_cdiv(g.M, 64), splits);
+        hipLaunchKernelGGL((k_wgrad<TA, TB, 2, 2, 1, 1>), grid, dim3(256), 0, st, g);
+    } else {
+        dim3 grid(fd_cdiv(g.J, 128), fd_cdiv(g.M, 64), splits);
+        hipLaunchKernelGGL((k_wgrad<TA, TB, 2, 2, 1, 2>), grid, dim3(256), 0, st, g);
+    }
+    return 0;
+}
+
+int dispatch_wgrad(int TA, int TB, const WgradArgs& g, int splits, hipStream_t st) {
+    if (TA == 1 && TB == 1) return launch_wgrad<1, 1>(g, splits, st);
+    if (TA == 3 && TB == 3) return launch_wgrad<3, 3>(g, splits, st);
+    if (TA == 7 && TB == 7) return launch_wgrad<7, 7>(g, splits, st);
+    if (TA == 5 && TB == 5) return launch_wgrad<5, 5>(g, splits, st);
+    fd_set_error("conv wgrad: unsupported kernel %dx%d", TA, TB);
+    return -1;
+}
+
+struct ConvShape {
+    int Ho, Wo;
+};
+bool conv_out_shape(const fd_conv_desc* d, ConvShape& s) {
+    s.Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    s.Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    return s.Ho > 0 && s.Wo > 0;
+}
+int check_desc(const fd_conv_desc* d, const char* who) {
+    FD_REQUIRE(d, "%s: desc is NULL", who);
+    FD_REQUIRE(d->N > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0, "%s: bad sizes", who);
+    FD_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 5 || d->KH == 7), "%s: kernel %dx%d unsupported", who,
+               d->KH, d->KW);
+    FD_REQUIRE(d->stride == 1 || d->stride == 2, "%s: stride %d unsupported", who, d->stride);
+    FD_REQUIRE(d->pad >= 0 && d->pad <= d->KH / 2 + 1, "%s: pad %d unsupported", who, d->pad);
+    FD_REQUIRE(d->pad_mode == 0 || (d->pad_mode == 1 && d->stride == 1 && d->pad == 1 && d->H >= 2 && d->W >= 2),
+               "%s: reflect padding needs stride 1, pad 1", who);
+    FD_REQUIRE(d->act >= 0 && d->act <= 4, "%s: bad activation", who);
+    return 0;
+}
+inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                             void* stream) {
+    if (int rc = check_desc(d, "fd_conv2d_fwd")) return rc;
+    FD_REQUIRE(x && w && y, "fd_conv2d_fwd: NULL tensor");
+    ConvShape s;
+    FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_fwd: empty output");
+    GemmArgs g = {};
+    g.A = w; g.X = x; g.Y = y; g.bias = bias;
+    g.M = d->Cout; g.K = d->Cin * d->KH * d->KW;
+    g.Nb = d->N; g.C = d->Cin; g.Hi = d->H; g.Wi = d->W;
+    g.NY = s.Ho; g.NX = s.Wo;
+    g.sy = d->stride; g.oy = -d->pad; g.da = 1; g.sx = d->stride; g.ox = -d->pad; g.db = 1;
+    g.pad_mode = d->pad_mode;
+    g.out_ns = (long)d->Cout * s.Ho * s.Wo; g.out_cs = (long)s.Ho * s.Wo;
+    g.out_w = s.Wo; g.osy = 1; g.ooy = 0; g.osx = 1; g.oox = 0;
+    g.act = d->act; g.in_norm = d->in_norm;
+    if (int rc = dispatch_gemm(d->KH, d->KW, g, (hipStream_t)stream)) return rc;
+    FD_LAUNCH_CHECK("fd_conv2d_fwd");
+    return 0;
+}
+
+extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
+    if (!d) return 0;
+    long wt = (long)d->Cin * d->Cout * d->KH * d->KW;
+    long padded = d->pad_mode == 1 ? (long)d->N * d->Cin * (d->H + 2) * (d->W + 2) : 0;
+    return wt + padded;
+}
+
+extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* ws,
+                                  void* stream) {
+    if (int rc = check_desc(d, "fd_conv2d_bwd_data")) return rc;
+    FD_REQUIRE(gy && w && gx && ws, "fd_conv2d_bwd_data: NULL tensor");
+    ConvShape s;
+    FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_data: empty output");
+    hipStream_t st = (hipStream_t)stream;
+    const int KH = d->KH, KW = d->KW;
+    float* wt = ws;
+    GemmArgs g = {};
+    g.X = gy; g.bias = nullptr; g.act = 0; g.in_norm = 0; g.pad_mode = 0;
+    g.M = d->Cin; g.Nb = d->N; g.C = d->Cout; g.Hi = s.Ho; g.Wi = s.Wo;
+    if (d->stride == 1) {
+        const long nw = (long)d->Cin * d->Cout * KH * KW;
+        hipLaunchKernelGGL(k_weight_relayout, dim3(ew_blocks(nw)), dim3(256), 0, st, w, wt, d->Cout, d->Cin, KH, KW, KH, KW,
+                           KH - 1, -1, KW - 1, -1);
+        FD_LAUNCH_CHECK("fd_conv2d_bwd_data(relayout)");
+        g.A = wt; g.K = d->Cout * KH * KW;
+        g.sy = 1; g.da = 1; g.sx = 1; g.db = 1;
+        g.osy = 1; g.ooy = 0; g.osx = 1; g.oox = 0;
+        if (d->pad_mode == 1) {   // gradient on the reflect-padded grid, then fold
+            float* gpad = ws + nw;
+            g.NY = d->H + 2; g.NX = d->W + 2; g.oy = -(KH - 1); g.ox = -(KW - 1);
+            g.Y = gpad; g.out_w = d->W + 2;
+            g.out_cs = (long)(d->H + 2) * (d->W + 2); g.out_ns = g.out_cs * d->Cin;
+            if (int rc = dispatch_gemm(KH, KW, g, st)) return rc;
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(reflect)");
+            const long n = (long)d->N * d->Cin * d->H * d->W;
+            hipLaunchKernelGGL(k_reflect_fold, dim3(ew_blocks(n)), dim3(256), 0, st, gpad, gx, (long)d->N * d->Cin, d->H,
+                               d->W);
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(fold)");
+            return 0;
+        }
+        g.NY = d->H; g.NX = d->W; g.oy = -(KH - 1 - d->pad); g.ox = -(KW - 1 - d->pad);
+        g.Y = gx; g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin;
+        if (int rc = dispatch_gemm(KH, KW, g, st)) return rc;
+        FD_LAUNCH_CHECK("fd_conv2d_bwd_data");
+        return 0;
+    }
+    // stride 2: four output-parity classes, each a dense conv over its own tap subset
+    g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin; g.Y = gx;
+    bool need_zero = false;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            const int kh0 = (ph + d->pad) & 1, kw0 = (pw + d->pad) & 1;
+            if (kh0 >= KH || kw0 >= KW) need_zero = true;
+        }
+    if (need_zero) {
+        if (hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->Cin * d->H * d->W, st) != hipSuccess) {
+            fd_set_error("fd_conv2d_bwd_data: memset failed");
+            return -1;
+        }
+    }
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            const int kh0 = (ph + d->pad) & 1, kw0 = (pw + d->pad) & 1;
+            if (kh0 >= KH || kw0 >= KW) continue;
+            const int TA = (KH - kh0 + 1) / 2, TB = (KW - kw0 + 1) / 2;
+            const int NY = (d->H - ph + 1) / 2, NX = (d->W - pw + 1) / 2;
+            if (NY <= 0 || NX <= 0) continue;
+            const long nw = (long)d->Cin * d->Cout * TA * TB;
+            hipLaunchKernelGGL(k_weight_relayout, dim3(ew_blocks(nw)), dim3(256), 0, st, w, wt, d->Cout, d->Cin, KH, KW, TA,
+                               TB, kh0, 2, kw0, 2);
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(relayout s2)");
+            g.A = wt; g.K = d->Cout * TA * TB;
+            g.NY = NY; g.NX = NX;
+            g.sy = 1; g.oy = (ph + d->pad - kh0) / 2; g.da = -1;
+            g.sx = 1; g.ox = (pw + d->pad - kw0) / 2; g.db = -1;
+            g.osy = 2; g.ooy = ph; g.osx = 2; g.oox = pw;
+            if (int rc = dispatch_gemm(TA, TB, g, st)) return rc;
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(s2)");
+        }
+    return 0;
+}
+
+namespace {
+int wgrad_splits(const fd_conv_desc* d, const ConvShape& s) {
+    const long Np = (long)d->N * s.Ho * s.Wo;
+    const long J = (long)d->Cin * d->KH * d->KW;
+    const long tiles = (long)fd_cdiv(J, (d->Cout <= 32 || J <= 64) ? 64 : 128) * fd_cdiv(d->Cout, 64);
+    long want = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU
+    long maxs = (Np + 255) / 256;                     // at least 256 pixels per split
+    long sp = want < maxs ? want : maxs;
+    if (sp < 1) sp = 1;
+    if (sp > 512) sp = 512;
+    return (int)sp;
+}
+}  // namespace
+
+extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
+    if (!d) return 0;
+    ConvShape s;
+    if (!conv_out_shape(d, s)) return 0;
+    const int sp = wgrad_splits(d, s);
+    return sp > 1 ? (long)sp * d->Cout * d->Cin * d->KH * d->KW : 0;
+}
+
+extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* gbias,
+                                    float* ws, void* stream) {
+    if (int rc = check_desc(d, "fd_conv2d_bwd_weight")) return rc;
+    FD_REQUIRE(x && gy && gw, "fd_conv2d_bwd_weight: NULL tensor");
+    ConvShape s;
+    FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_weight: empty output");
+    hipStream_t st = (hipStream_t)stream;
+    const int sp = wgrad_splits(d, s);
+    FD_REQUIRE(sp == 1 || ws, "fd_conv2d_bwd_weight: workspace required");
+    WgradArgs g = {};
+    g.dY = gy; g.X = x; g.out = sp > 1 ? ws : gw;
+    g.M = d->Cout; g.J = d->Cin * d->KH * d->KW;
+    g.Nb = d->N; g.C = d->Cin; g.Hi = d->H; g.Wi = d->W;
+    g.NY = s.Ho; g.NX = s.Wo;
+    g.sy = d->stride; g.oy = -d->pad; g.da = 1; g.sx = d->stride; g.ox = -d->pad; g.db = 1;
+    g.pad_mode = d->pad_mode; g.in_norm = d->in_norm;
+    g.dy_cs = (long)s.Ho * s.Wo; g.dy_ns = g.dy_cs * d->Cout;
+    const long Np = (long)d->N * s.Ho * s.Wo;
+    long pps = (Np + sp - 1) / sp;
+    pps = (pps + 31) / 32 * 32;
+    g.pix_per_split = pps;
+    if (int rc = dispatch_wgrad(d->KH, d->KW, g, sp, st)) return rc;
+    FD_LAUNCH_CHECK("fd_conv2d_bwd_weight");
+    if (sp > 1) {
+        const long n = (long)g.M * g.J;
+        hipLaunchKernelGGL(k_reduce_slabs, dim3(ew_blocks(n)), dim3(256), 0, st, ws, gw, n, sp);
+        FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(reduce)");
+    }
+    if (gbias) {
+        hipLaunchKernelGGL(k_channel_sum, dim3(d->Cout), dim3(256), 0, st, gy, gbias, d->N, d->Cout, (long)s.Ho * s.Wo);
+        FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(bias)");
+    }
+    return 0;
+}

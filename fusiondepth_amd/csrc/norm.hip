@@ -1,0 +1,210 @@
+// BatchNorm2d (training-mode batch statistics) fused with the residual add + ReLU tail of the ResNet blocks.
+// Reference: torchvision ResNet BasicBlock/Bottleneck as driven by networks/resnet_encoder.py:95-101 in
+// train mode (trainer.py:207-211).  HBM-bound: forward = 1 statistics pass + 1 apply pass, backward = 1
+// reduction pass + 1 apply pass; statistics use shifted single-pass sums (shift = first element of the
+// channel) so var = E[(x-k)^2] - E[x-k]^2 does not cancel catastrophically.  Deterministic: per-(channel,
+// slice) partials are combined in slice order by every consumer.
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+inline int bn_splits(int N, int C, long HW) {
+    const long per_channel = (long)N * HW;
+    long s = 1024 / C;
+    if (s < 1) s = 1;
+    const long max_s = (per_channel + 2047) / 2048;
+    if (s > max_s) s = max_s;
+    if (s > 64) s = 64;
+    return (int)(s < 1 ? 1 : s);
+}
+
+// iterate the elements [lo,hi) of channel c's flattened (n, hw) index space
+template <typename F>
+__device__ __forceinline__ void for_channel_range(long lo, long hi, long HW, int C, int c, F&& f) {
+    for (long i = lo + threadIdx.x; i < hi; i += NT) {
+        const long n = i / HW, r = i - n * HW;
+        f((n * C + c) * HW + r);
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_bn_stats(const float* __restrict__ x, float* __restrict__ part, int N, int C,
+                                                 long HW, int splits) {
+    __shared__ float red[4 * 2];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const long M = (long)N * HW, per = (M + splits - 1) / splits;
+    const long lo = (long)s * per, hi = lo + per < M ? lo + per : M;
+    const float shift = x[(long)c * HW];
+    float acc[2] = {0.f, 0.f};
+    for_channel_range(lo, hi, HW, C, c, [&](long o) { const float d = x[o] - shift; acc[0] += d; acc[1] += d * d; });
+    const float r = fd_block_sum_n<2, 4>(acc, red);
+    if (threadIdx.x < 2) part[((long)c * splits + s) * 2 + threadIdx.x] = r;
+}
+
+struct BnStat { float mean, var; };
+__device__ __forceinline__ BnStat bn_finalize(const float* __restrict__ part, const float* __restrict__ x, int c,
+                                              long HW, int splits, float M) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int s = 0; s < splits; ++s) { s1 += part[((long)c * splits + s) * 2]; s2 += part[((long)c * splits + s) * 2 + 1]; }
+    const float shift = x[(long)c * HW];
+    const float m = s1 / M;
+    BnStat st;
+    st.mean = shift + m;
+    st.var = fmaxf(s2 / M - m * m, 0.f);
+    return st;
+}
+
+// y = relu?( (x-mean)*invstd*w + b + residual? ); grid (plane chunks, N*C)
+__global__ void __launch_bounds__(NT) k_bn_apply_train(const float* __restrict__ x, const float* __restrict__ weight,
+                                                       const float* __restrict__ bias, const float* __restrict__ residual,
+                                                       float* __restrict__ y, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_invstd, const float* __restrict__ part,
+                                                       int N, int C, long HW, int splits, float eps, float momentum,
+                                                       int relu) {
+    const int nc = blockIdx.y, c = nc % C;
+    const float M = (float)N * (float)HW;
+    const BnStat st = bn_finalize(part, x, c, HW, splits, M);
+    const float invstd = 1.0f / sqrtf(st.var + eps);
+    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0) {   // once per channel (n == 0)
+        save_mean[c] = st.mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const float unbiased = M > 1.f ? st.var * (M / (M - 1.f)) : st.var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * st.mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        }
+    }
+    const float a = invstd * (weight ? weight[c] : 1.f);
+    const float b = (bias ? bias[c] : 0.f) - st.mean * a;
+    const long base = (long)nc * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
+        float v = x[base + i] * a + b;
+        if (residual) v += residual[base + i];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[base + i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_bn_apply_eval(const float* __restrict__ x, const float* __restrict__ weight,
+                                                      const float* __restrict__ bias, const float* __restrict__ residual,
+                                                      float* __restrict__ y, const float* __restrict__ running_mean,
+                                                      const float* __restrict__ running_var, int C, long HW, float eps,
+                                                      int relu) {
+    const int nc = blockIdx.y, c = nc % C;
+    const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float a = invstd * (weight ? weight[c] : 1.f);
+    const float b = (bias ? bias[c] : 0.f) - running_mean[c] * a;
+    const long base = (long)nc * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
+        float v = x[base + i] * a + b;
+        if (residual) v += residual[base + i];
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[base + i] = v;
+    }
+}
+
+// partial sums of dy' and dy'*xhat   (dy' = dy masked by the ReLU)
+__global__ void __launch_bounds__(NT) k_bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ gy, const float* __restrict__ save_mean,
+                                                      const float* __restrict__ save_invstd, float* __restrict__ part,
+                                                      int N, int C, long HW, int splits, int relu) {
+    __shared__ float red[4 * 2];
+    const int c = blockIdx.x, s = blockIdx.y;
+    const long M = (long)N * HW, per = (M + splits - 1) / splits;
+    const long lo = (long)s * per, hi = lo + per < M ? lo + per : M;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    float acc[2] = {0.f, 0.f};
+    for_channel_range(lo, hi, HW, C, c, [&](long o) {
+        float g = gy[o];
+        if (relu && !(y[o] > 0.f)) g = 0.f;
+        acc[0] += g;
+        acc[1] += g * ((x[o] - mean) * invstd);
+    });
+    const float r = fd_block_sum_n<2, 4>(acc, red);
+    if (threadIdx.x < 2) part[((long)c * splits + s) * 2 + threadIdx.x] = r;
+}
+
+__global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ gy, const float* __restrict__ weight,
+                                                     const float* __restrict__ save_mean,
+                                                     const float* __restrict__ save_invstd, float* __restrict__ gx,
+                                                     float* __restrict__ gweight, float* __restrict__ gbias,
+                                                     float* __restrict__ g_res, const float* __restrict__ part, int N,
+                                                     int C, long HW, int splits, int relu) {
+    const int nc = blockIdx.y, c = nc % C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int s = 0; s < splits; ++s) { s1 += part[((long)c * splits + s) * 2]; s2 += part[((long)c * splits + s) * 2 + 1]; }
+    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0) {
+        if (gbias) gbias[c] = s1;
+        if (gweight) gweight[c] = s2;
+    }
+    const float M = (float)N * (float)HW;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float k = (weight ? weight[c] : 1.f) * invstd;
+    const float m1 = s1 / M, m2 = s2 / M;
+    const long base = (long)nc * HW;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
+        float g = gy[base + i];
+        if (relu && !(y[base + i] > 0.f)) g = 0.f;
+        if (g_res) g_res[base + i] = g;
+        const float xh = (x[base + i] - mean) * invstd;
+        gx[base + i] = k * (g - m1 - xh * m2);
+    }
+}
+
+inline int plane_blocks(long HW) {
+    long b = (HW + NT * 4 - 1) / (NT * 4);
+    return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
+}
+
+}  // namespace
+
+extern "C" long fd_bn_ws_floats(int N, int C, int H, int W) { return (long)C * bn_splits(N, C, (long)H * W) * 2; }
+
+extern "C" int fd_bn_train_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                               float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws,
+                               int N, int C, int H, int W, float eps, float momentum, int relu, void* stream) {
+    FD_REQUIRE(x && y && save_mean && save_invstd && ws && N > 0 && C > 0 && H > 0 && W > 0, "fd_bn_train_fwd: bad args");
+    FD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "fd_bn_train_fwd: running stats must come in pairs");
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const int sp = bn_splits(N, C, HW);
+    hipLaunchKernelGGL(k_bn_stats, dim3(C, sp), dim3(NT), 0, st, x, ws, N, C, HW, sp);
+    FD_LAUNCH_CHECK("fd_bn_train_fwd(stats)");
+    hipLaunchKernelGGL(k_bn_apply_train, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, weight, bias, residual, y,
+                       running_mean, running_var, save_mean, save_invstd, ws, N, C, HW, sp, eps, momentum, relu);
+    FD_LAUNCH_CHECK("fd_bn_train_fwd(apply)");
+    return 0;
+}
+
+extern "C" int fd_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                              const float* running_mean, const float* running_var, int N, int C, int H, int W, float eps,
+                              int relu, void* stream) {
+    FD_REQUIRE(x && y && running_mean && running_var && N > 0 && C > 0 && H > 0 && W > 0, "fd_bn_eval_fwd: bad args");
+    const long HW = (long)H * W;
+    hipLaunchKernelGGL(k_bn_apply_eval, dim3(plane_blocks(HW), N * C), dim3(NT), 0, (hipStream_t)stream, x, weight, bias,
+                       residual, y, running_mean, running_var, C, HW, eps, relu);
+    FD_LAUNCH_CHECK("fd_bn_eval_fwd");
+    return 0;
+}
+
+extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float* weight,
+                               const float* save_mean, const float* save_invstd, float* gx, float* gweight, float* gbias,
+                               float* g_residual, float* ws, int N, int C, int H, int W, int relu, void* stream) {
+    FD_REQUIRE(x && gy && save_mean && save_invstd && gx && ws && N > 0 && C > 0 && H > 0 && W > 0,
+               "fd_bn_train_bwd: bad args");
+    FD_REQUIRE(!relu || y, "fd_bn_train_bwd: the forward output is needed for the ReLU mask");
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const int sp = bn_splits(N, C, HW);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(C, sp), dim3(NT), 0, st, x, y, gy, save_mean, save_invstd, ws, N, C, HW, sp,
+                       relu);
+    FD_LAUNCH_CHECK("fd_bn_train_bwd(reduce)");
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, y, gy, weight, save_mean,
+                       save_invstd, gx, gweight, gbias, g_residual, ws, N, C, HW, sp, relu);
+    FD_LAUNCH_CHECK("fd_bn_train_bwd(apply)");
+    return 0;
+}

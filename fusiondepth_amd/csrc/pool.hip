@@ -1,0 +1,316 @@
+// Memory-bound glue kernels of the network stack: 3x3/s2 max-pool (resnet_encoder.py:98), decoder input
+// assembly = nearest x2 upsample + skip concat + feature fusion (depth_decoder.py:69-83, layers.py:229-232),
+// activation backward, axpby, spatial mean (pose_decoder.py:44-46), depth metrics (layers.py:284-302) and
+// the Adam update (trainer.py:129,247).  All 1 thread per output element, coalesced along W.
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+inline int ew_blocks(long n) {
+    long b = (n + NT - 1) / NT;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+#define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (n); i += (long)gridDim.x * NT)
+
+// ---- max-pool 3x3 stride 2 pad 1; first maximum in (kh,kw) raster order wins, as ATen does (val > max) ----
+__global__ void __launch_bounds__(NT) k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y,
+                                                    uint8_t* __restrict__ idx, long planes, int H, int W, int Ho, int Wo) {
+    const long n = planes * Ho * Wo;
+    GRID_STRIDE(i, n) {
+        const int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
+        const long pl = i / ((long)Wo * Ho);
+        const float* p = x + pl * H * W;
+        float best = -INFINITY;
+        int bi = 0;
+        bool any = false;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = ho * 2 - 1 + kh;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = wo * 2 - 1 + kw;
+                if (w < 0 || w >= W) continue;
+                const float v = p[(long)h * W + w];
+                if (!any || v > best || v != v) { best = v; bi = kh * 3 + kw; any = true; }
+            }
+        }
+        y[i] = best;
+        idx[i] = (uint8_t)bi;
+    }
+}
+// gather form of the scatter-add: each input pixel checks the <=4 windows that contain it
+__global__ void __launch_bounds__(NT) k_maxpool_bwd(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                    float* __restrict__ gx, long planes, int H, int W, int Ho, int Wo) {
+    const long n = planes * H * W;
+    GRID_STRIDE(i, n) {
+        const int w = (int)(i % W), h = (int)((i / W) % H);
+        const long pl = i / ((long)W * H);
+        const float* g = gy + pl * Ho * Wo;
+        const uint8_t* ix = idx + pl * Ho * Wo;
+        float s = 0.f;
+        for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {   // windows with 2ho-1 <= h <= 2ho+1
+            if (ho < 0 || ho >= Ho) continue;
+            const int kh = h - (2 * ho - 1);
+            if (kh < 0 || kh > 2) continue;
+            for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+                if (wo < 0 || wo >= Wo) continue;
+                const int kw = w - (2 * wo - 1);
+                if (kw < 0 || kw > 2) continue;
+                if (ix[(long)ho * Wo + wo] == kh * 3 + kw) s += g[(long)ho * Wo + wo];
+            }
+        }
+        gx[i] = s;
+    }
+}
+
+// ---- decoder input assembly ----
+__global__ void __launch_bounds__(NT) k_upcat_fwd(const float* __restrict__ a, const float* __restrict__ s1,
+                                                  const float* __restrict__ s2, const float* __restrict__ s3,
+                                                  float* __restrict__ out, int N, int Ca, int Cs, int C3, int h, int w) {
+    const int H = 2 * h, W = 2 * w, Ct = Ca + Cs + C3;
+    const long n = (long)N * Ct * H * W;
+    GRID_STRIDE(i, n) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((long)W * H)) % Ct);
+        const long b = i / ((long)W * H * Ct);
+        float v;
+        if (c < Ca) v = a[((b * Ca + c) * h + (y >> 1)) * w + (x >> 1)];
+        else if (c < Ca + Cs) {
+            const long o = ((b * Cs + (c - Ca)) * H + y) * W + x;
+            v = s1[o];
+            if (s2) v += s2[o];
+        } else v = s3[((b * C3 + (c - Ca - Cs)) * H + y) * W + x];
+        out[i] = v;
+    }
+}
+__global__ void __launch_bounds__(NT) k_upcat_bwd_a(const float* __restrict__ gout, float* __restrict__ ga, int N, int Ca,
+                                                    int Ct, int h, int w) {
+    const int H = 2 * h, W = 2 * w;
+    const long n = (long)N * Ca * h * w;
+    GRID_STRIDE(i, n) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const int c = (int)((i / ((long)w * h)) % Ca);
+        const long b = i / ((long)w * h * Ca);
+        const float* g = gout + ((b * Ct + c) * H + 2 * y) * W + 2 * x;
+        ga[i] = (g[0] + g[1]) + (g[W] + g[W + 1]);
+    }
+}
+__global__ void __launch_bounds__(NT) k_slice_channels(const float* __restrict__ src, float* __restrict__ dst, int N,
+                                                       int Ct, int c0, int Cn, long plane) {
+    const long n = (long)N * Cn * plane;
+    GRID_STRIDE(i, n) {
+        const long r = i % plane;
+        const int c = (int)((i / plane) % Cn);
+        const long b = i / (plane * Cn);
+        dst[i] = src[(b * Ct + c0 + c) * plane + r];
+    }
+}
+__global__ void __launch_bounds__(NT) k_up2_fwd(const float* __restrict__ x, float* __restrict__ y, long planes, int h,
+                                                int w) {
+    const int H = 2 * h, W = 2 * w;
+    const long n = planes * H * W;
+    GRID_STRIDE(i, n) {
+        const int xx = (int)(i % W), yy = (int)((i / W) % H);
+        const long pl = i / ((long)W * H);
+        y[i] = x[(pl * h + (yy >> 1)) * w + (xx >> 1)];
+    }
+}
+__global__ void __launch_bounds__(NT) k_up2_bwd(const float* __restrict__ gy, float* __restrict__ gx, long planes, int h,
+                                                int w) {
+    const int W = 2 * w;
+    const long n = planes * h * w;
+    GRID_STRIDE(i, n) {
+        const int xx = (int)(i % w), yy = (int)((i / w) % h);
+        const long pl = i / ((long)w * h);
+        const float* g = gy + (pl * 2 * h + 2 * yy) * W + 2 * xx;
+        gx[i] = (g[0] + g[1]) + (g[W] + g[W + 1]);
+    }
+}
+
+// ---- elementwise ----
+__global__ void __launch_bounds__(NT) k_act_bwd(const float* __restrict__ y, const float* __restrict__ gy,
+                                                float* __restrict__ out, long n, int act) {
+    GRID_STRIDE(i, n) {
+        const float v = y[i], g = gy[i];
+        float d;
+        if (act == 1) d = v > 0.f ? 1.f : 0.f;
+        else if (act == 2) d = v > 0.f ? 1.f : v + 1.f;        // ELU(alpha=1): y = e^x - 1  =>  dy/dx = y + 1
+        else if (act == 3) d = v * (1.f - v);
+        else if (act == 4) d = 1.f - v * v;
+        else d = 1.f;
+        out[i] = g * d;
+    }
+}
+__global__ void __launch_bounds__(NT) k_axpby(const float* __restrict__ a, const float* __restrict__ b,
+                                              float* __restrict__ out, long n, float alpha, float beta) {
+    GRID_STRIDE(i, n) out[i] = alpha * a[i] + beta * b[i];
+}
+
+// one wave per plane: out = scale * mean(plane)
+__global__ void __launch_bounds__(64) k_spatial_mean(const float* __restrict__ x, float* __restrict__ out, long plane_size,
+                                                     float scale) {
+    const float* p = x + (long)blockIdx.x * plane_size;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < plane_size; i += 64) s += p[i];
+    s = fd_wave_sum(s);
+    if (threadIdx.x == 0) out[blockIdx.x] = scale * (s / (float)plane_size);
+}
+__global__ void __launch_bounds__(NT) k_spatial_mean_bwd(const float* __restrict__ gout, float* __restrict__ gx,
+                                                         long planes, long plane_size, float scale) {
+    const long n = planes * plane_size;
+    GRID_STRIDE(i, n) gx[i] = gout[i / plane_size] * (scale / (float)plane_size);
+}
+
+// ---- depth metrics ----
+__global__ void __launch_bounds__(NT) k_depth_err_part(const float* __restrict__ gt, const float* __restrict__ pr, long n,
+                                                       float* __restrict__ part) {
+    __shared__ float red[4 * 7];
+    float a[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    GRID_STRIDE(i, n) {
+        const float g = gt[i], p = pr[i];
+        const float d = g - p, th = fmaxf(g / p, p / g), l = logf(g) - logf(p);
+        a[0] += fabsf(d) / g; a[1] += d * d / g; a[2] += d * d; a[3] += l * l;
+        a[4] += th < 1.25f ? 1.f : 0.f; a[5] += th < 1.25f * 1.25f ? 1.f : 0.f; a[6] += th < 1.25f * 1.25f * 1.25f ? 1.f : 0.f;
+    }
+    const float s = fd_block_sum_n<7, 4>(a, red);
+    if (threadIdx.x < 7) part[(long)blockIdx.x * 7 + threadIdx.x] = s;
+}
+__global__ void k_depth_err_fin(const float* __restrict__ part, int nblk, float n, float* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t >= 7) return;
+    float s = 0.f;
+    for (int i = 0; i < nblk; ++i) s += part[(long)i * 7 + t];
+    s /= n;
+    out[t] = (t == 2 || t == 3) ? sqrtf(s) : s;
+}
+
+// ---- Adam ----
+__global__ void __launch_bounds__(NT) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, long n, float step_size, float b1, float b2, float eps,
+                                             float sqrt_bc2, float gscale) {
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
+    }
+}
+
+}  // namespace
+
+extern "C" int fd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream) {
+    FD_REQUIRE(x && y && idx && N > 0 && C > 0 && H > 0 && W > 0, "fd_maxpool3x3s2_fwd: bad args");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long planes = (long)N * C;
+    hipLaunchKernelGGL(k_maxpool_fwd, dim3(ew_blocks(planes * Ho * Wo)), dim3(NT), 0, (hipStream_t)stream, x, y, idx,
+                       planes, H, W, Ho, Wo);
+    FD_LAUNCH_CHECK("fd_maxpool3x3s2_fwd");
+    return 0;
+}
+extern "C" int fd_maxpool3x3s2_bwd(const float* gy, const uint8_t* idx, float* gx, int N, int C, int H, int W,
+                                   void* stream) {
+    FD_REQUIRE(gy && idx && gx && N > 0 && C > 0 && H > 0 && W > 0, "fd_maxpool3x3s2_bwd: bad args");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long planes = (long)N * C;
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_blocks(planes * H * W)), dim3(NT), 0, (hipStream_t)stream, gy, idx, gx,
+                       planes, H, W, Ho, Wo);
+    FD_LAUNCH_CHECK("fd_maxpool3x3s2_bwd");
+    return 0;
+}
+
+extern "C" int fd_upcat_fwd(const float* a, const float* s1, const float* s2, const float* s3, float* out, int N, int Ca,
+                            int Cs, int C3, int h, int w, void* stream) {
+    FD_REQUIRE(a && out && N > 0 && Ca > 0 && Cs >= 0 && C3 >= 0 && h > 0 && w > 0, "fd_upcat_fwd: bad args");
+    FD_REQUIRE((Cs == 0 || s1) && (C3 == 0 || s3) && !(s2 && !s1), "fd_upcat_fwd: missing skip tensor");
+    const long n = (long)N * (Ca + Cs + C3) * 4 * h * w;
+    hipLaunchKernelGGL(k_upcat_fwd, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, a, s1, s2, s3, out, N, Ca, Cs,
+                       C3, h, w);
+    FD_LAUNCH_CHECK("fd_upcat_fwd");
+    return 0;
+}
+extern "C" int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, int N, int Ca, int Cs, int C3, int h,
+                            int w, void* stream) {
+    FD_REQUIRE(gout && N > 0 && Ca > 0 && h > 0 && w > 0, "fd_upcat_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int Ct = Ca + Cs + C3;
+    const long plane = 4L * h * w;
+    if (ga) {
+        hipLaunchKernelGGL(k_upcat_bwd_a, dim3(ew_blocks((long)N * Ca * h * w)), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w);
+        FD_LAUNCH_CHECK("fd_upcat_bwd(a)");
+    }
+    if (gs && Cs > 0) {
+        hipLaunchKernelGGL(k_slice_channels, dim3(ew_blocks((long)N * Cs * plane)), dim3(NT), 0, st, gout, gs, N, Ct, Ca, Cs,
+                           plane);
+        FD_LAUNCH_CHECK("fd_upcat_bwd(s)");
+    }
+    if (g3 && C3 > 0) {
+        hipLaunchKernelGGL(k_slice_channels, dim3(ew_blocks((long)N * C3 * plane)), dim3(NT), 0, st, gout, g3, N, Ct, Ca + Cs,
+                           C3, plane);
+        FD_LAUNCH_CHECK("fd_upcat_bwd(3)");
+    }
+    return 0;
+}
+extern "C" int fd_upsample2x_fwd(const float* x, float* y, long planes, int h, int w, void* stream) {
+    FD_REQUIRE(x && y && planes > 0 && h > 0 && w > 0, "fd_upsample2x_fwd: bad args");
+    hipLaunchKernelGGL(k_up2_fwd, dim3(ew_blocks(planes * 4 * h * w)), dim3(NT), 0, (hipStream_t)stream, x, y, planes, h, w);
+    FD_LAUNCH_CHECK("fd_upsample2x_fwd");
+    return 0;
+}
+extern "C" int fd_upsample2x_bwd(const float* gy, float* gx, long planes, int h, int w, void* stream) {
+    FD_REQUIRE(gy && gx && planes > 0 && h > 0 && w > 0, "fd_upsample2x_bwd: bad args");
+    hipLaunchKernelGGL(k_up2_bwd, dim3(ew_blocks(planes * h * w)), dim3(NT), 0, (hipStream_t)stream, gy, gx, planes, h, w);
+    FD_LAUNCH_CHECK("fd_upsample2x_bwd");
+    return 0;
+}
+
+extern "C" int fd_act_bwd(const float* y, const float* gy, float* gpre, long n, int act, void* stream) {
+    FD_REQUIRE(y && gy && gpre && n >= 0 && act >= 0 && act <= 4, "fd_act_bwd: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_act_bwd, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, y, gy, gpre, n, act);
+    FD_LAUNCH_CHECK("fd_act_bwd");
+    return 0;
+}
+extern "C" int fd_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream) {
+    FD_REQUIRE(a && b && out && n >= 0, "fd_axpby: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, a, b, out, n, alpha, beta);
+    FD_LAUNCH_CHECK("fd_axpby");
+    return 0;
+}
+extern "C" int fd_spatial_mean_fwd(const float* x, float* out, long planes, long plane_size, float scale, void* stream) {
+    FD_REQUIRE(x && out && planes > 0 && plane_size > 0, "fd_spatial_mean_fwd: bad args");
+    hipLaunchKernelGGL(k_spatial_mean, dim3((unsigned)planes), dim3(64), 0, (hipStream_t)stream, x, out, plane_size, scale);
+    FD_LAUNCH_CHECK("fd_spatial_mean_fwd");
+    return 0;
+}
+extern "C" int fd_spatial_mean_bwd(const float* gout, float* gx, long planes, long plane_size, float scale, void* stream) {
+    FD_REQUIRE(gout && gx && planes > 0 && plane_size > 0, "fd_spatial_mean_bwd: bad args");
+    hipLaunchKernelGGL(k_spatial_mean_bwd, dim3(ew_blocks(planes * plane_size)), dim3(NT), 0, (hipStream_t)stream, gout, gx,
+                       planes, plane_size, scale);
+    FD_LAUNCH_CHECK("fd_spatial_mean_bwd");
+    return 0;
+}
+extern "C" int fd_depth_errors(const float* gt, const float* pred, long n, float* out, float* ws, void* stream) {
+    FD_REQUIRE(gt && pred && out && ws && n > 0, "fd_depth_errors: bad args");
+    int nb = ew_blocks(n);
+    nb = nb > 256 ? 256 : nb;
+    hipLaunchKernelGGL(k_depth_err_part, dim3(nb), dim3(NT), 0, (hipStream_t)stream, gt, pred, n, ws);
+    FD_LAUNCH_CHECK("fd_depth_errors");
+    hipLaunchKernelGGL(k_depth_err_fin, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, nb, (float)n, out);
+    FD_LAUNCH_CHECK("fd_depth_errors(fin)");
+    return 0;
+}
+extern "C" int fd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                            float beta1, float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale,
+                            void* stream) {
+    FD_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && bias_corr1 > 0 && bias_corr2 > 0, "fd_adam_step: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_adam, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       lr / bias_corr1, beta1, beta2, eps, sqrtf(bias_corr2), grad_scale);
+    FD_LAUNCH_CHECK("fd_adam_step");
+    return 0;
+}

@@ -359,3 +359,259 @@ def photo_loss(disp, T_list, K, inv_K, src_list, target, ident=None, noise=None,
     T1 = T_list[1] if len(T_list) > 1 else None
     s1 = src_list[1] if len(src_list) > 1 else None
     return _PhotoLoss.apply(disp, T_list[0], T1, K, inv_K, src_list[0], s1, target, ident, noise, beam, po, materialize)
+
+
+# ------------------------------------------------------------------------------------ conv stack --
+ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3, "tanh": 4}
+PAD_MODE = {"zero": 0, "reflect": 1}
+
+
+def _conv_desc(x, w, stride, pad, pad_mode, act, in_norm):
+    d = _lib.ConvDesc()
+    d.N, d.Cin, d.H, d.W = x.shape
+    d.Cout, cin_w, d.KH, d.KW = w.shape
+    if cin_w != d.Cin:
+        raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (d.Cin, cin_w))
+    d.stride, d.pad, d.pad_mode, d.act, d.in_norm = stride, pad, pad_mode, act, int(in_norm)
+    return d
+
+
+def _conv_out_hw(d):
+    return (d.H + 2 * d.pad - d.KH) // d.stride + 1, (d.W + 2 * d.pad - d.KW) // d.stride + 1
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+        x, w = f32(x), f32(w)
+        bias = f32(bias) if bias is not None else None
+        _need_cuda(x, w)
+        d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
+        Ho, Wo = _conv_out_hw(d)
+        y = _empty((d.N, d.Cout, Ho, Wo), x)
+        call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), stream())
+        ctx.save_for_backward(x, w, y if act != 0 else None)
+        ctx.desc, ctx.has_bias = d, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        d = ctx.desc
+        gy = f32(gy)
+        if d.act != 0:
+            gpre = torch.empty_like(gy)
+            call("fd_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), d.act, stream())
+            gy = gpre
+        dp = ctypes.addressof(d)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            ws = _empty((max(query("fd_conv2d_bwd_data_ws_floats", dp), 1),), x)
+            call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(w), ptr(gx), ptr(ws), stream())
+            if d.in_norm:   # d/dx of (x - 0.45) / 0.225
+                call("fd_axpby", ptr(gx), ptr(gx), ptr(gx), gx.numel(), 1.0 / 0.225, 0.0, stream())
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(w)
+            gb = _empty((d.Cout,), x) if ctx.has_bias else None
+            ws = _empty((max(query("fd_conv2d_bwd_weight_ws_floats", dp), 1),), x)
+            call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), stream())
+        return gx, gw, gb, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", in_norm=False):
+    """act(conv2d(pad(x)) + bias) on the MFMA implicit-GEMM kernels; ``in_norm`` folds the encoder's
+    (x-0.45)/0.225 into the tap loads (resnet_encoder.py:94)."""
+    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), PAD_MODE[pad_mode], ACT[act], bool(in_norm))
+
+
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
+        x = f32(x)
+        _need_cuda(x)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        res = f32(residual) if residual is not None else None
+        if training:
+            mean, invstd = _empty((C,), x), _empty((C,), x)
+            ws = _empty((query("fd_bn_ws_floats", N, C, H, W),), x)
+            call("fd_bn_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
+                 ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, float(eps), float(momentum), int(relu), stream())
+            ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        else:
+            call("fd_bn_eval_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
+                 N, C, H, W, float(eps), int(relu), stream())
+        ctx.training, ctx.relu, ctx.has_res = bool(training), int(relu), residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.training:
+            raise RuntimeError("BatchNorm backward is implemented for training mode only (frozen nets run under no_grad)")
+        x, y, weight, mean, invstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gy = f32(gy)
+        gx = torch.empty_like(x)
+        gw, gb = _empty((C,), x), _empty((C,), x)
+        gres = torch.empty_like(x) if ctx.has_res and ctx.needs_input_grad[3] else None
+        ws = _empty((query("fd_bn_ws_floats", N, C, H, W),), x)
+        call("fd_bn_train_bwd", ptr(x), ptr(y), ptr(gy), ptr(weight), ptr(mean), ptr(invstd), ptr(gx), ptr(gw), ptr(gb),
+             ptr(gres), ptr(ws), N, C, H, W, ctx.relu, stream())
+        if ctx.has_res and gres is None and ctx.needs_input_grad[3]:
+            gres = gy
+        return gx, gw, gb, gres, None, None, None, None, None, None
+
+
+def batch_norm(x, bn, residual=None, relu=False):
+    """nn.BatchNorm2d semantics (batch statistics + running-stat update in training mode) fused with the
+    optional residual add and ReLU.  ``bn`` is an ``nn.BatchNorm2d`` used as the parameter/buffer holder."""
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BatchNorm.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, training, bn.momentum,
+                            bn.eps, relu)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = f32(x)
+        _need_cuda(x)
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = _empty((N, C, Ho, Wo), x)
+        idx = _empty((N, C, Ho, Wo), x, torch.uint8)
+        call("fd_maxpool3x3s2_fwd", ptr(x), ptr(y), ptr(idx), N, C, H, W, stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        gx = _empty(ctx.shape, gy)
+        call("fd_maxpool3x3s2_bwd", ptr(f32(gy)), ptr(idx), ptr(gx), N, C, H, W, stream())
+        return gx
+
+
+def max_pool3x3s2(x):
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1)."""
+    return _MaxPool.apply(x)
+
+
+class _UpCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, s1, s2, s3):
+        a = f32(a)
+        _need_cuda(a)
+        N, Ca, h, w = a.shape
+        s1 = f32(s1) if s1 is not None else None
+        s2 = f32(s2) if s2 is not None else None
+        s3 = f32(s3) if s3 is not None else None
+        Cs = s1.shape[1] if s1 is not None else 0
+        C3 = s3.shape[1] if s3 is not None else 0
+        out = _empty((N, Ca + Cs + C3, 2 * h, 2 * w), a)
+        call("fd_upcat_fwd", ptr(a), ptr(s1), ptr(s2), ptr(s3), ptr(out), N, Ca, Cs, C3, h, w, stream())
+        ctx.dims = (N, Ca, Cs, C3, h, w)
+        ctx.has = (s1 is not None, s2 is not None, s3 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, Ca, Cs, C3, h, w = ctx.dims
+        g = f32(g)
+        need_s = (ctx.has[0] and ctx.needs_input_grad[1]) or (ctx.has[1] and ctx.needs_input_grad[2])
+        ga = _empty((N, Ca, h, w), g) if ctx.needs_input_grad[0] else None
+        gs = _empty((N, Cs, 2 * h, 2 * w), g) if need_s else None
+        g3 = _empty((N, C3, 2 * h, 2 * w), g) if ctx.has[2] and ctx.needs_input_grad[3] else None
+        call("fd_upcat_bwd", ptr(g), ptr(ga), ptr(gs), ptr(g3), N, Ca, Cs, C3, h, w, stream())
+        return ga, gs if ctx.has[0] else None, gs if ctx.has[1] else None, g3
+
+
+def upsample_concat(a, skip=None, skip_add=None, extra=None):
+    """cat([nearest_up2(a), skip (+ skip_add), extra], 1)  — depth_decoder.py:75-83 in one pass."""
+    return _UpCat.apply(a, skip, skip_add, extra)
+
+
+class _Up2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = f32(x)
+        _need_cuda(x)
+        N, C, h, w = x.shape
+        y = _empty((N, C, 2 * h, 2 * w), x)
+        call("fd_upsample2x_fwd", ptr(x), ptr(y), N * C, h, w, stream())
+        ctx.shape = x.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, h, w = ctx.shape
+        gx = _empty(ctx.shape, g)
+        call("fd_upsample2x_bwd", ptr(f32(g)), ptr(gx), N * C, h, w, stream())
+        return gx
+
+
+def upsample_nearest2x(x):
+    return _Up2.apply(x)
+
+
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = f32(a), f32(b)
+        _need_cuda(a, b)
+        out = torch.empty_like(a)
+        call("fd_axpby", ptr(a), ptr(b), ptr(out), a.numel(), 1.0, 1.0, stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    """Feature fusion a + b (depth_decoder.py:70, pose_decoder.py:31)."""
+    return _Add.apply(a, b)
+
+
+class _SpatialMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = f32(x)
+        _need_cuda(x)
+        N, C, H, W = x.shape
+        out = _empty((N, C), x)
+        call("fd_spatial_mean_fwd", ptr(x), ptr(out), N * C, H * W, float(scale), stream())
+        ctx.shape, ctx.scale = x.shape, float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.shape
+        gx = _empty(ctx.shape, g)
+        call("fd_spatial_mean_bwd", ptr(f32(g)), ptr(gx), N * C, H * W, ctx.scale, stream())
+        return gx, None
+
+
+def spatial_mean(x, scale=1.0):
+    """scale * x.mean(3).mean(2)  (pose_decoder.py:44-46)."""
+    return _SpatialMean.apply(x, scale)
+
+
+def depth_errors(gt, pred):
+    """layers.py:284-302 on matched 1-D tensors -> 7 scalars (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3)."""
+    gt, pred = f32(gt.detach()).reshape(-1), f32(pred.detach()).reshape(-1)
+    _need_cuda(gt, pred)
+    out, ws = _empty((7,), gt), _empty((7 * 256,), gt)
+    call("fd_depth_errors", ptr(gt), ptr(pred), gt.numel(), ptr(out), ptr(ws), stream())
+    return tuple(out[i] for i in range(7))
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    """One torch.optim.Adam update of a flat fp32 tensor, in place."""
+    bc1, bc2 = 1.0 - betas[0] ** step, 1.0 - betas[1] ** step
+    call("fd_adam_step", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr), betas[0],
+         betas[1], float(eps), bc1, bc2, float(grad_scale), stream())

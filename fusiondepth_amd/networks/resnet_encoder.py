@@ -1,0 +1,141 @@
+"""HIP-backed ``ResnetEncoder`` (reference networks/resnet_encoder.py:53-103).
+
+The reference builds its trunk from torchvision 0.9 (``models.resnet18/34/50/101/152``, or the
+multi-image subclass at :11-50).  torchvision is not a dependency here: ``ResNetTrunk`` declares the same
+module tree (so ``state_dict()`` keys/shapes are identical: ``encoder.conv1.weight``,
+``encoder.layer1.0.bn1.running_mean``, ..., including the unused ``encoder.fc.*``) with ``nn.Conv2d`` /
+``nn.BatchNorm2d`` used purely as parameter/buffer holders.  Every forward op is a libfdhip kernel:
+MFMA implicit-GEMM convs, BatchNorm fused with the residual add + ReLU, 3x3/s2 max-pool.
+"""
+import numpy as np
+import torch.nn as nn
+
+from .. import functional as FD
+
+_SPEC = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]),
+         101: ("bottleneck", [3, 4, 23, 3]), 152: ("bottleneck", [3, 8, 36, 3])}
+
+
+def _conv(x, conv, in_norm=False):
+    return FD.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0], in_norm=in_norm)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+
+    def forward(self, x):
+        identity = x
+        if self.downsample is not None:
+            identity = FD.batch_norm(_conv(x, self.downsample[0]), self.downsample[1])
+        out = FD.batch_norm(_conv(x, self.conv1), self.bn1, relu=True)
+        return FD.batch_norm(_conv(out, self.conv2), self.bn2, residual=identity, relu=True)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)     # v1.5: stride on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = None
+        if stride != 1 or inplanes != planes * 4:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+
+    def forward(self, x):
+        identity = x
+        if self.downsample is not None:
+            identity = FD.batch_norm(_conv(x, self.downsample[0]), self.downsample[1])
+        out = FD.batch_norm(_conv(x, self.conv1), self.bn1, relu=True)
+        out = FD.batch_norm(_conv(out, self.conv2), self.bn2, relu=True)
+        return FD.batch_norm(_conv(out, self.conv3), self.bn3, residual=identity, relu=True)
+
+
+class _Stage(nn.Sequential):
+    def forward(self, x):
+        for blk in self:
+            x = blk(x)
+        return x
+
+
+class ResNetTrunk(nn.Module):
+    """Module tree of torchvision's ``ResNet`` (conv1, bn1, layer1..4, fc)."""
+
+    def __init__(self, num_layers, in_channels):
+        super().__init__()
+        kind, counts = _SPEC[num_layers]
+        block = BasicBlock if kind == "basic" else Bottleneck
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for li, (planes, n) in enumerate(zip((64, 128, 256, 512), counts)):
+            blocks = []
+            for bi in range(n):
+                blocks.append(block(inplanes, planes, (1 if li == 0 else 2) if bi == 0 else 1))
+                inplanes = planes * block.expansion
+            setattr(self, "layer%d" % (li + 1), _Stage(*blocks))
+        self.fc = nn.Linear(inplanes, 1000)       # never used (resnet_encoder.py:92-103); kept for checkpoint parity
+        for m in self.modules():                  # torchvision / resnet_encoder.py:25-30 initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+
+def stem_channels(num_input_images, cat4beam_to_color, cat2channel, beam_encoder, refine_encoder):
+    """resnet_encoder.py:76-87: which conv1 the flags select."""
+    if cat4beam_to_color:
+        return 4
+    if cat2channel:
+        return 5
+    if beam_encoder:
+        return num_input_images * 2 if num_input_images > 1 else 2
+    if refine_encoder:
+        return 6
+    return 3 * num_input_images
+
+
+class ResnetEncoder(nn.Module):
+    """Same constructor/forward contract as the reference (resnet_encoder.py:56-57,92-103)."""
+
+    def __init__(self, num_layers, pretrained, num_input_images=1, cat4beam_to_color=False, cat2channel=False,
+                 beam_encoder=False, refine_encoder=False):
+        super().__init__()
+        if num_layers not in _SPEC:
+            raise ValueError("{} is not a valid number of resnet layers".format(num_layers))
+        if pretrained:
+            raise RuntimeError("ImageNet weights cannot be downloaded here (no network); run with "
+                               "--weights_init scratch or load a checkpoint via load_state_dict")
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        self.encoder = ResNetTrunk(num_layers, stem_channels(num_input_images, cat4beam_to_color, cat2channel,
+                                                              beam_encoder, refine_encoder))
+        if num_layers > 34:
+            self.num_ch_enc[1:] *= 4
+
+    def forward(self, input_image):
+        e = self.encoder
+        # (x - 0.45) / 0.225 (resnet_encoder.py:94) is folded into conv1's tap loads
+        x = FD.conv2d(input_image, e.conv1.weight, None, stride=2, pad=3, in_norm=True)
+        f0 = FD.batch_norm(x, e.bn1, relu=True)
+        f1 = e.layer1(FD.max_pool3x3s2(f0))
+        f2 = e.layer2(f1)
+        f3 = e.layer3(f2)
+        f4 = e.layer4(f3)
+        self.features = [f0, f1, f2, f3, f4]
+        return self.features

@@ -137,6 +137,90 @@ int fd_smooth_fwd(const float* disp, const float* img, float* out, float* ws, in
 int fd_smooth_bwd(const float* disp, const float* img, const float* g, float* d_disp, float* ws, int B, int H, int W,
                   int normalize, void* stream);
 
+/* ------------------------------------------------------------------ convolution stack ---------- */
+
+/* One 2-D convolution, NCHW fp32, square kernel 1/3/5/7, stride 1|2, symmetric padding.
+ * Replaces nn.Conv2d / layers.Conv3x3 / layers.ConvBlock call sites:
+ *   networks/resnet_encoder.py:95,98-101 (torchvision ResNet convs, zero pad, no bias),
+ *   layers.py:115-130 (ReflectionPad2d(1)+Conv2d 3x3 + bias), layers.py:100-112 (+ELU),
+ *   networks/depth_decoder.py:92 (dispconv + sigmoid), networks/pose_decoder.py:35-42 (+ReLU). */
+typedef struct {
+    int N, Cin, H, W;       /* input  [N,Cin,H,W]                    */
+    int Cout, KH, KW;       /* weight [Cout,Cin,KH,KW] (OIHW)        */
+    int stride, pad;
+    int pad_mode;           /* 0 zero, 1 reflect (stride 1, pad 1)   */
+    int act;                /* epilogue: 0 none, 1 ReLU, 2 ELU, 3 sigmoid, 4 tanh (applied after bias) */
+    int in_norm;            /* 1: taps read (x-0.45)/0.225 (resnet_encoder.py:94), padding stays 0 */
+} fd_conv_desc;
+
+/* y [N,Cout,Ho,Wo] = act(conv(x, w) + bias);  bias may be NULL. */
+int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* stream);
+/* gx [N,Cin,H,W] = d/dx of sum(conv(x,w) * gy)  (gy is the gradient w.r.t. the PRE-activation output;
+ * apply fd_act_bwd first when act != 0).  ws: fd_conv2d_bwd_data_ws_floats(d) floats. */
+long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d);
+int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* ws, void* stream);
+/* gw [Cout,Cin,KH,KW], gbias [Cout] (NULL to skip).  ws: fd_conv2d_bwd_weight_ws_floats(d) floats (may be 0). */
+long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d);
+int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* gbias, float* ws,
+                         void* stream);
+
+/* gpre = gy * act'(y)  where y is the activation OUTPUT (1 ReLU, 2 ELU(alpha=1), 3 sigmoid, 4 tanh). */
+int fd_act_bwd(const float* y, const float* gy, float* gpre, long n, int act, void* stream);
+
+/* nn.BatchNorm2d in training mode (torchvision ResNet; trainer.py:207-211 set_train), optionally fused with the
+ * residual add and ReLU of a BasicBlock/Bottleneck tail:  y = relu?( bn(x) + residual? ).
+ * save_mean / save_invstd [C] are written for the backward; running_mean / running_var are updated in place
+ * with `momentum` (unbiased variance), as torch does.  ws: fd_bn_ws_floats(N,C,H,W). */
+long fd_bn_ws_floats(int N, int C, int H, int W);
+int fd_bn_train_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                    float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws, int N, int C,
+                    int H, int W, float eps, float momentum, int relu, void* stream);
+/* eval-mode BN (running statistics), same fusion options. */
+int fd_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                   const float* running_mean, const float* running_var, int N, int C, int H, int W, float eps, int relu,
+                   void* stream);
+/* Backward of the fused op.  y = forward output (for the ReLU mask when relu=1).  gx, gweight, gbias are
+ * written; g_residual (if non-NULL) receives the masked upstream gradient (the residual branch's gradient). */
+int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float* weight, const float* save_mean,
+                    const float* save_invstd, float* gx, float* gweight, float* gbias, float* g_residual, float* ws, int N,
+                    int C, int H, int W, int relu, void* stream);
+
+/* nn.MaxPool2d(3, stride 2, padding 1) (resnet_encoder.py:98).  idx [N,C,Ho,Wo] u8 = argmax tap (0..8). */
+int fd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream);
+int fd_maxpool3x3s2_bwd(const float* gy, const uint8_t* idx, float* gx, int N, int C, int H, int W, void* stream);
+
+/* Decoder input assembly (networks/depth_decoder.py:75-83): out = cat([nearest_up2(a), s1 (+ s2), s3], dim=1).
+ * a [N,Ca,h,w] -> channels [0,Ca) at (2h,2w); s1,s2 [N,Cs,2h,2w] (s2 optional addend: beam-feature fusion
+ * depth_decoder.py:78); s3 [N,C3,2h,2w] optional (refiner depth_maps, :81-82).  Any of s1/s3 may be NULL. */
+int fd_upcat_fwd(const float* a, const float* s1, const float* s2, const float* s3, float* out, int N, int Ca, int Cs,
+                 int C3, int h, int w, void* stream);
+/* ga [N,Ca,h,w] (2x2 sums), gs [N,Cs,2h,2w] (shared by s1 and s2), g3 [N,C3,2h,2w]; each may be NULL. */
+int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, int N, int Ca, int Cs, int C3, int h, int w,
+                 void* stream);
+/* layers.py:229-232 upsample (nearest x2) alone */
+int fd_upsample2x_fwd(const float* x, float* y, long planes, int h, int w, void* stream);
+int fd_upsample2x_bwd(const float* gy, float* gx, long planes, int h, int w, void* stream);
+
+/* out = a + b (feature fusion depth_decoder.py:70, pose_decoder.py:31) ; out = alpha*a + beta*b */
+int fd_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream);
+
+/* pose_decoder.py:44-46: out[n][c] = scale * mean over (H,W) of x[n][c]; and its adjoint. */
+int fd_spatial_mean_fwd(const float* x, float* out, long planes, long plane_size, float scale, void* stream);
+int fd_spatial_mean_bwd(const float* gout, float* gx, long planes, long plane_size, float scale, void* stream);
+
+/* layers.py:284-302 compute_depth_errors on n matched (gt, pred) values: out[7] =
+ * abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3.  ws: 7*256 floats. */
+int fd_depth_errors(const float* gt, const float* pred, long n, float* out, float* ws, void* stream);
+
+/* ------------------------------------------------------------------ optimiser ------------------ */
+
+/* torch.optim.Adam step (trainer.py:129,247) over a flat parameter segment:
+ *   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g*g ; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+ * with step_size = lr/bc1, bc1 = 1-b1^t, bc2 = 1-b2^t computed by the caller.  grad_scale multiplies g first
+ * (1/world_size averaging for data parallel).  */
+int fd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
+                 float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+
 /* ------------------------------------------------------------------ sparse LiDAR --------------- */
 
 /* gen2channel.py:60-117 get_4beam_2channel, gather formulation (race-free, bit-exact vs the

@@ -65,4 +65,25 @@ def check_grad_compact(gold, key, actual, rtol=1e-4, atol=1e-6):
     scale = float(gold[key + "@l2"])
     assert_close(a.reshape(-1)[::97], gold[key + "@s97"], rtol, atol + 1e-6 * scale, key + "@s97")
     assert abs(np.sqrt((a.astype(np.float64) ** 2).sum()) - scale) <= 1e-4 * scale + 1e-7, key + "@l2"
-    assert abs(a.astype(np.float64).sum() - float(gold[key + "@sum"])) <= 1e-4 * scale + 1e-6, key + "@sum"
+    want_sum = float(gold[key + "@sum"])
+    assert abs(a.astype(np.float64).sum() - want_sum) <= 1e-4 * (scale + abs(want_sum)) + 1e-6, key + "@sum"
+
+
+def assert_mostly_close(actual, expected, rtol, atol, what="", max_bad_frac=1e-2, agg_rtol=1e-3):
+    """Per-element tolerance for all but a tiny fraction of elements, plus an aggregate (L1) bound.
+
+    Used for gradient maps of the photometric loss: a pixel whose argmin / clamp / |.| branch sits
+    within float rounding of a tie legitimately takes the other branch on a different summation
+    order, which changes the gradient at that pixel (and its 3x3 neighbours) by O(1) relative."""
+    a = np.asarray(actual, dtype=np.float64)
+    e = np.asarray(expected, dtype=np.float64)
+    assert a.shape == e.shape, "%s: shape %s vs %s" % (what, a.shape, e.shape)
+    err = np.abs(a - e)
+    bad = err > atol + rtol * np.abs(e)
+    frac = bad.mean()
+    agg = err.sum() / max(np.abs(e).sum(), 1e-30)
+    if frac > max_bad_frac or agg > agg_rtol:
+        i = np.unravel_index(np.argmax(err), err.shape)
+        raise AssertionError("%s: %.4f%% of elements out of tolerance (allowed %.4f%%), aggregate rel-L1 %.3g "
+                             "(allowed %.3g); worst at %s: got %.9g want %.9g"
+                             % (what, 100 * frac, 100 * max_bad_frac, agg, agg_rtol, i, a[i], e[i]))

@@ -1,0 +1,353 @@
+"""GPU parity tests for the network stack: MFMA implicit-GEMM conv (fwd / dgrad / wgrad), fused BatchNorm,
+max-pool, decoder input assembly, Adam, and the HIP-backed ``networks`` modules against the CPU oracle
+and the reference-generated golden vectors.  1e-4 relative (north star) unless noted."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import inputs as gin
+from conftest import assert_close, check_grad_compact
+from oracle import layers as OL
+from oracle import networks as ON
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def FD():
+    from fusiondepth_amd import functional
+    return functional
+
+
+@pytest.fixture(scope="module")
+def NW():
+    from fusiondepth_amd import networks
+    return networks
+
+
+def dev(t):
+    return t.detach().clone().cuda()
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def relclose(got, want, what, rtol=1e-4, arel=1e-4):
+    want = np.asarray(want)
+    assert_close(got, want, rtol=rtol, atol=arel * max(float(np.abs(want).max()), 1e-30), what=what)
+
+
+ACTS = {"none": lambda v: v, "relu": F.relu, "elu": F.elu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+
+CONV_CASES = [
+    # N, Cin, H, W, Cout, K, stride, pad, mode, act, bias, in_norm
+    (2, 3, 32, 48, 64, 7, 2, 3, "zero", "none", False, True),      # RGB stem
+    (2, 2, 32, 48, 64, 7, 2, 3, "zero", "none", False, True),      # beam stem
+    (1, 6, 30, 44, 64, 7, 2, 3, "zero", "none", False, True),      # pose-pair stem, odd output sizes
+    (2, 64, 16, 24, 64, 3, 1, 1, "zero", "none", False, False),    # layer1
+    (2, 64, 16, 24, 128, 3, 2, 1, "zero", "none", False, False),   # layer2.0.conv1
+    (2, 64, 16, 24, 128, 1, 2, 0, "zero", "none", False, False),   # downsample
+    (2, 64, 15, 23, 128, 3, 2, 1, "zero", "none", False, False),   # odd input, stride 2
+    (2, 64, 15, 23, 128, 1, 2, 0, "zero", "none", False, False),
+    (1, 256, 6, 20, 512, 3, 2, 1, "zero", "none", False, False),   # layer4.0.conv1 (full-size shape)
+    (2, 64, 8, 12, 256, 1, 1, 0, "zero", "none", False, False),    # bottleneck 1x1
+    (2, 512, 2, 3, 256, 3, 1, 1, "reflect", "elu", True, False),   # upconv(4,0) at 64x96 input
+    (2, 96, 16, 24, 32, 3, 1, 1, "reflect", "elu", True, False),   # upconv(1,1)
+    (1, 16, 64, 96, 16, 3, 1, 1, "reflect", "elu", True, False),   # upconv(0,1)
+    (2, 16, 33, 50, 1, 3, 1, 1, "reflect", "sigmoid", True, False),  # dispconv, ragged
+    (2, 22, 16, 24, 1, 3, 1, 1, "reflect", "tanh", True, False),   # refiner dispconv
+    (2, 5, 16, 24, 7, 3, 1, 1, "zero", "none", True, False),       # Conv3x3(use_refl=False)
+    (2, 512, 2, 3, 256, 1, 1, 0, "zero", "relu", True, False),     # pose squeeze
+    (2, 256, 2, 3, 256, 3, 1, 1, "zero", "relu", True, False),     # pose conv
+    (2, 256, 2, 3, 12, 1, 1, 0, "zero", "none", True, False),      # pose out
+    (2, 16, 20, 28, 32, 5, 2, 2, "zero", "relu", True, False),     # PoseCNN 5x5
+    (1, 64, 48, 160, 64, 3, 1, 1, "zero", "none", False, False),   # layer1 at full 192x640 resolution
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_conv2d_fwd_bwd(FD, case):
+    N, Cin, H, W, Cout, K, stride, pad, mode, act, has_bias, in_norm = case
+    import zlib
+    rng = np.random.RandomState(zlib.crc32(repr(case).encode()) % (2 ** 31))
+    x = torch.from_numpy(rng.rand(N, Cin, H, W).astype(np.float32) if in_norm else rng.randn(N, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rng.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32))
+    b = torch.from_numpy((0.1 * rng.randn(Cout)).astype(np.float32)) if has_bias else None
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bo = b.clone().requires_grad_(True) if has_bias else None
+    xin = (xo - 0.45) / 0.225 if in_norm else xo
+    if mode == "reflect":
+        yo = F.conv2d(F.pad(xin, (pad,) * 4, mode="reflect"), wo, bo, stride)
+    else:
+        yo = F.conv2d(xin, wo, bo, stride, pad)
+    yo = ACTS[act](yo)
+    cot = torch.from_numpy(rng.randn(*yo.shape).astype(np.float32))
+    want = torch.autograd.grad((yo * cot).sum(), [xo, wo] + ([bo] if has_bias else []))
+
+    xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+    bg = dev(b).requires_grad_(True) if has_bias else None
+    yg = FD.conv2d(xg, wg, bg, stride, pad, mode, act, in_norm)
+    got = torch.autograd.grad((yg * dev(cot)).sum(), [xg, wg] + ([bg] if has_bias else []))
+    relclose(cpu(yg), cpu(yo), "conv fwd")
+    relclose(cpu(got[0]), cpu(want[0]), "conv dgrad")
+    relclose(cpu(got[1]), cpu(want[1]), "conv wgrad")
+    if has_bias:
+        relclose(cpu(got[2]), cpu(want[2]), "conv bias grad")
+
+
+def test_conv_transpose_detecting(FD):
+    """A = I-style check with asymmetric data: a conv whose weight is a one-hot tap must shift/copy channels
+    exactly (catches row/col swaps in the MFMA fragment maps bit-exactly)."""
+    N, C, H, W = 1, 40, 9, 70
+    x = torch.arange(N * C * H * W, dtype=torch.float32).reshape(N, C, H, W).cuda() % 1013
+    w = torch.zeros(C, C, 3, 3)
+    for co in range(C):
+        w[co, (co * 7 + 3) % C, co % 3, (co // 3) % 3] = 1.0
+    y = FD.conv2d(x, w.cuda(), None, 1, 1, "zero", "none", False)
+    want = F.conv2d(x.cpu(), w, None, 1, 1)
+    assert torch.equal(y.cpu(), want)
+
+
+@pytest.mark.parametrize("N,C,H,W,res,relu", [(2, 64, 16, 24, False, True), (2, 64, 16, 24, True, True),
+                                              (6, 128, 3, 5, True, True), (2, 16, 33, 50, False, False),
+                                              (1, 64, 96, 320, False, True), (3, 512, 2, 3, True, True)])
+def test_batchnorm_train(FD, N, C, H, W, res, relu):
+    rng = np.random.RandomState(N * 1000 + C)
+    x = torch.from_numpy((rng.randn(N, C, H, W) * 2 + 3 * rng.randn(1, C, 1, 1)).astype(np.float32))
+    r = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32)) if res else None
+    bn_o = torch.nn.BatchNorm2d(C)
+    gin.fill_params(bn_o, 5)
+    bn_g = torch.nn.BatchNorm2d(C)
+    bn_g.load_state_dict(bn_o.state_dict())
+    bn_g.cuda()
+    xo = x.clone().requires_grad_(True)
+    ro = r.clone().requires_grad_(True) if res else None
+    yo = bn_o(xo)
+    if res:
+        yo = yo + ro
+    if relu:
+        yo = F.relu(yo)
+    cot = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32))
+    leaves_o = [xo, bn_o.weight, bn_o.bias] + ([ro] if res else [])
+    want = torch.autograd.grad((yo * cot).sum(), leaves_o)
+    xg = dev(x).requires_grad_(True)
+    rg = dev(r).requires_grad_(True) if res else None
+    yg = FD.batch_norm(xg, bn_g, residual=rg, relu=relu)
+    got = torch.autograd.grad((yg * dev(cot)).sum(), [xg, bn_g.weight, bn_g.bias] + ([rg] if res else []))
+    relclose(cpu(yg), cpu(yo), "bn fwd", arel=2e-5)
+    for a, b, nm in zip(got, want, ["gx", "gweight", "gbias", "gres"]):
+        relclose(cpu(a), cpu(b), "bn " + nm, rtol=2e-4, arel=2e-4)
+    relclose(cpu(bn_g.running_mean), cpu(bn_o.running_mean), "running_mean")
+    relclose(cpu(bn_g.running_var), cpu(bn_o.running_var), "running_var")
+    assert int(bn_g.num_batches_tracked) == int(bn_o.num_batches_tracked) == 1
+    bn_o.eval(), bn_g.eval()
+    with torch.no_grad():
+        ye_o = F.relu(bn_o(x)) if relu else bn_o(x)
+        ye_g = FD.batch_norm(dev(x), bn_g, relu=relu)
+    relclose(cpu(ye_g), cpu(ye_o), "bn eval fwd", arel=2e-5)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 8, 16, 24), (1, 3, 15, 23), (1, 64, 96, 320), (2, 2, 1, 1), (1, 1, 2, 5)])
+def test_maxpool(FD, N, C, H, W):
+    rng = np.random.RandomState(H * W)
+    x = torch.from_numpy(np.maximum(rng.randn(N, C, H, W), 0).astype(np.float32))   # ReLU-like: many exact ties at 0
+    xo = x.clone().requires_grad_(True)
+    yo = F.max_pool2d(xo, 3, 2, 1)
+    cot = torch.from_numpy(rng.randn(*yo.shape).astype(np.float32))
+    want = torch.autograd.grad((yo * cot).sum(), xo)[0]
+    xg = dev(x).requires_grad_(True)
+    yg = FD.max_pool3x3s2(xg)
+    got = torch.autograd.grad((yg * dev(cot)).sum(), xg)[0]
+    assert torch.equal(yg.cpu(), yo.detach()), "max-pool forward must be exact"
+    relclose(cpu(got), cpu(want), "max-pool backward (tie routing = first max)", rtol=1e-6, arel=1e-6)
+
+
+def test_upcat_upsample_add_mean(FD):
+    rng = np.random.RandomState(4)
+    N, Ca, Cs, C3, h, w = 2, 5, 7, 6, 6, 9
+    mk = lambda *s: torch.from_numpy(rng.randn(*s).astype(np.float32))
+    a, s1, s2, s3 = mk(N, Ca, h, w), mk(N, Cs, 2 * h, 2 * w), mk(N, Cs, 2 * h, 2 * w), mk(N, C3, 2 * h, 2 * w)
+    for use in [(True, True, True), (True, False, False), (False, False, False), (True, True, False), (True, False, True)]:
+        ts_o = [t.clone().requires_grad_(True) for t in (a, s1, s2, s3)]
+        parts = [OL.upsample(ts_o[0])]
+        if use[0]:
+            parts.append(ts_o[1] + ts_o[2] if use[1] else ts_o[1])
+        if use[2]:
+            parts.append(ts_o[3])
+        yo = torch.cat(parts, 1)
+        cot = mk(*yo.shape)
+        leaves = [ts_o[0]] + ([ts_o[1]] if use[0] else []) + ([ts_o[2]] if use[1] else []) + ([ts_o[3]] if use[2] else [])
+        want = torch.autograd.grad((yo * cot).sum(), leaves)
+        ts_g = [dev(t).requires_grad_(True) for t in (a, s1, s2, s3)]
+        yg = FD.upsample_concat(ts_g[0], ts_g[1] if use[0] else None, ts_g[2] if use[1] else None, ts_g[3] if use[2] else None)
+        lg = [ts_g[0]] + ([ts_g[1]] if use[0] else []) + ([ts_g[2]] if use[1] else []) + ([ts_g[3]] if use[2] else [])
+        got = torch.autograd.grad((yg * dev(cot)).sum(), lg)
+        assert torch.equal(yg.cpu(), yo.detach()), "upcat fwd %s" % (use,)
+        for g1, g2 in zip(got, want):
+            relclose(cpu(g1), cpu(g2), "upcat bwd %s" % (use,), rtol=1e-6, arel=1e-6)
+    xg = dev(a).requires_grad_(True)
+    assert torch.equal(FD.upsample_nearest2x(xg).cpu(), OL.upsample(a))
+    assert torch.equal(FD.add(dev(s1), dev(s2)).cpu(), s1 + s2)
+    x = mk(3, 12, 6, 20)
+    xo = x.clone().requires_grad_(True)
+    mo = 0.01 * xo.mean(3).mean(2)
+    cot = mk(3, 12)
+    want = torch.autograd.grad((mo * cot).sum(), xo)[0]
+    xg = dev(x).requires_grad_(True)
+    mg = FD.spatial_mean(xg, 0.01)
+    got = torch.autograd.grad((mg * dev(cot)).sum(), xg)[0]
+    relclose(cpu(mg), cpu(mo), "spatial mean", rtol=1e-5, arel=1e-6)
+    relclose(cpu(got), cpu(want), "spatial mean bwd", rtol=1e-6, arel=1e-6)
+
+
+def test_depth_errors_and_adam(FD, golden):
+    g = golden("layers_b2_32x64")
+    errs = FD.depth_errors(torch.from_numpy(g["errs_gt"]).cuda(), torch.from_numpy(g["errs_pred"]).cuda())
+    assert_close([float(e) for e in errs], g["errs"], rtol=1e-5, atol=0, what="compute_depth_errors vs reference")
+    rng = np.random.RandomState(8)
+    p0 = torch.from_numpy(rng.randn(10007).astype(np.float32))
+    po = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([po], 1.5e-4)
+    pg, m, v = dev(p0), torch.zeros(10007).cuda(), torch.zeros(10007).cuda()
+    for step in range(1, 6):
+        grad = torch.from_numpy(rng.randn(10007).astype(np.float32))
+        po.grad = grad.clone()
+        opt.step()
+        FD.adam_step(pg, dev(grad), m, v, step, 1.5e-4)
+    assert_close(cpu(pg), cpu(po), rtol=1e-6, atol=1e-7, what="Adam after 5 steps")
+
+
+# ------------------------------------------------------------------------------------------------ networks
+def _same_weights(mod_g, mod_o, seed):
+    gin.fill_params(mod_o, seed)
+    mod_g.load_state_dict(mod_o.state_dict())
+    return mod_g.cuda()
+
+
+@pytest.mark.parametrize("layers,kw,cin,B,H,W", [(18, {}, 3, 2, 64, 96), (18, dict(beam_encoder=True), 2, 2, 64, 96),
+                                                 (18, dict(num_input_images=2), 6, 2, 64, 96),
+                                                 (18, dict(num_input_images=2, beam_encoder=True), 4, 3, 32, 64),
+                                                 (18, {}, 3, 2, 128, 192), (50, {}, 3, 2, 128, 192)])
+def test_resnet_encoder_fwd_bwd_vs_oracle(NW, layers, kw, cin, B, H, W):
+    """Train-mode BatchNorm over a handful of samples (layer4 sees B*2*3 values per channel here) amplifies fp32
+    rounding, so the fp32 CPU oracle itself is only accurate to ~1e-3 on the deepest gradients.  Ground truth
+    is therefore the oracle run in float64; the HIP result must be within 1e-4 relative, or within 5x the
+    fp32 oracle's own error (ATen's CPU BatchNorm accumulates in double, ours in fp32), whichever is larger."""
+    enc_o = ON.ResnetEncoder(layers, False, **kw)
+    enc_g = _same_weights(NW.ResnetEncoder(layers, False, **kw), enc_o, 21)
+    import copy
+    enc_d = copy.deepcopy(enc_o).double()
+    enc_o.train(), enc_g.train(), enc_d.train()
+    rng = np.random.RandomState(17)
+    x = torch.from_numpy(rng.rand(B, cin, H, W).astype(np.float32))
+    fo, fd_, fg = enc_o(x), enc_d(x.double()), enc_g(dev(x))
+    cots = [torch.from_numpy(rng.randn(*f.shape).astype(np.float32)) for f in fo]
+
+    def agg(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return np.abs(a - b).sum() / max(np.abs(b).sum(), 1e-30)
+
+    report, bad = [], []
+    for i in range(5):
+        e_hip, e_cpu = agg(cpu(fg[i]), cpu(fd_[i])), agg(cpu(fo[i]), cpu(fd_[i]))
+        report.append(("feature%d" % i, e_hip, e_cpu))
+    keep = lambda m: [(n, p) for n, p in m.named_parameters() if ".fc." not in n]
+    names = [n for n, _ in keep(enc_o)]
+    want32 = torch.autograd.grad(sum((f * c).sum() for f, c in zip(fo, cots)), [p for _, p in keep(enc_o)])
+    want64 = torch.autograd.grad(sum((f * c.double()).sum() for f, c in zip(fd_, cots)), [p for _, p in keep(enc_d)])
+    got = torch.autograd.grad(sum((f * dev(c)).sum() for f, c in zip(fg, cots)), [p for _, p in keep(enc_g)])
+    for n, a, b32, b64 in zip(names, got, want32, want64):
+        report.append((n, agg(cpu(a), cpu(b64)), agg(cpu(b32), cpu(b64))))
+    for n, e_hip, e_cpu in report:
+        if e_hip > max(1e-4, 5 * e_cpu):
+            bad.append("%s: HIP err %.3g vs fp32-oracle err %.3g" % (n, e_hip, e_cpu))
+    worst = max(report, key=lambda r: r[1])
+    print("worst: %s HIP %.3g (fp32 CPU oracle %.3g)" % worst)
+    assert not bad, "\n".join(bad[:20])
+    sd_o, sd_g = enc_d.state_dict(), enc_g.state_dict()
+    for k in sd_o:
+        if "running" in k:
+            relclose(cpu(sd_g[k]), cpu(sd_o[k]), k, rtol=2e-4, arel=2e-4)
+
+
+def test_depth_and_pose_decoders_vs_reference_golden(NW, golden):
+    g = golden("decoders_b2_64x96")
+    B, H, W = 2, 64, 96
+    rng = np.random.RandomState(202)
+    ch = np.array([64, 64, 128, 256, 512])
+    feats, beams = gin.feature_pyramids(rng, B, H, W, ch)
+    fg = [dev(t).requires_grad_(True) for t in feats]
+    bg = [dev(t).requires_grad_(True) for t in beams]
+    dec = gin.fill_params(NW.DepthDecoder(ch), 11).cuda()
+    o = dec(fg, beam_features=bg)
+    for s in range(4):
+        relclose(cpu(o[("disp", s)]), g["dec_disp%d" % s], "disp%d vs reference" % s)
+    loss = sum((o[("disp", s)] * torch.from_numpy(g["dec_cot%d" % s]).cuda()).sum() for s in range(4))
+    grads = torch.autograd.grad(loss, fg + bg + list(dec.parameters()))
+    for i in range(5):
+        check_grad_compact(g, "dec_gfeat%d" % i, cpu(grads[i]), rtol=1e-3, atol=1e-4 * float(np.abs(cpu(grads[i])).max()))
+        check_grad_compact(g, "dec_gbeam%d" % i, cpu(grads[5 + i]), rtol=1e-3, atol=1e-4 * float(np.abs(cpu(grads[5 + i])).max()))
+    for (k, _), gv in zip(dec.named_parameters(), grads[10:]):
+        check_grad_compact(g, "dec_g/" + k.replace(".", "/"), cpu(gv), rtol=1e-3, atol=1e-4 * float(np.abs(cpu(gv)).max()))
+    o2 = dec([dev(t) for t in feats])
+    relclose(cpu(o2[("disp", 0)]), g["dec_nobeam_disp0"], "no-beam disp0 vs reference")
+
+    pose = gin.fill_params(NW.PoseDecoder(ch, num_input_features=1, num_frames_to_predict_for=2), 12).cuda()
+    f4, b4 = dev(feats[4]).requires_grad_(True), dev(beams[4]).requires_grad_(True)
+    aa, tr = pose([[None] * 4 + [f4]], beam_inputs=[[None] * 4 + [b4]])
+    relclose(cpu(aa), g["pose_aa"], "axisangle vs reference")
+    relclose(cpu(tr), g["pose_tr"], "translation vs reference")
+    gr = torch.autograd.grad((aa * torch.from_numpy(g["pose_cot_a"]).cuda()).sum() +
+                             (tr * torch.from_numpy(g["pose_cot_t"]).cuda()).sum(), [f4, b4] + list(pose.parameters()))
+    relclose(cpu(gr[0]), g["pose_gf4"], "pose g f4 vs reference", rtol=1e-3)
+    relclose(cpu(gr[1]), g["pose_gb4"], "pose g b4 vs reference", rtol=1e-3)
+    for (k, _), gv in zip(pose.named_parameters(), gr[2:]):
+        check_grad_compact(g, "pose_g/" + k.replace(".", "/"), cpu(gv), rtol=1e-3, atol=1e-4 * float(np.abs(cpu(gv)).max()))
+
+    pcnn = gin.fill_params(NW.PoseCNN(2), 13).cuda()
+    xin = torch.from_numpy(np.random.RandomState(213).rand(B, 6, H, W).astype(np.float32)).cuda()
+    a2, t2 = pcnn(xin)
+    relclose(cpu(a2), g["posecnn_aa"], "PoseCNN axisangle vs reference")
+    relclose(cpu(t2), g["posecnn_tr"], "PoseCNN translation vs reference")
+
+
+def test_refine_decoder_variant_vs_reference_golden(NW, golden):
+    g = golden("decoder_refine_b2_64x96")
+    B, H, W = 2, 64, 96
+    rng = np.random.RandomState(202)
+    ch = np.array([64, 64, 128, 256, 512])
+    feats, beams = gin.feature_pyramids(rng, B, H, W, ch)
+    dec2 = gin.fill_params(NW.DepthDecoder(ch, road=True, catxy=True, deep=True), 14).cuda()
+    rng2 = np.random.RandomState(214)
+    dm = {("disp", s): torch.from_numpy(rng2.rand(B, 6, H // 2 ** s, W // 2 ** s).astype(np.float32)).cuda() for s in range(4)}
+    o = dec2([dev(t) for t in feats], beam_features=[dev(t) for t in beams], depth_maps=dm, tanh=True)
+    for s in range(4):
+        relclose(cpu(o[("disp", s)]), g["disp%d" % s], "refine disp%d vs reference" % s)
+
+
+def test_layers_module_api(golden):
+    """Drop-in ``layers`` classes keep the reference's constructor/forward signatures."""
+    from fusiondepth_amd import layers as L
+    g = golden("layers_b2_32x64")
+    B, H, W = 2, 32, 64
+    inp, rng = gin.batch_inputs(101, B, H, W)
+    depth = torch.from_numpy(g["d2d_depth"]).cuda()
+    pts = L.BackprojectDepth(B, H, W)(depth, dev(inp[("inv_K", 0)]))
+    grid = L.Project3D(B, H, W)(pts, dev(inp[("K", 0)]), torch.from_numpy(g["pj_T"]).cuda())
+    relclose(cpu(grid), g["pj_grid"], "layers.Project3D")
+    cb = L.ConvBlock(5, 7).cuda()
+    with torch.no_grad():
+        cb.conv.conv.weight.copy_(torch.from_numpy(g["cb_w"]))
+        cb.conv.conv.bias.copy_(torch.from_numpy(g["cb_b"]))
+    relclose(cpu(cb(torch.from_numpy(g["cb_x"]).cuda())), g["cb_y"], "layers.ConvBlock vs reference")
+    c3 = L.Conv3x3(5, 1, use_refl=False).cuda()
+    with torch.no_grad():
+        c3.conv.weight.copy_(torch.from_numpy(g["c3_w"]))
+        c3.conv.bias.copy_(torch.from_numpy(g["c3_b"]))
+    relclose(cpu(c3(torch.from_numpy(g["cb_x"]).cuda())), g["c3_y"], "layers.Conv3x3(zero pad) vs reference")
+    relclose(cpu(L.upsample(torch.from_numpy(g["cb_x"]).cuda())), g["up_y"], "layers.upsample")
+    relclose(cpu(L.SSIM()(dev(inp[("color", 0, 0)]), dev(inp[("color", 1, 0)]))), g["ssim"], "layers.SSIM", arel=2e-5)
+    relclose(cpu(L.Cat_xy(B, H, W)(depth, dev(inp[("inv_K", 0)]))), g["catxy"], "layers.Cat_xy")
+    assert list(cb.state_dict().keys()) == ["conv.conv.weight", "conv.conv.bias"]
