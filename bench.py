@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Benchmark of the FusionDepth training hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+    python bench.py --gpus N --steps K --warmup W          # N>1: launched by torch.distributed.run, one rank per GPU
+
+One "step" = one optimiser step of the reference trainer at --batch_size 12 (ResNet-18, 640x192, 4-beam):
+trainer.py:28-41 turns that into 2 accumulated micro-batches of 6 images per process, then Adam.  Inputs are synthetic
+KITTI-shaped tensors already resident in HBM; everything inside the timed region is the real work: 6 ResNet passes,
+decoder, pose decoder, fused photometric/LiDAR loss at 4 scales, full backward, gradient all-reduce (N>1), Adam.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# analytic forward MACs per image of the conv stack, R18 / R50 at 640x192
+CONV_GFLOP_FWD_BWD = {(18, 192, 640): 187.3, (50, 192, 640): 406.1, (18, 320, 1024): 499.4, (50, 320, 1024): 1083.0}
+LOSS_BYTES_PER_PIXEL = 343.7          # compulsory fwd+bwd HBM traffic of the fused loss path per image
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--num_layers", type=int, default=18)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--batch_size", type=int, default=12, help="per-process --batch_size of the reference trainer")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters):
+    """Average duration of fn() measured with HIP events on the stream the kernels are launched on."""
+    fn()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / iters
+
+
+def roofline_probes(args, tr, batch):
+    """Live per-kernel measurements: the dominant MFMA conv shape and the fused loss kernels."""
+    from fusiondepth_amd import functional as FD
+    out = {}
+    B = tr.batch_size
+    # dominant kernel: layer1 3x3 64->64 convs at H/4 x W/4 (16 of the 26 GMAC-heaviest launches per ResNet-18 pass)
+    h4, w4 = args.height // 4, args.width // 4
+    x = torch.randn(B, 64, h4, w4, device="cuda")
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+    with torch.no_grad():
+        ms = event_time_ms(lambda: FD.conv2d(x, w, None, 1, 1), 50)
+    flops = 2.0 * B * h4 * w4 * 64 * 64 * 9
+    out["roofline"] = {"bound": "mfma", "kernel": "k_gather_gemm<3,3> (layer1 conv 64->64 @%dx%d, B=%d)" % (h4, w4, B),
+                       "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "ms_per_launch": ms}
+    # fused loss path (HBM-bound): forward + backward kernels of the four scales
+    H, W = args.height, args.width
+    po = FD.PhotoOptions()
+    tgt = batch[("color", 0, 0)]
+    srcs = [batch[("color", -1, 0)], batch[("color", 1, 0)]]
+    ident = tr.identity_losses(batch, 0)
+    I = torch.eye(4, device="cuda").repeat(B, 1, 1)
+    I[:, 0, 3] = 0.05
+    disps = [torch.rand(B, 1, H >> s, W >> s, device="cuda").mul_(0.1).add_(0.02).requires_grad_(True) for s in range(4)]
+    noise = torch.randn(B, 2, H, W, device="cuda")
+
+    def loss_fwd_bwd():
+        tot = 0
+        for s in range(4):
+            photo, si = FD.photo_loss(disps[s], [I, I], batch[("K", 0)], batch[("inv_K", 0)], srcs, tgt, ident, noise,
+                                      batch["4beam"], po)[:2]
+            tot = tot + photo + si
+        tot.backward()
+    ms = event_time_ms(loss_fwd_bwd, 20)
+    byts = LOSS_BYTES_PER_PIXEL * H * W * B
+    out["roofline_loss_path"] = {"bound": "hbm", "kernel": "k_photo_fwd + k_photo_bwd x 4 scales (+finalize/adjoint)",
+                                 "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "ms_per_launch": ms}
+    return out
+
+
+def cpu_baseline(args):
+    """Reference-equivalent CPU step (oracle = the restatement proven equal to the imported reference), bounded sample:
+    BASELINE.json configs[0]: ResNet-18, 640x192, batch 2, fp32, all host cores."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import inputs as gin
+    from oracle import trainer as OT
+    from oracle import scatter as OS
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B, H, W = 2, args.height, args.width
+    opt = OT.default_opt(height=H, width=W, batch_size=B, num_layers=args.num_layers)
+    ot = OT.OracleTrainer(opt, seed=0)
+    inp, rng = gin.batch_inputs(7, B, H, W)
+    two = np.stack([np.stack(OS.scatter_2channel_c(inp["4beam"][b, 0].numpy(), (max(int(round(76 * H / 192)), 2), min(int(round(190 * H / 192)), H - 2), 2, W - 2))) for b in range(B)])
+    for f in (0, -1, 1):
+        inp[("2channel", f, 0)] = torch.from_numpy(two)
+    inp["2channel"] = torch.from_numpy(two)
+    times = []
+    for i in range(4):          # 1 warm-up + 3 timed steps (~15-25 s of CPU work)
+        t0 = time.time()
+        ot.micro_step({k: v.clone() for k, v in inp.items()})
+        times.append(time.time() - t0)
+    step = float(np.median(times[1:]))
+    return {"value": B / step, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "3 timed optimiser steps (after 1 warm-up) of the oracle trainer, ResNet-%d %dx%d batch %d fp32, "
+                      "torch CPU %d threads; median %.2f s/step" % (args.num_layers, W, H, B, cores, step)}
+
+
+def main():
+    args = parse()
+    from fusiondepth_amd import dp, synthetic
+    from fusiondepth_amd.options import MonodepthOptions
+    from fusiondepth_amd.trainer import Trainer
+    rank, world, local_rank = dp.init_from_env()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    opt = MonodepthOptions().parse(["--num_layers", str(args.num_layers), "--weights_init", "scratch", "--batch_size",
+                                    str(args.batch_size), "--height", str(args.height), "--width", str(args.width)])
+    tr = Trainer(opt, rank=rank, world_size=world, verbose=(rank == 0))
+    mbs = [synthetic.make_batch(tr.batch_size, args.height, args.width, seed=1234 + 17 * rank + i)
+           for i in range(tr.accumulate_step)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step(mbs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = tr.train_step(mbs)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    images = args.steps * opt.batch_size * world
+    loss_val = float(losses["loss"])
+    result = {
+        "metric": "training images/sec (640x192, ResNet-18, 4-beam)", "value": images / dt, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ResNet-%d encoders + DepthDecoder + PoseDecoder, %dx%d, 4-beam LiDAR, --batch_size %d per GPU "
+                               "(= %d accumulated micro-batches of %d), frames [0,-1,1], 4 scales, fwd+bwd+Adam"
+                               % (args.num_layers, args.width, args.height, opt.batch_size, tr.accumulate_step, tr.batch_size),
+                   "global_batch": opt.batch_size * world, "parallelism": "dp%d" % world},
+        "final_loss": loss_val,
+    }
+    key = (args.num_layers, args.height, args.width)
+    if key in CONV_GFLOP_FWD_BWD:
+        tf = CONV_GFLOP_FWD_BWD[key] * 1e9 * (images / world) / dt / 1e12
+        result["step_mfma_frac"] = tf / PEAK_FP32_MFMA_TFLOPS
+        result["step_conv_tflops_per_gpu"] = tf
+    if rank == 0 and not args.no_roofline:
+        result.update(roofline_probes(args, tr, mbs[0]))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -259,7 +259,7 @@ def scatter_2channel(beam, roi=(76, 190, 2, 638), expand=2):
 
 def scaled_roi(H, W):
     """ROI of gen2channel.py:64-65 (rows 76..189, cols 2..637 of 192x640) scaled to another size."""
-    return (int(round(76 * H / 192)), int(round(190 * H / 192)), 2, W - 2)
+    return (max(int(round(76 * H / 192)), 2), min(int(round(190 * H / 192)), H - 2), 2, W - 2)
 
 
 # ------------------------------------------------------------------------------------ fused loss --

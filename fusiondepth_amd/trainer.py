@@ -1,0 +1,387 @@
+"""MI355X-native ``Trainer`` — same class/method surface as the reference ``trainer.py`` (Trainer.__init__,
+set_train/set_eval, process_batch, predict_poses, generate_images_pred, compute_reprojection_loss,
+compute_losses, compute_depth_losses, save_model/load_model), driven by ``options.MonodepthOptions``.
+
+What differs, by design:
+  * every op is a libfdhip kernel; per pyramid scale, generate_images_pred + the photometric/SI part of
+    compute_losses are ONE fused kernel (csrc/photometric.hip) — the reference's ("depth",0,s), ("sample",f,s),
+    ("color",f,s) tensors are only materialised when ``materialize_outputs`` is set (logging / tests);
+  * all trainable tensors live in one flat buffer: Adam is one fused launch, and data-parallel training
+    (one process per GPU, RCCL all-reduce over xGMI, see dp.py) is added — the reference is single-GPU;
+  * the data loader / wandb / tensorboard shell of the reference is out of scope (SURVEY.md §2 rows 11,12):
+    batches are dicts with the reference's schema, e.g. from ``synthetic.make_batch``.
+Reference lines are cited per method.
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dp
+from . import functional as FD
+from . import networks
+from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transformation_from_parameters
+
+MODEL_ORDER = ["encoder", "beam_encoder", "beam_encoder_pose", "depth", "pose_encoder", "pose", "predictive_mask"]
+
+
+def derived_hparams(opt, vram_gib):
+    """trainer.py:28-41: epochs, accumulate_step, lr, StepLR step and micro-batch derived from --batch_size."""
+    accumulate = 2 if vram_gib < 15 else 1
+    if opt.batch_size > 8:
+        accumulate *= 2
+    return dict(num_epochs=(8 * 17) // opt.batch_size, accumulate_step=accumulate,
+                learning_rate=opt.learning_rate * (opt.batch_size / 8),
+                scheduler_step_size=int(opt.scheduler_step_size * (8 / opt.batch_size)),
+                micro_batch=int(opt.batch_size / accumulate))
+
+
+class Trainer:
+    def __init__(self, options, device=None, rank=0, world_size=1, materialize_outputs=False, verbose=True):
+        self.opt = options
+        if self.opt.no_cuda or not torch.cuda.is_available():
+            raise RuntimeError("fusiondepth_amd.Trainer needs an MI355X: there is no CPU path (use oracle/ for CPU checks)")
+        self.device = torch.device(device if device is not None else "cuda")
+        self.rank, self.world_size = rank, world_size
+        self.materialize_outputs = materialize_outputs
+
+        vram = torch.cuda.get_device_properties(self.device).total_memory / 1024 ** 3      # trainer.py:30-35
+        hp = derived_hparams(self.opt, vram)
+        self.opt.num_epochs = hp["num_epochs"]                                                # trainer.py:28
+        self.accumulate_step = hp["accumulate_step"]
+        self.learning_rate = hp["learning_rate"]
+        self.scheduler_step_size = hp["scheduler_step_size"]
+        self.batch_size = hp["micro_batch"]                                                   # per-process micro-batch
+        self.log_path = os.path.join(self.opt.log_dir, self.opt.model_name)
+
+        assert self.opt.height % 32 == 0, "'height' must be a multiple of 32"                 # trainer.py:47-48
+        assert self.opt.width % 32 == 0, "'width' must be a multiple of 32"
+        assert self.opt.frame_ids[0] == 0, "frame_ids must start with 0"
+        if self.opt.use_stereo or self.opt.predictive_mask or self.opt.pose_model_type == "shared":
+            raise NotImplementedError("stereo / predictive_mask / shared pose encoder are ablations outside the hot path "
+                                      "(SURVEY.md §8); supported: separate_resnet and posecnn pose nets")
+        if self.opt.v1_multiscale and self.opt.trainer_siloss == "true":
+            raise NotImplementedError("--v1_multiscale together with the LiDAR SI loss is not supported by the fused kernel "
+                                      "(the SI term is evaluated at the sampling resolution); pass --trainer_siloss false")
+        self.num_scales = len(self.opt.scales)
+        self.num_input_frames = len(self.opt.frame_ids)
+        self.num_pose_frames = 2 if self.opt.pose_model_input == "pairs" else self.num_input_frames
+        self.use_pose_net = True
+
+        # ---- networks (trainer.py:66-127) --------------------------------------------------------------
+        pre = self.opt.weights_init == "pretrained"
+        m = {}
+        m["encoder"] = networks.ResnetEncoder(self.opt.num_layers, pre, cat4beam_to_color=self.opt.cat_4beam_to_color,
+                                              cat2channel=self.opt.cat2start)
+        if self.opt.beam_encoder:
+            m["beam_encoder"] = networks.ResnetEncoder(self.opt.num_layers, pre, beam_encoder=True)
+            m["beam_encoder_pose"] = networks.ResnetEncoder(self.opt.num_layers, pre, num_input_images=self.num_pose_frames,
+                                                            beam_encoder=True)
+        m["depth"] = networks.DepthDecoder(m["encoder"].num_ch_enc, self.opt.scales, cat2end=self.opt.cat2end)
+        if self.opt.pose_model_type == "separate_resnet":
+            m["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, pre, num_input_images=self.num_pose_frames)
+            m["pose"] = networks.PoseDecoder(m["pose_encoder"].num_ch_enc, num_input_features=1, num_frames_to_predict_for=2)
+        elif self.opt.pose_model_type == "posecnn":
+            m["pose"] = networks.PoseCNN(self.num_input_frames if self.opt.pose_model_input == "all" else 2)
+        self.models = {k: m[k].to(self.device) for k in MODEL_ORDER if k in m}
+        dp.broadcast_module_state(self.models.values())
+        self.parameters_to_train = []
+        for k in self.models:
+            self.parameters_to_train += list(self.models[k].parameters())
+
+        # ---- optimiser (trainer.py:129-131): Adam + StepLR(gamma 0.1), on one flat buffer ----------------
+        self.flat = dp.FlatParameters(self.parameters_to_train)
+        self.exp_avg = torch.zeros_like(self.flat.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
+        self.adam_step_count = 0
+        self.lr = self.learning_rate
+        self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)
+        if self.opt.train_load_weights_folder is not None:
+            self.load_model()
+
+        # API-parity members (trainer.py:180-194); the fused kernel does not need baked pixel grids
+        if not self.opt.no_ssim:
+            self.ssim = SSIM()
+        self.backproject_depth, self.project_3d = {}, {}
+        for scale in self.opt.scales:
+            h, w = self.opt.height // (2 ** scale), self.opt.width // (2 ** scale)
+            self.backproject_depth[scale] = BackprojectDepth(self.batch_size, h, w)
+            self.project_3d[scale] = Project3D(self.batch_size, h, w)
+        self.photo_options = FD.PhotoOptions(self.opt.min_depth, self.opt.max_depth, self.opt.no_ssim,
+                                             self.opt.avg_reprojection, self.opt.gdc_loss_threshold, self.opt.si_var)
+        self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
+        self.epoch, self.step, self.batch_idx = 0, 0, 0
+        self.best = 10.0
+        self.start_time = time.time()
+        self.set_train()
+        self.flat.zero_grad()
+        if verbose and rank == 0:
+            n = sum(p.numel() for p in self.parameters_to_train)
+            print("fusiondepth_amd.Trainer: %d parameters (%.1f MB fp32), accumulating %d steps, single batch size = %d, "
+                  "lr %.3g, %d rank(s)" % (n, n * 4 / 1e6, self.accumulate_step, self.batch_size, self.lr, world_size))
+
+    # ------------------------------------------------------------------------------------------------
+    def set_train(self):
+        """trainer.py:207-211"""
+        for m in self.models.values():
+            m.train()
+
+    def set_eval(self):
+        """trainer.py:213-217"""
+        for m in self.models.values():
+            m.eval()
+
+    # ------------------------------------------------------------------------------------------------
+    def train_step(self, micro_batches):
+        """One optimiser step = ``accumulate_step`` micro-batches (trainer.py:237-248).  Returns the losses of the
+        last micro-batch (device tensors; nothing is synchronised here)."""
+        assert len(micro_batches) == self.accumulate_step
+        losses = None
+        for i, inputs in enumerate(micro_batches):
+            last = i == self.accumulate_step - 1
+            outputs, losses = self.process_batch(inputs)
+            loss = losses["loss"] / self.accumulate_step
+            if last:
+                self.grad_sync.arm()
+            loss.backward()
+            self.batch_idx += 1
+        scale = self.grad_sync.finish() if self.world_size > 1 else 1.0
+        self.optimizer_step(scale)
+        self.step += 1
+        return losses
+
+    def optimizer_step(self, grad_scale=1.0):
+        """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8).step(); zero_grad()  as one fused kernel."""
+        self.adam_step_count += 1
+        FD.adam_step(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
+                     self.lr, grad_scale=grad_scale)
+        self.flat.zero_grad()
+
+    def end_epoch(self):
+        """StepLR(step_size, 0.1).step()  (trainer.py:266)."""
+        self.epoch += 1
+        if self.scheduler_step_size > 0 and self.epoch % self.scheduler_step_size == 0:
+            self.lr *= 0.1
+
+    # ------------------------------------------------------------------------------------------------
+    def process_batch(self, inputs, val=False):
+        """trainer.py:268-319 (default separate-pose-encoder path)."""
+        for key, ipt in inputs.items():
+            if key != "date" and key != "path" and torch.is_tensor(ipt) and ipt.device != self.device:
+                inputs[key] = ipt.to(self.device)
+        if self.opt.cat_4beam_to_color:
+            features = self.models["encoder"](torch.cat((inputs["color_aug", 0, 0], inputs["4beam"]), 1))
+        elif self.opt.cat2start:
+            features = self.models["encoder"](torch.cat((inputs["color_aug", 0, 0], inputs["2channel"]), 1))
+        else:
+            features = self.models["encoder"](inputs["color_aug", 0, 0])
+        if self.opt.cat2end:
+            outputs = self.models["depth"](features, two_channel=inputs["2channel"])
+        elif self.opt.beam_encoder:
+            beam_features = self.models["beam_encoder"](inputs["2channel"])
+            outputs = self.models["depth"](features, beam_features=beam_features)
+        else:
+            outputs = self.models["depth"](features)
+        outputs = dict(outputs)
+        if self.use_pose_net and not val:
+            outputs.update(self.predict_poses(inputs, features))
+        losses = {}
+        if val:
+            self.generate_images_pred(inputs, outputs, [0])
+        else:
+            self.generate_images_pred(inputs, outputs, self.opt.frame_ids)
+            losses = self.compute_losses(inputs, outputs)
+        return outputs, losses
+
+    def predict_poses(self, inputs, features):
+        """trainer.py:321-388."""
+        outputs = {}
+        if self.num_pose_frames == 2:
+            for f_i in self.opt.frame_ids[1:]:
+                order = (f_i, 0) if f_i < 0 else (0, f_i)                     # temporal order (trainer.py:338-346)
+                pose_inputs = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
+                if self.opt.pose_model_type == "separate_resnet":
+                    pose_inputs = [self.models["pose_encoder"](pose_inputs)]
+                if self.opt.beam_encoder and self.opt.pose_model_type == "separate_resnet":
+                    beam = torch.cat([inputs["2channel", i, 0] for i in order], 1)
+                    beam_inputs = [self.models["beam_encoder_pose"](beam)]
+                    axisangle, translation = self.models["pose"](pose_inputs, beam_inputs=beam_inputs)
+                else:
+                    axisangle, translation = self.models["pose"](pose_inputs)
+                outputs[("axisangle", 0, f_i)] = axisangle
+                outputs[("translation", 0, f_i)] = translation
+                outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0],
+                                                                                invert=(f_i < 0))
+        else:
+            pose_inputs = torch.cat([inputs[("color_aug", i, 0)] for i in self.opt.frame_ids], 1)
+            if self.opt.pose_model_type == "separate_resnet":
+                pose_inputs = [self.models["pose_encoder"](pose_inputs)]
+            axisangle, translation = self.models["pose"](pose_inputs)
+            for i, f_i in enumerate(self.opt.frame_ids[1:]):
+                outputs[("axisangle", 0, f_i)] = axisangle
+                outputs[("translation", 0, f_i)] = translation
+                outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(axisangle[:, i], translation[:, i])
+        return outputs
+
+    # ------------------------------------------------------------------------------------------------
+    def identity_losses(self, inputs, source_scale=0):
+        """trainer.py:515-528: the identity reprojection losses do not depend on the pyramid scale when
+        source_scale == 0, so they are computed once per batch ([B,NF,H,W]) instead of once per scale."""
+        target = inputs[("color", 0, source_scale)]
+        fids = self.opt.frame_ids[1:]
+        B, _, H, W = target.shape
+        ident = torch.empty(B, len(fids), H, W, device=target.device)
+        for i, f in enumerate(fids):
+            FD.reprojection_loss_map(inputs[("color", f, source_scale)], target, not self.opt.no_ssim, out=ident[:, i:i + 1])
+        if self.opt.avg_reprojection:
+            ident = ident.mean(1, keepdim=True)
+        return ident
+
+    def generate_images_pred(self, inputs, outputs, frame_ids):
+        """trainer.py:425-474 fused with the per-pixel part of compute_losses (trainer.py:509-567, 577-589).
+
+        Stores, per scale s, outputs[("photo", s)] = (to_optimise.mean(), si_loss) and
+        "identity_selection/s"; and, if ``materialize_outputs``, the reference's ("depth",0,s), ("sample",f,s),
+        ("color",f,s), ("color_identity",f,s)."""
+        fids = [f for f in frame_ids[1:]]
+        if not fids:                                  # validation: depth only (trainer.py:311-312)
+            for scale in self.opt.scales:
+                disp = outputs[("disp", scale)]
+                if not self.opt.v1_multiscale:
+                    disp = FD.bilinear_upsample(disp, (self.opt.height, self.opt.width))
+                outputs[("depth", 0, scale)] = disp_to_depth(disp, self.opt.min_depth, self.opt.max_depth)[1]
+            return
+        automask = not self.opt.disable_automasking
+        use_si = self.opt.trainer_siloss == "true"
+        ident0 = self.identity_losses(inputs, 0) if (automask and not self.opt.v1_multiscale) else None
+        noise_in = inputs.get("_noise")               # injected tie-break noise (tests); else drawn like trainer.py:551-552
+        for scale in self.opt.scales:
+            src_s = scale if self.opt.v1_multiscale else 0
+            target = inputs[("color", 0, src_s)]
+            ident = None
+            if automask:
+                ident = ident0 if ident0 is not None else self.identity_losses(inputs, src_s)
+            noise = None
+            if ident is not None:
+                noise = noise_in[scale] if noise_in is not None else torch.randn(ident.shape, device=ident.device)
+            beam = inputs["4beam"] if (use_si and (self.opt.trainer_siloss_all_scale or scale == 0) and src_s == 0) else None
+            Ts = [outputs[("cam_T_cam", 0, f)] for f in fids]
+            srcs = [inputs[("color", f, src_s)] for f in fids]
+            photo, si, sel, depth, sample, color = FD.photo_loss(
+                outputs[("disp", scale)], Ts, inputs[("K", src_s)], inputs[("inv_K", src_s)], srcs, target, ident, noise,
+                beam, self.photo_options, self.materialize_outputs)
+            outputs[("photo", scale)] = (photo, si if beam is not None else None)
+            if automask:
+                n_id = ident.shape[1]
+                outputs["identity_selection/{}".format(scale)] = (sel > n_id - 1).float()
+            if self.materialize_outputs:
+                outputs[("depth", 0, scale)] = depth
+                for i, f in enumerate(fids):
+                    outputs[("sample", f, scale)] = sample[i]
+                    outputs[("color", f, scale)] = color[i]
+                    if automask:
+                        outputs[("color_identity", f, scale)] = inputs[("color", f, src_s)]
+
+    def compute_reprojection_loss(self, pred, target):
+        """trainer.py:476-488 (stand-alone, differentiable w.r.t. ``pred`` through the SSIM kernel)."""
+        l1_loss = torch.abs(target - pred).mean(1, True)
+        if self.opt.no_ssim:
+            return l1_loss
+        return 0.85 * FD.ssim(pred, target).mean(1, True) + 0.15 * l1_loss
+
+    def compute_losses(self, inputs, outputs):
+        """trainer.py:490-596: per scale  loss = min-reprojection mean + smoothness/2^s ; total += loss + si_loss."""
+        losses = {}
+        total_loss = 0
+        for scale in self.opt.scales:
+            photo, si = outputs[("photo", scale)]
+            smooth = FD.normalized_smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)])
+            loss = photo + self.opt.disparity_smoothness * smooth / (2 ** scale)
+            total_loss = total_loss + loss
+            losses["loss/{}".format(scale)] = loss
+            if si is not None:
+                total_loss = total_loss + si
+                losses["loss/si_loss{}".format(scale)] = si
+        losses["loss"] = total_loss / self.num_scales
+        return losses
+
+    # ------------------------------------------------------------------------------------------------
+    def compute_depth_losses(self, inputs, outputs, losses, accumulate=False):
+        """trainer.py:598-630 — monitoring metrics vs depth_gt (Garg crop, median scaling)."""
+        depth_pred = outputs[("depth", 0, 0)].detach()
+        gt_h, gt_w = inputs["depth_gt"].shape[2:]
+        depth_pred = torch.clamp(FD.bilinear_upsample(depth_pred, (gt_h, gt_w)), 1e-3, 80) if gt_h >= depth_pred.shape[2] \
+            else torch.clamp(torch.nn.functional.interpolate(depth_pred, [gt_h, gt_w], mode="bilinear", align_corners=False), 1e-3, 80)
+        depth_gt = inputs["depth_gt"]
+        mask = depth_gt > 0
+        crop = torch.zeros_like(mask)
+        crop[:, :, 153:371, 44:1197] = 1
+        mask = mask * crop
+        gt, pred = depth_gt[mask], depth_pred[mask]
+        pred = torch.clamp(pred * (torch.median(gt) / torch.median(pred)), min=1e-3, max=80)
+        errs = FD.depth_errors(gt, pred)
+        for i, metric in enumerate(self.depth_metric_names):
+            v = np.array(errs[i].cpu())
+            losses[metric] = losses.get(metric, 0.0) + v if accumulate else v
+
+    def val(self, batches):
+        """trainer.py:390-423 on an iterable of batches (depth only, eval-mode BN)."""
+        self.set_eval()
+        losses = {m: 0.0 for m in self.depth_metric_names}
+        n = 0
+        with torch.no_grad():
+            for inputs in batches:
+                outputs, _ = self.process_batch(inputs, val=True)
+                if "depth_gt" in inputs:
+                    self.compute_depth_losses(inputs, outputs, losses, accumulate=True)
+                n += 1
+        for m in self.depth_metric_names:
+            losses[m] /= max(n, 1)
+        self.set_train()
+        return losses
+
+    # ------------------------------------------------------------------------------------------------
+    def save_model(self, name=None):
+        """trainer.py:694-715: one state_dict per network under models/weights_<epoch|name>/ (+ height/width/
+        use_stereo in encoder.pth) and adam.pth."""
+        tag = "weights_{}".format(self.epoch if name is None else name)
+        folder = os.path.join(self.log_path, "models", tag)
+        os.makedirs(folder, exist_ok=True)
+        for model_name, model in self.models.items():
+            to_save = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            if model_name == "encoder":
+                to_save["height"], to_save["width"], to_save["use_stereo"] = self.opt.height, self.opt.width, self.opt.use_stereo
+            torch.save(to_save, os.path.join(folder, "{}.pth".format(model_name)))
+        torch.save({"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.adam_step_count,
+                    "lr": self.lr}, os.path.join(folder, "adam.pth"))
+        return folder
+
+    def load_model(self):
+        """trainer.py:717-746."""
+        folder = os.path.expanduser(self.opt.train_load_weights_folder)
+        assert os.path.isdir(folder), "Cannot find folder {}".format(folder)
+        for n in self.opt.models_to_load:
+            if n not in self.models:
+                continue
+            path = os.path.join(folder, "{}.pth".format(n))
+            model_dict = self.models[n].state_dict()
+            pretrained = torch.load(path, map_location="cpu")
+            with torch.no_grad():
+                for k, v in pretrained.items():
+                    if k in model_dict:
+                        model_dict[k].copy_(v)              # in place: parameters stay views of the flat buffer
+        adam = os.path.join(folder, "adam.pth")
+        if os.path.isfile(adam):
+            st = torch.load(adam, map_location="cpu")
+            if "exp_avg" in st and st["exp_avg"].numel() == self.exp_avg.numel():
+                self.exp_avg.copy_(st["exp_avg"]); self.exp_avg_sq.copy_(st["exp_avg_sq"])
+                self.adam_step_count = int(st["step"])
+
+    def save_opts(self):
+        """trainer.py:683-692."""
+        folder = os.path.join(self.log_path, "models")
+        os.makedirs(folder, exist_ok=True)
+        with open(os.path.join(folder, "opt.json"), "w") as f:
+            json.dump(self.opt.__dict__.copy(), f, indent=2)

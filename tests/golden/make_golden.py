@@ -295,9 +295,27 @@ def gold_scatter(get2ch):
     save("scatter_192x640", **out)
 
 
+def gold_options():
+    """Flag surface of the reference's argparse (options.py:9-480): name -> default/type/choices/action."""
+    import json
+    import options as ref_options
+    parser = ref_options.MonodepthOptions().parser
+    table = {}
+    for a in parser._actions:
+        if not a.option_strings or a.dest == "help":
+            continue
+        table[a.dest] = {"flag": a.option_strings[0], "default": a.default, "nargs": a.nargs,
+                         "type": getattr(a.type, "__name__", None), "choices": list(a.choices) if a.choices else None,
+                         "action": type(a).__name__}
+    path = os.path.join(HERE, "options_surface.json")
+    json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote options_surface.json (%d flags)" % len(table))
+
+
 def main():
     torch.set_num_threads(8)
     RL, RT, DD, PD, PC, get2ch = load_reference()
+    gold_options()
     gold_layers(RL)
     gold_decoders(DD, PD, PC)
     gold_losses(RL, RT, "losses_b2_64x96", 404, 2, 64, 96, full_arrays=True)
