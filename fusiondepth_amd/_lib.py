@@ -60,7 +60,8 @@ SIGNATURES = {
     "fd_smooth_fwd": ("ppppiiiip", "i"),
     "fd_smooth_bwd": ("pppppiiiip", "i"),
     "fd_scatter_2channel": ("ppiiiiiiiip", "i"),
-    "fd_conv2d_fwd": ("pppppp", "i"),
+    "fd_conv2d_fwd_ws_floats": ("p", "l"),
+    "fd_conv2d_fwd": ("ppppppp", "i"),
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_data": ("pppppp", "i"),
     "fd_conv2d_bwd_weight_ws_floats": ("p", "l"),
@@ -81,6 +82,7 @@ SIGNATURES = {
     "fd_spatial_mean_bwd": ("ppllfp", "i"),
     "fd_depth_errors": ("pplppp", "i"),
     "fd_adam_step": ("ppppl" "fffffff" "p", "i"),
+    "fd_adam_step_dev": ("ppppl" "p" "ffff" "p", "i"),
 }
 
 _lock = threading.Lock()

@@ -14,6 +14,7 @@
 // register-staged double-buffered LDS (one barrier per chunk).
 #include "../../include/fdhip.h"
 #include "fd_common.h"
+#include "conv_fast.h"
 
 namespace {
 
@@ -48,7 +49,7 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i >= n ? 2 * n - 2 - i : i;
 }
 
-template <int TA, int TB, int WAVES_M, int WAVES_N, int WM, int WN>
+template <int TA, int TB, int WAVES_M, int WAVES_N, int WM, int WN, bool NORM>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gather_gemm(GemmArgs g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
@@ -90,12 +91,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gather_gemm(GemmArgs
     // ---- A loader: k column ka, m rows ma + MP*i
     const int ka = tid % BK, ma = tid / BK;
 
+    // raw loaded values + validity flags; the select happens when the registers are written to LDS, so that
+    // nothing consumes a load result (and forces an s_waitcnt) before the MFMA loop of the current chunk
     float ra[NA_LOAD], rb[NB_LOAD];
+    bool oka[NA_LOAD], okb[NB_LOAD];
     auto load_chunk = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NA_LOAD; ++i) {
             const int m = m0 + ma + MP * i, k = k0 + ka;
-            ra[i] = (m < g.M && k < g.K) ? g.A[(long)m * g.K + k] : 0.f;
+            oka[i] = m < g.M && k < g.K;
+            ra[i] = g.A[oka[i] ? (long)m * g.K + k : 0];
         }
 #pragma unroll
         for (int i = 0; i < NB_LOAD; ++i) {
@@ -103,22 +108,27 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gather_gemm(GemmArgs
             const int c = k / (TA * TB), t = k - c * (TA * TB);
             const int ta = t / TB, tb = t - ta * TB;
             int r = ry0 + ta * g.da, cc = cx0 + tb * g.db;
-            bool ok = pvalid && k < g.K;
-            if (g.pad_mode == 1) { r = reflect_idx(r, g.Hi); cc = reflect_idx(cc, g.Wi); }
-            else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
-            float v = 0.f;
-            if (ok) {
-                v = g.X[nbase + c * chw + (long)r * g.Wi + cc];
-                if (g.in_norm) v = (v - 0.45f) / 0.225f;
-            }
-            rb[i] = v;
+            const bool inside = r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
+            const int rr = reflect_idx(r, g.Hi), cr = reflect_idx(cc, g.Wi);
+            const bool refl = g.pad_mode == 1;
+            r = refl ? rr : r; cc = refl ? cr : cc;
+            const bool ok = pvalid && k < g.K && (refl || inside);
+            // branch-free: always issue the load (from a safe address) so the loads of a chunk stay in flight
+            // together instead of being serialised by per-branch s_waitcnt
+            const long off = ok ? nbase + c * chw + (long)r * g.Wi + cc : 0;
+            rb[i] = g.X[off];
+            okb[i] = ok;
         }
     };
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) sA[buf][ka * LDA + ma + MP * i] = ra[i];
+        for (int i = 0; i < NA_LOAD; ++i) sA[buf][ka * LDA + ma + MP * i] = oka[i] ? ra[i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) sB[buf][(kr + RP * i) * LDB + jn] = rb[i];
+        for (int i = 0; i < NB_LOAD; ++i) {
+            float v = rb[i];
+            if (NORM) v = (v - 0.45f) / 0.225f;                    // resnet_encoder.py:94, padding stays 0
+            sB[buf][(kr + RP * i) * LDB + jn] = okb[i] ? v : 0.f;
+        }
     };
 
     f32x16 acc[WM][WN];
@@ -229,6 +239,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad(WgradArgs g) {
     }
 
     float ra[NA_LOAD], rb[NB_LOAD];
+    bool oka[NA_LOAD], okb[NB_LOAD];
     auto load_chunk = [&](long pc) __attribute__((always_inline)) {
         const long p = pc + pl;
         const bool pv = p < pend;
@@ -240,29 +251,31 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad(WgradArgs g) {
 #pragma unroll
         for (int i = 0; i < NA_LOAD; ++i) {
             const int m = m0 + rw + RPW * i;
-            ra[i] = (pv && m < g.M) ? dy[(long)m * g.dy_cs] : 0.f;
+            oka[i] = pv && m < g.M;
+            ra[i] = dy[oka[i] ? (long)m * g.dy_cs : 0];
         }
         const int ry0 = y * g.sy + g.oy, cx0 = x * g.sx + g.ox;
         const float* xb = g.X + (long)n * g.C * chw;
+        const bool refl = g.pad_mode == 1;
 #pragma unroll
         for (int i = 0; i < NB_LOAD; ++i) {
             int r = ry0 + jro[i], cc = cx0 + jco[i];
-            bool ok = pv && jc[i] >= 0;
-            if (g.pad_mode == 1) { r = reflect_idx(r, g.Hi); cc = reflect_idx(cc, g.Wi); }
-            else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
-            float v = 0.f;
-            if (ok) {
-                v = xb[jc[i] * chw + (long)r * g.Wi + cc];
-                if (g.in_norm) v = (v - 0.45f) / 0.225f;
-            }
-            rb[i] = v;
+            const bool inside = r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
+            const int rr = reflect_idx(r, g.Hi), cr = reflect_idx(cc, g.Wi);
+            r = refl ? rr : r; cc = refl ? cr : cc;
+            okb[i] = pv && jc[i] >= 0 && (refl || inside);
+            rb[i] = xb[okb[i] ? jc[i] * chw + (long)r * g.Wi + cc : 0];     // branch-free (see k_gather_gemm)
         }
     };
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) sA[buf][pl * LDA + rw + RPW * i] = ra[i];
+        for (int i = 0; i < NA_LOAD; ++i) sA[buf][pl * LDA + rw + RPW * i] = oka[i] ? ra[i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) sB[buf][pl * LDB + rw + RPW * i] = rb[i];
+        for (int i = 0; i < NB_LOAD; ++i) {
+            float v = rb[i];
+            if (g.in_norm) v = (v - 0.45f) / 0.225f;
+            sB[buf][pl * LDB + rw + RPW * i] = okb[i] ? v : 0.f;
+        }
     };
 
     f32x16 acc[WM][WN];
@@ -360,18 +373,29 @@ __global__ void k_reflect_fold(const float* __restrict__ gp, float* __restrict__
     }
 }
 
-// per-channel sum over (n, y, x) — bias gradient.  One workgroup per channel.
-__global__ void __launch_bounds__(256) k_channel_sum(const float* __restrict__ x, float* __restrict__ out, int Nb, int C,
-                                                     long plane) {
+// per-channel sum over (n, y, x) — bias gradient.  Two deterministic stages: (channel, slice) partials, then a
+// fixed-order sum over the slices.
+constexpr int CS_SPLITS = 32;
+__global__ void __launch_bounds__(256) k_channel_sum_part(const float* __restrict__ x, float* __restrict__ part, int Nb,
+                                                          int C, long plane) {
     __shared__ float red[4];
-    const int c = blockIdx.x;
+    const int c = blockIdx.x, s = blockIdx.y;
+    const long total = (long)Nb * plane, per = (total + CS_SPLITS - 1) / CS_SPLITS;
+    const long lo = (long)s * per, hi = lo + per < total ? lo + per : total;
     float v[1] = {0.f};
-    for (int n = 0; n < Nb; ++n) {
-        const float* p = x + ((long)n * C + c) * plane;
-        for (long i = threadIdx.x; i < plane; i += 256) v[0] += p[i];
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const long n = i / plane, r = i - n * plane;
+        v[0] += x[(n * C + c) * plane + r];
     }
-    const float s = fd_block_sum_n<1, 4>(v, red);
-    if (threadIdx.x == 0) out[c] = s;
+    const float sum = fd_block_sum_n<1, 4>(v, red);
+    if (threadIdx.x == 0) part[(long)c * CS_SPLITS + s] = sum;
+}
+__global__ void k_channel_sum_fin(const float* __restrict__ part, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < CS_SPLITS; ++i) s += part[(long)c * CS_SPLITS + i];
+    out[c] = s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,14 +410,21 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
     };
     // pick the largest tile that still yields >= ~2 workgroups per CU
     auto blocks = [&](int BM, int BN) { return (long)fd_cdiv(Np, BN) * fd_cdiv(g.M, BM); };
+    constexpr bool CAN_NORM = (TA == 7 && TB == 7);
+    if (g.in_norm && !CAN_NORM) { fd_set_error("conv: in_norm is only built for the 7x7 stem"); return -1; }
+    if (CAN_NORM && g.in_norm) {
+        if (blocks(64, 128) >= 512) go(k_gather_gemm<TA, TB, 2, 2, 1, 2, CAN_NORM>, 64, 128, 256);
+        else go(k_gather_gemm<TA, TB, 2, 2, 1, 1, CAN_NORM>, 64, 64, 256);
+        return 0;
+    }
     if (g.M <= 32) {
-        go(k_gather_gemm<TA, TB, 1, 4, 1, 1>, 32, 128, 256);
+        go(k_gather_gemm<TA, TB, 1, 4, 1, 1, false>, 32, 128, 256);
     } else if (g.M >= 128 && blocks(128, 128) >= 512) {
-        go(k_gather_gemm<TA, TB, 2, 2, 2, 2>, 128, 128, 256);
+        go(k_gather_gemm<TA, TB, 2, 2, 2, 2, false>, 128, 128, 256);
     } else if (blocks(64, 128) >= 512) {
-        go(k_gather_gemm<TA, TB, 2, 2, 1, 2>, 64, 128, 256);
+        go(k_gather_gemm<TA, TB, 2, 2, 1, 2, false>, 64, 128, 256);
     } else {
-        go(k_gather_gemm<TA, TB, 2, 2, 1, 1>, 64, 64, 256);
+        go(k_gather_gemm<TA, TB, 2, 2, 1, 1, false>, 64, 64, 256);
     }
     return 0;
 }
@@ -463,12 +494,52 @@ inline int ew_blocks(long n) {
 
 }  // namespace
 
-extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+namespace {
+inline long align4(long n) { return (n + 3) / 4 * 4; }
+inline bool fast_fwd_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->in_norm; }
+inline bool fast_dgrad_ok(const fd_conv_desc* d) { return d->Cout % 16 == 0; }
+inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->in_norm; }
+
+void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
+    f = FastGemmArgs{};
+    f.M = d->Cout; f.C = d->Cin; f.T = d->KH * d->KW; f.TB = d->KW; f.K = f.T * f.C;
+    f.Nb = d->N; f.Hi = d->H; f.Wi = d->W; f.NY = s.Ho; f.NX = s.Wo;
+    f.sy = d->stride; f.oy = -d->pad; f.da = 1; f.sx = d->stride; f.ox = -d->pad; f.db = 1;
+    f.pad_mode = d->pad_mode;
+    f.out_cs = (long)s.Ho * s.Wo; f.out_ns = f.out_cs * d->Cout; f.out_total = f.out_ns * d->N;
+    f.slab_stride = f.out_total;
+    f.out_w = s.Wo; f.osy = 1; f.ooy = 0; f.osx = 1; f.oox = 0;
+    f.act = d->act;
+}
+}  // namespace
+
+extern "C" long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d) {
+    if (!d) return 0;
+    ConvShape s;
+    if (!conv_out_shape(d, s) || !fast_fwd_ok(d)) return 0;
+    FastGemmArgs f;
+    fill_fwd_args(d, s, f);
+    return align4((long)d->Cout * f.K) + fast_splitk_slab_floats(f, nullptr);
+}
+
+extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* ws,
                              void* stream) {
     if (int rc = check_desc(d, "fd_conv2d_fwd")) return rc;
     FD_REQUIRE(x && w && y, "fd_conv2d_fwd: NULL tensor");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_fwd: empty output");
+    FD_REQUIRE((long)d->N * d->Cin * d->H * d->W < (1L << 31) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 31),
+               "fd_conv2d_fwd: tensor too large for 32-bit offsets");
+    hipStream_t st = (hipStream_t)stream;
+    if (fast_fwd_ok(d)) {
+        FD_REQUIRE(ws, "fd_conv2d_fwd: workspace required (fd_conv2d_fwd_ws_floats)");
+        FastGemmArgs f;
+        fill_fwd_args(d, s, f);
+        if (int rc = fast_weight_relayout(w, ws, d->Cout, d->Cin, d->KH, d->KW, d->KH, d->KW, 0, 1, 0, 1, 0, st)) return rc;
+        f.A = ws; f.X = x; f.Y = y; f.bias = bias;
+        f.slabs = ws + align4((long)d->Cout * f.K);
+        return fast_gemm_launch(f, st);
+    }
     GemmArgs g = {};
     g.A = w; g.X = x; g.Y = y; g.bias = bias;
     g.M = d->Cout; g.K = d->Cin * d->KH * d->KW;
@@ -479,16 +550,27 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
     g.out_ns = (long)d->Cout * s.Ho * s.Wo; g.out_cs = (long)s.Ho * s.Wo;
     g.out_w = s.Wo; g.osy = 1; g.ooy = 0; g.osx = 1; g.oox = 0;
     g.act = d->act; g.in_norm = d->in_norm;
-    if (int rc = dispatch_gemm(d->KH, d->KW, g, (hipStream_t)stream)) return rc;
+    if (int rc = dispatch_gemm(d->KH, d->KW, g, st)) return rc;
     FD_LAUNCH_CHECK("fd_conv2d_fwd");
     return 0;
 }
 
 extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
-    long wt = (long)d->Cin * d->Cout * d->KH * d->KW;
-    long padded = d->pad_mode == 1 ? (long)d->N * d->Cin * (d->H + 2) * (d->W + 2) : 0;
-    return wt + padded;
+    ConvShape s;
+    if (!conv_out_shape(d, s)) return 0;
+    const long wt = align4((long)d->Cin * d->Cout * d->KH * d->KW);
+    const long padded = d->pad_mode == 1 ? align4((long)d->N * d->Cin * (d->H + 2) * (d->W + 2)) : 0;
+    long slabs = 0;
+    if (fast_dgrad_ok(d) && d->stride == 1) {          // split-K only on the stride-1 path
+        FastGemmArgs f = {};
+        f.M = d->Cin; f.C = d->Cout; f.T = d->KH * d->KW; f.Nb = d->N;
+        f.NY = d->pad_mode == 1 ? d->H + 2 : d->H; f.NX = d->pad_mode == 1 ? d->W + 2 : d->W;
+        f.osy = 1; f.osx = 1;
+        f.out_total = (long)d->N * d->Cin * f.NY * f.NX;
+        slabs = fast_splitk_slab_floats(f, nullptr);
+    }
+    return wt + padded + slabs;
 }
 
 extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* ws,
@@ -497,27 +579,54 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
     FD_REQUIRE(gy && w && gx && ws, "fd_conv2d_bwd_data: NULL tensor");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_data: empty output");
+    FD_REQUIRE((long)d->N * d->Cin * (d->H + 2) * (d->W + 2) < (1L << 31) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 31),
+               "fd_conv2d_bwd_data: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
     const int KH = d->KH, KW = d->KW;
+    const bool fast = fast_dgrad_ok(d);
     float* wt = ws;
+    const long wt_n = align4((long)d->Cin * d->Cout * KH * KW);
+    float* gpad = ws + wt_n;
+    const long pad_n = d->pad_mode == 1 ? align4((long)d->N * d->Cin * (d->H + 2) * (d->W + 2)) : 0;
+    float* slabs = ws + wt_n + pad_n;
+
+    // common geometry of "a conv over gy": channels = Cout, spatial = Ho x Wo
     GemmArgs g = {};
     g.X = gy; g.bias = nullptr; g.act = 0; g.in_norm = 0; g.pad_mode = 0;
     g.M = d->Cin; g.Nb = d->N; g.C = d->Cout; g.Hi = s.Ho; g.Wi = s.Wo;
-    if (d->stride == 1) {
-        const long nw = (long)d->Cin * d->Cout * KH * KW;
-        hipLaunchKernelGGL(k_weight_relayout, dim3(ew_blocks(nw)), dim3(256), 0, st, w, wt, d->Cout, d->Cin, KH, KW, KH, KW,
-                           KH - 1, -1, KW - 1, -1);
+    auto run = [&](int TA, int TB, int kh0, int dkh, int kw0, int dkw, bool allow_split) -> int {
+        if (fast) {
+            if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, KH, KW, TA, TB, kh0, dkh, kw0, dkw, 1, st)) return rc;
+            FastGemmArgs f = {};
+            f.A = wt; f.X = gy; f.Y = g.Y; f.bias = nullptr;
+            f.M = d->Cin; f.C = d->Cout; f.T = TA * TB; f.TB = TB; f.K = f.T * f.C;
+            f.Nb = d->N; f.Hi = s.Ho; f.Wi = s.Wo; f.NY = g.NY; f.NX = g.NX;
+            f.sy = g.sy; f.oy = g.oy; f.da = g.da; f.sx = g.sx; f.ox = g.ox; f.db = g.db;
+            f.pad_mode = 0;
+            f.out_ns = g.out_ns; f.out_cs = g.out_cs; f.out_w = g.out_w;
+            f.osy = g.osy; f.ooy = g.ooy; f.osx = g.osx; f.oox = g.oox;
+            f.out_total = (long)d->N * g.out_ns; f.slab_stride = f.out_total;
+            f.slabs = slabs;       // split-K is only chosen for unit-stride outputs (fast_splitk_slab_floats)
+            (void)allow_split;
+            return fast_gemm_launch(f, st);
+        }
+        hipLaunchKernelGGL(k_weight_relayout, dim3(ew_blocks((long)d->Cin * d->Cout * TA * TB)), dim3(256), 0, st, w, wt, d->Cout,
+                           d->Cin, KH, KW, TA, TB, kh0, dkh, kw0, dkw);
         FD_LAUNCH_CHECK("fd_conv2d_bwd_data(relayout)");
-        g.A = wt; g.K = d->Cout * KH * KW;
+        g.A = wt; g.K = d->Cout * TA * TB;
+        if (int rc = dispatch_gemm(TA, TB, g, st)) return rc;
+        FD_LAUNCH_CHECK("fd_conv2d_bwd_data(gemm)");
+        return 0;
+    };
+
+    if (d->stride == 1) {
         g.sy = 1; g.da = 1; g.sx = 1; g.db = 1;
         g.osy = 1; g.ooy = 0; g.osx = 1; g.oox = 0;
-        if (d->pad_mode == 1) {   // gradient on the reflect-padded grid, then fold
-            float* gpad = ws + nw;
+        if (d->pad_mode == 1) {   // gradient on the reflect-padded grid, then fold (adjoint of ReflectionPad2d(1))
             g.NY = d->H + 2; g.NX = d->W + 2; g.oy = -(KH - 1); g.ox = -(KW - 1);
             g.Y = gpad; g.out_w = d->W + 2;
             g.out_cs = (long)(d->H + 2) * (d->W + 2); g.out_ns = g.out_cs * d->Cin;
-            if (int rc = dispatch_gemm(KH, KW, g, st)) return rc;
-            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(reflect)");
+            if (int rc = run(KH, KW, KH - 1, -1, KW - 1, -1, true)) return rc;
             const long n = (long)d->N * d->Cin * d->H * d->W;
             hipLaunchKernelGGL(k_reflect_fold, dim3(ew_blocks(n)), dim3(256), 0, st, gpad, gx, (long)d->N * d->Cin, d->H,
                                d->W);
@@ -526,18 +635,14 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
         }
         g.NY = d->H; g.NX = d->W; g.oy = -(KH - 1 - d->pad); g.ox = -(KW - 1 - d->pad);
         g.Y = gx; g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin;
-        if (int rc = dispatch_gemm(KH, KW, g, st)) return rc;
-        FD_LAUNCH_CHECK("fd_conv2d_bwd_data");
-        return 0;
+        return run(KH, KW, KH - 1, -1, KW - 1, -1, true);
     }
     // stride 2: four output-parity classes, each a dense conv over its own tap subset
     g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin; g.Y = gx;
     bool need_zero = false;
     for (int ph = 0; ph < 2; ++ph)
-        for (int pw = 0; pw < 2; ++pw) {
-            const int kh0 = (ph + d->pad) & 1, kw0 = (pw + d->pad) & 1;
-            if (kh0 >= KH || kw0 >= KW) need_zero = true;
-        }
+        for (int pw = 0; pw < 2; ++pw)
+            if (((ph + d->pad) & 1) >= KH || ((pw + d->pad) & 1) >= KW) need_zero = true;
     if (need_zero) {
         if (hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->Cin * d->H * d->W, st) != hipSuccess) {
             fd_set_error("fd_conv2d_bwd_data: memset failed");
@@ -551,17 +656,11 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
             const int TA = (KH - kh0 + 1) / 2, TB = (KW - kw0 + 1) / 2;
             const int NY = (d->H - ph + 1) / 2, NX = (d->W - pw + 1) / 2;
             if (NY <= 0 || NX <= 0) continue;
-            const long nw = (long)d->Cin * d->Cout * TA * TB;
-            hipLaunchKernelGGL(k_weight_relayout, dim3(ew_blocks(nw)), dim3(256), 0, st, w, wt, d->Cout, d->Cin, KH, KW, TA,
-                               TB, kh0, 2, kw0, 2);
-            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(relayout s2)");
-            g.A = wt; g.K = d->Cout * TA * TB;
             g.NY = NY; g.NX = NX;
             g.sy = 1; g.oy = (ph + d->pad - kh0) / 2; g.da = -1;
             g.sx = 1; g.ox = (pw + d->pad - kw0) / 2; g.db = -1;
             g.osy = 2; g.ooy = ph; g.osx = 2; g.oox = pw;
-            if (int rc = dispatch_gemm(TA, TB, g, st)) return rc;
-            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(s2)");
+            if (int rc = run(TA, TB, kh0, 2, kw0, 2, false)) return rc;
         }
     return 0;
 }
@@ -572,10 +671,10 @@ int wgrad_splits(const fd_conv_desc* d, const ConvShape& s) {
     const long J = (long)d->Cin * d->KH * d->KW;
     const long tiles = (long)fd_cdiv(J, (d->Cout <= 32 || J <= 64) ? 64 : 128) * fd_cdiv(d->Cout, 64);
     long want = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU
-    long maxs = (Np + 255) / 256;                     // at least 256 pixels per split
+    long maxs = (Np + 511) / 512;                     // at least 512 pixels per split
     long sp = want < maxs ? want : maxs;
     if (sp < 1) sp = 1;
-    if (sp > 512) sp = 512;
+    if (sp > 96) sp = 96;
     return (int)sp;
 }
 }  // namespace
@@ -584,41 +683,60 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s)) return 0;
-    const int sp = wgrad_splits(d, s);
-    return sp > 1 ? (long)sp * d->Cout * d->Cin * d->KH * d->KW : 0;
+    const long wsz = (long)d->Cout * d->Cin * d->KH * d->KW;
+    long slabs;
+    if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
+    else { const int sp = wgrad_splits(d, s); slabs = sp > 1 ? (long)sp * wsz : 0; }
+    const long bias_part = (long)d->Cout * CS_SPLITS;
+    return slabs > bias_part ? slabs : bias_part;          // the two uses are sequential on the stream
 }
 
 extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* gbias,
                                     float* ws, void* stream) {
     if (int rc = check_desc(d, "fd_conv2d_bwd_weight")) return rc;
-    FD_REQUIRE(x && gy && gw, "fd_conv2d_bwd_weight: NULL tensor");
+    FD_REQUIRE(x && gy && gw && ws, "fd_conv2d_bwd_weight: NULL tensor / workspace");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_weight: empty output");
+    FD_REQUIRE((long)d->N * d->Cin * d->H * d->W < (1L << 31) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 31),
+               "fd_conv2d_bwd_weight: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
-    const int sp = wgrad_splits(d, s);
-    FD_REQUIRE(sp == 1 || ws, "fd_conv2d_bwd_weight: workspace required");
-    WgradArgs g = {};
-    g.dY = gy; g.X = x; g.out = sp > 1 ? ws : gw;
-    g.M = d->Cout; g.J = d->Cin * d->KH * d->KW;
-    g.Nb = d->N; g.C = d->Cin; g.Hi = d->H; g.Wi = d->W;
-    g.NY = s.Ho; g.NX = s.Wo;
-    g.sy = d->stride; g.oy = -d->pad; g.da = 1; g.sx = d->stride; g.ox = -d->pad; g.db = 1;
-    g.pad_mode = d->pad_mode; g.in_norm = d->in_norm;
-    g.dy_cs = (long)s.Ho * s.Wo; g.dy_ns = g.dy_cs * d->Cout;
     const long Np = (long)d->N * s.Ho * s.Wo;
-    long pps = (Np + sp - 1) / sp;
-    pps = (pps + 31) / 32 * 32;
-    g.pix_per_split = pps;
-    if (int rc = dispatch_wgrad(d->KH, d->KW, g, sp, st)) return rc;
-    FD_LAUNCH_CHECK("fd_conv2d_bwd_weight");
-    if (sp > 1) {
-        const long n = (long)g.M * g.J;
-        hipLaunchKernelGGL(k_reduce_slabs, dim3(ew_blocks(n)), dim3(256), 0, st, ws, gw, n, sp);
-        FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(reduce)");
+    if (fast_wgrad_ok(d)) {
+        FastWgradArgs f = {};
+        f.dY = gy; f.X = x; f.slabs = ws;
+        f.M = d->Cout; f.C = d->Cin; f.T = d->KH * d->KW; f.TB = d->KW;
+        f.Nb = d->N; f.Hi = d->H; f.Wi = d->W; f.NY = s.Ho; f.NX = s.Wo;
+        f.sy = d->stride; f.oy = -d->pad; f.da = 1; f.sx = d->stride; f.ox = -d->pad; f.db = 1;
+        f.pad_mode = d->pad_mode;
+        f.dy_cs = (long)s.Ho * s.Wo; f.dy_ns = f.dy_cs * d->Cout;
+        if (int rc = fast_wgrad_launch(f, gw, fast_wgrad_splits(f.M, f.C, f.T, Np), st)) return rc;
+    } else {
+        const int sp = wgrad_splits(d, s);
+        WgradArgs g = {};
+        g.dY = gy; g.X = x; g.out = sp > 1 ? ws : gw;
+        g.M = d->Cout; g.J = d->Cin * d->KH * d->KW;
+        g.Nb = d->N; g.C = d->Cin; g.Hi = d->H; g.Wi = d->W;
+        g.NY = s.Ho; g.NX = s.Wo;
+        g.sy = d->stride; g.oy = -d->pad; g.da = 1; g.sx = d->stride; g.ox = -d->pad; g.db = 1;
+        g.pad_mode = d->pad_mode; g.in_norm = d->in_norm;
+        g.dy_cs = (long)s.Ho * s.Wo; g.dy_ns = g.dy_cs * d->Cout;
+        long pps = (Np + sp - 1) / sp;
+        pps = (pps + 31) / 32 * 32;
+        g.pix_per_split = pps;
+        if (int rc = dispatch_wgrad(d->KH, d->KW, g, sp, st)) return rc;
+        FD_LAUNCH_CHECK("fd_conv2d_bwd_weight");
+        if (sp > 1) {
+            const long n = (long)g.M * g.J;
+            hipLaunchKernelGGL(k_reduce_slabs, dim3(ew_blocks(n)), dim3(256), 0, st, ws, gw, n, sp);
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(reduce)");
+        }
     }
     if (gbias) {
-        hipLaunchKernelGGL(k_channel_sum, dim3(d->Cout), dim3(256), 0, st, gy, gbias, d->N, d->Cout, (long)s.Ho * s.Wo);
+        hipLaunchKernelGGL(k_channel_sum_part, dim3(d->Cout, CS_SPLITS), dim3(256), 0, st, gy, ws, d->N, d->Cout,
+                           (long)s.Ho * s.Wo);
         FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(bias)");
+        hipLaunchKernelGGL(k_channel_sum_fin, dim3(fd_cdiv(d->Cout, 64)), dim3(64), 0, st, ws, gbias, d->Cout);
+        FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(bias fin)");
     }
     return 0;
 }

@@ -1,0 +1,39 @@
+// Internal interface between conv.hip (C-ABI entry points, shape logic) and conv_fast.hip (fast-path kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct FastGemmArgs {
+    const float* A;      // [M][T][C] re-laid-out weights
+    const float* X;      // gathered tensor [Nb][C][Hi][Wi]
+    float* Y;            // output (affine pixel map below)
+    const float* bias;   // [M] or null
+    float* slabs;        // split-K workspace (splits * out_total floats) or null
+    long slab_stride, out_total;
+    int M, K;            // K = T * C
+    int Nb, C, Hi, Wi;
+    int NY, NX;          // GEMM-N domain per image
+    int T, TB;           // taps, taps per row
+    int sy, oy, da, sx, ox, db;
+    int pad_mode;
+    long out_ns, out_cs;
+    int out_w, osy, ooy, osx, oox;
+    int act;
+    int xcd_swizzle;
+};
+
+struct FastWgradArgs {
+    const float* dY; const float* X; float* slabs;   // slabs [splits][M][T][C]
+    int M, C, T, TB;
+    int Nb, Hi, Wi, NY, NX;
+    int sy, oy, da, sx, ox, db;
+    int pad_mode;
+    long dy_ns, dy_cs;
+    long pix_per_split;
+};
+
+long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out);
+int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st);
+int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh, int kw0,
+                         int dkw, int mode, hipStream_t st);
+int fast_wgrad_splits(int M, int C, int T, long Np);
+int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, hipStream_t st);

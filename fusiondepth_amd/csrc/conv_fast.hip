@@ -1,0 +1,459 @@
+// Fast path of the FP32 MFMA implicit-GEMM convolution for channel counts that are multiples of 16 (every
+// ResNet / decoder / pose conv except the 7x7 stems, 1-channel dispconv gradients and 12-channel pose output).
+//
+// What changed w.r.t. the generic kernel in conv.hip (measured there: ~19 VALU per MFMA, 25-40 TFLOP/s):
+//   * GEMM-K is ordered (tap, channel) instead of (channel, tap): a K-chunk = ONE tap x BKC consecutive channels,
+//     so the tap's bounds / reflect logic runs once per chunk and the BKC loads of a thread are
+//     base + i * stride (one v_add each) with a wave-uniform base pointer (SGPR) + 32-bit lane offsets;
+//   * each wave owns up to 2x2 accumulator tiles of 32x32 (64x64 outputs) => 4 MFMAs per 4 LDS operand reads,
+//     64 MFMAs (4096 SIMD cycles) per barrier at BKC = 32, enough to cover the HBM latency of the next chunk;
+//   * weights are re-laid-out to [M][tap][channel] by a tiny prep kernel and loaded as float4;
+//   * small-N layers (layer3/4 at micro-batch 6: N = 2880 / 720 pixels) are split over K into deterministic
+//     slabs so that >= 256 workgroups exist; a finishing kernel sums the slabs and applies bias + activation.
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+#include "conv_fast.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    if (act == 3) return 1.0f / (1.0f + expf(-v));
+    if (act == 4) return tanhf(v);
+    return v;
+}
+__device__ __forceinline__ int refl_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BKC>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmArgs g) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
+    constexpr int LDA = BM + 1, LDB = BN;
+    constexpr int RP = NT / BN;                 // channel rows per pass of the activation loader
+    constexpr int NB_LOAD = BKC / RP;
+    constexpr int A_V4_PER_ROW = BKC / 4;       // float4 per weight row per chunk
+    constexpr int A_ROWS_PER_PASS = NT / A_V4_PER_ROW;
+    constexpr int NA_LOAD = (BM + A_ROWS_PER_PASS - 1) / A_ROWS_PER_PASS;
+    constexpr bool A_PARTIAL = (BM % A_ROWS_PER_PASS) != 0;      // fewer weight rows than loader rows: some threads idle
+    static_assert(NT % BN == 0 && BKC % RP == 0, "tile/loader mismatch");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                           // [2][BKC * LDA]
+    float* sB = smem + 2 * BKC * LDA;           // [2][BKC * LDB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    int bx = blockIdx.x;
+    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    const int m0 = blockIdx.y * BM;
+    const long p0 = (long)bx * BN;
+    const int plane = g.NY * g.NX;
+    const long Np = (long)g.Nb * plane;
+    const unsigned chw = (unsigned)(g.Hi * g.Wi);
+    const int cpt = g.C / BKC;                  // chunks per tap
+    const int nchunk_all = g.T * cpt;
+    // split-K: this workgroup handles chunks [ch_lo, ch_hi)
+    const int per_split = (nchunk_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int ch_lo = blockIdx.z * per_split;
+    const int ch_hi = ch_lo + per_split < nchunk_all ? ch_lo + per_split : nchunk_all;
+
+    // ---- activation loader: fixed pixel column, channel rows kr + RP*i
+    const int jn = tid % BN;
+    const int kr = __builtin_amdgcn_readfirstlane(tid / BN);
+    const long pg = p0 + jn;
+    const bool pvalid = pg < Np;
+    int ry0, cx0;
+    unsigned nbase;
+    {
+        const long pp = pvalid ? pg : 0;
+        const int n = (int)(pp / plane);
+        const int rem = (int)(pp - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        ry0 = y * g.sy + g.oy; cx0 = x * g.sx + g.ox;
+        nbase = (unsigned)n * (unsigned)g.C * chw;
+    }
+    // ---- weight loader: float4 column a4 of row ar + A_ROWS_PER_PASS*i
+    const int a4 = tid % A_V4_PER_ROW, ar = tid / A_V4_PER_ROW;
+
+    float4 ra[NA_LOAD];
+    float rb[NB_LOAD];
+    bool okb = false;
+    auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+        const int t = ch / cpt, c0 = (ch - t * cpt) * BKC;          // wave-uniform
+        const int ta = t / g.TB, tb = t - ta * g.TB;
+        const unsigned k0 = (unsigned)t * (unsigned)g.C + (unsigned)c0;
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) {
+            int m = m0 + ar + A_ROWS_PER_PASS * i;
+            m = m < g.M ? m : g.M - 1;                                // rows >= M are never stored by the epilogue
+            if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM)
+                ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)((unsigned)m * (unsigned)g.K + k0 + 4u * a4));
+        }
+        int r = ry0 + ta * g.da, cc = cx0 + tb * g.db;
+        bool ok = pvalid;
+        if (g.pad_mode == 1) { r = refl_idx(r, g.Hi); cc = refl_idx(cc, g.Wi); }
+        else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
+        okb = ok;
+        unsigned off = ok ? nbase + (unsigned)(c0 + kr) * chw + (unsigned)(r * g.Wi + cc) : 0u;
+        const unsigned step = ok ? (unsigned)RP * chw : 0u;
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) { rb[i] = g.X[off]; off += step; }
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+        float* a = sA + buf * BKC * LDA;
+        float* b = sB + buf * BKC * LDB;
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) {
+            if (A_PARTIAL && ar + A_ROWS_PER_PASS * i >= BM) continue;
+            float* q = a + (4 * a4) * LDA + ar + A_ROWS_PER_PASS * i;
+            q[0] = ra[i].x; q[LDA] = ra[i].y; q[2 * LDA] = ra[i].z; q[3 * LDA] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) b[(kr + RP * i) * LDB + jn] = okb ? rb[i] : 0.f;
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int arow = lane >> 5, acol = lane & 31;
+    if (ch_lo < ch_hi) {
+        load_chunk(ch_lo);
+        store_chunk(0);
+        __syncthreads();
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+            const int cur = (ch - ch_lo) & 1;
+            if (ch + 1 < ch_hi) load_chunk(ch + 1);
+            const float* pa = sA + cur * BKC * LDA + arow * LDA + wave_m * 32 * WM + acol;
+            const float* pb = sB + cur * BKC * LDB + arow * LDB + wave_n * 32 * WN + acol;
+#pragma unroll
+            for (int kk = 0; kk < BKC / 2; ++kk) {
+                float av[WM], bv[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) av[i] = pa[kk * 2 * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 2 * LDB + j * 32];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (ch + 1 < ch_hi) store_chunk(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+    const bool final_pass = gridDim.z == 1;
+    float* Y = final_pass ? g.Y : g.slabs + (size_t)blockIdx.z * g.slab_stride;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const long p = p0 + wave_n * 32 * WN + j * 32 + acol;
+        if (p >= Np) continue;
+        const int n = (int)(p / plane);
+        const int rem = (int)(p - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        float* yo = Y + (long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                if (m < g.M) {
+                    float v = acc[i][j][r];
+                    if (final_pass) {
+                        if (g.bias) v += g.bias[m];
+                        v = act_apply(v, g.act);
+                    }
+                    yo[(long)m * g.out_cs] = v;
+                }
+            }
+    }
+}
+
+// Y[i] = act(sum_z slabs[z][i] + bias[channel(i)])   (fixed z order => deterministic)
+__global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ slabs, float* __restrict__ Y,
+                                                       const float* __restrict__ bias, long total, long slab_stride,
+                                                       int splits, long out_cs, int M, int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * slab_stride + i];
+        if (bias) s += bias[(i / out_cs) % M];
+        Y[i] = act_apply(s, act);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// dW2[m][t][c] = sum_p dY[m][p] * X[n(p)][c][tap t of p]; one workgroup = (tap t, BNC channels) x BM rows x
+// a slice of the pixels.  GEMM-K = pixels, 32 per chunk, lanes along pixels (coalesced dY and X rows).
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgradArgs g) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
+    constexpr int BP = 32;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int RPW = NT / BP;
+    constexpr int NA_LOAD = BM / RPW, NB_LOAD = BN / RPW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                           // [2][BP * LDA]
+    float* sB = smem + 2 * BP * LDA;            // [2][BP * LDB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int cblocks = (g.C + BN - 1) / BN;
+    const int t = blockIdx.x / cblocks, c0 = (blockIdx.x - t * cblocks) * BN;
+    const int ta = t / g.TB, tb = t - ta * g.TB;
+    const int m0 = blockIdx.y * BM;
+    const int plane = g.NY * g.NX;
+    const long Np = (long)g.Nb * plane;
+    const unsigned chw = (unsigned)(g.Hi * g.Wi);
+    const long pbeg = (long)blockIdx.z * g.pix_per_split;
+    long pend = pbeg + g.pix_per_split;
+    if (pend > Np) pend = Np;
+
+    const int pl = tid % BP, rw = tid / BP;
+    const int ncol = g.C - c0 < BN ? g.C - c0 : BN;          // valid channel columns of this tile
+    const int nrow = g.M - m0 < BM ? g.M - m0 : BM;
+
+    float ra[NA_LOAD], rb[NB_LOAD];
+    bool okp = false, okx = false;
+    auto load_chunk = [&](long pc) __attribute__((always_inline)) {
+        const long p = pc + pl;
+        const bool pv = p < pend;
+        const long pp = pv ? p : 0;
+        const int n = (int)(pp / plane);
+        const int rem = (int)(pp - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        okp = pv;
+        unsigned offa = pv ? (unsigned)n * (unsigned)g.dy_ns + (unsigned)(m0 + rw) * (unsigned)g.dy_cs + (unsigned)rem : 0u;
+        const unsigned stepa = pv ? (unsigned)RPW * (unsigned)g.dy_cs : 0u;
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) {
+            ra[i] = g.dY[(rw + RPW * i) < nrow ? offa : 0u];
+            offa += stepa;
+        }
+        int r = y * g.sy + g.oy + ta * g.da, cc = x * g.sx + g.ox + tb * g.db;
+        bool ok = pv;
+        if (g.pad_mode == 1) { r = refl_idx(r, g.Hi); cc = refl_idx(cc, g.Wi); }
+        else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
+        okx = ok;
+        unsigned offb = ok ? ((unsigned)n * (unsigned)g.C + (unsigned)(c0 + rw)) * chw + (unsigned)(r * g.Wi + cc) : 0u;
+        const unsigned stepb = ok ? (unsigned)RPW * chw : 0u;
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) {
+            rb[i] = g.X[(rw + RPW * i) < ncol ? offb : 0u];
+            offb += stepb;
+        }
+    };
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+        float* a = sA + buf * BP * LDA;
+        float* b = sB + buf * BP * LDB;
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) a[pl * LDA + rw + RPW * i] = (okp && (rw + RPW * i) < nrow) ? ra[i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) b[pl * LDB + rw + RPW * i] = (okx && (rw + RPW * i) < ncol) ? rb[i] : 0.f;
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunk = pend > pbeg ? (int)((pend - pbeg + BP - 1) / BP) : 0;
+    const int arow = lane >> 5, acol = lane & 31;
+    if (nchunk > 0) {
+        load_chunk(pbeg);
+        store_chunk(0);
+        __syncthreads();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int cur = ch & 1;
+            if (ch + 1 < nchunk) load_chunk(pbeg + (long)(ch + 1) * BP);
+            const float* pa = sA + cur * BP * LDA + arow * LDA + wave_m * 32 * WM + acol;
+            const float* pb = sB + cur * BP * LDB + arow * LDB + wave_n * 32 * WN + acol;
+#pragma unroll
+            for (int kk = 0; kk < BP / 2; ++kk) {
+                float av[WM], bv[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) av[i] = pa[kk * 2 * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 2 * LDB + j * 32];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+            if (ch + 1 < nchunk) store_chunk(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // slab layout [z][m][t][c]
+    float* out = g.slabs + (size_t)blockIdx.z * g.M * g.T * g.C;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int c = c0 + wave_n * 32 * WN + j * 32 + acol;
+        if (c >= g.C) continue;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                if (m < g.M) out[((size_t)m * g.T + t) * g.C + c] = acc[i][j][r];
+            }
+    }
+}
+
+// gw[m][c][t] (OIHW) = sum_z slabs[z][m][t][c]
+__global__ void __launch_bounds__(256) k_wgrad_finish(const float* __restrict__ slabs, float* __restrict__ gw, int M, int C,
+                                                      int T, int splits) {
+    const long n = (long)M * C * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % T);
+        const int c = (int)((i / T) % C);
+        const int m = (int)(i / ((long)T * C));
+        const size_t src = ((size_t)m * T + t) * C + c;
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + src];
+        gw[i] = s;
+    }
+}
+
+// A2[m][(a,b)][c]:  mode 0 (forward)  A2[co][t][ci] = W[co][ci][kh0+dkh*a][kw0+dkw*b]
+//                   mode 1 (dgrad)    A2[ci][t][co] = W[co][ci][kh0+dkh*a][kw0+dkw*b]
+__global__ void __launch_bounds__(256) k_weight_relayout_tc(const float* __restrict__ W, float* __restrict__ A2, int Co,
+                                                            int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh, int kw0,
+                                                            int dkw, int mode) {
+    const int Mr = mode ? Ci : Co, Cr = mode ? Co : Ci;
+    const long n = (long)Mr * TA * TB * Cr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cr);
+        const int b = (int)((i / Cr) % TB);
+        const int a = (int)((i / ((long)Cr * TB)) % TA);
+        const int m = (int)(i / ((long)Cr * TB * TA));
+        const int co = mode ? c : m, ci = mode ? m : c;
+        A2[i] = W[(((long)co * Ci + ci) * KH + kh0 + dkh * a) * KW + kw0 + dkw * b];
+    }
+}
+
+inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BKC>
+void launch_cfg(const FastGemmArgs& a, int splits, hipStream_t st) {
+    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
+    const long Np = (long)a.Nb * a.NY * a.NX;
+    const int gx = fd_cdiv(Np, BN), gy = fd_cdiv(a.M, BM);
+    FastGemmArgs g = a;
+    g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
+    const size_t lds = sizeof(float) * 2 * BKC * ((BM + 1) + BN);
+    auto kern = k_conv_fast<WAVES_M, WAVES_N, WM, WN, BKC>;
+    static bool attr_set = false;
+    if (!attr_set) {   // allow > 64 KiB of dynamic LDS
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(64 * WAVES_M * WAVES_N), lds, st, g);
+}
+
+}  // namespace
+
+long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out) {
+    const long Np = (long)a.Nb * a.NY * a.NX;
+    const int BM = a.M > 64 ? 128 : (a.M > 32 ? 64 : 32);
+    const int BN = a.M > 32 ? 128 : 256;
+    const long tiles = (long)fd_cdiv(Np, BN) * fd_cdiv(a.M, BM);
+    const int bkc = (a.C % 32 == 0) ? 32 : 16;
+    const int nchunk = a.T * (a.C / bkc);
+    int splits = 1;
+    if (tiles < 256 && a.osy == 1 && a.osx == 1) {
+        splits = (int)((384 + tiles - 1) / tiles);
+        const int max_by_k = nchunk / 4 > 0 ? nchunk / 4 : 1;       // >= 4 chunks (128 MFMA k-steps) per split
+        if (splits > max_by_k) splits = max_by_k;
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
+    }
+    if (splits_out) *splits_out = splits;
+    return splits > 1 ? (long)splits * a.out_total : 0;
+}
+
+int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
+    int splits = 1;
+    fast_splitk_slab_floats(a, &splits);
+    if (splits > 1 && !a.slabs) { fd_set_error("conv: split-K workspace missing"); return -1; }
+    const bool b32 = a.C % 32 == 0;
+    if (a.M > 64) {
+        if (b32) launch_cfg<2, 2, 2, 2, 32>(a, splits, st); else launch_cfg<2, 2, 2, 2, 16>(a, splits, st);
+    } else if (a.M > 32) {
+        if (b32) launch_cfg<2, 2, 1, 2, 32>(a, splits, st); else launch_cfg<2, 2, 1, 2, 16>(a, splits, st);
+    } else {
+        if (b32) launch_cfg<1, 4, 1, 2, 32>(a, splits, st); else launch_cfg<1, 4, 1, 2, 16>(a, splits, st);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_conv_fast launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    if (splits > 1) {
+        hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(a.out_total)), dim3(256), 0, st, a.slabs, a.Y, a.bias, a.out_total,
+                           a.slab_stride, splits, a.out_cs, a.M, a.act);
+        e = hipGetLastError();
+        if (e != hipSuccess) { fd_set_error("k_splitk_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    return 0;
+}
+
+int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh,
+                         int kw0, int dkw, int mode, hipStream_t st) {
+    const long n = (long)Co * Ci * TA * TB;
+    hipLaunchKernelGGL(k_weight_relayout_tc, dim3(ew_blocks(n)), dim3(256), 0, st, W, A2, Co, Ci, KH, KW, TA, TB, kh0, dkh,
+                       kw0, dkw, mode);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_weight_relayout_tc launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+int fast_wgrad_splits(int M, int C, int T, long Np) {
+    const int bn = C >= 128 ? 128 : 64;
+    const long tiles = (long)T * fd_cdiv(C, bn) * fd_cdiv(M, M > 32 ? 64 : 32);
+    long want = (512 + tiles - 1) / tiles;
+    const long maxs = (Np + 511) / 512;
+    long sp = want < maxs ? want : maxs;
+    if (sp < 1) sp = 1;
+    if (sp > 64) sp = 64;
+    return (int)sp;
+}
+
+int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, hipStream_t st) {
+    FastWgradArgs g = a;
+    const long Np = (long)a.Nb * a.NY * a.NX;
+    long pps = (Np + splits - 1) / splits;
+    pps = (pps + 31) / 32 * 32;
+    g.pix_per_split = pps;
+    auto go = [&](auto kern, int BM, int BN) {
+        const size_t lds = sizeof(float) * 2 * 32 * ((BM + 1) + (BN + 1));
+        dim3 grid(a.T * fd_cdiv(a.C, BN), fd_cdiv(a.M, BM), splits);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);
+    };
+    if (a.M <= 32) go(k_wgrad_fast<1, 4, 1, 1>, 32, 128);
+    else if (a.C >= 128) go(k_wgrad_fast<2, 2, 1, 2>, 64, 128);
+    else go(k_wgrad_fast<2, 2, 1, 1>, 64, 64);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_wgrad_fast launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    const long n = (long)a.M * a.C * a.T;
+    hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks(n)), dim3(256), 0, st, a.slabs, gw, a.M, a.C, a.T, splits);
+    e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}

@@ -200,6 +200,22 @@ __global__ void __launch_bounds__(NT) k_adam(float* __restrict__ p, const float*
     }
 }
 
+__global__ void k_adam_tick(float* __restrict__ state) { state[0] += 1.0f; }
+__global__ void __launch_bounds__(NT) k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, long n, const float* __restrict__ state, float b1,
+                                                 float b2, float eps, float gscale) {
+    const float step = state[0], lr = state[1];
+    const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+    const float step_size = lr / bc1, sqrt_bc2 = sqrtf(bc2);
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) / sqrt_bc2 + eps));
+    }
+}
+
 }  // namespace
 
 extern "C" int fd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream) {
@@ -312,5 +328,17 @@ extern "C" int fd_adam_step(float* param, const float* grad, float* exp_avg, flo
     hipLaunchKernelGGL(k_adam, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                        lr / bias_corr1, beta1, beta2, eps, sqrtf(bias_corr2), grad_scale);
     FD_LAUNCH_CHECK("fd_adam_step");
+    return 0;
+}
+
+extern "C" int fd_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state,
+                                float beta1, float beta2, float eps, float grad_scale, void* stream) {
+    FD_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && n >= 0, "fd_adam_step_dev: bad args");
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+    FD_LAUNCH_CHECK("fd_adam_step_dev(tick)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_adam_dev, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       state, beta1, beta2, eps, grad_scale);
+    FD_LAUNCH_CHECK("fd_adam_step_dev");
     return 0;
 }

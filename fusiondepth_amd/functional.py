@@ -389,7 +389,9 @@ class _Conv2d(torch.autograd.Function):
         d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
         Ho, Wo = _conv_out_hw(d)
         y = _empty((d.N, d.Cout, Ho, Wo), x)
-        call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), stream())
+        nws = query("fd_conv2d_fwd_ws_floats", ctypes.addressof(d))
+        ws = _empty((nws,), x) if nws > 0 else None
+        call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(ws), stream())
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.desc, ctx.has_bias = d, bias is not None
         return y
@@ -615,3 +617,9 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
     bc1, bc2 = 1.0 - betas[0] ** step, 1.0 - betas[1] ** step
     call("fd_adam_step", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr), betas[0],
          betas[1], float(eps), bc1, bc2, float(grad_scale), stream())
+
+
+def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+    """Adam update whose step counter / lr live in ``state`` (device, [step, lr]) — hipGraph-replay safe."""
+    call("fd_adam_step_dev", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(state), betas[0],
+         betas[1], float(eps), float(grad_scale), stream())

@@ -97,6 +97,8 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.adam_step_count = 0
         self.lr = self.learning_rate
+        self.adam_state = torch.tensor([0.0, self.lr], device=self.device)      # [step, lr] on the device (graph-safe)
+        self._graph = None
         self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)
         if self.opt.train_load_weights_folder is not None:
             self.load_model()
@@ -153,10 +155,11 @@ class Trainer:
         return losses
 
     def optimizer_step(self, grad_scale=1.0):
-        """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8).step(); zero_grad()  as one fused kernel."""
+        """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8).step(); zero_grad()  as one fused kernel.  The step
+        counter and lr are read from device memory so the launch can live inside a captured hipGraph."""
         self.adam_step_count += 1
-        FD.adam_step(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.adam_step_count,
-                     self.lr, grad_scale=grad_scale)
+        FD.adam_step_dev(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.adam_state,
+                         grad_scale=grad_scale)
         self.flat.zero_grad()
 
     def end_epoch(self):
@@ -164,6 +167,59 @@ class Trainer:
         self.epoch += 1
         if self.scheduler_step_size > 0 and self.epoch % self.scheduler_step_size == 0:
             self.lr *= 0.1
+            self.adam_state[1] = self.lr
+
+    # ------------------------------------------------------------------------------------------------
+    def train_step_graphed(self, micro_batches):
+        """``train_step`` replayed from a captured hipGraph (HIP graphs instead of a tracing compiler): the ~4500
+        kernel launches of one optimiser step cost one graph launch on the host.  The first call runs eagerly
+        (allocator warm-up), the second captures, later calls copy the new batch into the captured input buffers
+        and replay.  With several ranks the forward/backward micro-steps are replayed and the gradient all-reduce +
+        Adam run after the graph."""
+        if self._graph is None:
+            self._static_mbs = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in mb.items()} for mb in micro_batches]
+            self._graph = "warm"
+            # warm up on the stream the capture will use, so that autograd's AccumulateGrad nodes are bound to it
+            self._side = torch.cuda.Stream()
+            self._side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._side):
+                losses = self.train_step(self._static_mbs)
+            torch.cuda.current_stream().wait_stream(self._side)
+            return losses
+        for dst, src in zip(self._static_mbs, micro_batches):
+            if dst is src:
+                continue
+            for k, v in src.items():
+                if torch.is_tensor(v) and dst[k].data_ptr() != v.data_ptr():
+                    dst[k].copy_(v)
+        if self._graph == "warm":
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._side):
+                self._static_losses = self._graph_body(self._static_mbs)
+            self._graph = g
+        self._graph.replay()
+        if self.world_size > 1:
+            self._sync_and_step()
+        self.adam_step_count += 0 if self.world_size > 1 else 1
+        self.step += 1
+        self.batch_idx += self.accumulate_step
+        return self._static_losses
+
+    def _graph_body(self, mbs):
+        losses = None
+        for inputs in mbs:
+            outputs, losses = self.process_batch(inputs)
+            (losses["loss"] / self.accumulate_step).backward()
+        if self.world_size == 1:
+            FD.adam_step_dev(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.adam_state)
+            self.flat.flat_grad.zero_()
+        return {k: v.detach() for k, v in losses.items()}
+
+    def _sync_and_step(self):
+        import torch.distributed as dist
+        dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM)
+        self.optimizer_step(1.0 / self.world_size)
 
     # ------------------------------------------------------------------------------------------------
     def process_batch(self, inputs, val=False):

@@ -153,8 +153,11 @@ typedef struct {
     int in_norm;            /* 1: taps read (x-0.45)/0.225 (resnet_encoder.py:94), padding stays 0 */
 } fd_conv_desc;
 
-/* y [N,Cout,Ho,Wo] = act(conv(x, w) + bias);  bias may be NULL. */
-int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* stream);
+/* y [N,Cout,Ho,Wo] = act(conv(x, w) + bias);  bias may be NULL.  ws: fd_conv2d_fwd_ws_floats(d) floats (weight
+ * re-layout + split-K slabs of the fast path; may be 0 -> ws may be NULL). */
+long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d);
+int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* ws,
+                  void* stream);
 /* gx [N,Cin,H,W] = d/dx of sum(conv(x,w) * gy)  (gy is the gradient w.r.t. the PRE-activation output;
  * apply fd_act_bwd first when act != 0).  ws: fd_conv2d_bwd_data_ws_floats(d) floats. */
 long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d);
@@ -220,6 +223,10 @@ int fd_depth_errors(const float* gt, const float* pred, long n, float* out, floa
  * (1/world_size averaging for data parallel).  */
 int fd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr, float beta1,
                  float beta2, float eps, float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+/* Same update with the step counter and learning rate held on the device (state[0] = step count as float, incremented
+ * by this call; state[1] = lr), so that a captured hipGraph of the training step stays valid across replays. */
+int fd_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float* state, float beta1,
+                     float beta2, float eps, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------ sparse LiDAR --------------- */
 
