@@ -498,7 +498,7 @@ namespace {
 inline long align4(long n) { return (n + 3) / 4 * 4; }
 inline bool fast_fwd_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->in_norm; }
 inline bool fast_dgrad_ok(const fd_conv_desc* d) { return d->Cout % 16 == 0; }
-inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->in_norm; }
+inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && d->Cin >= 64 && !d->in_norm; }   // narrow layers: a (tap, channel) tile would be mostly padding
 
 void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
     f = FastGemmArgs{};

@@ -135,18 +135,29 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
             if (ch + 1 < ch_hi) load_chunk(ch + 1);
             const float* pa = sA + cur * BKC * LDA + arow * LDA + wave_m * 32 * WM + acol;
             const float* pb = sB + cur * BKC * LDB + arow * LDB + wave_n * 32 * WN + acol;
+            // software-pipelined operand fetch: the LDS reads of k-step kk+1 are in flight while the MFMAs of
+            // k-step kk execute (two register sets), so the matrix pipe never waits on LDS latency
+            float av[2][WM], bv[2][WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[0][i] = pa[i * 32];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[0][j] = pb[j * 32];
 #pragma unroll
             for (int kk = 0; kk < BKC / 2; ++kk) {
-                float av[WM], bv[WN];
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk + 1 < BKC / 2) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) av[i] = pa[kk * 2 * LDA + i * 32];
+                    for (int i = 0; i < WM; ++i) av[nb][i] = pa[(kk + 1) * 2 * LDA + i * 32];
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 2 * LDB + j * 32];
+                    for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (ch + 1 < ch_hi) store_chunk(cur ^ 1);
             __syncthreads();
@@ -283,18 +294,27 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
             if (ch + 1 < nchunk) load_chunk(pbeg + (long)(ch + 1) * BP);
             const float* pa = sA + cur * BP * LDA + arow * LDA + wave_m * 32 * WM + acol;
             const float* pb = sB + cur * BP * LDB + arow * LDB + wave_n * 32 * WN + acol;
+            float av[2][WM], bv[2][WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[0][i] = pa[i * 32];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[0][j] = pb[j * 32];
 #pragma unroll
             for (int kk = 0; kk < BP / 2; ++kk) {
-                float av[WM], bv[WN];
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk + 1 < BP / 2) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) av[i] = pa[kk * 2 * LDA + i * 32];
+                    for (int i = 0; i < WM; ++i) av[nb][i] = pa[(kk + 1) * 2 * LDA + i * 32];
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 2 * LDB + j * 32];
+                    for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (ch + 1 < nchunk) store_chunk(cur ^ 1);
             __syncthreads();

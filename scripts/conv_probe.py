@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import torch
 from fusiondepth_amd import functional as FD
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-B = 6
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 SHAPES = [  # name, Cin, H, W, Cout, K, stride, pad, mode
     ("layer1 3x3 64->64 @48x160", 64, 48, 160, 64, 3, 1, 1, "zero"),
     ("layer2 3x3 128->128 @24x80", 128, 24, 80, 128, 3, 1, 1, "zero"),
