@@ -43,17 +43,29 @@ def parse():
     return ap.parse_args()
 
 
-def event_time_ms(fn, iters):
-    """Average duration of fn() measured with HIP events on the stream the kernels are launched on."""
-    fn()
-    torch.cuda.synchronize()
-    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(iters):
+def graph_time_ms(fn, launches=20, replays=5):
+    """Average device time of one fn() call: `launches` calls are captured into a hipGraph and replayed, timed with
+    HIP events on the capture/replay stream, so host launch overhead is excluded (kernel time only)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()                                           # warm-up: allocator, hipFuncSetAttribute, autograd nodes
         fn()
-    end.record()
-    torch.cuda.synchronize()
-    return start.elapsed_time(end) / iters
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(launches):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        for _ in range(replays):
+            g.replay()
+        end.record()
+        torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    return start.elapsed_time(end) / (launches * replays)
 
 
 def roofline_probes(args, tr, batch):
@@ -61,16 +73,19 @@ def roofline_probes(args, tr, batch):
     from fusiondepth_amd import functional as FD
     out = {}
     B = tr.batch_size
-    # dominant kernel: layer1 3x3 64->64 convs at H/4 x W/4 (16 of the 26 GMAC-heaviest launches per ResNet-18 pass)
-    h4, w4 = args.height // 4, args.width // 4
-    x = torch.randn(B, 64, h4, w4, device="cuda")
-    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+    # dominant kernel: the 3x3 convolutions of the ResNet trunks (k_conv_fast).  Probe = layer2's 128->128 conv at
+    # H/8 x W/8, forward (the data-gradient launch is the same kernel with re-laid-out weights).
+    h8, w8 = args.height // 8, args.width // 8
+    x = torch.randn(B, 128, h8, w8, device="cuda")
+    w = torch.randn(128, 128, 3, 3, device="cuda") * 0.03
     with torch.no_grad():
-        ms = event_time_ms(lambda: FD.conv2d(x, w, None, 1, 1), 50)
-    flops = 2.0 * B * h4 * w4 * 64 * 64 * 9
-    out["roofline"] = {"bound": "mfma", "kernel": "k_gather_gemm<3,3> (layer1 conv 64->64 @%dx%d, B=%d)" % (h4, w4, B),
+        ms = graph_time_ms(lambda: FD.conv2d(x, w, None, 1, 1))
+    flops = 2.0 * B * h8 * w8 * 128 * 128 * 9
+    out["roofline"] = {"bound": "mfma", "kernel": "k_conv_fast (ResNet layer2 conv 3x3 128->128 @%dx%d, micro-batch %d; incl. its "
+                       "weight re-layout + split-K finish launches)" % (h8, w8, B),
                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                       "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "ms_per_launch": ms}
+                       "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "us_per_launch": ms * 1e3,
+                       "flop_per_launch": flops}
     # fused loss path (HBM-bound): forward + backward kernels of the four scales
     H, W = args.height, args.width
     po = FD.PhotoOptions()
@@ -89,11 +104,13 @@ def roofline_probes(args, tr, batch):
                                       batch["4beam"], po)[:2]
             tot = tot + photo + si
         tot.backward()
-    ms = event_time_ms(loss_fwd_bwd, 20)
+    ms = graph_time_ms(loss_fwd_bwd, launches=5)
     byts = LOSS_BYTES_PER_PIXEL * H * W * B
-    out["roofline_loss_path"] = {"bound": "hbm", "kernel": "k_photo_fwd + k_photo_bwd x 4 scales (+finalize/adjoint)",
+    out["roofline_loss_path"] = {"bound": "hbm", "kernel": "k_photo_fwd + k_photo_bwd x 4 scales (+ finalize / upsample-adjoint "
+                                 "/ projection-matrix launches), micro-batch %d" % B,
                                  "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "ms_per_launch": ms}
+                                 "frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "us_per_launch": ms * 1e3,
+                                 "bytes_per_launch": byts}
     return out
 
 
