@@ -158,7 +158,7 @@ def main():
     from fusiondepth_amd.trainer import Trainer
     rank, world, local_rank = dp.init_from_env()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     opt = MonodepthOptions().parse(["--num_layers", str(args.num_layers), "--weights_init", "scratch", "--batch_size",
                                     str(args.batch_size), "--height", str(args.height), "--width", str(args.width)])
     tr = Trainer(opt, rank=rank, world_size=world, verbose=(rank == 0))

@@ -83,7 +83,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     float4 ra[NA_LOAD];
     float rb[NB_LOAD];
     bool okb = false;
-    auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+    // state of the chunk being fetched (set by prep_chunk, consumed by the load/store slices)
+    unsigned a_off[NA_LOAD], b_off = 0u, b_step = 0u;
+    auto prep_chunk = [&](int ch) __attribute__((always_inline)) {
         const int t = ch / cpt, c0 = (ch - t * cpt) * BKC;          // wave-uniform
         const int ta = t / g.TB, tb = t - ta * g.TB;
         const unsigned k0 = (unsigned)t * (unsigned)g.C + (unsigned)c0;
@@ -91,30 +93,27 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
         for (int i = 0; i < NA_LOAD; ++i) {
             int m = m0 + ar + A_ROWS_PER_PASS * i;
             m = m < g.M ? m : g.M - 1;                                // rows >= M are never stored by the epilogue
-            if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM)
-                ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)((unsigned)m * (unsigned)g.K + k0 + 4u * a4));
+            a_off[i] = (unsigned)m * (unsigned)g.K + k0 + 4u * a4;
         }
         int r = ry0 + ta * g.da, cc = cx0 + tb * g.db;
         bool ok = pvalid;
         if (g.pad_mode == 1) { r = refl_idx(r, g.Hi); cc = refl_idx(cc, g.Wi); }
         else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
         okb = ok;
-        unsigned off = ok ? nbase + (unsigned)(c0 + kr) * chw + (unsigned)(r * g.Wi + cc) : 0u;
-        const unsigned step = ok ? (unsigned)RP * chw : 0u;
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) { rb[i] = g.X[off]; off += step; }
+        b_off = ok ? nbase + (unsigned)(c0 + kr) * chw + (unsigned)(r * g.Wi + cc) : 0u;
+        b_step = ok ? (unsigned)RP * chw : 0u;
     };
-    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
-        float* a = sA + buf * BKC * LDA;
-        float* b = sB + buf * BKC * LDB;
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) {
-            if (A_PARTIAL && ar + A_ROWS_PER_PASS * i >= BM) continue;
-            float* q = a + (4 * a4) * LDA + ar + A_ROWS_PER_PASS * i;
-            q[0] = ra[i].x; q[LDA] = ra[i].y; q[2 * LDA] = ra[i].z; q[3 * LDA] = ra[i].w;
-        }
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) b[(kr + RP * i) * LDB + jn] = okb ? rb[i] : 0.f;
+    auto load_a = [&](int i) __attribute__((always_inline)) {
+        if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)a_off[i]);
+    };
+    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = g.X[b_off + (unsigned)i * b_step]; };
+    auto store_a = [&](int buf, int i) __attribute__((always_inline)) {
+        if (A_PARTIAL && ar + A_ROWS_PER_PASS * i >= BM) return;
+        float* q = sA + buf * BKC * LDA + (4 * a4) * LDA + ar + A_ROWS_PER_PASS * i;
+        q[0] = ra[i].x; q[LDA] = ra[i].y; q[2 * LDA] = ra[i].z; q[3 * LDA] = ra[i].w;
+    };
+    auto store_b = [&](int buf, int i) __attribute__((always_inline)) {
+        sB[buf * BKC * LDB + (kr + RP * i) * LDB + jn] = okb ? rb[i] : 0.f;
     };
 
     f32x16 acc[WM][WN];
@@ -125,33 +124,57 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    constexpr int NK = BKC / 2;          // MFMA k-steps per chunk
+    constexpr int HS = NK / 2;           // first half of the k-steps issues the next chunk's loads, second half stores them
     const int arow = lane >> 5, acol = lane & 31;
     if (ch_lo < ch_hi) {
-        load_chunk(ch_lo);
-        store_chunk(0);
+        prep_chunk(ch_lo);
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) load_b(i);
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) store_a(0, i);
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) store_b(0, i);
         __syncthreads();
         for (int ch = ch_lo; ch < ch_hi; ++ch) {
             const int cur = (ch - ch_lo) & 1;
-            if (ch + 1 < ch_hi) load_chunk(ch + 1);
+            const bool has_next = ch + 1 < ch_hi;
+            if (has_next) prep_chunk(ch + 1);
             const float* pa = sA + cur * BKC * LDA + arow * LDA + wave_m * 32 * WM + acol;
             const float* pb = sB + cur * BKC * LDB + arow * LDB + wave_n * 32 * WN + acol;
-            // software-pipelined operand fetch: the LDS reads of k-step kk+1 are in flight while the MFMAs of
-            // k-step kk execute (two register sets), so the matrix pipe never waits on LDS latency
+            // Fine-grained software pipeline: LDS operand reads of k-step kk+1, the global loads of chunk ch+1 (first half
+            // of the k-steps) and their LDS stores into the other buffer (second half) are issued in the shadow of the
+            // MFMAs of k-step kk, so the matrix pipe sees no separate load / store phases.
             float av[2][WM], bv[2][WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i) av[0][i] = pa[i * 32];
 #pragma unroll
             for (int j = 0; j < WN; ++j) bv[0][j] = pb[j * 32];
 #pragma unroll
-            for (int kk = 0; kk < BKC / 2; ++kk) {
+            for (int kk = 0; kk < NK; ++kk) {
                 const int cb = kk & 1, nb = cb ^ 1;
-                if (kk + 1 < BKC / 2) {
+                if (kk + 1 < NK) {
 #pragma unroll
                     for (int i = 0; i < WM; ++i) av[nb][i] = pa[(kk + 1) * 2 * LDA + i * 32];
 #pragma unroll
                     for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
                 }
-                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
+                if (has_next) {
+                    if (kk < HS) {
+#pragma unroll
+                        for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
+#pragma unroll
+                        for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
+#pragma unroll
+                        for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the memory ops ahead of this step's MFMAs
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -159,7 +182,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (ch + 1 < ch_hi) store_chunk(cur ^ 1);
             __syncthreads();
         }
     }
@@ -238,7 +260,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
 
     float ra[NA_LOAD], rb[NB_LOAD];
     bool okp = false, okx = false;
-    auto load_chunk = [&](long pc) __attribute__((always_inline)) {
+    unsigned offa = 0u, stepa = 0u, offb = 0u, stepb = 0u;
+    auto prep_chunk = [&](long pc) __attribute__((always_inline)) {
         const long p = pc + pl;
         const bool pv = p < pend;
         const long pp = pv ? p : 0;
@@ -246,33 +269,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
         const int rem = (int)(pp - (long)n * plane);
         const int y = rem / g.NX, x = rem - y * g.NX;
         okp = pv;
-        unsigned offa = pv ? (unsigned)n * (unsigned)g.dy_ns + (unsigned)(m0 + rw) * (unsigned)g.dy_cs + (unsigned)rem : 0u;
-        const unsigned stepa = pv ? (unsigned)RPW * (unsigned)g.dy_cs : 0u;
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) {
-            ra[i] = g.dY[(rw + RPW * i) < nrow ? offa : 0u];
-            offa += stepa;
-        }
+        offa = pv ? (unsigned)n * (unsigned)g.dy_ns + (unsigned)(m0 + rw) * (unsigned)g.dy_cs + (unsigned)rem : 0u;
+        stepa = pv ? (unsigned)RPW * (unsigned)g.dy_cs : 0u;
         int r = y * g.sy + g.oy + ta * g.da, cc = x * g.sx + g.ox + tb * g.db;
         bool ok = pv;
         if (g.pad_mode == 1) { r = refl_idx(r, g.Hi); cc = refl_idx(cc, g.Wi); }
         else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
         okx = ok;
-        unsigned offb = ok ? ((unsigned)n * (unsigned)g.C + (unsigned)(c0 + rw)) * chw + (unsigned)(r * g.Wi + cc) : 0u;
-        const unsigned stepb = ok ? (unsigned)RPW * chw : 0u;
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) {
-            rb[i] = g.X[(rw + RPW * i) < ncol ? offb : 0u];
-            offb += stepb;
-        }
+        offb = ok ? ((unsigned)n * (unsigned)g.C + (unsigned)(c0 + rw)) * chw + (unsigned)(r * g.Wi + cc) : 0u;
+        stepb = ok ? (unsigned)RPW * chw : 0u;
     };
-    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
-        float* a = sA + buf * BP * LDA;
-        float* b = sB + buf * BP * LDB;
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) a[pl * LDA + rw + RPW * i] = (okp && (rw + RPW * i) < nrow) ? ra[i] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) b[pl * LDB + rw + RPW * i] = (okx && (rw + RPW * i) < ncol) ? rb[i] : 0.f;
+    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = g.dY[(rw + RPW * i) < nrow ? offa + (unsigned)i * stepa : 0u]; };
+    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = g.X[(rw + RPW * i) < ncol ? offb + (unsigned)i * stepb : 0u]; };
+    auto store_a = [&](int buf, int i) __attribute__((always_inline)) {
+        sA[buf * BP * LDA + pl * LDA + rw + RPW * i] = (okp && (rw + RPW * i) < nrow) ? ra[i] : 0.f;
+    };
+    auto store_b = [&](int buf, int i) __attribute__((always_inline)) {
+        sB[buf * BP * LDB + pl * LDB + rw + RPW * i] = (okx && (rw + RPW * i) < ncol) ? rb[i] : 0.f;
     };
 
     f32x16 acc[WM][WN];
@@ -284,14 +297,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nchunk = pend > pbeg ? (int)((pend - pbeg + BP - 1) / BP) : 0;
+    constexpr int NK = BP / 2, HS = NK / 2;
     const int arow = lane >> 5, acol = lane & 31;
     if (nchunk > 0) {
-        load_chunk(pbeg);
-        store_chunk(0);
+        prep_chunk(pbeg);
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) load_b(i);
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) store_a(0, i);
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) store_b(0, i);
         __syncthreads();
         for (int ch = 0; ch < nchunk; ++ch) {
             const int cur = ch & 1;
-            if (ch + 1 < nchunk) load_chunk(pbeg + (long)(ch + 1) * BP);
+            const bool has_next = ch + 1 < nchunk;
+            if (has_next) prep_chunk(pbeg + (long)(ch + 1) * BP);
             const float* pa = sA + cur * BP * LDA + arow * LDA + wave_m * 32 * WM + acol;
             const float* pb = sB + cur * BP * LDB + arow * LDB + wave_n * 32 * WN + acol;
             float av[2][WM], bv[2][WN];
@@ -300,15 +322,28 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
 #pragma unroll
             for (int j = 0; j < WN; ++j) bv[0][j] = pb[j * 32];
 #pragma unroll
-            for (int kk = 0; kk < BP / 2; ++kk) {
+            for (int kk = 0; kk < NK; ++kk) {
                 const int cb = kk & 1, nb = cb ^ 1;
-                if (kk + 1 < BP / 2) {
+                if (kk + 1 < NK) {
 #pragma unroll
                     for (int i = 0; i < WM; ++i) av[nb][i] = pa[(kk + 1) * 2 * LDA + i * 32];
 #pragma unroll
                     for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
                 }
-                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ahead of this step's MFMAs
+                if (has_next) {
+                    if (kk < HS) {
+#pragma unroll
+                        for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
+#pragma unroll
+                        for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
+#pragma unroll
+                        for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -316,7 +351,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (ch + 1 < nchunk) store_chunk(cur ^ 1);
             __syncthreads();
         }
     }
