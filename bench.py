@@ -73,16 +73,17 @@ def roofline_probes(args, tr, batch):
     from fusiondepth_amd import functional as FD
     out = {}
     B = tr.batch_size
-    # dominant kernel: the 3x3 convolutions of the ResNet trunks (k_conv_fast).  Probe = layer2's 128->128 conv at
-    # H/8 x W/8, forward (the data-gradient launch is the same kernel with re-laid-out weights).
-    h8, w8 = args.height // 8, args.width // 8
-    x = torch.randn(B, 128, h8, w8, device="cuda")
-    w = torch.randn(128, 128, 3, 3, device="cuda") * 0.03
+    # dominant kernel: the 3x3 convolutions of the ResNet trunks (k_conv_fast).  Probe = layer1's 64->64 conv at
+    # H/4 x W/4, forward (the data-gradient launch is the same kernel with re-laid-out weights).  In the training step
+    # four such streams run concurrently; the probe runs alone.
+    h8, w8 = args.height // 4, args.width // 4
+    x = torch.randn(B, 64, h8, w8, device="cuda")
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.03
     with torch.no_grad():
         ms = graph_time_ms(lambda: FD.conv2d(x, w, None, 1, 1))
-    flops = 2.0 * B * h8 * w8 * 128 * 128 * 9
-    out["roofline"] = {"bound": "mfma", "kernel": "k_conv_fast (ResNet layer2 conv 3x3 128->128 @%dx%d, micro-batch %d; incl. its "
-                       "weight re-layout + split-K finish launches)" % (h8, w8, B),
+    flops = 2.0 * B * h8 * w8 * 64 * 64 * 9
+    out["roofline"] = {"bound": "mfma", "kernel": "k_conv_fast (ResNet layer1 conv 3x3 64->64 @%dx%d, micro-batch %d, alone on the "
+                       "GPU; incl. its weight re-layout launch)" % (h8, w8, B),
                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "us_per_launch": ms * 1e3,
                        "flop_per_launch": flops}

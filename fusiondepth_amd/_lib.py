@@ -60,10 +60,12 @@ SIGNATURES = {
     "fd_smooth_fwd": ("ppppiiiip", "i"),
     "fd_smooth_bwd": ("pppppiiiip", "i"),
     "fd_scatter_2channel": ("ppiiiiiiiip", "i"),
+    "fd_conv2d_fwd_wt_floats": ("p", "l"),
     "fd_conv2d_fwd_ws_floats": ("p", "l"),
-    "fd_conv2d_fwd": ("ppppppp", "i"),
+    "fd_conv2d_fwd": ("pppppp" "i" "pp", "i"),
+    "fd_conv2d_bwd_data_wt_floats": ("p", "l"),
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
-    "fd_conv2d_bwd_data": ("pppppp", "i"),
+    "fd_conv2d_bwd_data": ("ppppp" "i" "pp", "i"),
     "fd_conv2d_bwd_weight_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_weight": ("ppppppp", "i"),
     "fd_act_bwd": ("ppplip", "i"),

@@ -513,17 +513,22 @@ void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
 }
 }  // namespace
 
+extern "C" long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d) {
+    if (!d || !fast_fwd_ok(d)) return 0;
+    return align4((long)d->Cout * d->Cin * d->KH * d->KW);
+}
+
 extern "C" long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s) || !fast_fwd_ok(d)) return 0;
     FastGemmArgs f;
     fill_fwd_args(d, s, f);
-    return align4((long)d->Cout * f.K) + fast_splitk_slab_floats(f, nullptr);
+    return fast_splitk_slab_floats(f, nullptr);
 }
 
-extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* ws,
-                             void* stream) {
+extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
+                             int wt_ready, float* ws, void* stream) {
     if (int rc = check_desc(d, "fd_conv2d_fwd")) return rc;
     FD_REQUIRE(x && w && y, "fd_conv2d_fwd: NULL tensor");
     ConvShape s;
@@ -532,12 +537,13 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
                "fd_conv2d_fwd: tensor too large for 32-bit offsets");
     hipStream_t st = (hipStream_t)stream;
     if (fast_fwd_ok(d)) {
-        FD_REQUIRE(ws, "fd_conv2d_fwd: workspace required (fd_conv2d_fwd_ws_floats)");
+        FD_REQUIRE(wt, "fd_conv2d_fwd: weight-layout buffer required (fd_conv2d_fwd_wt_floats)");
         FastGemmArgs f;
         fill_fwd_args(d, s, f);
-        if (int rc = fast_weight_relayout(w, ws, d->Cout, d->Cin, d->KH, d->KW, d->KH, d->KW, 0, 1, 0, 1, 0, st)) return rc;
-        f.A = ws; f.X = x; f.Y = y; f.bias = bias;
-        f.slabs = ws + align4((long)d->Cout * f.K);
+        if (!wt_ready)
+            if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, d->KH, d->KW, d->KH, d->KW, 0, 1, 0, 1, 0, st)) return rc;
+        f.A = wt; f.X = x; f.Y = y; f.bias = bias;
+        f.slabs = ws;
         return fast_gemm_launch(f, st);
     }
     GemmArgs g = {};
@@ -555,11 +561,16 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
     return 0;
 }
 
+extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
+    if (!d) return 0;
+    return (d->stride == 1 ? 1 : 4) * align4((long)d->Cin * d->Cout * d->KH * d->KW);
+}
+
 extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s)) return 0;
-    const long wt = align4((long)d->Cin * d->Cout * d->KH * d->KW);
+    const long wt = 0;
     const long padded = d->pad_mode == 1 ? align4((long)d->N * d->Cin * (d->H + 2) * (d->W + 2)) : 0;
     long slabs = 0;
     if (fast_dgrad_ok(d) && d->stride == 1) {          // split-K only on the stride-1 path
@@ -573,10 +584,10 @@ extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
     return wt + padded + slabs;
 }
 
-extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* ws,
-                                  void* stream) {
+extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt_base,
+                                  int wt_ready, float* ws, void* stream) {
     if (int rc = check_desc(d, "fd_conv2d_bwd_data")) return rc;
-    FD_REQUIRE(gy && w && gx && ws, "fd_conv2d_bwd_data: NULL tensor");
+    FD_REQUIRE(gy && w && gx && wt_base, "fd_conv2d_bwd_data: NULL tensor");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_data: empty output");
     FD_REQUIRE((long)d->N * d->Cin * (d->H + 2) * (d->W + 2) < (1L << 31) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 31),
@@ -584,11 +595,12 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
     hipStream_t st = (hipStream_t)stream;
     const int KH = d->KH, KW = d->KW;
     const bool fast = fast_dgrad_ok(d);
-    float* wt = ws;
     const long wt_n = align4((long)d->Cin * d->Cout * KH * KW);
-    float* gpad = ws + wt_n;
+    float* wt = wt_base;                       // per parity class: wt_base + class * wt_n
+    float* gpad = ws;
     const long pad_n = d->pad_mode == 1 ? align4((long)d->N * d->Cin * (d->H + 2) * (d->W + 2)) : 0;
-    float* slabs = ws + wt_n + pad_n;
+    float* slabs = ws ? ws + pad_n : nullptr;
+    FD_REQUIRE(ws || (pad_n == 0), "fd_conv2d_bwd_data: workspace required for reflect padding");
 
     // common geometry of "a conv over gy": channels = Cout, spatial = Ho x Wo
     GemmArgs g = {};
@@ -596,7 +608,8 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
     g.M = d->Cin; g.Nb = d->N; g.C = d->Cout; g.Hi = s.Ho; g.Wi = s.Wo;
     auto run = [&](int TA, int TB, int kh0, int dkh, int kw0, int dkw, bool allow_split) -> int {
         if (fast) {
-            if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, KH, KW, TA, TB, kh0, dkh, kw0, dkw, 1, st)) return rc;
+            if (!wt_ready)
+                if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, KH, KW, TA, TB, kh0, dkh, kw0, dkw, 1, st)) return rc;
             FastGemmArgs f = {};
             f.A = wt; f.X = gy; f.Y = g.Y; f.bias = nullptr;
             f.M = d->Cin; f.C = d->Cout; f.T = TA * TB; f.TB = TB; f.K = f.T * f.C;
@@ -610,9 +623,11 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
             (void)allow_split;
             return fast_gemm_launch(f, st);
         }
-        hipLaunchKernelGGL(k_weight_relayout, dim3(ew_blocks((long)d->Cin * d->Cout * TA * TB)), dim3(256), 0, st, w, wt, d->Cout,
-                           d->Cin, KH, KW, TA, TB, kh0, dkh, kw0, dkw);
-        FD_LAUNCH_CHECK("fd_conv2d_bwd_data(relayout)");
+        if (!wt_ready) {
+            hipLaunchKernelGGL(k_weight_relayout, dim3(ew_blocks((long)d->Cin * d->Cout * TA * TB)), dim3(256), 0, st, w, wt,
+                               d->Cout, d->Cin, KH, KW, TA, TB, kh0, dkh, kw0, dkw);
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(relayout)");
+        }
         g.A = wt; g.K = d->Cout * TA * TB;
         if (int rc = dispatch_gemm(TA, TB, g, st)) return rc;
         FD_LAUNCH_CHECK("fd_conv2d_bwd_data(gemm)");
@@ -660,6 +675,7 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
             g.sy = 1; g.oy = (ph + d->pad - kh0) / 2; g.da = -1;
             g.sx = 1; g.ox = (pw + d->pad - kw0) / 2; g.db = -1;
             g.osy = 2; g.ooy = ph; g.osx = 2; g.oox = pw;
+            wt = wt_base + (long)(ph * 2 + pw) * wt_n;
             if (int rc = run(TA, TB, kh0, 2, kw0, 2, false)) return rc;
         }
     return 0;

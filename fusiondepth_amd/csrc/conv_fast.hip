@@ -13,6 +13,7 @@
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include "conv_fast.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -426,33 +427,81 @@ void launch_cfg(const FastGemmArgs& a, int splits, hipStream_t st) {
 
 }  // namespace
 
-long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out) {
+namespace {
+// Tile / split-K choice.  Workgroups resident on one CU share its four matrix pipes, so a launch takes
+// ~ceil(blocks / 256) block-times: pick the configuration whose block count fills the 256 CUs most evenly
+// (measured: 360 blocks of 128x128 leave 30 % of the chip idle, 720 blocks of 64x128 do not).
+struct FastChoice { int cfg; int splits; };   // cfg 0: 128x128, 1: 64x128, 2: 32x256
+int g_policy = -1;   // 0: cost model for an otherwise idle GPU; 1: efficiency first (the trainer runs 4 streams concurrently)
+int policy() {
+    if (g_policy < 0) { const char* e = getenv("FD_CONV_POLICY"); g_policy = e ? atoi(e) : 0; }
+    return g_policy;
+}
+FastChoice choose_config(const FastGemmArgs& a) {
+    if (policy() == 1) {
+        // Largest tile that M allows (best MFMA : LDS ratio); split K only when even the concurrent streams of the training
+        // step cannot fill the chip (< 64 tiles), and keep >= 8 chunks per split.
+        const long Np1 = (long)a.Nb * a.NY * a.NX;
+        const int c = a.M > 64 ? 0 : (a.M > 32 ? 1 : 2);
+        const int bm1[3] = {128, 64, 32}, bn1[3] = {128, 128, 256};
+        const long tiles = (long)fd_cdiv(Np1, bn1[c]) * fd_cdiv(a.M, bm1[c]);
+        const int bkc1 = (a.C % 32 == 0) ? 32 : 16;
+        const int nchunk1 = a.T * (a.C / bkc1);
+        int sp = 1;
+        if (a.osy == 1 && a.osx == 1 && a.slab_stride > 0 && tiles < 64) {
+            sp = (int)((128 + tiles - 1) / tiles);
+            const int cap = nchunk1 / 8 > 0 ? nchunk1 / 8 : 1;
+            if (sp > cap) sp = cap;
+            if (sp > 8) sp = 8;
+        }
+        return {c, sp};
+    }
     const long Np = (long)a.Nb * a.NY * a.NX;
-    const int BM = a.M > 64 ? 128 : (a.M > 32 ? 64 : 32);
-    const int BN = a.M > 32 ? 128 : 256;
-    const long tiles = (long)fd_cdiv(Np, BN) * fd_cdiv(a.M, BM);
     const int bkc = (a.C % 32 == 0) ? 32 : 16;
     const int nchunk = a.T * (a.C / bkc);
-    int splits = 1;
-    if (tiles < 256 && a.osy == 1 && a.osx == 1) {
-        splits = (int)((384 + tiles - 1) / tiles);
-        const int max_by_k = nchunk / 4 > 0 ? nchunk / 4 : 1;       // >= 4 chunks (128 MFMA k-steps) per split
-        if (splits > max_by_k) splits = max_by_k;
-        if (splits > 32) splits = 32;
-        if (splits < 1) splits = 1;
+    const bool can_split = a.osy == 1 && a.osx == 1 && a.slab_stride > 0;
+    const int bm[3] = {128, 64, 32}, bn[3] = {128, 128, 256};
+    // measured model (scripts/conv_ksweep.py): a launch takes ceil(blocks/256) "block times"; a block time is
+    // chunks * t_chunk + t_fixed (prologue, first-chunk latency, epilogue); split-K adds a slab write + finish pass.
+    const double t_chunk[3] = {2.6, 1.45, 1.55}, t_fixed = 6.0;                 // microseconds
+    const double scale = bkc == 32 ? 1.0 : 0.55;
+    FastChoice best = {a.M > 64 ? 0 : (a.M > 32 ? 1 : 2), 1};
+    double best_t = 1e30;
+    for (int c = 0; c < 3; ++c) {
+        if (c == 0 && a.M <= 64) continue;
+        if (c == 2 && a.M > 32) continue;
+        if (c == 1 && a.M <= 32) continue;
+        const long tiles = (long)fd_cdiv(Np, bn[c]) * fd_cdiv(a.M, bm[c]);
+        const int max_split = can_split ? (nchunk / 4 > 0 ? (nchunk / 4 < 16 ? nchunk / 4 : 16) : 1) : 1;
+        for (int sp = 1; sp <= max_split; ++sp) {
+            const long blocks = tiles * sp;
+            const double rounds = (double)((blocks + 255) / 256);
+            const double per_block = ((double)nchunk / sp) * t_chunk[c] * scale + t_fixed;
+            double t = rounds * per_block;
+            if (sp > 1) t += 3.0 + (double)(sp + 1) * (double)a.out_total * 4.0 / 4.0e6;
+            if (t < best_t) { best_t = t; best = {c, sp}; }
+        }
     }
-    if (splits_out) *splits_out = splits;
-    return splits > 1 ? (long)splits * a.out_total : 0;
+    return best;
+}
+}  // namespace
+
+long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out) {
+    FastGemmArgs probe = a;
+    if (probe.slab_stride <= 0) probe.slab_stride = probe.out_total > 0 ? probe.out_total : 1;   // sizing query
+    const FastChoice ch = choose_config(probe);
+    if (splits_out) *splits_out = ch.splits;
+    return ch.splits > 1 ? (long)ch.splits * a.out_total : 0;
 }
 
 int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
-    int splits = 1;
-    fast_splitk_slab_floats(a, &splits);
+    const FastChoice ch = choose_config(a);
+    const int splits = ch.splits;
     if (splits > 1 && !a.slabs) { fd_set_error("conv: split-K workspace missing"); return -1; }
     const bool b32 = a.C % 32 == 0;
-    if (a.M > 64) {
+    if (ch.cfg == 0) {
         if (b32) launch_cfg<2, 2, 2, 2, 32>(a, splits, st); else launch_cfg<2, 2, 2, 2, 16>(a, splits, st);
-    } else if (a.M > 32) {
+    } else if (ch.cfg == 1) {
         if (b32) launch_cfg<2, 2, 1, 2, 32>(a, splits, st); else launch_cfg<2, 2, 1, 2, 16>(a, splits, st);
     } else {
         if (b32) launch_cfg<1, 4, 1, 2, 32>(a, splits, st); else launch_cfg<1, 4, 1, 2, 16>(a, splits, st);

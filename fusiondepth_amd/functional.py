@@ -380,9 +380,47 @@ def _conv_out_hw(d):
     return (d.H + 2 * d.pad - d.KH) // d.stride + 1, (d.W + 2 * d.pad - d.KW) // d.stride + 1
 
 
+# Cache of kernel-side weight layouts for parameters whose owner opted in (``enable_weight_cache``; the Trainer does).
+# A layout is re-derived when the parameter was modified through torch (``_version``) or by the fused Adam kernel
+# (``_WEIGHTS_EPOCH``, bumped by adam_step*), i.e. once per optimiser step instead of once per launch (the six ResNet
+# passes of the two micro-batches reuse the same weights).  Tensors that did not opt in are re-laid-out on every call.
+_WEIGHTS_EPOCH = [0]
+_WT_CACHE = {}
+_NEXT_CACHE_ID = [1]
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
+
+def enable_weight_cache(params):
+    for p in params:
+        if p.dim() == 4 and not hasattr(p, "_fd_cache_id"):
+            p._fd_cache_id = _NEXT_CACHE_ID[0]
+            _NEXT_CACHE_ID[0] += 1
+
+
+def _weight_layout(w, cache_id, kind, nfloats):
+    """-> (buffer, ready flag) for weight ``w`` and layout ``kind`` ('f' forward, 'd' data-gradient)."""
+    if cache_id is None:
+        return torch.empty((nfloats,), device=w.device, dtype=torch.float32), 0
+    key = (cache_id, kind)
+    stamp = (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
+    ent = _WT_CACHE.get(key)
+    if ent is not None and ent[1].numel() == nfloats:
+        if ent[0] == stamp:
+            return ent[1], 1
+        ent[0] = stamp
+        return ent[1], 0
+    buf = torch.empty((nfloats,), device=w.device, dtype=torch.float32)
+    _WT_CACHE[key] = [stamp, buf]
+    return buf, 0
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+        cache_id = getattr(w, "_fd_cache_id", None)
         x, w = f32(x), f32(w)
         bias = f32(bias) if bias is not None else None
         _need_cuda(x, w)
@@ -390,10 +428,12 @@ class _Conv2d(torch.autograd.Function):
         Ho, Wo = _conv_out_hw(d)
         y = _empty((d.N, d.Cout, Ho, Wo), x)
         nws = query("fd_conv2d_fwd_ws_floats", ctypes.addressof(d))
+        nwt = query("fd_conv2d_fwd_wt_floats", ctypes.addressof(d))
         ws = _empty((nws,), x) if nws > 0 else None
-        call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(ws), stream())
+        wt, ready = _weight_layout(w, cache_id, "f", nwt) if nwt > 0 else (None, 0)
+        call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), stream())
         ctx.save_for_backward(x, w, y if act != 0 else None)
-        ctx.desc, ctx.has_bias = d, bias is not None
+        ctx.desc, ctx.has_bias, ctx.cache_id = d, bias is not None, cache_id
         return y
 
     @staticmethod
@@ -410,7 +450,8 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             ws = _empty((max(query("fd_conv2d_bwd_data_ws_floats", dp), 1),), x)
-            call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(w), ptr(gx), ptr(ws), stream())
+            wt, ready = _weight_layout(w, ctx.cache_id, "d", query("fd_conv2d_bwd_data_wt_floats", dp))
+            call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(w), ptr(gx), ptr(wt), ready, ptr(ws), stream())
             if d.in_norm:   # d/dx of (x - 0.45) / 0.225
                 call("fd_axpby", ptr(gx), ptr(gx), ptr(gx), gx.numel(), 1.0 / 0.225, 0.0, stream())
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
@@ -615,11 +656,13 @@ def depth_errors(gt, pred):
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
     """One torch.optim.Adam update of a flat fp32 tensor, in place."""
     bc1, bc2 = 1.0 - betas[0] ** step, 1.0 - betas[1] ** step
+    bump_weights_epoch()
     call("fd_adam_step", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr), betas[0],
          betas[1], float(eps), bc1, bc2, float(grad_scale), stream())
 
 
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
     """Adam update whose step counter / lr live in ``state`` (device, [step, lr]) — hipGraph-replay safe."""
+    bump_weights_epoch()
     call("fd_adam_step_dev", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(state), betas[0],
          betas[1], float(eps), float(grad_scale), stream())

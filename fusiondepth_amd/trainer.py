@@ -93,12 +93,15 @@ class Trainer:
 
         # ---- optimiser (trainer.py:129-131): Adam + StepLR(gamma 0.1), on one flat buffer ----------------
         self.flat = dp.FlatParameters(self.parameters_to_train)
+        FD.enable_weight_cache(self.parameters_to_train)
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.adam_step_count = 0
         self.lr = self.learning_rate
         self.adam_state = torch.tensor([0.0, self.lr], device=self.device)      # [step, lr] on the device (graph-safe)
         self._graph = None
+        self._streams = []
+        self.parallel_streams = True
         self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)
         if self.opt.train_load_weights_folder is not None:
             self.load_model()
@@ -193,6 +196,7 @@ class Trainer:
                 if torch.is_tensor(v) and dst[k].data_ptr() != v.data_ptr():
                     dst[k].copy_(v)
         if self._graph == "warm":
+            FD.bump_weights_epoch()        # the captured step must (re)derive every weight layout at first use
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self._side):
@@ -222,27 +226,61 @@ class Trainer:
         self.optimizer_step(1.0 / self.world_size)
 
     # ------------------------------------------------------------------------------------------------
+    def _fork(self, idx):
+        """Side stream #idx, ordered after everything already queued on the current stream."""
+        while len(self._streams) <= idx:
+            self._streams.append(torch.cuda.Stream())
+        st = self._streams[idx]
+        st.wait_stream(torch.cuda.current_stream())
+        return st
+
+    def _join(self, st, tensors):
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(st)
+        for t in tensors:
+            t.record_stream(cur)
+
     def process_batch(self, inputs, val=False):
-        """trainer.py:268-319 (default separate-pose-encoder path)."""
+        """trainer.py:268-319 (default separate-pose-encoder path).
+
+        The six ResNet passes of a training batch (RGB encoder, beam encoder, and pose / beam-pose encoders for
+        frames -1 and +1) are mutually independent; at micro-batch 6 a single pass cannot fill 256 CUs (layer4 has
+        720 output pixels), so the four encoder modules are issued on separate HIP streams — inside the captured hipGraph they become
+        parallel branches — and joined before the decoders.  Autograd replays each backward on its forward stream,
+        so the backward passes overlap the same way."""
         for key, ipt in inputs.items():
             if key != "date" and key != "path" and torch.is_tensor(ipt) and ipt.device != self.device:
                 inputs[key] = ipt.to(self.device)
+        par = self.parallel_streams and not val and self.opt.pose_model_type == "separate_resnet" and self.num_pose_frames == 2
         if self.opt.cat_4beam_to_color:
-            features = self.models["encoder"](torch.cat((inputs["color_aug", 0, 0], inputs["4beam"]), 1))
+            enc_in = torch.cat((inputs["color_aug", 0, 0], inputs["4beam"]), 1)
         elif self.opt.cat2start:
-            features = self.models["encoder"](torch.cat((inputs["color_aug", 0, 0], inputs["2channel"]), 1))
+            enc_in = torch.cat((inputs["color_aug", 0, 0], inputs["2channel"]), 1)
         else:
-            features = self.models["encoder"](inputs["color_aug", 0, 0])
+            enc_in = inputs["color_aug", 0, 0]
+        pose_out = None
+        if par:
+            pose_out = self._launch_pose_encoders(inputs)          # 4 side streams, joined in predict_poses
+        beam_features = None
+        if self.opt.beam_encoder and not self.opt.cat2end:
+            if par:
+                st = self._fork(0)
+                with torch.cuda.stream(st):
+                    beam_features = self.models["beam_encoder"](inputs["2channel"])
+            else:
+                beam_features = self.models["beam_encoder"](inputs["2channel"])
+        features = self.models["encoder"](enc_in)
+        if par and beam_features is not None:
+            self._join(self._streams[0], beam_features)
         if self.opt.cat2end:
             outputs = self.models["depth"](features, two_channel=inputs["2channel"])
-        elif self.opt.beam_encoder:
-            beam_features = self.models["beam_encoder"](inputs["2channel"])
+        elif beam_features is not None:
             outputs = self.models["depth"](features, beam_features=beam_features)
         else:
             outputs = self.models["depth"](features)
         outputs = dict(outputs)
         if self.use_pose_net and not val:
-            outputs.update(self.predict_poses(inputs, features))
+            outputs.update(self.predict_poses(inputs, features, pose_out))
         losses = {}
         if val:
             self.generate_images_pred(inputs, outputs, [0])
@@ -251,21 +289,50 @@ class Trainer:
             losses = self.compute_losses(inputs, outputs)
         return outputs, losses
 
-    def predict_poses(self, inputs, features):
-        """trainer.py:321-388."""
+    def _launch_pose_encoders(self, inputs):
+        """pose_encoder / beam_encoder_pose for every source frame (trainer.py:336-351).  One stream per *module*: the
+        two passes of a module stay in the reference's order on one stream (its BatchNorm running statistics and cached
+        weight layouts are updated sequentially, exactly as in the reference), different modules run concurrently."""
+        res = {}
+        st_rgb = self._fork(1)
+        st_beam = self._fork(2) if self.opt.beam_encoder else None
+        for f_i in self.opt.frame_ids[1:]:
+            order = (f_i, 0) if f_i < 0 else (0, f_i)
+            with torch.cuda.stream(st_rgb):
+                rgb = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
+                pf = self.models["pose_encoder"](rgb)
+            bf = None
+            if st_beam is not None:
+                with torch.cuda.stream(st_beam):
+                    beam = torch.cat([inputs["2channel", i, 0] for i in order], 1)
+                    bf = self.models["beam_encoder_pose"](beam)
+            res[f_i] = (pf, st_rgb, bf, st_beam)
+        return res
+
+    def predict_poses(self, inputs, features, precomputed=None):
+        """trainer.py:321-388.  ``precomputed``: encoder features already launched on side streams."""
         outputs = {}
         if self.num_pose_frames == 2:
             for f_i in self.opt.frame_ids[1:]:
                 order = (f_i, 0) if f_i < 0 else (0, f_i)                     # temporal order (trainer.py:338-346)
-                pose_inputs = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
-                if self.opt.pose_model_type == "separate_resnet":
-                    pose_inputs = [self.models["pose_encoder"](pose_inputs)]
-                if self.opt.beam_encoder and self.opt.pose_model_type == "separate_resnet":
-                    beam = torch.cat([inputs["2channel", i, 0] for i in order], 1)
-                    beam_inputs = [self.models["beam_encoder_pose"](beam)]
-                    axisangle, translation = self.models["pose"](pose_inputs, beam_inputs=beam_inputs)
+                if precomputed is not None:
+                    pf, st, bf, st2 = precomputed[f_i]
+                    self._join(st, pf)
+                    if bf is not None:
+                        self._join(st2, bf)
+                        axisangle, translation = self.models["pose"]([pf], beam_inputs=[bf])
+                    else:
+                        axisangle, translation = self.models["pose"]([pf])
                 else:
-                    axisangle, translation = self.models["pose"](pose_inputs)
+                    pose_inputs = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
+                    if self.opt.pose_model_type == "separate_resnet":
+                        pose_inputs = [self.models["pose_encoder"](pose_inputs)]
+                    if self.opt.beam_encoder and self.opt.pose_model_type == "separate_resnet":
+                        beam = torch.cat([inputs["2channel", i, 0] for i in order], 1)
+                        beam_inputs = [self.models["beam_encoder_pose"](beam)]
+                        axisangle, translation = self.models["pose"](pose_inputs, beam_inputs=beam_inputs)
+                    else:
+                        axisangle, translation = self.models["pose"](pose_inputs)
                 outputs[("axisangle", 0, f_i)] = axisangle
                 outputs[("translation", 0, f_i)] = translation
                 outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0],

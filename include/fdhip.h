@@ -153,15 +153,22 @@ typedef struct {
     int in_norm;            /* 1: taps read (x-0.45)/0.225 (resnet_encoder.py:94), padding stays 0 */
 } fd_conv_desc;
 
-/* y [N,Cout,Ho,Wo] = act(conv(x, w) + bias);  bias may be NULL.  ws: fd_conv2d_fwd_ws_floats(d) floats (weight
- * re-layout + split-K slabs of the fast path; may be 0 -> ws may be NULL). */
+/* y [N,Cout,Ho,Wo] = act(conv(x, w) + bias);  bias may be NULL.
+ *   wt  caller-owned buffer of fd_conv2d_fwd_wt_floats(d) floats holding the kernel's weight layout ([Cout][tap][Cin]);
+ *       it is (re)written from `w` unless wt_ready != 0, so a caller may keep it across calls while `w` is unchanged
+ *       (the trainer re-derives it once per optimiser step).  May be NULL when the size query returns 0.
+ *   ws  scratch of fd_conv2d_fwd_ws_floats(d) floats (split-K slabs; may be 0 -> NULL). */
+long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d);
 long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d);
-int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* ws,
-                  void* stream);
+int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
+                  int wt_ready, float* ws, void* stream);
 /* gx [N,Cin,H,W] = d/dx of sum(conv(x,w) * gy)  (gy is the gradient w.r.t. the PRE-activation output;
- * apply fd_act_bwd first when act != 0).  ws: fd_conv2d_bwd_data_ws_floats(d) floats. */
+ * apply fd_act_bwd first when act != 0).  wt / wt_ready as in fd_conv2d_fwd (flipped / transposed layouts, one per
+ * output-parity class for stride 2: fd_conv2d_bwd_data_wt_floats(d) floats); ws: fd_conv2d_bwd_data_ws_floats(d). */
+long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d);
 long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d);
-int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* ws, void* stream);
+int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt, int wt_ready, float* ws,
+                       void* stream);
 /* gw [Cout,Cin,KH,KW], gbias [Cout] (NULL to skip).  ws: fd_conv2d_bwd_weight_ws_floats(d) floats (may be 0). */
 long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d);
 int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* gbias, float* ws,
