@@ -67,12 +67,12 @@ SIGNATURES = {
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_data": ("ppppp" "i" "pp", "i"),
     "fd_conv2d_bwd_weight_ws_floats": ("p", "l"),
-    "fd_conv2d_bwd_weight": ("ppppppp", "i"),
+    "fd_conv2d_bwd_weight": ("pppppp" "i" "p", "i"),
     "fd_act_bwd": ("ppplip", "i"),
     "fd_bn_ws_floats": ("iiii", "l"),
     "fd_bn_train_fwd": ("pppppppppp" "iiii" "ff" "ip", "i"),
     "fd_bn_eval_fwd": ("ppppppp" "iiii" "f" "ip", "i"),
-    "fd_bn_train_bwd": ("ppppppppppp" "iiii" "ip", "i"),
+    "fd_bn_train_bwd": ("ppppppppppp" "iiii" "iip", "i"),
     "fd_maxpool3x3s2_fwd": ("pppiiiip", "i"),
     "fd_maxpool3x3s2_bwd": ("pppiiiip", "i"),
     "fd_upcat_fwd": ("ppppp" "iiiiii" "p", "i"),

@@ -329,9 +329,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad(WgradArgs g) {
     }
 }
 
-__global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits) {
+__global__ void k_reduce_slabs(const float* __restrict__ slabs, float* __restrict__ out, long n, int splits, int accumulate) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float s = 0.f;
+        float s = accumulate ? out[i] : 0.f;
         for (int z = 0; z < splits; ++z) s += slabs[(long)z * n + i];
         out[i] = s;
     }
@@ -390,10 +390,10 @@ __global__ void __launch_bounds__(256) k_channel_sum_part(const float* __restric
     const float sum = fd_block_sum_n<1, 4>(v, red);
     if (threadIdx.x == 0) part[(long)c * CS_SPLITS + s] = sum;
 }
-__global__ void k_channel_sum_fin(const float* __restrict__ part, float* __restrict__ out, int C) {
+__global__ void k_channel_sum_fin(const float* __restrict__ part, float* __restrict__ out, int C, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s = 0.f;
+    float s = accumulate ? out[c] : 0.f;
     for (int i = 0; i < CS_SPLITS; ++i) s += part[(long)c * CS_SPLITS + i];
     out[c] = s;
 }
@@ -704,11 +704,12 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
     else { const int sp = wgrad_splits(d, s); slabs = sp > 1 ? (long)sp * wsz : 0; }
     const long bias_part = (long)d->Cout * CS_SPLITS;
+    if (slabs < wsz) slabs = wsz;                            // accumulate mode stages a single slab
     return slabs > bias_part ? slabs : bias_part;          // the two uses are sequential on the stream
 }
 
 extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* gbias,
-                                    float* ws, void* stream) {
+                                    float* ws, int accumulate, void* stream) {
     if (int rc = check_desc(d, "fd_conv2d_bwd_weight")) return rc;
     FD_REQUIRE(x && gy && gw && ws, "fd_conv2d_bwd_weight: NULL tensor / workspace");
     ConvShape s;
@@ -725,11 +726,12 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
         f.sy = d->stride; f.oy = -d->pad; f.da = 1; f.sx = d->stride; f.ox = -d->pad; f.db = 1;
         f.pad_mode = d->pad_mode;
         f.dy_cs = (long)s.Ho * s.Wo; f.dy_ns = f.dy_cs * d->Cout;
-        if (int rc = fast_wgrad_launch(f, gw, fast_wgrad_splits(f.M, f.C, f.T, Np), st)) return rc;
+        if (int rc = fast_wgrad_launch(f, gw, fast_wgrad_splits(f.M, f.C, f.T, Np), accumulate, st)) return rc;
     } else {
         const int sp = wgrad_splits(d, s);
+        const bool staged = sp > 1 || accumulate;
         WgradArgs g = {};
-        g.dY = gy; g.X = x; g.out = sp > 1 ? ws : gw;
+        g.dY = gy; g.X = x; g.out = staged ? ws : gw;
         g.M = d->Cout; g.J = d->Cin * d->KH * d->KW;
         g.Nb = d->N; g.C = d->Cin; g.Hi = d->H; g.Wi = d->W;
         g.NY = s.Ho; g.NX = s.Wo;
@@ -741,9 +743,9 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
         g.pix_per_split = pps;
         if (int rc = dispatch_wgrad(d->KH, d->KW, g, sp, st)) return rc;
         FD_LAUNCH_CHECK("fd_conv2d_bwd_weight");
-        if (sp > 1) {
+        if (staged) {
             const long n = (long)g.M * g.J;
-            hipLaunchKernelGGL(k_reduce_slabs, dim3(ew_blocks(n)), dim3(256), 0, st, ws, gw, n, sp);
+            hipLaunchKernelGGL(k_reduce_slabs, dim3(ew_blocks(n)), dim3(256), 0, st, ws, gw, n, sp, accumulate);
             FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(reduce)");
         }
     }
@@ -751,7 +753,7 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
         hipLaunchKernelGGL(k_channel_sum_part, dim3(d->Cout, CS_SPLITS), dim3(256), 0, st, gy, ws, d->N, d->Cout,
                            (long)s.Ho * s.Wo);
         FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(bias)");
-        hipLaunchKernelGGL(k_channel_sum_fin, dim3(fd_cdiv(d->Cout, 64)), dim3(64), 0, st, ws, gbias, d->Cout);
+        hipLaunchKernelGGL(k_channel_sum_fin, dim3(fd_cdiv(d->Cout, 64)), dim3(64), 0, st, ws, gbias, d->Cout, accumulate);
         FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(bias fin)");
     }
     return 0;

@@ -36,4 +36,4 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st);
 int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh, int kw0,
                          int dkw, int mode, hipStream_t st);
 int fast_wgrad_splits(int M, int C, int T, long Np);
-int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, hipStream_t st);
+int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st);

@@ -373,14 +373,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
 
 // gw[m][c][t] (OIHW) = sum_z slabs[z][m][t][c]
 __global__ void __launch_bounds__(256) k_wgrad_finish(const float* __restrict__ slabs, float* __restrict__ gw, int M, int C,
-                                                      int T, int splits) {
+                                                      int T, int splits, int accumulate) {
     const long n = (long)M * C * T;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int t = (int)(i % T);
         const int c = (int)((i / T) % C);
         const int m = (int)(i / ((long)T * C));
         const size_t src = ((size_t)m * T + t) * C + c;
-        float s = 0.f;
+        float s = accumulate ? gw[i] : 0.f;
         for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + src];
         gw[i] = s;
     }
@@ -538,7 +538,7 @@ int fast_wgrad_splits(int M, int C, int T, long Np) {
     return (int)sp;
 }
 
-int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, hipStream_t st) {
+int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st) {
     FastWgradArgs g = a;
     const long Np = (long)a.Nb * a.NY * a.NX;
     long pps = (Np + splits - 1) / splits;
@@ -555,7 +555,7 @@ int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, hipStream_t
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_wgrad_fast launch failed: %s", hipGetErrorString(e)); return (int)e; }
     const long n = (long)a.M * a.C * a.T;
-    hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks(n)), dim3(256), 0, st, a.slabs, gw, a.M, a.C, a.T, splits);
+    hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks(n)), dim3(256), 0, st, a.slabs, gw, a.M, a.C, a.T, splits, accumulate);
     e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
     return 0;

@@ -133,13 +133,13 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x
                                                      const float* __restrict__ save_invstd, float* __restrict__ gx,
                                                      float* __restrict__ gweight, float* __restrict__ gbias,
                                                      float* __restrict__ g_res, const float* __restrict__ part, int N,
-                                                     int C, long HW, int splits, int relu) {
+                                                     int C, long HW, int splits, int relu, int accumulate) {
     const int nc = blockIdx.y, c = nc % C;
     float s1 = 0.f, s2 = 0.f;
     for (int s = 0; s < splits; ++s) { s1 += part[((long)c * splits + s) * 2]; s2 += part[((long)c * splits + s) * 2 + 1]; }
     if (blockIdx.x == 0 && nc < C && threadIdx.x == 0) {
-        if (gbias) gbias[c] = s1;
-        if (gweight) gweight[c] = s2;
+        if (gbias) gbias[c] = (accumulate ? gbias[c] : 0.f) + s1;
+        if (gweight) gweight[c] = (accumulate ? gweight[c] : 0.f) + s2;
     }
     const float M = (float)N * (float)HW;
     const float mean = save_mean[c], invstd = save_invstd[c];
@@ -193,7 +193,8 @@ extern "C" int fd_bn_eval_fwd(const float* x, const float* weight, const float* 
 
 extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float* weight,
                                const float* save_mean, const float* save_invstd, float* gx, float* gweight, float* gbias,
-                               float* g_residual, float* ws, int N, int C, int H, int W, int relu, void* stream) {
+                               float* g_residual, float* ws, int N, int C, int H, int W, int relu, int accumulate,
+                               void* stream) {
     FD_REQUIRE(x && gy && save_mean && save_invstd && gx && ws && N > 0 && C > 0 && H > 0 && W > 0,
                "fd_bn_train_bwd: bad args");
     FD_REQUIRE(!relu || y, "fd_bn_train_bwd: the forward output is needed for the ReLU mask");
@@ -204,7 +205,7 @@ extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, 
                        relu);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(reduce)");
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, y, gy, weight, save_mean,
-                       save_invstd, gx, gweight, gbias, g_residual, ws, N, C, HW, sp, relu);
+                       save_invstd, gx, gweight, gbias, g_residual, ws, N, C, HW, sp, relu, accumulate);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(apply)");
     return 0;
 }

@@ -400,6 +400,20 @@ def enable_weight_cache(params):
             _NEXT_CACHE_ID[0] += 1
 
 
+def enable_direct_grad(params):
+    """Opt-in: weight / bias / BatchNorm-affine gradients are accumulated by the backward kernels straight into the
+    pre-allocated ``param.grad`` (a view of the trainer's flat gradient buffer) instead of being returned to autograd,
+    which would launch one ATen add per parameter per micro-batch (~600 tiny kernels per optimiser step)."""
+    for p in params:
+        p._fd_direct_grad = True
+
+
+def _direct_grad_target(p):
+    if p is not None and getattr(p, "_fd_direct_grad", False) and p.grad is not None and p.grad.is_contiguous():
+        return p.grad
+    return None
+
+
 def _weight_layout(w, cache_id, kind, nfloats):
     """-> (buffer, ready flag) for weight ``w`` and layout ``kind`` ('f' forward, 'd' data-gradient)."""
     if cache_id is None:
@@ -421,6 +435,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
         cache_id = getattr(w, "_fd_cache_id", None)
+        ctx.params = (w, bias)
         x, w = f32(x), f32(w)
         bias = f32(bias) if bias is not None else None
         _need_cuda(x, w)
@@ -455,10 +470,15 @@ class _Conv2d(torch.autograd.Function):
             if d.in_norm:   # d/dx of (x - 0.45) / 0.225
                 call("fd_axpby", ptr(gx), ptr(gx), ptr(gx), gx.numel(), 1.0 / 0.225, 0.0, stream())
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw = torch.empty_like(w)
-            gb = _empty((d.Cout,), x) if ctx.has_bias else None
+            tw = _direct_grad_target(ctx.params[0])
+            tb = _direct_grad_target(ctx.params[1]) if ctx.has_bias else None
+            direct = tw is not None and (not ctx.has_bias or tb is not None)
+            gw = tw if direct else torch.empty_like(w)
+            gb = (tb if direct else _empty((d.Cout,), x)) if ctx.has_bias else None
             ws = _empty((max(query("fd_conv2d_bwd_weight_ws_floats", dp), 1),), x)
-            call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), stream())
+            call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
+            if direct:
+                gw = gb = None          # already accumulated in place
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -471,6 +491,7 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", i
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
+        ctx.params = (weight, bias)
         x = f32(x)
         _need_cuda(x)
         N, C, H, W = x.shape
@@ -496,13 +517,15 @@ class _BatchNorm(torch.autograd.Function):
         N, C, H, W = x.shape
         gy = f32(gy)
         gx = torch.empty_like(x)
-        gw, gb = _empty((C,), x), _empty((C,), x)
+        tw, tb = _direct_grad_target(ctx.params[0]), _direct_grad_target(ctx.params[1])
+        direct = tw is not None and tb is not None
+        gw, gb = (tw, tb) if direct else (_empty((C,), x), _empty((C,), x))
         gres = torch.empty_like(x) if ctx.has_res and ctx.needs_input_grad[3] else None
         ws = _empty((query("fd_bn_ws_floats", N, C, H, W),), x)
         call("fd_bn_train_bwd", ptr(x), ptr(y), ptr(gy), ptr(weight), ptr(mean), ptr(invstd), ptr(gx), ptr(gw), ptr(gb),
-             ptr(gres), ptr(ws), N, C, H, W, ctx.relu, stream())
-        if ctx.has_res and gres is None and ctx.needs_input_grad[3]:
-            gres = gy
+             ptr(gres), ptr(ws), N, C, H, W, ctx.relu, int(direct), stream())
+        if direct:
+            gw = gb = None
         return gx, gw, gb, gres, None, None, None, None, None, None
 
 

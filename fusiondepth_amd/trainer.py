@@ -94,6 +94,7 @@ class Trainer:
         # ---- optimiser (trainer.py:129-131): Adam + StepLR(gamma 0.1), on one flat buffer ----------------
         self.flat = dp.FlatParameters(self.parameters_to_train)
         FD.enable_weight_cache(self.parameters_to_train)
+        FD.enable_direct_grad(self.parameters_to_train)
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.adam_step_count = 0
@@ -151,6 +152,7 @@ class Trainer:
             if last:
                 self.grad_sync.arm()
             loss.backward()
+            self._join_side_streams()
             self.batch_idx += 1
         scale = self.grad_sync.finish() if self.world_size > 1 else 1.0
         self.optimizer_step(scale)
@@ -215,6 +217,7 @@ class Trainer:
         for inputs in mbs:
             outputs, losses = self.process_batch(inputs)
             (losses["loss"] / self.accumulate_step).backward()
+            self._join_side_streams()
         if self.world_size == 1:
             FD.adam_step_dev(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.adam_state)
             self.flat.flat_grad.zero_()
@@ -226,6 +229,14 @@ class Trainer:
         self.optimizer_step(1.0 / self.world_size)
 
     # ------------------------------------------------------------------------------------------------
+    def _join_side_streams(self):
+        """Backward kernels of the encoder modules run on their forward streams and accumulate parameter gradients in
+        place (no AccumulateGrad node => autograd does not sync those streams for us): order everything before the
+        optimiser / all-reduce on the current stream."""
+        cur = torch.cuda.current_stream()
+        for st in self._streams:
+            cur.wait_stream(st)
+
     def _fork(self, idx):
         """Side stream #idx, ordered after everything already queued on the current stream."""
         while len(self._streams) <= idx:

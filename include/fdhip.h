@@ -169,10 +169,11 @@ long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d);
 long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d);
 int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt, int wt_ready, float* ws,
                        void* stream);
-/* gw [Cout,Cin,KH,KW], gbias [Cout] (NULL to skip).  ws: fd_conv2d_bwd_weight_ws_floats(d) floats (may be 0). */
+/* gw [Cout,Cin,KH,KW], gbias [Cout] (NULL to skip).  accumulate != 0: gw += / gbias += (gradient accumulation straight
+ * into the caller's buffers).  ws: fd_conv2d_bwd_weight_ws_floats(d) floats. */
 long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d);
 int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* gbias, float* ws,
-                         void* stream);
+                         int accumulate, void* stream);
 
 /* gpre = gy * act'(y)  where y is the activation OUTPUT (1 ReLU, 2 ELU(alpha=1), 3 sigmoid, 4 tanh). */
 int fd_act_bwd(const float* y, const float* gy, float* gpre, long n, int act, void* stream);
@@ -193,7 +194,7 @@ int fd_bn_eval_fwd(const float* x, const float* weight, const float* bias, const
  * written; g_residual (if non-NULL) receives the masked upstream gradient (the residual branch's gradient). */
 int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float* weight, const float* save_mean,
                     const float* save_invstd, float* gx, float* gweight, float* gbias, float* g_residual, float* ws, int N,
-                    int C, int H, int W, int relu, void* stream);
+                    int C, int H, int W, int relu, int accumulate /* gweight/gbias += */, void* stream);
 
 /* nn.MaxPool2d(3, stride 2, padding 1) (resnet_encoder.py:98).  idx [N,C,Ho,Wo] u8 = argmax tap (0..8). */
 int fd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream);
