@@ -47,8 +47,9 @@ def assert_close(actual, expected, rtol=1e-4, atol=1e-6, what=""):
     a = np.asarray(actual, dtype=np.float64)
     e = np.asarray(expected, dtype=np.float64)
     assert a.shape == e.shape, "%s: shape %s vs %s" % (what, a.shape, e.shape)
-    err = np.abs(a - e)
-    tol = atol + rtol * np.abs(e)
+    assert np.array_equal(np.isnan(a), np.isnan(e)), "%s: NaN pattern differs (%d vs %d NaNs)" % (what, np.isnan(a).sum(), np.isnan(e).sum())
+    err = np.nan_to_num(np.abs(a - e), nan=0.0)
+    tol = atol + rtol * np.nan_to_num(np.abs(e), nan=0.0)
     bad = err > tol
     if bad.any():
         i = np.unravel_index(np.argmax(err - tol), err.shape)
