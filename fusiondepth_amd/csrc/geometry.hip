@@ -423,8 +423,14 @@ __global__ void k_bilinear_bwd(const float* __restrict__ gy, float* __restrict__
     const int ry = (Hout + Hin - 1) / Hin, rx = (Wout + Win - 1) / Win;  // upsampling ratio (ceil)
     for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < Pi; p += (long)gridDim.x * blockDim.x) {
         int iy = (int)(p / Win), ix = (int)(p % Win);
-        int oy_lo = (iy - 1) * ry - 1, oy_hi = (iy + 2) * ry + 1;
-        int ox_lo = (ix - 1) * rx - 1, ox_hi = (ix + 2) * rx + 1;
+        // output rows whose source interval [y0, y1] contains iy satisfy (iy-0.5)*r - 0.5 <= oy < (iy+1.5)*r - 0.5
+        // (before edge clamping, which only adds rows at the borders handled by the max/min below); one extra on each side
+        int oy_lo = (2 * iy - 1) * ry / 2 - 2, oy_hi = (2 * iy + 3) * ry / 2 + 1;
+        int ox_lo = (2 * ix - 1) * rx / 2 - 2, ox_hi = (2 * ix + 3) * rx / 2 + 1;
+        if (iy == 0) oy_lo = 0;
+        if (ix == 0) ox_lo = 0;
+        if (iy == Hin - 1) oy_hi = Hout - 1;
+        if (ix == Win - 1) ox_hi = Wout - 1;
         oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
         oy_hi = oy_hi > Hout - 1 ? Hout - 1 : oy_hi; ox_hi = ox_hi > Wout - 1 ? Wout - 1 : ox_hi;
         float acc = 0.f;

@@ -229,7 +229,12 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
         }
         const float* Pf = a.P + ((long)b * NF + f) * 12;
         const float* src_b = a.src[f] + (long)b * 3 * P;
-        for (int i = tid; i < H1 * W1; i += NT) {
+        // fixed trip count + full unroll: the gathers of all iterations are independent, so the compiler can keep
+        // several pixels' loads in flight (the kernel is latency-bound, not bandwidth-bound, at 12-16 waves per CU)
+#pragma unroll
+        for (int it = 0; it < (H1 * W1 + NT - 1) / NT; ++it) {
+            const int i = tid + it * NT;
+            if (i >= H1 * W1) break;
             const int hy = i / W1, hx = i - hy * W1;
             const int ry = y0t - 1 + hy, rx = x0t - 1 + hx;
             const int gy = refl_clamp(ry, H), gx = refl_clamp(rx, W);
@@ -461,7 +466,10 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
         const float* src_b = a.src[f] + (long)b * 3 * P;
         const int my_sel = avg ? NI : NI + f;
         __syncthreads();  // previous readers of s_pred are done; s_tgt / s_sel are complete
-        for (int i = tid; i < H2 * W2; i += NT) {
+#pragma unroll
+        for (int it = 0; it < (H2 * W2 + NT - 1) / NT; ++it) {
+            const int i = tid + it * NT;
+            if (i >= H2 * W2) break;
             const int hy = i / W2, hx = i - hy * W2;
             const int gy = refl_clamp(y0t - 2 + hy, H), gx = refl_clamp(x0t - 2 + hx, W);
             Samp s;
@@ -542,13 +550,24 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     }
 }
 
-// gP[b][f][12] = sum over the tiles of image b (fixed order)
-__global__ void k_photo_bwd_fin(const float* __restrict__ part, float* __restrict__ gP, int tiles, int NF) {
+// gP[b][f][12] = sum over the tiles of image b.  One workgroup per image: thread (g, k) sums every 10th tile for entry k,
+// then the 10 group partials are added in a fixed order (deterministic).
+__global__ void __launch_bounds__(256) k_photo_bwd_fin(const float* __restrict__ part, float* __restrict__ gP, int tiles, int NF) {
+    __shared__ float red[10][24];
     const int b = blockIdx.x, t = threadIdx.x;
-    if (t >= NF * 12) return;
-    float s = 0.f;
-    for (int i = 0; i < tiles; ++i) s += part[((long)b * tiles + i) * 24 + t];
-    gP[(long)b * NF * 12 + t] = s;
+    const int k = t % 24, gidx = t / 24;
+    if (gidx < 10) {
+        float s = 0.f;
+        for (int i = gidx; i < tiles; i += 10) s += part[((long)b * tiles + i) * 24 + k];
+        red[gidx][k] = s;
+    }
+    __syncthreads();
+    if (t < NF * 12) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) s += red[j][t];
+        gP[(long)b * NF * 12 + t] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -727,7 +746,7 @@ extern "C" int fd_photo_bwd(const fd_photo_cfg* cfg, const float* disp, const fl
     if (a.cfg.use_ssim) hipLaunchKernelGGL(k_photo_bwd<true>, grid, dim3(NT), 0, st, a);
     else hipLaunchKernelGGL(k_photo_bwd<false>, grid, dim3(NT), 0, st, a);
     FD_LAUNCH_CHECK("fd_photo_bwd");
-    hipLaunchKernelGGL(k_photo_bwd_fin, dim3(cfg->B), dim3(64), 0, st, ws, gP, (int)(ntile / cfg->B), cfg->NF);
+    hipLaunchKernelGGL(k_photo_bwd_fin, dim3(cfg->B), dim3(256), 0, st, ws, gP, (int)(ntile / cfg->B), cfg->NF);
     FD_LAUNCH_CHECK("fd_photo_bwd_fin");
     if (!same) return fd_bilinear_up_bwd(a.d_up, d_disp, cfg->B, cfg->Hs, cfg->Ws, cfg->H, cfg->W, stream);
     return 0;

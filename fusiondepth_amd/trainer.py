@@ -401,7 +401,18 @@ class Trainer:
             if ident is not None:
                 noise = noise_in[scale] if noise_in is not None else torch.randn(ident.shape, device=ident.device)
             beam = inputs["4beam"] if (use_si and (self.opt.trainer_siloss_all_scale or scale == 0) and src_s == 0) else None
-            Ts = [outputs[("cam_T_cam", 0, f)] for f in fids]
+            if self.opt.pose_model_type == "posecnn":
+                # trainer.py:450-460: PoseCNN translations are rescaled by the mean inverse depth of this scale
+                disp_up = outputs[("disp", scale)]
+                if not self.opt.v1_multiscale:
+                    disp_up = FD.bilinear_upsample(disp_up, (self.opt.height, self.opt.width))
+                inv_depth = disp_to_depth(disp_up, self.opt.min_depth, self.opt.max_depth)[0]       # 1 / depth
+                mean_inv_depth = FD.spatial_mean(inv_depth, 1.0)                                       # [B,1]
+                Ts = [transformation_from_parameters(outputs[("axisangle", 0, f)][:, 0],
+                                                     outputs[("translation", 0, f)][:, 0] * mean_inv_depth[:, None, :],
+                                                     f < 0) for f in fids]
+            else:
+                Ts = [outputs[("cam_T_cam", 0, f)] for f in fids]
             srcs = [inputs[("color", f, src_s)] for f in fids]
             photo, si, sel, depth, sample, color = FD.photo_loss(
                 outputs[("disp", scale)], Ts, inputs[("K", src_s)], inputs[("inv_K", src_s)], srcs, target, ident, noise,
