@@ -69,10 +69,10 @@ SIGNATURES = {
     "fd_conv2d_bwd_weight_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_weight": ("pppppp" "i" "p", "i"),
     "fd_act_bwd": ("ppplip", "i"),
-    "fd_bn_ws_floats": ("iiii", "l"),
-    "fd_bn_train_fwd": ("pppppppppp" "iiii" "ff" "ip", "i"),
+    "fd_bn_ws_floats": ("iiiii", "l"),
+    "fd_bn_train_fwd": ("pppppppppp" "iiiii" "ff" "ip", "i"),
     "fd_bn_eval_fwd": ("ppppppp" "iiii" "f" "ip", "i"),
-    "fd_bn_train_bwd": ("ppppppppppp" "iiii" "iip", "i"),
+    "fd_bn_train_bwd": ("ppppppppppp" "iiiii" "iip", "i"),
     "fd_maxpool3x3s2_fwd": ("pppiiiip", "i"),
     "fd_maxpool3x3s2_bwd": ("pppiiiip", "i"),
     "fd_upcat_fwd": ("ppppp" "iiiiii" "p", "i"),

@@ -23,32 +23,37 @@ inline int bn_splits(int N, int C, long HW) {
 
 // iterate the elements [lo,hi) of channel c's flattened (n, hw) index space
 template <typename F>
-__device__ __forceinline__ void for_channel_range(long lo, long hi, long HW, int C, int c, F&& f) {
+__device__ __forceinline__ void for_channel_range(long lo, long hi, long HW, int C, int c, long n0, F&& f) {
     for (long i = lo + threadIdx.x; i < hi; i += NT) {
         const long n = i / HW, r = i - n * HW;
-        f((n * C + c) * HW + r);
+        f(((n0 + n) * C + c) * HW + r);
     }
 }
 
+// N = samples PER GROUP; group g = blockIdx.z covers samples [g*N, (g+1)*N): statistics are per (group, channel), which
+// is exactly what G separate forward passes over the sub-batches would compute (the pose encoders see frames -1 and +1
+// as two passes in the reference; here they are one launch with G = 2).
 __global__ void __launch_bounds__(NT) k_bn_stats(const float* __restrict__ x, float* __restrict__ part, int N, int C,
                                                  long HW, int splits) {
     __shared__ float red[4 * 2];
-    const int c = blockIdx.x, s = blockIdx.y;
+    const int c = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
     const long M = (long)N * HW, per = (M + splits - 1) / splits;
     const long lo = (long)s * per, hi = lo + per < M ? lo + per : M;
-    const float shift = x[(long)c * HW];
+    const long n0 = (long)g * N;
+    const float shift = x[(n0 * C + c) * HW];
     float acc[2] = {0.f, 0.f};
-    for_channel_range(lo, hi, HW, C, c, [&](long o) { const float d = x[o] - shift; acc[0] += d; acc[1] += d * d; });
+    for_channel_range(lo, hi, HW, C, c, n0, [&](long o) { const float d = x[o] - shift; acc[0] += d; acc[1] += d * d; });
     const float r = fd_block_sum_n<2, 4>(acc, red);
-    if (threadIdx.x < 2) part[((long)c * splits + s) * 2 + threadIdx.x] = r;
+    if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
 }
 
 struct BnStat { float mean, var; };
-__device__ __forceinline__ BnStat bn_finalize(const float* __restrict__ part, const float* __restrict__ x, int c,
-                                              long HW, int splits, float M) {
+__device__ __forceinline__ BnStat bn_finalize(const float* __restrict__ part, const float* __restrict__ x, int c, int C,
+                                              int g, int Ng, long HW, int splits, float M) {
     float s1 = 0.f, s2 = 0.f;
-    for (int s = 0; s < splits; ++s) { s1 += part[((long)c * splits + s) * 2]; s2 += part[((long)c * splits + s) * 2 + 1]; }
-    const float shift = x[(long)c * HW];
+    const long pb = ((long)g * C + c) * splits;
+    for (int s = 0; s < splits; ++s) { s1 += part[(pb + s) * 2]; s2 += part[(pb + s) * 2 + 1]; }
+    const float shift = x[((long)g * Ng * C + c) * HW];
     const float m = s1 / M;
     BnStat st;
     st.mean = shift + m;
@@ -63,19 +68,27 @@ __global__ void __launch_bounds__(NT) k_bn_apply_train(const float* __restrict__
                                                        float* __restrict__ running_var, float* __restrict__ save_mean,
                                                        float* __restrict__ save_invstd, const float* __restrict__ part,
                                                        int N, int C, long HW, int splits, float eps, float momentum,
-                                                       int relu) {
-    const int nc = blockIdx.y, c = nc % C;
+                                                       int relu, int G) {
+    // N = samples per group; blockIdx.y enumerates (sample, channel) over all G*N samples
+    const int nc = blockIdx.y, c = nc % C, n = nc / C, g = n / N;
     const float M = (float)N * (float)HW;
-    const BnStat st = bn_finalize(part, x, c, HW, splits, M);
+    const BnStat st = bn_finalize(part, x, c, C, g, N, HW, splits, M);
     const float invstd = 1.0f / sqrtf(st.var + eps);
-    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0) {   // once per channel (n == 0)
-        save_mean[c] = st.mean;
-        save_invstd[c] = invstd;
-        if (running_mean) {
-            const float unbiased = M > 1.f ? st.var * (M / (M - 1.f)) : st.var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * st.mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    if (blockIdx.x == 0 && n == g * N && threadIdx.x == 0) {   // once per (group, channel)
+        save_mean[g * C + c] = st.mean;
+        save_invstd[g * C + c] = invstd;
+    }
+    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0 && running_mean) {
+        // running statistics: the G momentum updates are applied in group order by ONE thread, i.e. exactly as G
+        // consecutive forward passes would have applied them
+        float rm = running_mean[c], rv = running_var[c];
+        for (int gg = 0; gg < G; ++gg) {
+            const BnStat sg = bn_finalize(part, x, c, C, gg, N, HW, splits, M);
+            const float unbiased = M > 1.f ? sg.var * (M / (M - 1.f)) : sg.var;
+            rm = (1.f - momentum) * rm + momentum * sg.mean;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
         }
+        running_mean[c] = rm; running_var[c] = rv;
     }
     const float a = invstd * (weight ? weight[c] : 1.f);
     const float b = (bias ? bias[c] : 0.f) - st.mean * a;
@@ -112,19 +125,19 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_reduce(const float* __restrict__ 
                                                       const float* __restrict__ save_invstd, float* __restrict__ part,
                                                       int N, int C, long HW, int splits, int relu) {
     __shared__ float red[4 * 2];
-    const int c = blockIdx.x, s = blockIdx.y;
+    const int c = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
     const long M = (long)N * HW, per = (M + splits - 1) / splits;
     const long lo = (long)s * per, hi = lo + per < M ? lo + per : M;
-    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float mean = save_mean[g * C + c], invstd = save_invstd[g * C + c];
     float acc[2] = {0.f, 0.f};
-    for_channel_range(lo, hi, HW, C, c, [&](long o) {
+    for_channel_range(lo, hi, HW, C, c, (long)g * N, [&](long o) {
         float g = gy[o];
         if (relu && !(y[o] > 0.f)) g = 0.f;
         acc[0] += g;
         acc[1] += g * ((x[o] - mean) * invstd);
     });
     const float r = fd_block_sum_n<2, 4>(acc, red);
-    if (threadIdx.x < 2) part[((long)c * splits + s) * 2 + threadIdx.x] = r;
+    if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
 }
 
 __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y,
@@ -133,16 +146,24 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x
                                                      const float* __restrict__ save_invstd, float* __restrict__ gx,
                                                      float* __restrict__ gweight, float* __restrict__ gbias,
                                                      float* __restrict__ g_res, const float* __restrict__ part, int N,
-                                                     int C, long HW, int splits, int relu, int accumulate) {
-    const int nc = blockIdx.y, c = nc % C;
+                                                     int C, long HW, int splits, int relu, int accumulate, int G) {
+    const int nc = blockIdx.y, c = nc % C, n = nc / C, g = n / N;
     float s1 = 0.f, s2 = 0.f;
-    for (int s = 0; s < splits; ++s) { s1 += part[((long)c * splits + s) * 2]; s2 += part[((long)c * splits + s) * 2 + 1]; }
-    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0) {
-        if (gbias) gbias[c] = (accumulate ? gbias[c] : 0.f) + s1;
-        if (gweight) gweight[c] = (accumulate ? gweight[c] : 0.f) + s2;
+    const long pb = ((long)g * C + c) * splits;
+    for (int s = 0; s < splits; ++s) { s1 += part[(pb + s) * 2]; s2 += part[(pb + s) * 2 + 1]; }
+    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0) {   // parameter gradients: sum over the groups, in group order
+        float t1 = 0.f, t2 = 0.f;
+        for (int gg = 0; gg < G; ++gg) {
+            float u1 = 0.f, u2 = 0.f;
+            const long qb = ((long)gg * C + c) * splits;
+            for (int s = 0; s < splits; ++s) { u1 += part[(qb + s) * 2]; u2 += part[(qb + s) * 2 + 1]; }
+            t1 += u1; t2 += u2;
+        }
+        if (gbias) gbias[c] = (accumulate ? gbias[c] : 0.f) + t1;
+        if (gweight) gweight[c] = (accumulate ? gweight[c] : 0.f) + t2;
     }
     const float M = (float)N * (float)HW;
-    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float mean = save_mean[g * C + c], invstd = save_invstd[g * C + c];
     const float k = (weight ? weight[c] : 1.f) * invstd;
     const float m1 = s1 / M, m2 = s2 / M;
     const long base = (long)nc * HW;
@@ -162,20 +183,25 @@ inline int plane_blocks(long HW) {
 
 }  // namespace
 
-extern "C" long fd_bn_ws_floats(int N, int C, int H, int W) { return (long)C * bn_splits(N, C, (long)H * W) * 2; }
+extern "C" long fd_bn_ws_floats(int N, int C, int H, int W, int groups) {
+    if (groups < 1 || N % groups) return 0;
+    return (long)groups * C * bn_splits(N / groups, C, (long)H * W) * 2;
+}
 
 extern "C" int fd_bn_train_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
                                float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws,
-                               int N, int C, int H, int W, float eps, float momentum, int relu, void* stream) {
+                               int N, int C, int H, int W, int groups, float eps, float momentum, int relu, void* stream) {
     FD_REQUIRE(x && y && save_mean && save_invstd && ws && N > 0 && C > 0 && H > 0 && W > 0, "fd_bn_train_fwd: bad args");
+    FD_REQUIRE(groups >= 1 && N % groups == 0, "fd_bn_train_fwd: batch %d is not divisible into %d groups", N, groups);
     FD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "fd_bn_train_fwd: running stats must come in pairs");
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
-    const int sp = bn_splits(N, C, HW);
-    hipLaunchKernelGGL(k_bn_stats, dim3(C, sp), dim3(NT), 0, st, x, ws, N, C, HW, sp);
+    const int Ng = N / groups;
+    const int sp = bn_splits(Ng, C, HW);
+    hipLaunchKernelGGL(k_bn_stats, dim3(C, sp, groups), dim3(NT), 0, st, x, ws, Ng, C, HW, sp);
     FD_LAUNCH_CHECK("fd_bn_train_fwd(stats)");
     hipLaunchKernelGGL(k_bn_apply_train, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, weight, bias, residual, y,
-                       running_mean, running_var, save_mean, save_invstd, ws, N, C, HW, sp, eps, momentum, relu);
+                       running_mean, running_var, save_mean, save_invstd, ws, Ng, C, HW, sp, eps, momentum, relu, groups);
     FD_LAUNCH_CHECK("fd_bn_train_fwd(apply)");
     return 0;
 }
@@ -193,19 +219,21 @@ extern "C" int fd_bn_eval_fwd(const float* x, const float* weight, const float* 
 
 extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float* weight,
                                const float* save_mean, const float* save_invstd, float* gx, float* gweight, float* gbias,
-                               float* g_residual, float* ws, int N, int C, int H, int W, int relu, int accumulate,
+                               float* g_residual, float* ws, int N, int C, int H, int W, int groups, int relu, int accumulate,
                                void* stream) {
     FD_REQUIRE(x && gy && save_mean && save_invstd && gx && ws && N > 0 && C > 0 && H > 0 && W > 0,
                "fd_bn_train_bwd: bad args");
+    FD_REQUIRE(groups >= 1 && N % groups == 0, "fd_bn_train_bwd: batch %d is not divisible into %d groups", N, groups);
     FD_REQUIRE(!relu || y, "fd_bn_train_bwd: the forward output is needed for the ReLU mask");
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
-    const int sp = bn_splits(N, C, HW);
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(C, sp), dim3(NT), 0, st, x, y, gy, save_mean, save_invstd, ws, N, C, HW, sp,
-                       relu);
+    const int Ng = N / groups;
+    const int sp = bn_splits(Ng, C, HW);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(C, sp, groups), dim3(NT), 0, st, x, y, gy, save_mean, save_invstd, ws, Ng, C, HW,
+                       sp, relu);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(reduce)");
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, y, gy, weight, save_mean,
-                       save_invstd, gx, gweight, gbias, g_residual, ws, N, C, HW, sp, relu, accumulate);
+                       save_invstd, gx, gweight, gbias, g_residual, ws, Ng, C, HW, sp, relu, accumulate, groups);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(apply)");
     return 0;
 }

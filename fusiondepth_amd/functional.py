@@ -490,18 +490,19 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", i
 
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, groups):
         ctx.params = (weight, bias)
+        ctx.groups = groups
         x = f32(x)
         _need_cuda(x)
         N, C, H, W = x.shape
         y = torch.empty_like(x)
         res = f32(residual) if residual is not None else None
         if training:
-            mean, invstd = _empty((C,), x), _empty((C,), x)
-            ws = _empty((query("fd_bn_ws_floats", N, C, H, W),), x)
+            mean, invstd = _empty((groups * C,), x), _empty((groups * C,), x)
+            ws = _empty((query("fd_bn_ws_floats", N, C, H, W, groups),), x)
             call("fd_bn_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
-                 ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, float(eps), float(momentum), int(relu), stream())
+                 ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, groups, float(eps), float(momentum), int(relu), stream())
             ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
         else:
             call("fd_bn_eval_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
@@ -521,22 +522,41 @@ class _BatchNorm(torch.autograd.Function):
         direct = tw is not None and tb is not None
         gw, gb = (tw, tb) if direct else (_empty((C,), x), _empty((C,), x))
         gres = torch.empty_like(x) if ctx.has_res and ctx.needs_input_grad[3] else None
-        ws = _empty((query("fd_bn_ws_floats", N, C, H, W),), x)
+        ws = _empty((query("fd_bn_ws_floats", N, C, H, W, ctx.groups),), x)
         call("fd_bn_train_bwd", ptr(x), ptr(y), ptr(gy), ptr(weight), ptr(mean), ptr(invstd), ptr(gx), ptr(gw), ptr(gb),
-             ptr(gres), ptr(ws), N, C, H, W, ctx.relu, int(direct), stream())
+             ptr(gres), ptr(ws), N, C, H, W, ctx.groups, ctx.relu, int(direct), stream())
         if direct:
             gw = gb = None
-        return gx, gw, gb, gres, None, None, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None
+
+
+_BN_GROUPS = [1]
+
+
+class bn_groups:
+    """``with bn_groups(G):`` every training-mode BatchNorm inside treats its batch as G consecutive sub-batches that are
+    normalised (and tracked in the running statistics) independently, i.e. exactly like G separate forward passes."""
+
+    def __init__(self, groups):
+        self.groups = int(groups)
+
+    def __enter__(self):
+        self.prev = _BN_GROUPS[0]
+        _BN_GROUPS[0] = self.groups
+
+    def __exit__(self, *a):
+        _BN_GROUPS[0] = self.prev
 
 
 def batch_norm(x, bn, residual=None, relu=False):
     """nn.BatchNorm2d semantics (batch statistics + running-stat update in training mode) fused with the
     optional residual add and ReLU.  ``bn`` is an ``nn.BatchNorm2d`` used as the parameter/buffer holder."""
     training = bn.training
+    groups = _BN_GROUPS[0] if training else 1
     if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        bn.num_batches_tracked.add_(groups)
     return _BatchNorm.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, training, bn.momentum,
-                            bn.eps, relu)
+                            bn.eps, relu, groups)
 
 
 class _MaxPool(torch.autograd.Function):

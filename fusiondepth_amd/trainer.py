@@ -301,39 +301,49 @@ class Trainer:
         return outputs, losses
 
     def _launch_pose_encoders(self, inputs):
-        """pose_encoder / beam_encoder_pose for every source frame (trainer.py:336-351).  One stream per *module*: the
-        two passes of a module stay in the reference's order on one stream (its BatchNorm running statistics and cached
-        weight layouts are updated sequentially, exactly as in the reference), different modules run concurrently."""
+        """pose_encoder / beam_encoder_pose for the source frames (trainer.py:336-351), one stream per module.
+
+        The reference runs each module once per source frame (batch B).  Here the frame pairs are stacked along the batch
+        axis and run as ONE pass of batch 2B with grouped BatchNorm (``FD.bn_groups(2)``): per-sample arithmetic, the
+        per-pass batch statistics and the order of the running-statistics updates are those of the two separate passes,
+        but every kernel sees twice the pixels (layer4: 1 440 instead of 720) and half the launches are issued."""
+        fids = self.opt.frame_ids[1:]
+        orders = [(f, 0) if f < 0 else (0, f) for f in fids]
         res = {}
         st_rgb = self._fork(1)
-        st_beam = self._fork(2) if self.opt.beam_encoder else None
-        for f_i in self.opt.frame_ids[1:]:
-            order = (f_i, 0) if f_i < 0 else (0, f_i)
-            with torch.cuda.stream(st_rgb):
-                rgb = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
+        with torch.cuda.stream(st_rgb):
+            rgb = torch.cat([torch.cat([inputs["color_aug", i, 0] for i in o], 1) for o in orders], 0)
+            with FD.bn_groups(len(fids)):
                 pf = self.models["pose_encoder"](rgb)
-            bf = None
-            if st_beam is not None:
-                with torch.cuda.stream(st_beam):
-                    beam = torch.cat([inputs["2channel", i, 0] for i in order], 1)
+        bf, st_beam = None, None
+        if self.opt.beam_encoder:
+            st_beam = self._fork(2)
+            with torch.cuda.stream(st_beam):
+                beam = torch.cat([torch.cat([inputs["2channel", i, 0] for i in o], 1) for o in orders], 0)
+                with FD.bn_groups(len(fids)):
                     bf = self.models["beam_encoder_pose"](beam)
-            res[f_i] = (pf, st_rgb, bf, st_beam)
+        res["stacked"] = (pf, st_rgb, bf, st_beam)
         return res
 
     def predict_poses(self, inputs, features, precomputed=None):
         """trainer.py:321-388.  ``precomputed``: encoder features already launched on side streams."""
         outputs = {}
         if self.num_pose_frames == 2:
-            for f_i in self.opt.frame_ids[1:]:
+            stacked = None
+            if precomputed is not None:
+                pf, st, bf, st2 = precomputed["stacked"]
+                self._join(st, pf)
+                if bf is not None:
+                    self._join(st2, bf)
+                    aa_all, tr_all = self.models["pose"]([pf], beam_inputs=[bf])       # batch = len(fids) * B
+                else:
+                    aa_all, tr_all = self.models["pose"]([pf])
+                stacked = (aa_all, tr_all)
+            for k, f_i in enumerate(self.opt.frame_ids[1:]):
                 order = (f_i, 0) if f_i < 0 else (0, f_i)                     # temporal order (trainer.py:338-346)
-                if precomputed is not None:
-                    pf, st, bf, st2 = precomputed[f_i]
-                    self._join(st, pf)
-                    if bf is not None:
-                        self._join(st2, bf)
-                        axisangle, translation = self.models["pose"]([pf], beam_inputs=[bf])
-                    else:
-                        axisangle, translation = self.models["pose"]([pf])
+                if stacked is not None:
+                    Bq = stacked[0].shape[0] // len(self.opt.frame_ids[1:])
+                    axisangle, translation = stacked[0][k * Bq:(k + 1) * Bq], stacked[1][k * Bq:(k + 1) * Bq]
                 else:
                     pose_inputs = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
                     if self.opt.pose_model_type == "separate_resnet":

@@ -180,12 +180,15 @@ int fd_act_bwd(const float* y, const float* gy, float* gpre, long n, int act, vo
 
 /* nn.BatchNorm2d in training mode (torchvision ResNet; trainer.py:207-211 set_train), optionally fused with the
  * residual add and ReLU of a BasicBlock/Bottleneck tail:  y = relu?( bn(x) + residual? ).
- * save_mean / save_invstd [C] are written for the backward; running_mean / running_var are updated in place
- * with `momentum` (unbiased variance), as torch does.  ws: fd_bn_ws_floats(N,C,H,W). */
-long fd_bn_ws_floats(int N, int C, int H, int W);
+ * `groups` G >= 1 splits the batch into G consecutive sub-batches that are normalised independently — bit-for-bit what G
+ * separate forward passes would do (predict_poses runs the pose encoders once per source frame, trainer.py:336-351; the
+ * trainer batches those passes) — including G in-order momentum updates of the running statistics.
+ * save_mean / save_invstd [G*C] are written for the backward; running_mean / running_var are updated in place
+ * with `momentum` (unbiased variance), as torch does.  ws: fd_bn_ws_floats(N,C,H,W,G). */
+long fd_bn_ws_floats(int N, int C, int H, int W, int groups);
 int fd_bn_train_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
                     float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws, int N, int C,
-                    int H, int W, float eps, float momentum, int relu, void* stream);
+                    int H, int W, int groups, float eps, float momentum, int relu, void* stream);
 /* eval-mode BN (running statistics), same fusion options. */
 int fd_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
                    const float* running_mean, const float* running_var, int N, int C, int H, int W, float eps, int relu,
@@ -194,7 +197,7 @@ int fd_bn_eval_fwd(const float* x, const float* weight, const float* bias, const
  * written; g_residual (if non-NULL) receives the masked upstream gradient (the residual branch's gradient). */
 int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float* weight, const float* save_mean,
                     const float* save_invstd, float* gx, float* gweight, float* gbias, float* g_residual, float* ws, int N,
-                    int C, int H, int W, int relu, int accumulate /* gweight/gbias += */, void* stream);
+                    int C, int H, int W, int groups, int relu, int accumulate /* gweight/gbias += */, void* stream);
 
 /* nn.MaxPool2d(3, stride 2, padding 1) (resnet_encoder.py:98).  idx [N,C,Ho,Wo] u8 = argmax tap (0..8). */
 int fd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream);

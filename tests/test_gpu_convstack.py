@@ -379,3 +379,39 @@ def test_layers_module_api(golden):
     relclose(cpu(L.SSIM()(dev(inp[("color", 0, 0)]), dev(inp[("color", 1, 0)]))), g["ssim"], "layers.SSIM", arel=2e-5)
     relclose(cpu(L.Cat_xy(B, H, W)(depth, dev(inp[("inv_K", 0)]))), g["catxy"], "layers.Cat_xy")
     assert list(cb.state_dict().keys()) == ["conv.conv.weight", "conv.conv.bias"]
+
+
+@pytest.mark.parametrize("N,C,H,W,G,res", [(4, 64, 12, 18, 2, True), (12, 128, 3, 5, 2, False), (6, 16, 9, 7, 3, True)])
+def test_grouped_batchnorm_equals_separate_passes(FD, N, C, H, W, G, res):
+    """FD.bn_groups(G): one launch over a stacked batch == G consecutive forward passes (statistics, outputs, gradients,
+    and the in-order momentum updates of the running statistics)."""
+    rng = np.random.RandomState(N + C)
+    x = torch.from_numpy((rng.randn(N, C, H, W) * 2 + rng.randn(N, 1, 1, 1)).astype(np.float32))
+    r = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32)) if res else None
+    cot = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32))
+    bn_o = gin.fill_params(torch.nn.BatchNorm2d(C), 5)
+    bn_g = torch.nn.BatchNorm2d(C)
+    bn_g.load_state_dict(bn_o.state_dict())
+    bn_g.cuda()
+    xo = x.clone().requires_grad_(True)
+    ro = r.clone().requires_grad_(True) if res else None
+    Ng = N // G
+    outs = []
+    for g in range(G):
+        y = bn_o(xo[g * Ng:(g + 1) * Ng])
+        if res:
+            y = y + ro[g * Ng:(g + 1) * Ng]
+        outs.append(F.relu(y))
+    yo = torch.cat(outs, 0)
+    want = torch.autograd.grad((yo * cot).sum(), [xo, bn_o.weight, bn_o.bias] + ([ro] if res else []))
+    xg = dev(x).requires_grad_(True)
+    rg = dev(r).requires_grad_(True) if res else None
+    with FD.bn_groups(G):
+        yg = FD.batch_norm(xg, bn_g, residual=rg, relu=True)
+    got = torch.autograd.grad((yg * dev(cot)).sum(), [xg, bn_g.weight, bn_g.bias] + ([rg] if res else []))
+    relclose(cpu(yg), cpu(yo), "grouped bn fwd", arel=2e-5)
+    for a, b, nm in zip(got, want, ["gx", "gweight", "gbias", "gres"]):
+        relclose(cpu(a), cpu(b), "grouped bn " + nm, rtol=2e-4, arel=2e-4)
+    relclose(cpu(bn_g.running_mean), cpu(bn_o.running_mean), "running_mean after %d in-order updates" % G)
+    relclose(cpu(bn_g.running_var), cpu(bn_o.running_var), "running_var after %d in-order updates" % G)
+    assert int(bn_g.num_batches_tracked) == int(bn_o.num_batches_tracked) == G
