@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--batch_size", type=int, default=12, help="per-process --batch_size of the reference trainer")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--no_stack", action="store_true", help="run the accumulated micro-batches sequentially (reference order) "
+                    "instead of as one stacked pass with grouped BatchNorm")
     ap.add_argument("--no_roofline", action="store_true")
     return ap.parse_args()
 
@@ -163,6 +165,7 @@ def main():
     opt = MonodepthOptions().parse(["--num_layers", str(args.num_layers), "--weights_init", "scratch", "--batch_size",
                                     str(args.batch_size), "--height", str(args.height), "--width", str(args.width)])
     tr = Trainer(opt, rank=rank, world_size=world, verbose=(rank == 0))
+    tr.stack_microbatches = not args.no_stack
     mbs = [synthetic.make_batch(tr.batch_size, args.height, args.width, seed=1234 + 17 * rank + i)
            for i in range(tr.accumulate_step)]
 
@@ -195,7 +198,8 @@ def main():
         "config": {"workload": "ResNet-%d encoders + DepthDecoder + PoseDecoder, %dx%d, 4-beam LiDAR, --batch_size %d per GPU "
                                "(= %d accumulated micro-batches of %d), frames [0,-1,1], 4 scales, fwd+bwd+Adam"
                                % (args.num_layers, args.width, args.height, opt.batch_size, tr.accumulate_step, tr.batch_size),
-                   "global_batch": opt.batch_size * world, "parallelism": "dp%d" % world, "launch": "eager" if args.eager else "hipGraph replay"},
+                   "global_batch": opt.batch_size * world, "parallelism": "dp%d" % world, "launch": "eager" if args.eager else "hipGraph replay",
+                   "micro_batches": "stacked (grouped BatchNorm)" if tr.stack_microbatches else "sequential"},
         "final_loss": loss_val,
     }
     key = (args.num_layers, args.height, args.width)

@@ -22,7 +22,8 @@ class PhotoCfg(ctypes.Structure):
     _fields_ = [("min_depth", _D), ("max_depth", _D),
                 ("B", _I), ("H", _I), ("W", _I), ("Hs", _I), ("Ws", _I), ("NF", _I),
                 ("use_ssim", _I), ("avg_reprojection", _I),
-                ("si_depth_scale", _F), ("si_beam_scale", _F), ("si_threshold", _F), ("si_var", _F), ("eps", _F)]
+                ("si_depth_scale", _F), ("si_beam_scale", _F), ("si_threshold", _F), ("si_var", _F), ("eps", _F),
+                ("groups", _I)]
 
 
 class ConvDesc(ctypes.Structure):

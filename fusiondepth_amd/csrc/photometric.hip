@@ -308,27 +308,41 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
     }
 }
 
-// one workgroup: fixed-order reduction of the per-tile partials, then the scalar loss terms
-__global__ void __launch_bounds__(256) k_photo_finalize(const float* __restrict__ ws, int nblk, float count, float si_var,
-                                                        int have_beam, float* __restrict__ out) {
+// one workgroup per group (+ the photometric mean over all groups in block 0): fixed-order reduction of the per-tile
+// partials, then the scalar loss terms.  A "group" is a sub-batch whose SI-log loss is evaluated on its own — the
+// accumulated micro-batches of one optimiser step run as one stacked batch (trainer.py:237-248 sums their losses).
+//   out[0] = mean over ALL pixels of the min-reprojection loss     out[4] = mean over groups of si_loss_g
+//   out[8 + 4g ..] = n_valid_g, mean(d)_g, var_g, si_loss_g
+__global__ void __launch_bounds__(256) k_photo_finalize(const float* __restrict__ ws, int tiles_per_group, int groups,
+                                                        float count, float si_var, int have_beam, float* __restrict__ out) {
     __shared__ float s_red[4 * 4];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = threadIdx.x; i < nblk; i += 256)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] += ws[(long)i * 4 + k];
-    const float s = fd_block_sum_n<4, 4>(acc, s_red);
     __shared__ float tot[4];
+    const int g = blockIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < tiles_per_group; i += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] += ws[((long)g * tiles_per_group + i) * 4 + k];
+    const float s = fd_block_sum_n<4, 4>(acc, s_red);
     if (threadIdx.x < 4) tot[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[0] = tot[0] / count;
         const float n = tot[1];
         const float m1 = tot[2] / n, m2 = tot[3] / n;
         const float var = m2 - si_var * (m1 * m1);
-        out[1] = n; out[2] = m1; out[3] = var;
-        out[4] = have_beam ? sqrtf(var) * 0.1f : 0.f;
-        out[5] = 0.f; out[6] = 0.f; out[7] = 0.f;
+        float* o = out + 8 + 4 * g;
+        o[0] = n; o[1] = m1; o[2] = var;
+        o[3] = have_beam ? sqrtf(var) * 0.1f : 0.f;
+        out[8 + 4 * groups + g] = tot[0];           // per-group sum of the min-reprojection loss
     }
+}
+__global__ void k_photo_finalize2(float* __restrict__ out, int groups, float count) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sum = 0.f, si = 0.f;
+    for (int g = 0; g < groups; ++g) { sum += out[8 + 4 * groups + g]; si += out[8 + 4 * g + 3]; }
+    out[0] = sum / count;
+    out[1] = out[8]; out[2] = out[9]; out[3] = out[10];      // group 0 statistics (back-compat for groups == 1)
+    out[4] = si / (float)groups;
+    out[5] = 0.f; out[6] = 0.f; out[7] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -521,8 +535,9 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     if (NF > 1) frame_pass(1, gP1);   // NF is workgroup-uniform
 
     // SI-log term and conversion depth -> upsampled disparity
-    const float n_valid = a.stats[1], m1 = a.stats[2], var = a.stats[3];
-    const float k_si = a.beam ? a.g[1] * 0.1f / (sqrtf(var) * n_valid) : 0.f;
+    const int grp = b / (cfg.B / cfg.groups);
+    const float n_valid = a.stats[8 + 4 * grp], m1 = a.stats[9 + 4 * grp], var = a.stats[10 + 4 * grp];
+    const float k_si = a.beam ? a.g[1] / (float)cfg.groups * 0.1f / (sqrtf(var) * n_valid) : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int y = y0t + ty * 4 + i;
@@ -685,6 +700,8 @@ int check_cfg(const fd_photo_cfg* c, const char* who) {
     FD_REQUIRE(c->B > 0 && c->H >= 4 && c->W >= 4 && c->Hs > 0 && c->Ws > 0 && c->Hs <= c->H && c->Ws <= c->W,
                "%s: bad sizes B=%d H=%d W=%d Hs=%d Ws=%d", who, c->B, c->H, c->W, c->Hs, c->Ws);
     FD_REQUIRE(c->NF == 1 || c->NF == 2, "%s: NF must be 1 or 2 (got %d)", who, c->NF);
+    FD_REQUIRE(c->groups >= 1 && c->groups <= 16 && c->B % c->groups == 0, "%s: batch %d not divisible into %d groups", who, c->B,
+               c->groups);
     FD_REQUIRE(c->min_depth > 0 && c->max_depth > c->min_depth, "%s: bad depth range", who);
     return 0;
 }
@@ -714,9 +731,11 @@ extern "C" int fd_photo_fwd(const fd_photo_cfg* cfg, const float* disp, const fl
     else hipLaunchKernelGGL(k_photo_fwd<false>, grid, dim3(NT), 0, st, a);
     FD_LAUNCH_CHECK("fd_photo_fwd");
     const float count = (float)cfg->B * (float)cfg->H * (float)cfg->W;
-    hipLaunchKernelGGL(k_photo_finalize, dim3(1), dim3(256), 0, st, ws, (int)tile_count(cfg->B, cfg->H, cfg->W), count,
-                       cfg->si_var, beam ? 1 : 0, out);
+    hipLaunchKernelGGL(k_photo_finalize, dim3(cfg->groups), dim3(256), 0, st, ws,
+                       (int)(tile_count(cfg->B, cfg->H, cfg->W) / cfg->groups), cfg->groups, count, cfg->si_var, beam ? 1 : 0, out);
     FD_LAUNCH_CHECK("fd_photo_finalize");
+    hipLaunchKernelGGL(k_photo_finalize2, dim3(1), dim3(64), 0, st, out, cfg->groups, count);
+    FD_LAUNCH_CHECK("fd_photo_finalize2");
     return 0;
 }
 

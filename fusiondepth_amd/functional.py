@@ -274,8 +274,9 @@ class PhotoOptions:
         self.si_depth_scale, self.si_beam_scale = float(si_depth_scale), float(si_beam_scale)
 
 
-def _photo_cfg(po, B, H, W, Hs, Ws, NF):
+def _photo_cfg(po, B, H, W, Hs, Ws, NF, groups=1):
     c = _lib.PhotoCfg()
+    c.groups = groups
     c.min_depth, c.max_depth = po.min_depth, po.max_depth
     c.B, c.H, c.W, c.Hs, c.Ws, c.NF = B, H, W, Hs, Ws, NF
     c.use_ssim = 0 if po.no_ssim else 1
@@ -292,7 +293,7 @@ class _PhotoLoss(torch.autograd.Function):
     non-differentiable by-products (``None`` unless requested)."""
 
     @staticmethod
-    def forward(ctx, disp, T0, T1, K, inv_K, src0, src1, target, ident, noise, beam, po, materialize):
+    def forward(ctx, disp, T0, T1, K, inv_K, src0, src1, target, ident, noise, beam, po, materialize, groups):
         disp, K, inv_K, target = f32(disp), f32(K), f32(inv_K), f32(target)
         _need_cuda(disp, K, inv_K, target, src0)
         NF = 1 if src1 is None else 2
@@ -306,13 +307,13 @@ class _PhotoLoss(torch.autograd.Function):
         ident = f32(ident) if ident is not None else None
         noise = f32(noise) if noise is not None else None
         beam = f32(beam) if beam is not None else None
-        cfg = _photo_cfg(po, B, H, W, Hs, Ws, NF)
+        cfg = _photo_cfg(po, B, H, W, Hs, Ws, NF, groups)
         sel = _empty((B, H, W), disp, torch.uint8)
         depth = _empty((B, 1, H, W), disp) if materialize else None
         sample = _empty((NF, B, H, W, 2), disp) if materialize else None
         color = _empty((NF, B, 3, H, W), disp) if materialize else None
         ws = _empty((query("fd_photo_ws_floats", B, H, W),), disp)
-        out = _empty((8,), disp)
+        out = _empty((96,), disp)
         src_arr = (ctypes.c_void_p * 2)(ptr(srcs[0]), ptr(srcs[-1]))
         call("fd_photo_fwd", ctypes.addressof(cfg), ptr(disp), ptr(inv_K), ptr(P), ctypes.addressof(src_arr),
              ptr(target), ptr(ident), ptr(noise), ptr(beam), ptr(sel), ptr(depth), ptr(sample), ptr(color), ptr(ws),
@@ -349,16 +350,18 @@ class _PhotoLoss(torch.autograd.Function):
                 gTs.append(gT)
             else:
                 gTs.append(None)
-        return (d_disp, gTs[0], gTs[1]) + (None,) * 10
+        return (d_disp, gTs[0], gTs[1]) + (None,) * 11
 
 
 def photo_loss(disp, T_list, K, inv_K, src_list, target, ident=None, noise=None, beam=None, po=None,
-               materialize=False):
-    """Fused per-scale loss.  T_list / src_list: one or two source frames."""
+               materialize=False, groups=1):
+    """Fused per-scale loss.  T_list / src_list: one or two source frames.  ``groups``: the batch is that many stacked
+    micro-batches; the SI-log loss is evaluated per micro-batch and averaged."""
     po = po or PhotoOptions()
     T1 = T_list[1] if len(T_list) > 1 else None
     s1 = src_list[1] if len(src_list) > 1 else None
-    return _PhotoLoss.apply(disp, T_list[0], T1, K, inv_K, src_list[0], s1, target, ident, noise, beam, po, materialize)
+    return _PhotoLoss.apply(disp, T_list[0], T1, K, inv_K, src_list[0], s1, target, ident, noise, beam, po, materialize,
+                            int(groups))
 
 
 # ------------------------------------------------------------------------------------ conv stack --

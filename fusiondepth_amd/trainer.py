@@ -103,6 +103,7 @@ class Trainer:
         self._graph = None
         self._streams = []
         self.parallel_streams = True
+        self.stack_microbatches = True
         self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)
         if self.opt.train_load_weights_folder is not None:
             self.load_model()
@@ -140,20 +141,47 @@ class Trainer:
             m.eval()
 
     # ------------------------------------------------------------------------------------------------
+    def stack_micro_batches(self, micro_batches):
+        """Concatenate the accumulated micro-batches along the batch axis (see ``train_step``)."""
+        if len(micro_batches) == 1:
+            return micro_batches[0]
+        out = {}
+        for k, v0 in micro_batches[0].items():
+            if torch.is_tensor(v0):
+                out[k] = torch.cat([mb[k] for mb in micro_batches], 0)
+            elif k == "_noise":
+                out[k] = [torch.cat([mb[k][s] for mb in micro_batches], 0) for s in range(len(v0))]
+            else:
+                out[k] = v0
+        return out
+
     def train_step(self, micro_batches):
-        """One optimiser step = ``accumulate_step`` micro-batches (trainer.py:237-248).  Returns the losses of the
-        last micro-batch (device tensors; nothing is synchronised here)."""
+        """One optimiser step = ``accumulate_step`` micro-batches (trainer.py:237-248: loss/accumulate, backward, step
+        every accumulate-th batch).
+
+        With ``stack_microbatches`` (default) the micro-batches run as ONE stacked forward/backward: BatchNorm normalises
+        each micro-batch separately (``FD.bn_groups``, running statistics updated in micro-batch order), the SI-log loss is
+        evaluated per micro-batch, and the other loss terms are means, so loss = sum_g loss_g / accumulate_step and its
+        gradient equal the reference's accumulated values while every kernel sees twice the work per launch.
+        Returns the loss dict (device tensors; nothing is synchronised here)."""
         assert len(micro_batches) == self.accumulate_step
-        losses = None
-        for i, inputs in enumerate(micro_batches):
-            last = i == self.accumulate_step - 1
-            outputs, losses = self.process_batch(inputs)
-            loss = losses["loss"] / self.accumulate_step
-            if last:
-                self.grad_sync.arm()
-            loss.backward()
+        if self.stack_microbatches:
+            self.grad_sync.arm()
+            outputs, losses = self.process_batch(self.stack_micro_batches(micro_batches), groups=self.accumulate_step)
+            losses["loss"].backward()
             self._join_side_streams()
-            self.batch_idx += 1
+            self.batch_idx += self.accumulate_step
+        else:
+            losses = None
+            for i, inputs in enumerate(micro_batches):
+                last = i == self.accumulate_step - 1
+                outputs, losses = self.process_batch(inputs)
+                loss = losses["loss"] / self.accumulate_step
+                if last:
+                    self.grad_sync.arm()
+                loss.backward()
+                self._join_side_streams()
+                self.batch_idx += 1
         scale = self.grad_sync.finish() if self.world_size > 1 else 1.0
         self.optimizer_step(scale)
         self.step += 1
@@ -182,43 +210,71 @@ class Trainer:
         and replay.  With several ranks the forward/backward micro-steps are replayed and the gradient all-reduce +
         Adam run after the graph."""
         if self._graph is None:
-            self._static_mbs = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in mb.items()} for mb in micro_batches]
+            if self.stack_microbatches:
+                self._static_in = self.stack_micro_batches(micro_batches)
+                if len(micro_batches) == 1:
+                    self._static_in = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self._static_in.items()}
+            else:
+                self._static_in = [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in mb.items()} for mb in micro_batches]
+            self._last_mbs = micro_batches
             self._graph = "warm"
             # warm up on the stream the capture will use, so that autograd's AccumulateGrad nodes are bound to it
             self._side = torch.cuda.Stream()
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
-                losses = self.train_step(self._static_mbs)
+                losses = self._graph_body(self._static_in)
+                if self.world_size > 1:
+                    self._sync_and_step()
             torch.cuda.current_stream().wait_stream(self._side)
+            self.step += 1
+            self.batch_idx += self.accumulate_step
             return losses
-        for dst, src in zip(self._static_mbs, micro_batches):
-            if dst is src:
-                continue
-            for k, v in src.items():
-                if torch.is_tensor(v) and dst[k].data_ptr() != v.data_ptr():
-                    dst[k].copy_(v)
+        if micro_batches is not self._last_mbs:
+            self._copy_into_static(micro_batches)
+            self._last_mbs = micro_batches
         if self._graph == "warm":
             FD.bump_weights_epoch()        # the captured step must (re)derive every weight layout at first use
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self._side):
-                self._static_losses = self._graph_body(self._static_mbs)
+                self._static_losses = self._graph_body(self._static_in)
             self._graph = g
         self._graph.replay()
         if self.world_size > 1:
             self._sync_and_step()
-        self.adam_step_count += 0 if self.world_size > 1 else 1
         self.step += 1
         self.batch_idx += self.accumulate_step
         return self._static_losses
 
-    def _graph_body(self, mbs):
-        losses = None
-        for inputs in mbs:
-            outputs, losses = self.process_batch(inputs)
-            (losses["loss"] / self.accumulate_step).backward()
+    def _copy_into_static(self, micro_batches):
+        if not self.stack_microbatches:
+            for dst, src in zip(self._static_in, micro_batches):
+                for k, v in src.items():
+                    if torch.is_tensor(v):
+                        dst[k].copy_(v)
+            return
+        for i, mb in enumerate(micro_batches):
+            for k, v in mb.items():
+                if torch.is_tensor(v):
+                    n = v.shape[0]
+                    self._static_in[k][i * n:(i + 1) * n].copy_(v)
+                elif k == "_noise":
+                    for s_, t in enumerate(v):
+                        self._static_in[k][s_][i * t.shape[0]:(i + 1) * t.shape[0]].copy_(t)
+
+    def _graph_body(self, static_in):
+        if self.stack_microbatches:
+            outputs, losses = self.process_batch(static_in, groups=self.accumulate_step)
+            losses["loss"].backward()
             self._join_side_streams()
+        else:
+            losses = None
+            for inputs in static_in:
+                outputs, losses = self.process_batch(inputs)
+                (losses["loss"] / self.accumulate_step).backward()
+                self._join_side_streams()
         if self.world_size == 1:
+            self.adam_step_count += 1
             FD.adam_step_dev(self.flat.flat_param, self.flat.flat_grad, self.exp_avg, self.exp_avg_sq, self.adam_state)
             self.flat.flat_grad.zero_()
         return {k: v.detach() for k, v in losses.items()}
@@ -251,8 +307,9 @@ class Trainer:
         for t in tensors:
             t.record_stream(cur)
 
-    def process_batch(self, inputs, val=False):
-        """trainer.py:268-319 (default separate-pose-encoder path).
+    def process_batch(self, inputs, val=False, groups=1):
+        """trainer.py:268-319 (default separate-pose-encoder path).  ``groups`` > 1: ``inputs`` holds that many micro-batches
+        stacked along the batch axis (see ``train_step``).
 
         The six ResNet passes of a training batch (RGB encoder, beam encoder, and pose / beam-pose encoders for
         frames -1 and +1) are mutually independent; at micro-batch 6 a single pass cannot fill 256 CUs (layer4 has
@@ -269,18 +326,22 @@ class Trainer:
             enc_in = torch.cat((inputs["color_aug", 0, 0], inputs["2channel"]), 1)
         else:
             enc_in = inputs["color_aug", 0, 0]
+        self._groups = groups
         pose_out = None
+        if groups > 1 and not par:
+            raise NotImplementedError("stacked micro-batches need the separate_resnet pose path; set stack_microbatches=False")
         if par:
-            pose_out = self._launch_pose_encoders(inputs)          # 4 side streams, joined in predict_poses
+            pose_out = self._launch_pose_encoders(inputs)          # side streams, joined in predict_poses
         beam_features = None
         if self.opt.beam_encoder and not self.opt.cat2end:
             if par:
                 st = self._fork(0)
-                with torch.cuda.stream(st):
+                with torch.cuda.stream(st), FD.bn_groups(groups):
                     beam_features = self.models["beam_encoder"](inputs["2channel"])
             else:
                 beam_features = self.models["beam_encoder"](inputs["2channel"])
-        features = self.models["encoder"](enc_in)
+        with FD.bn_groups(groups):
+            features = self.models["encoder"](enc_in)
         if par and beam_features is not None:
             self._join(self._streams[0], beam_features)
         if self.opt.cat2end:
@@ -309,19 +370,27 @@ class Trainer:
         but every kernel sees twice the pixels (layer4: 1 440 instead of 720) and half the launches are issued."""
         fids = self.opt.frame_ids[1:]
         orders = [(f, 0) if f < 0 else (0, f) for f in fids]
+        G = self._groups
+        Bg = inputs["color_aug", 0, 0].shape[0] // G
+
+        def stack(key):
+            # reference pass order: for each micro-batch g, for each source frame f  (trainer.py:237-248 + 336-351)
+            pairs = [torch.cat([inputs[key, i, 0] for i in o], 1) for o in orders]
+            if G == 1:
+                return torch.cat(pairs, 0)
+            return torch.cat([p[g * Bg:(g + 1) * Bg] for g in range(G) for p in pairs], 0)
+
         res = {}
         st_rgb = self._fork(1)
         with torch.cuda.stream(st_rgb):
-            rgb = torch.cat([torch.cat([inputs["color_aug", i, 0] for i in o], 1) for o in orders], 0)
-            with FD.bn_groups(len(fids)):
-                pf = self.models["pose_encoder"](rgb)
+            with FD.bn_groups(G * len(fids)):
+                pf = self.models["pose_encoder"](stack("color_aug"))
         bf, st_beam = None, None
         if self.opt.beam_encoder:
             st_beam = self._fork(2)
             with torch.cuda.stream(st_beam):
-                beam = torch.cat([torch.cat([inputs["2channel", i, 0] for i in o], 1) for o in orders], 0)
-                with FD.bn_groups(len(fids)):
-                    bf = self.models["beam_encoder_pose"](beam)
+                with FD.bn_groups(G * len(fids)):
+                    bf = self.models["beam_encoder_pose"](stack("2channel"))
         res["stacked"] = (pf, st_rgb, bf, st_beam)
         return res
 
@@ -342,8 +411,14 @@ class Trainer:
             for k, f_i in enumerate(self.opt.frame_ids[1:]):
                 order = (f_i, 0) if f_i < 0 else (0, f_i)                     # temporal order (trainer.py:338-346)
                 if stacked is not None:
-                    Bq = stacked[0].shape[0] // len(self.opt.frame_ids[1:])
-                    axisangle, translation = stacked[0][k * Bq:(k + 1) * Bq], stacked[1][k * Bq:(k + 1) * Bq]
+                    nf, G = len(self.opt.frame_ids[1:]), self._groups
+                    Bq = stacked[0].shape[0] // (nf * G)                 # rows are ordered (micro-batch g, frame k, sample)
+                    if G == 1:
+                        axisangle, translation = stacked[0][k * Bq:(k + 1) * Bq], stacked[1][k * Bq:(k + 1) * Bq]
+                    else:
+                        sl = [slice((g * nf + k) * Bq, (g * nf + k + 1) * Bq) for g in range(G)]
+                        axisangle = torch.cat([stacked[0][q] for q in sl], 0)
+                        translation = torch.cat([stacked[1][q] for q in sl], 0)
                 else:
                     pose_inputs = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
                     if self.opt.pose_model_type == "separate_resnet":
@@ -426,7 +501,7 @@ class Trainer:
             srcs = [inputs[("color", f, src_s)] for f in fids]
             photo, si, sel, depth, sample, color = FD.photo_loss(
                 outputs[("disp", scale)], Ts, inputs[("K", src_s)], inputs[("inv_K", src_s)], srcs, target, ident, noise,
-                beam, self.photo_options, self.materialize_outputs)
+                beam, self.photo_options, self.materialize_outputs, getattr(self, "_groups", 1))
             outputs[("photo", scale)] = (photo, si if beam is not None else None)
             if automask:
                 n_id = ident.shape[1]

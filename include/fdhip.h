@@ -100,9 +100,13 @@ int fd_reproj_loss_map(const float* pred, const float* target, float* out, long 
  *   depth_out/sample_out/color_out   optional materialised ("depth",0,s) [B,1,H,W],
  *                           ("sample",f,s) [NF][B,H,W,2], ("color",f,s) [NF][B,3,H,W]  (NULL to skip)
  *   ws        workspace of fd_photo_ws_floats(B,H,W) floats (per-block partial sums)
- *   out       [8] floats: 0 to_optimise.mean(), 1 n_valid, 2 mean(d), 3 mean(d^2)-si_var*mean(d)^2,
- *             4 si_loss, 5..7 reserved
+ *   out       [FD_PHOTO_OUT_FLOATS] floats: 0 to_optimise.mean() over the whole batch, 4 si_loss averaged over the
+ *             `groups` sub-batches, 8+4g.. per group g: n_valid, mean(d), mean(d^2)-si_var*mean(d)^2, si_loss_g
+ *             (1..3 repeat group 0; the rest is scratch)
+ *   cfg.groups  G >= 1: the batch is G stacked micro-batches (trainer.py:237-248 accumulates their losses); the SI-log
+ *             loss, which is not linear in the batch, is evaluated per micro-batch and averaged.
  */
+#define FD_PHOTO_OUT_FLOATS 96
 typedef struct {
     double min_depth, max_depth; /* opt.min_depth / opt.max_depth (doubles: 1/0.1 must be exactly 10) */
     int B, H, W, Hs, Ws, NF;
@@ -113,6 +117,7 @@ typedef struct {
     float si_threshold;     /* opt.gdc_loss_threshold */
     float si_var;           /* opt.si_var */
     float eps;              /* Project3D eps 1e-7 */
+    int groups;             /* number of stacked micro-batches (>= 1) */
 } fd_photo_cfg;
 
 long fd_photo_ws_floats(int B, int H, int W);

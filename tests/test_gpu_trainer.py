@@ -229,3 +229,42 @@ def test_posecnn_variant_runs_and_matches_oracle_losses():
         OT.generate_images_pred(sopt, inp, o2)
         ls = OT.compute_losses(sopt, inp, o2, {s: noise[s]})
         assert_close(float(losses["loss/%d" % s]), float(ls["loss/%d" % s]), rtol=2e-4, atol=1e-6, what="posecnn loss/%d" % s)
+
+
+def test_stacked_microbatches_equal_sequential_accumulation():
+    """train_step with the accumulated micro-batches stacked into one pass (grouped BatchNorm, per-micro-batch SI loss)
+    must give the gradients, BatchNorm running statistics and loss terms of the reference's sequential accumulation."""
+    from fusiondepth_amd.trainer import Trainer
+    from fusiondepth_amd import synthetic
+    B, H, W = 5, 64, 96
+    mbs = []
+    for i in range(2):
+        inp, noise = _batch(B, H, W, 700 + i)
+        g = {k: v.cuda() for k, v in inp.items()}
+        g["_noise"] = [n.cuda() for n in noise]
+        mbs.append(g)
+    res = {}
+    for stacked in (False, True):
+        tr = Trainer(_opts(batch_size=10), verbose=False)
+        assert tr.accumulate_step == 2 and tr.batch_size == 5
+        with torch.no_grad():
+            tr.flat.flat_param.copy_(torch.linspace(-3, 3, tr.flat.numel(), device="cuda").sin() * 0.04)
+            for m in tr.models.values():
+                for n, b in m.named_buffers():
+                    if "running_var" in n:
+                        b.fill_(1.0)
+                    elif "running_mean" in n:
+                        b.zero_()
+        tr.stack_microbatches = stacked
+        grabbed = {}
+        tr.optimizer_step = lambda scale=1.0: grabbed.update(grad=tr.flat.flat_grad.clone())
+        losses = tr.train_step([dict(m) for m in mbs])
+        bufs = torch.cat([b.detach().float().reshape(-1) for m in tr.models.values() for n, b in m.named_buffers()])
+        res[stacked] = (grabbed["grad"], bufs, {k: float(v) for k, v in losses.items()})
+    g0, g1 = res[False][0].cpu().numpy().astype(np.float64), res[True][0].cpu().numpy().astype(np.float64)
+    rel = np.abs(g1 - g0).sum() / np.abs(g0).sum()
+    assert rel < 2e-4, "aggregate gradient difference stacked vs sequential: %.3g" % rel
+    assert_close(res[True][1].cpu().numpy(), res[False][1].cpu().numpy(), rtol=1e-4, atol=1e-5, what="BN buffers after the step")
+    # the sequential path reports the LAST micro-batch's losses, the stacked path the mean over micro-batches
+    tr2 = Trainer(_opts(batch_size=10), verbose=False)
+    assert tr2.stack_microbatches
