@@ -26,6 +26,20 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 4) return tanhf(v);
     return v;
 }
+// Raw buffer resources: 32-bit byte offsets against a wave-uniform base (one VALU add per load instead of a 64-bit
+// address chain) and hardware range checking - an offset >= 2^31 reads as 0.0f without touching memory, which is how
+// padding taps, pixels past the end and the "no next chunk" case are expressed (no selects, no branches in the loop).
+typedef unsigned u32x4 __attribute__((__vector_size__(16)));
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)OOB, 0x00020000);
+}
+__device__ __forceinline__ float ldg32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float4 ldg128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
 __device__ __forceinline__ int refl_idx(int i, int n) {
     i = i < 0 ? -i : i;
     return i >= n ? 2 * n - 2 - i : i;
@@ -81,40 +95,44 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     // ---- weight loader: float4 column a4 of row ar + A_ROWS_PER_PASS*i
     const int a4 = tid % A_V4_PER_ROW, ar = tid / A_V4_PER_ROW;
 
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A), rsX = make_rsrc(g.X);
     float4 ra[NA_LOAD];
     float rb[NB_LOAD];
-    bool okb = false;
-    // state of the chunk being fetched (set by prep_chunk, consumed by the load/store slices)
-    unsigned a_off[NA_LOAD], b_off = 0u, b_step = 0u;
-    auto prep_chunk = [&](int ch) __attribute__((always_inline)) {
-        const int t = ch / cpt, c0 = (ch - t * cpt) * BKC;          // wave-uniform
-        const int ta = t / g.TB, tb = t - ta * g.TB;
-        const unsigned k0 = (unsigned)t * (unsigned)g.C + (unsigned)c0;
+    // state of the chunk being fetched (set by prep_chunk, consumed by the load/store slices); byte offsets
+    unsigned a_off[NA_LOAD], b_off = OOB;
+    const unsigned b_step = 4u * (unsigned)RP * chw;                  // wave-uniform
+    // (tap row, tap column, first channel) of the next chunk to prepare: advanced incrementally, all wave-uniform
+    int pc_ta, pc_tb, pc_c0;
+    { const int t = ch_lo / cpt; pc_c0 = (ch_lo - t * cpt) * BKC; pc_ta = t / g.TB; pc_tb = t - pc_ta * g.TB; }
+    const bool refl = g.pad_mode == 1;
+    auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
+        const unsigned k0 = (unsigned)(pc_ta * g.TB + pc_tb) * (unsigned)g.C + (unsigned)pc_c0;
 #pragma unroll
         for (int i = 0; i < NA_LOAD; ++i) {
             int m = m0 + ar + A_ROWS_PER_PASS * i;
             m = m < g.M ? m : g.M - 1;                                // rows >= M are never stored by the epilogue
-            a_off[i] = (unsigned)m * (unsigned)g.K + k0 + 4u * a4;
+            a_off[i] = live ? 4u * ((unsigned)m * (unsigned)g.K + k0 + 4u * a4) : OOB;
         }
-        int r = ry0 + ta * g.da, cc = cx0 + tb * g.db;
-        bool ok = pvalid;
-        if (g.pad_mode == 1) { r = refl_idx(r, g.Hi); cc = refl_idx(cc, g.Wi); }
-        else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
-        okb = ok;
-        b_off = ok ? nbase + (unsigned)(c0 + kr) * chw + (unsigned)(r * g.Wi + cc) : 0u;
-        b_step = ok ? (unsigned)RP * chw : 0u;
+        int r = ry0 + pc_ta * g.da, cc = cx0 + pc_tb * g.db;
+        const bool inb = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
+        const int rr = refl_idx(r, g.Hi), rc = refl_idx(cc, g.Wi);
+        r = refl ? rr : r; cc = refl ? rc : cc;
+        const bool ok = pvalid & live & (refl | inb);
+        b_off = ok ? 4u * (nbase + (unsigned)(pc_c0 + kr) * chw + (unsigned)(r * g.Wi + cc)) : OOB;
+        pc_c0 += BKC;
+        if (pc_c0 >= g.C) { pc_c0 = 0; ++pc_tb; if (pc_tb >= g.TB) { pc_tb = 0; ++pc_ta; } }
     };
     auto load_a = [&](int i) __attribute__((always_inline)) {
-        if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)a_off[i]);
+        if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM) ra[i] = ldg128(rsA, a_off[i]);
     };
-    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = g.X[b_off + (unsigned)i * b_step]; };
+    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = ldg32(rsX, b_off + (unsigned)i * b_step); };
     auto store_a = [&](int buf, int i) __attribute__((always_inline)) {
         if (A_PARTIAL && ar + A_ROWS_PER_PASS * i >= BM) return;
         float* q = sA + buf * BKC * LDA + (4 * a4) * LDA + ar + A_ROWS_PER_PASS * i;
         q[0] = ra[i].x; q[LDA] = ra[i].y; q[2 * LDA] = ra[i].z; q[3 * LDA] = ra[i].w;
     };
     auto store_b = [&](int buf, int i) __attribute__((always_inline)) {
-        sB[buf * BKC * LDB + (kr + RP * i) * LDB + jn] = okb ? rb[i] : 0.f;
+        sB[buf * BKC * LDB + (kr + RP * i) * LDB + jn] = rb[i];
     };
 
     f32x16 acc[WM][WN];
@@ -129,7 +147,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     constexpr int HS = NK / 2;           // first half of the k-steps issues the next chunk's loads, second half stores them
     const int arow = lane >> 5, acol = lane & 31;
     if (ch_lo < ch_hi) {
-        prep_chunk(ch_lo);
+        prep_chunk(true);
 #pragma unroll
         for (int i = 0; i < NA_LOAD; ++i) load_a(i);
 #pragma unroll
@@ -141,8 +159,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
         __syncthreads();
         for (int ch = ch_lo; ch < ch_hi; ++ch) {
             const int cur = (ch - ch_lo) & 1;
-            const bool has_next = ch + 1 < ch_hi;
-            if (has_next) prep_chunk(ch + 1);
+            prep_chunk(ch + 1 < ch_hi);                // past the end: every load is out of range (zeros, no traffic)
             const float* pa = sA + cur * BKC * LDA + arow * LDA + wave_m * 32 * WM + acol;
             const float* pb = sB + cur * BKC * LDB + arow * LDB + wave_n * 32 * WN + acol;
             // Fine-grained software pipeline: LDS operand reads of k-step kk+1, the global loads of chunk ch+1 (first half
@@ -162,18 +179,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
 #pragma unroll
                     for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
                 }
-                if (has_next) {
-                    if (kk < HS) {
+                if (kk < HS) {
 #pragma unroll
-                        for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
 #pragma unroll
-                        for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
-                    } else {
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
+                } else {
 #pragma unroll
-                        for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
 #pragma unroll
-                        for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
-                    }
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the memory ops ahead of this step's MFMAs
 #pragma unroll
@@ -259,35 +274,48 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
     const int ncol = g.C - c0 < BN ? g.C - c0 : BN;          // valid channel columns of this tile
     const int nrow = g.M - m0 < BM ? g.M - m0 : BM;
 
+    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(g.dY), rsX = make_rsrc(g.X);
     float ra[NA_LOAD], rb[NB_LOAD];
-    bool okp = false, okx = false;
-    unsigned offa = 0u, stepa = 0u, offb = 0u, stepb = 0u;
-    auto prep_chunk = [&](long pc) __attribute__((always_inline)) {
-        const long p = pc + pl;
-        const bool pv = p < pend;
-        const long pp = pv ? p : 0;
-        const int n = (int)(pp / plane);
-        const int rem = (int)(pp - (long)n * plane);
-        const int y = rem / g.NX, x = rem - y * g.NX;
-        okp = pv;
-        offa = pv ? (unsigned)n * (unsigned)g.dy_ns + (unsigned)(m0 + rw) * (unsigned)g.dy_cs + (unsigned)rem : 0u;
-        stepa = pv ? (unsigned)RPW * (unsigned)g.dy_cs : 0u;
+    // Byte offsets of this thread's dY rows / X channels.  Rows past the tile's valid range are clamped to the last valid
+    // one: their products land in accumulator rows / columns the epilogue never stores.
+    unsigned rowa[NA_LOAD], rowb[NB_LOAD];
+#pragma unroll
+    for (int i = 0; i < NA_LOAD; ++i) {
+        const int r = rw + RPW * i < nrow ? rw + RPW * i : nrow - 1;
+        rowa[i] = 4u * (unsigned)(m0 + r) * (unsigned)g.dy_cs;
+    }
+#pragma unroll
+    for (int i = 0; i < NB_LOAD; ++i) {
+        const int c = rw + RPW * i < ncol ? rw + RPW * i : ncol - 1;
+        rowb[i] = 4u * (unsigned)(c0 + c) * chw;
+    }
+    unsigned offa = OOB, offb = OOB;
+    // this lane's pixel of the next chunk: (image n, offset rem inside the plane), advanced by BP per chunk
+    int pn, prem;
+    { const long p = pbeg + pl; pn = (int)(p / plane); prem = (int)(p - (long)pn * plane); }
+    long pcur = pbeg + pl;
+    const float inv_nx = 1.0f / (float)g.NX;
+    const bool refl = g.pad_mode == 1;
+    auto prep_chunk = [&]() __attribute__((always_inline)) {      // pixels >= pend: everything out of range (zeros)
+        const bool pv = pcur < pend;
+        int y = (int)(((float)prem + 0.5f) * inv_nx);             // estimate within +-1 for planes < 2^23; fixed up below
+        int x = prem - y * g.NX;
+        if (x < 0) { --y; x += g.NX; }
+        if (x >= g.NX) { ++y; x -= g.NX; }
+        offa = pv ? 4u * ((unsigned)pn * (unsigned)g.dy_ns + (unsigned)prem) : OOB;
         int r = y * g.sy + g.oy + ta * g.da, cc = x * g.sx + g.ox + tb * g.db;
-        bool ok = pv;
-        if (g.pad_mode == 1) { r = refl_idx(r, g.Hi); cc = refl_idx(cc, g.Wi); }
-        else ok = ok && r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
-        okx = ok;
-        offb = ok ? ((unsigned)n * (unsigned)g.C + (unsigned)(c0 + rw)) * chw + (unsigned)(r * g.Wi + cc) : 0u;
-        stepb = ok ? (unsigned)RPW * chw : 0u;
+        const bool inb = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
+        const int rr = refl_idx(r, g.Hi), rc = refl_idx(cc, g.Wi);
+        r = refl ? rr : r; cc = refl ? rc : cc;
+        const bool ok = pv & (refl | inb);
+        offb = ok ? 4u * ((unsigned)pn * (unsigned)g.C * chw + (unsigned)(r * g.Wi + cc)) : OOB;
+        pcur += BP; prem += BP;
+        while (prem >= plane) { prem -= plane; ++pn; }
     };
-    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = g.dY[(rw + RPW * i) < nrow ? offa + (unsigned)i * stepa : 0u]; };
-    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = g.X[(rw + RPW * i) < ncol ? offb + (unsigned)i * stepb : 0u]; };
-    auto store_a = [&](int buf, int i) __attribute__((always_inline)) {
-        sA[buf * BP * LDA + pl * LDA + rw + RPW * i] = (okp && (rw + RPW * i) < nrow) ? ra[i] : 0.f;
-    };
-    auto store_b = [&](int buf, int i) __attribute__((always_inline)) {
-        sB[buf * BP * LDB + pl * LDB + rw + RPW * i] = (okx && (rw + RPW * i) < ncol) ? rb[i] : 0.f;
-    };
+    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = ldg32(rsY, offa + rowa[i]); };
+    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = ldg32(rsX, offb + rowb[i]); };
+    auto store_a = [&](int buf, int i) __attribute__((always_inline)) { sA[buf * BP * LDA + pl * LDA + rw + RPW * i] = ra[i]; };
+    auto store_b = [&](int buf, int i) __attribute__((always_inline)) { sB[buf * BP * LDB + pl * LDB + rw + RPW * i] = rb[i]; };
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -301,7 +329,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
     constexpr int NK = BP / 2, HS = NK / 2;
     const int arow = lane >> 5, acol = lane & 31;
     if (nchunk > 0) {
-        prep_chunk(pbeg);
+        prep_chunk();
 #pragma unroll
         for (int i = 0; i < NA_LOAD; ++i) load_a(i);
 #pragma unroll
@@ -313,8 +341,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
         __syncthreads();
         for (int ch = 0; ch < nchunk; ++ch) {
             const int cur = ch & 1;
-            const bool has_next = ch + 1 < nchunk;
-            if (has_next) prep_chunk(pbeg + (long)(ch + 1) * BP);
+            prep_chunk();
             const float* pa = sA + cur * BP * LDA + arow * LDA + wave_m * 32 * WM + acol;
             const float* pb = sB + cur * BP * LDB + arow * LDB + wave_n * 32 * WN + acol;
             float av[2][WM], bv[2][WN];
@@ -331,18 +358,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
 #pragma unroll
                     for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
                 }
-                if (has_next) {
-                    if (kk < HS) {
+                if (kk < HS) {
 #pragma unroll
-                        for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
 #pragma unroll
-                        for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
-                    } else {
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
+                } else {
 #pragma unroll
-                        for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
 #pragma unroll
-                        for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
-                    }
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -495,6 +520,9 @@ long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out) {
 }
 
 int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
+    if ((double)a.Nb * a.C * a.Hi * a.Wi * 4.0 >= 2147483648.0 || (double)a.M * a.K * 4.0 >= 2147483648.0) {
+        fd_set_error("conv: tensor exceeds the 2 GiB addressing range of the fast path"); return -1;
+    }
     const FastChoice ch = choose_config(a);
     const int splits = ch.splits;
     if (splits > 1 && !a.slabs) { fd_set_error("conv: split-K workspace missing"); return -1; }
@@ -541,6 +569,9 @@ int fast_wgrad_splits(int M, int C, int T, long Np) {
 int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st) {
     FastWgradArgs g = a;
     const long Np = (long)a.Nb * a.NY * a.NX;
+    if ((double)a.Nb * a.C * a.Hi * a.Wi * 4.0 >= 2147483648.0 || (double)a.Nb * (double)a.dy_ns * 4.0 >= 2147483648.0) {
+        fd_set_error("conv wgrad: tensor exceeds the 2 GiB addressing range of the fast path"); return -1;
+    }
     long pps = (Np + splits - 1) / splits;
     pps = (pps + 31) / 32 * 32;
     g.pix_per_split = pps;
