@@ -205,7 +205,10 @@ struct WgradArgs {
     long pix_per_split;
 };
 
-template <int TA, int TB, int WAVES_M, int WAVES_N, int WM, int WN>
+// Loader design (same recipe as conv_fast.hip): raw buffer loads with 32-bit byte offsets, out-of-range = 0.0f; every
+// per-row quantity (dY row offset, the (channel, tap) decode of a G row) is fixed per thread and precomputed; the pixel
+// decode advances incrementally; loads of chunk ch+1 / their LDS stores are interleaved with the MFMAs of chunk ch.
+template <int TA, int TB, int WAVES_M, int WAVES_N, int WM, int WN, bool REFL, bool NORM>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad(WgradArgs g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
@@ -220,62 +223,81 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad(WgradArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int m0 = blockIdx.y * BM, j0 = blockIdx.x * BN;
-    const long plane = (long)g.NY * g.NX, Np = (long)g.Nb * plane;
-    const long chw = (long)g.Hi * g.Wi;
+    const int plane = g.NY * g.NX;
+    const long Np = (long)g.Nb * plane;
+    const unsigned chw = (unsigned)(g.Hi * g.Wi);
     const long pbeg = (long)blockIdx.z * g.pix_per_split;
     long pend = pbeg + g.pix_per_split;
     if (pend > Np) pend = Np;
 
     const int pl = tid % BP, rw = tid / BP;      // pixel within chunk, first row handled
-    // per-thread tap decode of the NB_LOAD j rows it loads (fixed for the whole kernel)
-    int jc[NB_LOAD], jro[NB_LOAD], jco[NB_LOAD];
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY), rsX = fd_make_rsrc(g.X);
+    const int nrow = g.M - m0 < BM ? g.M - m0 : BM;
+    // dY rows past M are clamped to the last valid row: their products land in accumulator rows that are never stored
+    unsigned rowa[NA_LOAD];
+#pragma unroll
+    for (int i = 0; i < NA_LOAD; ++i) {
+        const int r = rw + RPW * i < nrow ? rw + RPW * i : nrow - 1;
+        rowa[i] = 4u * (unsigned)(m0 + r) * (unsigned)g.dy_cs;
+    }
+    // G rows j = (channel, tap): byte offset of the (channel, tap) relative to the pixel's gather origin, and the tap
+    // displacement for the bounds / reflect logic.  Rows >= J are clamped to row J-1 (their output columns are never stored).
+    unsigned joff[NB_LOAD];
+    int jro[NB_LOAD], jco[NB_LOAD];
 #pragma unroll
     for (int i = 0; i < NB_LOAD; ++i) {
-        const int j = j0 + rw + RPW * i;
+        const int j = j0 + rw + RPW * i < g.J ? j0 + rw + RPW * i : g.J - 1;
         const int c = j / (TA * TB), t = j - c * (TA * TB);
         const int ta = t / TB, tb = t - ta * TB;
-        jc[i] = j < g.J ? c : -1;
         jro[i] = ta * g.da; jco[i] = tb * g.db;
+        if (REFL) joff[i] = 4u * (unsigned)c * chw;
+        else joff[i] = 4u * ((unsigned)c * chw + (unsigned)(jro[i] * g.Wi + jco[i]));
     }
 
     float ra[NA_LOAD], rb[NB_LOAD];
-    bool oka[NA_LOAD], okb[NB_LOAD];
-    auto load_chunk = [&](long pc) __attribute__((always_inline)) {
-        const long p = pc + pl;
-        const bool pv = p < pend;
-        const long pp = pv ? p : 0;
-        const int n = (int)(pp / plane);
-        const int rem = (int)(pp - (long)n * plane);
-        const int y = rem / g.NX, x = rem - y * g.NX;
-        const float* dy = g.dY + (long)n * g.dy_ns + rem;
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) {
-            const int m = m0 + rw + RPW * i;
-            oka[i] = pv && m < g.M;
-            ra[i] = dy[oka[i] ? (long)m * g.dy_cs : 0];
-        }
-        const int ry0 = y * g.sy + g.oy, cx0 = x * g.sx + g.ox;
-        const float* xb = g.X + (long)n * g.C * chw;
-        const bool refl = g.pad_mode == 1;
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) {
-            int r = ry0 + jro[i], cc = cx0 + jco[i];
-            const bool inside = r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
-            const int rr = reflect_idx(r, g.Hi), cr = reflect_idx(cc, g.Wi);
-            r = refl ? rr : r; cc = refl ? cr : cc;
-            okb[i] = pv && jc[i] >= 0 && (refl || inside);
-            rb[i] = xb[okb[i] ? jc[i] * chw + (long)r * g.Wi + cc : 0];     // branch-free (see k_gather_gemm)
-        }
+    unsigned offa = FD_OOB, xbase = FD_OOB, okmask = 0u;
+    int ry0 = 0, cx0 = 0;
+    int pn, prem;
+    { const long p = pbeg + pl; pn = (int)(p / plane); prem = (int)(p - (long)pn * plane); }
+    long pcur = pbeg + pl;
+    const float inv_nx = 1.0f / (float)g.NX;
+    auto prep_chunk = [&]() __attribute__((always_inline)) {      // pixels >= pend: everything out of range (zeros)
+        const bool pv = pcur < pend;
+        int y = (int)(((float)prem + 0.5f) * inv_nx);             // estimate within +-1 for planes < 2^23; fixed up below
+        int x = prem - y * g.NX;
+        if (x < 0) { --y; x += g.NX; }
+        if (x >= g.NX) { ++y; x -= g.NX; }
+        offa = pv ? 4u * ((unsigned)pn * (unsigned)g.dy_ns + (unsigned)prem) : FD_OOB;
+        ry0 = y * g.sy + g.oy; cx0 = x * g.sx + g.ox;
+        // zero padding: origin of the gather window (may lie outside the image: the sum with joff is used only in bounds)
+        if (REFL) xbase = pv ? 4u * (unsigned)pn * (unsigned)g.C * chw : FD_OOB;
+        else xbase = 4u * ((unsigned)pn * (unsigned)g.C * chw + (unsigned)(ry0 * g.Wi + cx0));
+        if (!REFL && !pv) ry0 = -(1 << 20);                       // fails every bounds test below
+        pcur += BP; prem += BP;
+        while (prem >= plane) { prem -= plane; ++pn; }
+        okmask = 0u;
     };
-    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) sA[buf][pl * LDA + rw + RPW * i] = oka[i] ? ra[i] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) {
-            float v = rb[i];
-            if (g.in_norm) v = (v - 0.45f) / 0.225f;
-            sB[buf][pl * LDB + rw + RPW * i] = okb[i] ? v : 0.f;
+    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = fd_ldg32(rsY, offa + rowa[i]); };
+    auto load_b = [&](int i) __attribute__((always_inline)) {
+        const int r = ry0 + jro[i], cc = cx0 + jco[i];
+        unsigned off;
+        bool ok;
+        if (REFL) {
+            const int rr = reflect_idx(r, g.Hi), cr = reflect_idx(cc, g.Wi);
+            off = xbase + joff[i] + 4u * (unsigned)(rr * g.Wi + cr);          // xbase carries FD_OOB for pixels past the end
+            ok = true;
+        } else {
+            ok = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
+            off = ok ? xbase + joff[i] : FD_OOB;
         }
+        if (NORM) okmask |= ok ? (1u << i) : 0u;
+        rb[i] = fd_ldg32(rsX, off);
+    };
+    auto store_a = [&](int buf, int i) __attribute__((always_inline)) { sA[buf][pl * LDA + rw + RPW * i] = ra[i]; };
+    auto store_b = [&](int buf, int i) __attribute__((always_inline)) {
+        float v = rb[i];
+        if (NORM) v = ((okmask >> i) & 1u) ? (v - 0.45f) / 0.225f : 0.f;      // resnet_encoder.py:94, padding stays 0
+        sB[buf][pl * LDB + rw + RPW * i] = v;
     };
 
     f32x16 acc[WM][WN];
@@ -286,31 +308,58 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad(WgradArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunk = (int)((pend - pbeg + BP - 1) / BP);
+    const int nchunk = pend > pbeg ? (int)((pend - pbeg + BP - 1) / BP) : 0;
+    constexpr int NK = BP / 2, HS = NK / 2;
     const int arow = lane >> 5, acol = lane & 31;
     if (nchunk > 0) {
-        load_chunk(pbeg);
-        store_chunk(0);
+        prep_chunk();
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) load_b(i);
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) store_a(0, i);
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) store_b(0, i);
         __syncthreads();
         for (int ch = 0; ch < nchunk; ++ch) {
             const int cur = ch & 1;
-            if (ch + 1 < nchunk) load_chunk(pbeg + (long)(ch + 1) * BP);
+            prep_chunk();
             const float* pa = &sA[cur][arow * LDA + wave_m * 32 * WM + acol];
             const float* pb = &sB[cur][arow * LDB + wave_n * 32 * WN + acol];
+            float av[2][WM], bv[2][WN];
 #pragma unroll
-            for (int kk = 0; kk < BP / 2; ++kk) {
-                float av[WM], bv[WN];
+            for (int i = 0; i < WM; ++i) av[0][i] = pa[i * 32];
 #pragma unroll
-                for (int i = 0; i < WM; ++i) av[i] = pa[kk * 2 * LDA + i * 32];
+            for (int j = 0; j < WN; ++j) bv[0][j] = pb[j * 32];
 #pragma unroll
-                for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 2 * LDB + j * 32];
+            for (int kk = 0; kk < NK; ++kk) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk + 1 < NK) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) av[nb][i] = pa[(kk + 1) * 2 * LDA + i * 32];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
+                }
+                if (kk < HS) {
+#pragma unroll
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
+#pragma unroll
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
+#pragma unroll
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (ch + 1 < nchunk) store_chunk(cur ^ 1);
             __syncthreads();
         }
     }
@@ -448,12 +497,26 @@ int dispatch_gemm(int TA, int TB, const GemmArgs& g, hipStream_t st) {
 
 template <int TA, int TB>
 int launch_wgrad(const WgradArgs& g, int splits, hipStream_t st) {
-    if (g.M <= 32 || g.J <= 64) {
-        dim3 grid(fd_cdiv(g.J, 64), fd_cdiv(g.M, 64), splits);
-        hipLaunchKernelGGL((k_wgrad<TA, TB, 2, 2, 1, 1>), grid, dim3(256), 0, st, g);
+    constexpr bool CAN_REFL = (TA == 3 && TB == 3), CAN_NORM = (TA == 7 && TB == 7);
+    if (g.pad_mode == 1 && !CAN_REFL) { fd_set_error("conv wgrad: reflect padding is only built for 3x3"); return -1; }
+    if (g.in_norm && !CAN_NORM) { fd_set_error("conv wgrad: in_norm is only built for the 7x7 stem"); return -1; }
+    auto go = [&](auto kern, int BM, int BN) {
+        dim3 grid(fd_cdiv(g.J, BN), fd_cdiv(g.M, BM), splits);
+        hipLaunchKernelGGL(kern, grid, dim3(256), 0, st, g);
+    };
+    const bool refl = CAN_REFL && g.pad_mode == 1, norm = CAN_NORM && g.in_norm;
+    if (g.J <= 64) {
+        if (refl) go(k_wgrad<TA, TB, 2, 2, 1, 1, CAN_REFL, false>, 64, 64);
+        else if (norm) go(k_wgrad<TA, TB, 2, 2, 1, 1, false, CAN_NORM>, 64, 64);
+        else go(k_wgrad<TA, TB, 2, 2, 1, 1, false, false>, 64, 64);
+    } else if (g.M <= 32) {
+        if (refl) go(k_wgrad<TA, TB, 1, 4, 1, 1, CAN_REFL, false>, 32, 128);
+        else if (norm) go(k_wgrad<TA, TB, 1, 4, 1, 1, false, CAN_NORM>, 32, 128);
+        else go(k_wgrad<TA, TB, 1, 4, 1, 1, false, false>, 32, 128);
     } else {
-        dim3 grid(fd_cdiv(g.J, 128), fd_cdiv(g.M, 64), splits);
-        hipLaunchKernelGGL((k_wgrad<TA, TB, 2, 2, 1, 2>), grid, dim3(256), 0, st, g);
+        if (refl) go(k_wgrad<TA, TB, 2, 2, 1, 2, CAN_REFL, false>, 64, 128);
+        else if (norm) go(k_wgrad<TA, TB, 2, 2, 1, 2, false, CAN_NORM>, 64, 128);
+        else go(k_wgrad<TA, TB, 2, 2, 1, 2, false, false>, 64, 128);
     }
     return 0;
 }
@@ -685,7 +748,7 @@ namespace {
 int wgrad_splits(const fd_conv_desc* d, const ConvShape& s) {
     const long Np = (long)d->N * s.Ho * s.Wo;
     const long J = (long)d->Cin * d->KH * d->KW;
-    const long tiles = (long)fd_cdiv(J, (d->Cout <= 32 || J <= 64) ? 64 : 128) * fd_cdiv(d->Cout, 64);
+    const long tiles = J <= 64 ? (long)fd_cdiv(d->Cout, 64) : (long)fd_cdiv(J, 128) * fd_cdiv(d->Cout, d->Cout <= 32 ? 32 : 64);
     long want = (768 + tiles - 1) / tiles;            // ~3 workgroups per CU
     long maxs = (Np + 511) / 512;                     // at least 512 pixels per split
     long sp = want < maxs ? want : maxs;
@@ -714,8 +777,8 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
     FD_REQUIRE(x && gy && gw && ws, "fd_conv2d_bwd_weight: NULL tensor / workspace");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_weight: empty output");
-    FD_REQUIRE((long)d->N * d->Cin * d->H * d->W < (1L << 31) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 31),
-               "fd_conv2d_bwd_weight: tensor too large for 32-bit offsets");
+    FD_REQUIRE((long)d->N * d->Cin * d->H * d->W < (1L << 29) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 29),
+               "fd_conv2d_bwd_weight: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
     const long Np = (long)d->N * s.Ho * s.Wo;
     if (fast_wgrad_ok(d)) {

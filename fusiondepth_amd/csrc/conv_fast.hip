@@ -26,20 +26,6 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 4) return tanhf(v);
     return v;
 }
-// Raw buffer resources: 32-bit byte offsets against a wave-uniform base (one VALU add per load instead of a 64-bit
-// address chain) and hardware range checking - an offset >= 2^31 reads as 0.0f without touching memory, which is how
-// padding taps, pixels past the end and the "no next chunk" case are expressed (no selects, no branches in the loop).
-typedef unsigned u32x4 __attribute__((__vector_size__(16)));
-constexpr unsigned OOB = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)OOB, 0x00020000);
-}
-__device__ __forceinline__ float ldg32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
-}
-__device__ __forceinline__ float4 ldg128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
-}
 __device__ __forceinline__ int refl_idx(int i, int n) {
     i = i < 0 ? -i : i;
     return i >= n ? 2 * n - 2 - i : i;
@@ -95,11 +81,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     // ---- weight loader: float4 column a4 of row ar + A_ROWS_PER_PASS*i
     const int a4 = tid % A_V4_PER_ROW, ar = tid / A_V4_PER_ROW;
 
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A), rsX = make_rsrc(g.X);
+    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(g.A), rsX = fd_make_rsrc(g.X);
     float4 ra[NA_LOAD];
     float rb[NB_LOAD];
     // state of the chunk being fetched (set by prep_chunk, consumed by the load/store slices); byte offsets
-    unsigned a_off[NA_LOAD], b_off = OOB;
+    unsigned a_off[NA_LOAD], b_off = FD_OOB;
     const unsigned b_step = 4u * (unsigned)RP * chw;                  // wave-uniform
     // (tap row, tap column, first channel) of the next chunk to prepare: advanced incrementally, all wave-uniform
     int pc_ta, pc_tb, pc_c0;
@@ -111,21 +97,21 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
         for (int i = 0; i < NA_LOAD; ++i) {
             int m = m0 + ar + A_ROWS_PER_PASS * i;
             m = m < g.M ? m : g.M - 1;                                // rows >= M are never stored by the epilogue
-            a_off[i] = live ? 4u * ((unsigned)m * (unsigned)g.K + k0 + 4u * a4) : OOB;
+            a_off[i] = live ? 4u * ((unsigned)m * (unsigned)g.K + k0 + 4u * a4) : FD_OOB;
         }
         int r = ry0 + pc_ta * g.da, cc = cx0 + pc_tb * g.db;
         const bool inb = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
         const int rr = refl_idx(r, g.Hi), rc = refl_idx(cc, g.Wi);
         r = refl ? rr : r; cc = refl ? rc : cc;
         const bool ok = pvalid & live & (refl | inb);
-        b_off = ok ? 4u * (nbase + (unsigned)(pc_c0 + kr) * chw + (unsigned)(r * g.Wi + cc)) : OOB;
+        b_off = ok ? 4u * (nbase + (unsigned)(pc_c0 + kr) * chw + (unsigned)(r * g.Wi + cc)) : FD_OOB;
         pc_c0 += BKC;
         if (pc_c0 >= g.C) { pc_c0 = 0; ++pc_tb; if (pc_tb >= g.TB) { pc_tb = 0; ++pc_ta; } }
     };
     auto load_a = [&](int i) __attribute__((always_inline)) {
-        if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM) ra[i] = ldg128(rsA, a_off[i]);
+        if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM) ra[i] = fd_ldg128(rsA, a_off[i]);
     };
-    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = ldg32(rsX, b_off + (unsigned)i * b_step); };
+    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = fd_ldg32(rsX, b_off + (unsigned)i * b_step); };
     auto store_a = [&](int buf, int i) __attribute__((always_inline)) {
         if (A_PARTIAL && ar + A_ROWS_PER_PASS * i >= BM) return;
         float* q = sA + buf * BKC * LDA + (4 * a4) * LDA + ar + A_ROWS_PER_PASS * i;
@@ -274,7 +260,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
     const int ncol = g.C - c0 < BN ? g.C - c0 : BN;          // valid channel columns of this tile
     const int nrow = g.M - m0 < BM ? g.M - m0 : BM;
 
-    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(g.dY), rsX = make_rsrc(g.X);
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY), rsX = fd_make_rsrc(g.X);
     float ra[NA_LOAD], rb[NB_LOAD];
     // Byte offsets of this thread's dY rows / X channels.  Rows past the tile's valid range are clamped to the last valid
     // one: their products land in accumulator rows / columns the epilogue never stores.
@@ -289,7 +275,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
         const int c = rw + RPW * i < ncol ? rw + RPW * i : ncol - 1;
         rowb[i] = 4u * (unsigned)(c0 + c) * chw;
     }
-    unsigned offa = OOB, offb = OOB;
+    unsigned offa = FD_OOB, offb = FD_OOB;
     // this lane's pixel of the next chunk: (image n, offset rem inside the plane), advanced by BP per chunk
     int pn, prem;
     { const long p = pbeg + pl; pn = (int)(p / plane); prem = (int)(p - (long)pn * plane); }
@@ -302,18 +288,18 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
         int x = prem - y * g.NX;
         if (x < 0) { --y; x += g.NX; }
         if (x >= g.NX) { ++y; x -= g.NX; }
-        offa = pv ? 4u * ((unsigned)pn * (unsigned)g.dy_ns + (unsigned)prem) : OOB;
+        offa = pv ? 4u * ((unsigned)pn * (unsigned)g.dy_ns + (unsigned)prem) : FD_OOB;
         int r = y * g.sy + g.oy + ta * g.da, cc = x * g.sx + g.ox + tb * g.db;
         const bool inb = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
         const int rr = refl_idx(r, g.Hi), rc = refl_idx(cc, g.Wi);
         r = refl ? rr : r; cc = refl ? rc : cc;
         const bool ok = pv & (refl | inb);
-        offb = ok ? 4u * ((unsigned)pn * (unsigned)g.C * chw + (unsigned)(r * g.Wi + cc)) : OOB;
+        offb = ok ? 4u * ((unsigned)pn * (unsigned)g.C * chw + (unsigned)(r * g.Wi + cc)) : FD_OOB;
         pcur += BP; prem += BP;
         while (prem >= plane) { prem -= plane; ++pn; }
     };
-    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = ldg32(rsY, offa + rowa[i]); };
-    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = ldg32(rsX, offb + rowb[i]); };
+    auto load_a = [&](int i) __attribute__((always_inline)) { ra[i] = fd_ldg32(rsY, offa + rowa[i]); };
+    auto load_b = [&](int i) __attribute__((always_inline)) { rb[i] = fd_ldg32(rsX, offb + rowb[i]); };
     auto store_a = [&](int buf, int i) __attribute__((always_inline)) { sA[buf * BP * LDA + pl * LDA + rw + RPW * i] = ra[i]; };
     auto store_b = [&](int buf, int i) __attribute__((always_inline)) { sB[buf * BP * LDB + pl * LDB + rw + RPW * i] = rb[i]; };
 

@@ -80,3 +80,17 @@ __device__ __forceinline__ void fd_bilinear_src(int dst, float scale, int n_in, 
     l1 = s - (float)i0;
     l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
 }
+
+// Raw buffer resources: 32-bit byte offsets against a wave-uniform base (one VALU add per load instead of a 64-bit
+// address chain) and hardware range checking - an offset >= 2^31 reads as 0.0f without touching memory, which is how
+// padding taps, pixels past the end and the "no next chunk" case are expressed (no selects, no branches in the loop).
+constexpr unsigned FD_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fd_make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)FD_OOB, 0x00020000);
+}
+__device__ __forceinline__ float fd_ldg32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float4 fd_ldg128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
