@@ -14,6 +14,7 @@
 #include "fd_common.h"
 #include "conv_fast.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -474,7 +475,12 @@ FastChoice choose_config(const FastGemmArgs& a) {
     const int bm[3] = {128, 64, 32}, bn[3] = {128, 128, 256};
     // measured model (scripts/conv_ksweep.py): a launch takes ceil(blocks/256) "block times"; a block time is
     // chunks * t_chunk + t_fixed (prologue, first-chunk latency, epilogue); split-K adds a slab write + finish pass.
-    const double t_chunk[3] = {2.6, 1.45, 1.55}, t_fixed = 6.0;                 // microseconds
+    static double t_chunk[3] = {2.4, 1.2, 1.3}, t_fixed = 5.0;                 // microseconds
+    static bool tuned = false;
+    if (!tuned) {                                                                // FD_CONV_MODEL="t128,t64,t32,tfixed" (tuning aid)
+        if (const char* e = getenv("FD_CONV_MODEL")) sscanf(e, "%lf,%lf,%lf,%lf", &t_chunk[0], &t_chunk[1], &t_chunk[2], &t_fixed);
+        tuned = true;
+    }
     const double scale = bkc == 32 ? 1.0 : 0.55;
     FastChoice best = {a.M > 64 ? 0 : (a.M > 32 ? 1 : 2), 1};
     double best_t = 1e30;
