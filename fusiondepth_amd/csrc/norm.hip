@@ -6,43 +6,70 @@
 // slice) partials are combined in slice order by every consumer.
 #include "../../include/fdhip.h"
 #include "fd_common.h"
+#include <stdint.h>
 
 namespace {
 
 constexpr int NT = 256;
 
-inline int bn_splits(int N, int C, long HW) {
-    const long per_channel = (long)N * HW;
-    long s = 1024 / C;
+// number of plane slices per (group, channel): enough workgroups to fill the chip, >= 1024 floats of a plane per slice
+inline int bn_splits(int N, int C, long HW, int groups) {
+    long s = 2048 / ((long)C * groups);
     if (s < 1) s = 1;
-    const long max_s = (per_channel + 2047) / 2048;
+    const long max_s = (HW + 1023) / 1024;
     if (s > max_s) s = max_s;
     if (s > 64) s = 64;
     return (int)(s < 1 ? 1 : s);
 }
+inline bool bn_vec_ok(long HW, const void* a, const void* b, const void* c, const void* d, const void* e) {
+    auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+    return (HW & 3) == 0 && al(a) && al(b) && al(c) && al(d) && al(e);
+}
 
-// iterate the elements [lo,hi) of channel c's flattened (n, hw) index space
-template <typename F>
-__device__ __forceinline__ void for_channel_range(long lo, long hi, long HW, int C, int c, long n0, F&& f) {
-    for (long i = lo + threadIdx.x; i < hi; i += NT) {
-        const long n = i / HW, r = i - n * HW;
-        f(((n0 + n) * C + c) * HW + r);
+// A statistics / reduction workgroup covers slice s of the plane of channel c for every sample of group g: element
+// (n, r) with r in [lo, hi).  VEC: planes are multiples of 4 floats and 16-byte aligned, so each lane moves float4.
+template <bool VEC, typename F>
+__device__ __forceinline__ void for_channel_slice(int N, long HW, int C, int c, long n0, int s, int splits, F&& f) {
+    if (VEC) {
+        const long q = HW >> 2, per = (q + splits - 1) / splits;
+        const long lo = (long)s * per, hi = lo + per < q ? lo + per : q;
+        for (int n = 0; n < N; ++n) {
+            const long base = ((n0 + n) * C + c) * HW;
+            for (long i = lo + threadIdx.x; i < hi; i += NT) f(base + 4 * i);
+        }
+    } else {
+        const long per = (HW + splits - 1) / splits;
+        const long lo = (long)s * per, hi = lo + per < HW ? lo + per : HW;
+        for (int n = 0; n < N; ++n) {
+            const long base = ((n0 + n) * C + c) * HW;
+            for (long i = lo + threadIdx.x; i < hi; i += NT) f(base + i);
+        }
     }
 }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // N = samples PER GROUP; group g = blockIdx.z covers samples [g*N, (g+1)*N): statistics are per (group, channel), which
 // is exactly what G separate forward passes over the sub-batches would compute (the pose encoders see frames -1 and +1
 // as two passes in the reference; here they are one launch with G = 2).
+template <bool VEC>
 __global__ void __launch_bounds__(NT) k_bn_stats(const float* __restrict__ x, float* __restrict__ part, int N, int C,
                                                  long HW, int splits) {
     __shared__ float red[4 * 2];
     const int c = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
-    const long M = (long)N * HW, per = (M + splits - 1) / splits;
-    const long lo = (long)s * per, hi = lo + per < M ? lo + per : M;
     const long n0 = (long)g * N;
     const float shift = x[(n0 * C + c) * HW];
     float acc[2] = {0.f, 0.f};
-    for_channel_range(lo, hi, HW, C, c, n0, [&](long o) { const float d = x[o] - shift; acc[0] += d; acc[1] += d * d; });
+    for_channel_slice<VEC>(N, HW, C, c, n0, s, splits, [&](long o) {
+        if (VEC) {
+            const float4 v = ld4(x + o);
+            const float d0 = v.x - shift, d1 = v.y - shift, d2 = v.z - shift, d3 = v.w - shift;
+            acc[0] += (d0 + d1) + (d2 + d3);
+            acc[1] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        } else {
+            const float d = x[o] - shift; acc[0] += d; acc[1] += d * d;
+        }
+    });
     const float r = fd_block_sum_n<2, 4>(acc, red);
     if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
 }
@@ -62,6 +89,7 @@ __device__ __forceinline__ BnStat bn_finalize(const float* __restrict__ part, co
 }
 
 // y = relu?( (x-mean)*invstd*w + b + residual? ); grid (plane chunks, N*C)
+template <bool VEC>
 __global__ void __launch_bounds__(NT) k_bn_apply_train(const float* __restrict__ x, const float* __restrict__ weight,
                                                        const float* __restrict__ bias, const float* __restrict__ residual,
                                                        float* __restrict__ y, float* __restrict__ running_mean,
@@ -93,6 +121,16 @@ __global__ void __launch_bounds__(NT) k_bn_apply_train(const float* __restrict__
     const float a = invstd * (weight ? weight[c] : 1.f);
     const float b = (bias ? bias[c] : 0.f) - st.mean * a;
     const long base = (long)nc * HW;
+    if (VEC) {
+        for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (HW >> 2); i += (long)gridDim.x * NT) {
+            float4 v = ld4(x + base + 4 * i);
+            v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+            if (residual) { const float4 r = ld4(residual + base + 4 * i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+            if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+            st4(y + base + 4 * i, v);
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
         float v = x[base + i] * a + b;
         if (residual) v += residual[base + i];
@@ -120,26 +158,38 @@ __global__ void __launch_bounds__(NT) k_bn_apply_eval(const float* __restrict__ 
 }
 
 // partial sums of dy' and dy'*xhat   (dy' = dy masked by the ReLU)
+template <bool VEC>
 __global__ void __launch_bounds__(NT) k_bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ y,
                                                       const float* __restrict__ gy, const float* __restrict__ save_mean,
                                                       const float* __restrict__ save_invstd, float* __restrict__ part,
                                                       int N, int C, long HW, int splits, int relu) {
     __shared__ float red[4 * 2];
     const int c = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
-    const long M = (long)N * HW, per = (M + splits - 1) / splits;
-    const long lo = (long)s * per, hi = lo + per < M ? lo + per : M;
     const float mean = save_mean[g * C + c], invstd = save_invstd[g * C + c];
     float acc[2] = {0.f, 0.f};
-    for_channel_range(lo, hi, HW, C, c, (long)g * N, [&](long o) {
-        float g = gy[o];
-        if (relu && !(y[o] > 0.f)) g = 0.f;
-        acc[0] += g;
-        acc[1] += g * ((x[o] - mean) * invstd);
+    for_channel_slice<VEC>(N, HW, C, c, (long)g * N, s, splits, [&](long o) {
+        if (VEC) {
+            float4 d = ld4(gy + o);
+            if (relu) {
+                const float4 yy = ld4(y + o);
+                d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f; d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+            }
+            const float4 xx = ld4(x + o);
+            acc[0] += (d.x + d.y) + (d.z + d.w);
+            acc[1] += (d.x * ((xx.x - mean) * invstd) + d.y * ((xx.y - mean) * invstd)) +
+                      (d.z * ((xx.z - mean) * invstd) + d.w * ((xx.w - mean) * invstd));
+        } else {
+            float d = gy[o];
+            if (relu && !(y[o] > 0.f)) d = 0.f;
+            acc[0] += d;
+            acc[1] += d * ((x[o] - mean) * invstd);
+        }
     });
     const float r = fd_block_sum_n<2, 4>(acc, red);
     if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ gy, const float* __restrict__ weight,
                                                      const float* __restrict__ save_mean,
@@ -167,6 +217,25 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x
     const float k = (weight ? weight[c] : 1.f) * invstd;
     const float m1 = s1 / M, m2 = s2 / M;
     const long base = (long)nc * HW;
+    if (VEC) {
+        for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (HW >> 2); i += (long)gridDim.x * NT) {
+            const long o = base + 4 * i;
+            float4 d = ld4(gy + o);
+            if (relu) {
+                const float4 yy = ld4(y + o);
+                d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f; d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
+            }
+            if (g_res) st4(g_res + o, d);
+            const float4 xx = ld4(x + o);
+            float4 r;
+            r.x = k * (d.x - m1 - ((xx.x - mean) * invstd) * m2);
+            r.y = k * (d.y - m1 - ((xx.y - mean) * invstd) * m2);
+            r.z = k * (d.z - m1 - ((xx.z - mean) * invstd) * m2);
+            r.w = k * (d.w - m1 - ((xx.w - mean) * invstd) * m2);
+            st4(gx + o, r);
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
         float g = gy[base + i];
         if (relu && !(y[base + i] > 0.f)) g = 0.f;
@@ -185,7 +254,7 @@ inline int plane_blocks(long HW) {
 
 extern "C" long fd_bn_ws_floats(int N, int C, int H, int W, int groups) {
     if (groups < 1 || N % groups) return 0;
-    return (long)groups * C * bn_splits(N / groups, C, (long)H * W) * 2;
+    return (long)groups * C * bn_splits(N / groups, C, (long)H * W, groups) * 2;
 }
 
 extern "C" int fd_bn_train_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
@@ -197,10 +266,13 @@ extern "C" int fd_bn_train_fwd(const float* x, const float* weight, const float*
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
     const int Ng = N / groups;
-    const int sp = bn_splits(Ng, C, HW);
-    hipLaunchKernelGGL(k_bn_stats, dim3(C, sp, groups), dim3(NT), 0, st, x, ws, Ng, C, HW, sp);
+    const int sp = bn_splits(Ng, C, HW, groups);
+    const bool vec = bn_vec_ok(HW, x, y, residual, nullptr, nullptr);
+    auto stats = vec ? k_bn_stats<true> : k_bn_stats<false>;
+    auto apply = vec ? k_bn_apply_train<true> : k_bn_apply_train<false>;
+    hipLaunchKernelGGL(stats, dim3(C, sp, groups), dim3(NT), 0, st, x, ws, Ng, C, HW, sp);
     FD_LAUNCH_CHECK("fd_bn_train_fwd(stats)");
-    hipLaunchKernelGGL(k_bn_apply_train, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, weight, bias, residual, y,
+    hipLaunchKernelGGL(apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, weight, bias, residual, y,
                        running_mean, running_var, save_mean, save_invstd, ws, Ng, C, HW, sp, eps, momentum, relu, groups);
     FD_LAUNCH_CHECK("fd_bn_train_fwd(apply)");
     return 0;
@@ -228,11 +300,14 @@ extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, 
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
     const int Ng = N / groups;
-    const int sp = bn_splits(Ng, C, HW);
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(C, sp, groups), dim3(NT), 0, st, x, y, gy, save_mean, save_invstd, ws, Ng, C, HW,
+    const int sp = bn_splits(Ng, C, HW, groups);
+    const bool vec = bn_vec_ok(HW, x, y, gy, gx, g_residual);
+    auto reduce = vec ? k_bn_bwd_reduce<true> : k_bn_bwd_reduce<false>;
+    auto apply = vec ? k_bn_bwd_apply<true> : k_bn_bwd_apply<false>;
+    hipLaunchKernelGGL(reduce, dim3(C, sp, groups), dim3(NT), 0, st, x, y, gy, save_mean, save_invstd, ws, Ng, C, HW,
                        sp, relu);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(reduce)");
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, y, gy, weight, save_mean,
+    hipLaunchKernelGGL(apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, y, gy, weight, save_mean,
                        save_invstd, gx, gweight, gbias, g_residual, ws, Ng, C, HW, sp, relu, accumulate, groups);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(apply)");
     return 0;
