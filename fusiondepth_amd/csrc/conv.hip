@@ -405,11 +405,11 @@ __global__ void k_weight_relayout(const float* __restrict__ W, float* __restrict
 
 // Adjoint of ReflectionPad2d(1): fold the gradient on the padded grid [H+2][W+2] back onto [H][W].
 __global__ void k_reflect_fold(const float* __restrict__ gp, float* __restrict__ gx, long planes, int H, int W) {
-    const long n = planes * H * W;
     const int Wp = W + 2;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W), y = (int)((i / W) % H);
-        const long pl = i / ((long)W * H);
+    for (long pl = blockIdx.y; pl < planes; pl += gridDim.y)
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < H * W; r += gridDim.x * blockDim.x) {
+        const int y = r / W, x = r - y * W;
+        const long i = pl * H * W + r;
         const float* g = gp + pl * (long)(H + 2) * Wp;
         // padded rows that map to y: y+1 always; 0 if y == 1; H+1 if y == H-2
         int ys[3], nys = 0, xs[3], nxs = 0;
@@ -417,7 +417,7 @@ __global__ void k_reflect_fold(const float* __restrict__ gp, float* __restrict__
         xs[nxs++] = x + 1; if (x == 1) xs[nxs++] = 0; if (x == W - 2) xs[nxs++] = W + 1;
         float s = 0.f;
         for (int a = 0; a < nys; ++a)
-            for (int b = 0; b < nxs; ++b) s += g[(long)ys[a] * Wp + xs[b]];
+            for (int b = 0; b < nxs; ++b) s += g[ys[a] * Wp + xs[b]];
         gx[i] = s;
     }
 }
@@ -706,8 +706,9 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
             g.out_cs = (long)(d->H + 2) * (d->W + 2); g.out_ns = g.out_cs * d->Cin;
             if (int rc = run(KH, KW, KH - 1, -1, KW - 1, -1, true)) return rc;
             const long n = (long)d->N * d->Cin * d->H * d->W;
-            hipLaunchKernelGGL(k_reflect_fold, dim3(ew_blocks(n)), dim3(256), 0, st, gpad, gx, (long)d->N * d->Cin, d->H,
-                               d->W);
+            const long fold_planes = (long)d->N * d->Cin, fold_bx = ((long)d->H * d->W + 255) / 256;
+            hipLaunchKernelGGL(k_reflect_fold, dim3((unsigned)(fold_bx > 64 ? 64 : fold_bx), (unsigned)(fold_planes > 32768 ? 32768 : fold_planes)),
+                               dim3(256), 0, st, gpad, gx, fold_planes, d->H, d->W);
             FD_LAUNCH_CHECK("fd_conv2d_bwd_data(fold)");
             return 0;
         }

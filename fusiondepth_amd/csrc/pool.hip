@@ -13,14 +13,23 @@ inline int ew_blocks(long n) {
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 #define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (n); i += (long)gridDim.x * NT)
+// Plane-indexed launches: blockIdx.y strides over the (n, c) planes, blockIdx.x over the elements of one plane, so the
+// per-element index math is one 32-bit division instead of three 64-bit ones.
+#define PLANE_LOOP(pl, r, planes, psize)                                  \
+    for (long pl = blockIdx.y; pl < (planes); pl += gridDim.y)            \
+        for (int r = blockIdx.x * NT + threadIdx.x; r < (psize); r += gridDim.x * NT)
+inline dim3 plane_grid(long planes, long psize) {
+    long bx = (psize + NT - 1) / NT;
+    if (bx > 64) bx = 64;
+    return dim3((unsigned)(bx < 1 ? 1 : bx), (unsigned)(planes < 1 ? 1 : (planes > 32768 ? 32768 : planes)));
+}
 
 // ---- max-pool 3x3 stride 2 pad 1; first maximum in (kh,kw) raster order wins, as ATen does (val > max) ----
 __global__ void __launch_bounds__(NT) k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y,
                                                     uint8_t* __restrict__ idx, long planes, int H, int W, int Ho, int Wo) {
-    const long n = planes * Ho * Wo;
-    GRID_STRIDE(i, n) {
-        const int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
-        const long pl = i / ((long)Wo * Ho);
+    PLANE_LOOP(pl, r, planes, Ho * Wo) {
+        const int ho = r / Wo, wo = r - ho * Wo;
+        const long i = pl * Ho * Wo + r;
         const float* p = x + pl * H * W;
         float best = -INFINITY;
         int bi = 0;
@@ -33,7 +42,7 @@ __global__ void __launch_bounds__(NT) k_maxpool_fwd(const float* __restrict__ x,
             for (int kw = 0; kw < 3; ++kw) {
                 const int w = wo * 2 - 1 + kw;
                 if (w < 0 || w >= W) continue;
-                const float v = p[(long)h * W + w];
+                const float v = p[h * W + w];
                 if (!any || v > best || v != v) { best = v; bi = kh * 3 + kw; any = true; }
             }
         }
@@ -44,10 +53,9 @@ __global__ void __launch_bounds__(NT) k_maxpool_fwd(const float* __restrict__ x,
 // gather form of the scatter-add: each input pixel checks the <=4 windows that contain it
 __global__ void __launch_bounds__(NT) k_maxpool_bwd(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
                                                     float* __restrict__ gx, long planes, int H, int W, int Ho, int Wo) {
-    const long n = planes * H * W;
-    GRID_STRIDE(i, n) {
-        const int w = (int)(i % W), h = (int)((i / W) % H);
-        const long pl = i / ((long)W * H);
+    PLANE_LOOP(pl, r, planes, H * W) {
+        const int h = r / W, w = r - h * W;
+        const long i = pl * H * W + r;
         const float* g = gy + pl * Ho * Wo;
         const uint8_t* ix = idx + pl * Ho * Wo;
         float s = 0.f;
@@ -59,7 +67,7 @@ __global__ void __launch_bounds__(NT) k_maxpool_bwd(const float* __restrict__ gy
                 if (wo < 0 || wo >= Wo) continue;
                 const int kw = w - (2 * wo - 1);
                 if (kw < 0 || kw > 2) continue;
-                if (ix[(long)ho * Wo + wo] == kh * 3 + kw) s += g[(long)ho * Wo + wo];
+                if (ix[ho * Wo + wo] == kh * 3 + kw) s += g[ho * Wo + wo];
             }
         }
         gx[i] = s;
@@ -71,11 +79,11 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd(const float* __restrict__ a, c
                                                   const float* __restrict__ s2, const float* __restrict__ s3,
                                                   float* __restrict__ out, int N, int Ca, int Cs, int C3, int h, int w) {
     const int H = 2 * h, W = 2 * w, Ct = Ca + Cs + C3;
-    const long n = (long)N * Ct * H * W;
-    GRID_STRIDE(i, n) {
-        const int x = (int)(i % W), y = (int)((i / W) % H);
-        const int c = (int)((i / ((long)W * H)) % Ct);
-        const long b = i / ((long)W * H * Ct);
+    PLANE_LOOP(pl, r, (long)N * Ct, H * W) {
+        const int y = r / W, x = r - y * W;
+        const long b = pl / Ct;
+        const int c = (int)(pl - b * Ct);
+        const long i = pl * H * W + r;
         float v;
         if (c < Ca) v = a[((b * Ca + c) * h + (y >> 1)) * w + (x >> 1)];
         else if (c < Ca + Cs) {
@@ -89,44 +97,38 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd(const float* __restrict__ a, c
 __global__ void __launch_bounds__(NT) k_upcat_bwd_a(const float* __restrict__ gout, float* __restrict__ ga, int N, int Ca,
                                                     int Ct, int h, int w) {
     const int H = 2 * h, W = 2 * w;
-    const long n = (long)N * Ca * h * w;
-    GRID_STRIDE(i, n) {
-        const int x = (int)(i % w), y = (int)((i / w) % h);
-        const int c = (int)((i / ((long)w * h)) % Ca);
-        const long b = i / ((long)w * h * Ca);
+    PLANE_LOOP(pl, r, (long)N * Ca, h * w) {
+        const int y = r / w, x = r - y * w;
+        const long b = pl / Ca;
+        const int c = (int)(pl - b * Ca);
+        const long i = pl * h * w + r;
         const float* g = gout + ((b * Ct + c) * H + 2 * y) * W + 2 * x;
         ga[i] = (g[0] + g[1]) + (g[W] + g[W + 1]);
     }
 }
 __global__ void __launch_bounds__(NT) k_slice_channels(const float* __restrict__ src, float* __restrict__ dst, int N,
                                                        int Ct, int c0, int Cn, long plane) {
-    const long n = (long)N * Cn * plane;
-    GRID_STRIDE(i, n) {
-        const long r = i % plane;
-        const int c = (int)((i / plane) % Cn);
-        const long b = i / (plane * Cn);
-        dst[i] = src[(b * Ct + c0 + c) * plane + r];
+    PLANE_LOOP(pl, r, (long)N * Cn, plane) {
+        const long b = pl / Cn;
+        const int c = (int)(pl - b * Cn);
+        dst[pl * plane + r] = src[(b * Ct + c0 + c) * plane + r];
     }
 }
 __global__ void __launch_bounds__(NT) k_up2_fwd(const float* __restrict__ x, float* __restrict__ y, long planes, int h,
                                                 int w) {
     const int H = 2 * h, W = 2 * w;
-    const long n = planes * H * W;
-    GRID_STRIDE(i, n) {
-        const int xx = (int)(i % W), yy = (int)((i / W) % H);
-        const long pl = i / ((long)W * H);
-        y[i] = x[(pl * h + (yy >> 1)) * w + (xx >> 1)];
+    PLANE_LOOP(pl, r, planes, H * W) {
+        const int yy = r / W, xx = r - yy * W;
+        y[pl * H * W + r] = x[(pl * h + (yy >> 1)) * w + (xx >> 1)];
     }
 }
 __global__ void __launch_bounds__(NT) k_up2_bwd(const float* __restrict__ gy, float* __restrict__ gx, long planes, int h,
                                                 int w) {
     const int W = 2 * w;
-    const long n = planes * h * w;
-    GRID_STRIDE(i, n) {
-        const int xx = (int)(i % w), yy = (int)((i / w) % h);
-        const long pl = i / ((long)w * h);
+    PLANE_LOOP(pl, r, planes, h * w) {
+        const int yy = r / w, xx = r - yy * w;
         const float* g = gy + (pl * 2 * h + 2 * yy) * W + 2 * xx;
-        gx[i] = (g[0] + g[1]) + (g[W] + g[W + 1]);
+        gx[pl * h * w + r] = (g[0] + g[1]) + (g[W] + g[W + 1]);
     }
 }
 
@@ -222,7 +224,7 @@ extern "C" int fd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N
     FD_REQUIRE(x && y && idx && N > 0 && C > 0 && H > 0 && W > 0, "fd_maxpool3x3s2_fwd: bad args");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long planes = (long)N * C;
-    hipLaunchKernelGGL(k_maxpool_fwd, dim3(ew_blocks(planes * Ho * Wo)), dim3(NT), 0, (hipStream_t)stream, x, y, idx,
+    hipLaunchKernelGGL(k_maxpool_fwd, plane_grid(planes, (long)Ho * Wo), dim3(NT), 0, (hipStream_t)stream, x, y, idx,
                        planes, H, W, Ho, Wo);
     FD_LAUNCH_CHECK("fd_maxpool3x3s2_fwd");
     return 0;
@@ -232,7 +234,7 @@ extern "C" int fd_maxpool3x3s2_bwd(const float* gy, const uint8_t* idx, float* g
     FD_REQUIRE(gy && idx && gx && N > 0 && C > 0 && H > 0 && W > 0, "fd_maxpool3x3s2_bwd: bad args");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long planes = (long)N * C;
-    hipLaunchKernelGGL(k_maxpool_bwd, dim3(ew_blocks(planes * H * W)), dim3(NT), 0, (hipStream_t)stream, gy, idx, gx,
+    hipLaunchKernelGGL(k_maxpool_bwd, plane_grid(planes, (long)H * W), dim3(NT), 0, (hipStream_t)stream, gy, idx, gx,
                        planes, H, W, Ho, Wo);
     FD_LAUNCH_CHECK("fd_maxpool3x3s2_bwd");
     return 0;
@@ -243,7 +245,7 @@ extern "C" int fd_upcat_fwd(const float* a, const float* s1, const float* s2, co
     FD_REQUIRE(a && out && N > 0 && Ca > 0 && Cs >= 0 && C3 >= 0 && h > 0 && w > 0, "fd_upcat_fwd: bad args");
     FD_REQUIRE((Cs == 0 || s1) && (C3 == 0 || s3) && !(s2 && !s1), "fd_upcat_fwd: missing skip tensor");
     const long n = (long)N * (Ca + Cs + C3) * 4 * h * w;
-    hipLaunchKernelGGL(k_upcat_fwd, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, a, s1, s2, s3, out, N, Ca, Cs,
+    hipLaunchKernelGGL(k_upcat_fwd, plane_grid((long)N * (Ca + Cs + C3), 4L * h * w), dim3(NT), 0, (hipStream_t)stream, a, s1, s2, s3, out, N, Ca, Cs,
                        C3, h, w);
     FD_LAUNCH_CHECK("fd_upcat_fwd");
     return 0;
@@ -255,16 +257,16 @@ extern "C" int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, 
     const int Ct = Ca + Cs + C3;
     const long plane = 4L * h * w;
     if (ga) {
-        hipLaunchKernelGGL(k_upcat_bwd_a, dim3(ew_blocks((long)N * Ca * h * w)), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w);
+        hipLaunchKernelGGL(k_upcat_bwd_a, plane_grid((long)N * Ca, (long)h * w), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w);
         FD_LAUNCH_CHECK("fd_upcat_bwd(a)");
     }
     if (gs && Cs > 0) {
-        hipLaunchKernelGGL(k_slice_channels, dim3(ew_blocks((long)N * Cs * plane)), dim3(NT), 0, st, gout, gs, N, Ct, Ca, Cs,
+        hipLaunchKernelGGL(k_slice_channels, plane_grid((long)N * Cs, plane), dim3(NT), 0, st, gout, gs, N, Ct, Ca, Cs,
                            plane);
         FD_LAUNCH_CHECK("fd_upcat_bwd(s)");
     }
     if (g3 && C3 > 0) {
-        hipLaunchKernelGGL(k_slice_channels, dim3(ew_blocks((long)N * C3 * plane)), dim3(NT), 0, st, gout, g3, N, Ct, Ca + Cs,
+        hipLaunchKernelGGL(k_slice_channels, plane_grid((long)N * C3, plane), dim3(NT), 0, st, gout, g3, N, Ct, Ca + Cs,
                            C3, plane);
         FD_LAUNCH_CHECK("fd_upcat_bwd(3)");
     }
@@ -272,13 +274,13 @@ extern "C" int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, 
 }
 extern "C" int fd_upsample2x_fwd(const float* x, float* y, long planes, int h, int w, void* stream) {
     FD_REQUIRE(x && y && planes > 0 && h > 0 && w > 0, "fd_upsample2x_fwd: bad args");
-    hipLaunchKernelGGL(k_up2_fwd, dim3(ew_blocks(planes * 4 * h * w)), dim3(NT), 0, (hipStream_t)stream, x, y, planes, h, w);
+    hipLaunchKernelGGL(k_up2_fwd, plane_grid(planes, 4L * h * w), dim3(NT), 0, (hipStream_t)stream, x, y, planes, h, w);
     FD_LAUNCH_CHECK("fd_upsample2x_fwd");
     return 0;
 }
 extern "C" int fd_upsample2x_bwd(const float* gy, float* gx, long planes, int h, int w, void* stream) {
     FD_REQUIRE(gy && gx && planes > 0 && h > 0 && w > 0, "fd_upsample2x_bwd: bad args");
-    hipLaunchKernelGGL(k_up2_bwd, dim3(ew_blocks(planes * h * w)), dim3(NT), 0, (hipStream_t)stream, gy, gx, planes, h, w);
+    hipLaunchKernelGGL(k_up2_bwd, plane_grid(planes, (long)h * w), dim3(NT), 0, (hipStream_t)stream, gy, gx, planes, h, w);
     FD_LAUNCH_CHECK("fd_upsample2x_bwd");
     return 0;
 }

@@ -534,6 +534,24 @@ class _BatchNorm(torch.autograd.Function):
 
 
 _BN_GROUPS = [1]
+_BN_COUNTERS = [None]
+
+
+class defer_bn_counters:
+    """Collect the ``num_batches_tracked += groups`` updates of every BatchNorm called inside the block and apply them
+    with ONE multi-tensor launch on exit (80 one-element ATen kernels per optimiser step otherwise)."""
+
+    def __enter__(self):
+        self.prev = _BN_COUNTERS[0]
+        _BN_COUNTERS[0] = []
+        return self
+
+    def __exit__(self, *exc):
+        pending, _BN_COUNTERS[0] = _BN_COUNTERS[0], self.prev
+        if pending and exc[0] is None:
+            torch._foreach_add_([t for t, _ in pending], [int(g) for _, g in pending])
+        return False
+
 
 
 class bn_groups:
@@ -557,7 +575,10 @@ def batch_norm(x, bn, residual=None, relu=False):
     training = bn.training
     groups = _BN_GROUPS[0] if training else 1
     if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(groups)
+        if _BN_COUNTERS[0] is not None:
+            _BN_COUNTERS[0].append((bn.num_batches_tracked, groups))       # one multi-tensor add per step (trainer)
+        else:
+            bn.num_batches_tracked.add_(groups)
     return _BatchNorm.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, training, bn.momentum,
                             bn.eps, relu, groups)
 

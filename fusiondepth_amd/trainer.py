@@ -327,6 +327,10 @@ class Trainer:
         else:
             enc_in = inputs["color_aug", 0, 0]
         self._groups = groups
+        with FD.defer_bn_counters():
+            return self._process_batch(inputs, val, groups, par, enc_in)
+
+    def _process_batch(self, inputs, val, groups, par, enc_in):
         pose_out = None
         if groups > 1 and not par:
             raise NotImplementedError("stacked micro-batches need the separate_resnet pose path; set stack_microbatches=False")
