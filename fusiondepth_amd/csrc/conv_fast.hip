@@ -16,6 +16,9 @@
 #include <stdlib.h>
 #include <stdio.h>
 
+#ifndef FD_LS_DIV
+#define FD_LS_DIV 2
+#endif
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     constexpr int NK = BKC / 2;          // MFMA k-steps per chunk
-    constexpr int HS = NK / 2;           // first half of the k-steps issues the next chunk's loads, second half stores them
+    constexpr int LS = NK / FD_LS_DIV;   // the first LS k-steps issue the next chunk's loads, the last LS store them
     const int arow = lane >> 5, acol = lane & 31;
     if (ch_lo < ch_hi) {
         prep_chunk(true);
@@ -166,16 +169,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
 #pragma unroll
                     for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
                 }
-                if (kk < HS) {
+                if (kk < LS) {
 #pragma unroll
-                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * LS) / NA_LOAD == kk) load_a(i);
 #pragma unroll
-                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
-                } else {
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * LS) / NB_LOAD == kk) load_b(i);
+                } else if (kk >= NK - LS) {
 #pragma unroll
-                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * LS) / NA_LOAD == kk - (NK - LS)) store_a(cur ^ 1, i);
 #pragma unroll
-                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * LS) / NB_LOAD == kk - (NK - LS)) store_b(cur ^ 1, i);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // keep the memory ops ahead of this step's MFMAs
 #pragma unroll
@@ -313,7 +316,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nchunk = pend > pbeg ? (int)((pend - pbeg + BP - 1) / BP) : 0;
-    constexpr int NK = BP / 2, HS = NK / 2;
+    constexpr int NK = BP / 2, LS = NK / FD_LS_DIV;
     const int arow = lane >> 5, acol = lane & 31;
     if (nchunk > 0) {
         prep_chunk();
@@ -345,16 +348,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
 #pragma unroll
                     for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
                 }
-                if (kk < HS) {
+                if (kk < LS) {
 #pragma unroll
-                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk) load_a(i);
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * LS) / NA_LOAD == kk) load_a(i);
 #pragma unroll
-                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk) load_b(i);
-                } else {
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * LS) / NB_LOAD == kk) load_b(i);
+                } else if (kk >= NK - LS) {
 #pragma unroll
-                    for (int i = 0; i < NA_LOAD; ++i) if ((i * HS) / NA_LOAD == kk - HS) store_a(cur ^ 1, i);
+                    for (int i = 0; i < NA_LOAD; ++i) if ((i * LS) / NA_LOAD == kk - (NK - LS)) store_a(cur ^ 1, i);
 #pragma unroll
-                    for (int i = 0; i < NB_LOAD; ++i) if ((i * HS) / NB_LOAD == kk - HS) store_b(cur ^ 1, i);
+                    for (int i = 0; i < NB_LOAD; ++i) if ((i * LS) / NB_LOAD == kk - (NK - LS)) store_b(cur ^ 1, i);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
