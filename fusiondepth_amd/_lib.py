@@ -81,6 +81,7 @@ SIGNATURES = {
     "fd_upsample2x_fwd": ("ppliip", "i"),
     "fd_upsample2x_bwd": ("ppliip", "i"),
     "fd_axpby": ("ppplffp", "i"),
+    "fd_input_normalize": ("pplffp", "i"),
     "fd_spatial_mean_fwd": ("ppllfp", "i"),
     "fd_spatial_mean_bwd": ("ppllfp", "i"),
     "fd_depth_errors": ("pplppp", "i"),

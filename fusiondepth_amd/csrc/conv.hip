@@ -79,56 +79,46 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gather_gemm(GemmArgs
     const long pg = p0 + jn;
     const bool pvalid = pg < Np;
     int ry0 = 0, cx0 = 0;
-    long nbase = 0;
+    unsigned nbase = 0u;
     {
         const long pp = pvalid ? pg : 0;
         const int n = (int)(pp / plane);
         const int rem = (int)(pp - (long)n * plane);
         const int y = rem / g.NX, x = rem - y * g.NX;
         ry0 = y * g.sy + g.oy; cx0 = x * g.sx + g.ox;
-        nbase = (long)n * g.C * chw;
+        nbase = (unsigned)n * (unsigned)g.C * (unsigned)chw;
     }
     // ---- A loader: k column ka, m rows ma + MP*i
     const int ka = tid % BK, ma = tid / BK;
+    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(g.A), rsX = fd_make_rsrc(g.X);
+    const bool refl = g.pad_mode == 1;
 
-    // raw loaded values + validity flags; the select happens when the registers are written to LDS, so that
-    // nothing consumes a load result (and forces an s_waitcnt) before the MFMA loop of the current chunk
+    // Raw buffer loads (32-bit byte offsets, out-of-range = 0.0f): padding taps, k >= K, rows >= M and pixels past the end
+    // need no selects; only the NORM variant keeps a validity mask because its padding must stay 0 AFTER the affine map.
     float ra[NA_LOAD], rb[NB_LOAD];
-    bool oka[NA_LOAD], okb[NB_LOAD];
-    auto load_chunk = [&](int k0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) {
-            const int m = m0 + ma + MP * i, k = k0 + ka;
-            oka[i] = m < g.M && k < g.K;
-            ra[i] = g.A[oka[i] ? (long)m * g.K + k : 0];
-        }
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) {
-            const int k = k0 + kr + RP * i;            // wave-uniform
-            const int c = k / (TA * TB), t = k - c * (TA * TB);
-            const int ta = t / TB, tb = t - ta * TB;
-            int r = ry0 + ta * g.da, cc = cx0 + tb * g.db;
-            const bool inside = r >= 0 && r < g.Hi && cc >= 0 && cc < g.Wi;
-            const int rr = reflect_idx(r, g.Hi), cr = reflect_idx(cc, g.Wi);
-            const bool refl = g.pad_mode == 1;
-            r = refl ? rr : r; cc = refl ? cr : cc;
-            const bool ok = pvalid && k < g.K && (refl || inside);
-            // branch-free: always issue the load (from a safe address) so the loads of a chunk stay in flight
-            // together instead of being serialised by per-branch s_waitcnt
-            const long off = ok ? nbase + c * chw + (long)r * g.Wi + cc : 0;
-            rb[i] = g.X[off];
-            okb[i] = ok;
-        }
+    unsigned okmask = 0u;
+    int k0 = 0;                                        // first k of the chunk being fetched
+    auto load_a = [&](int i) __attribute__((always_inline)) {
+        const int m = m0 + ma + MP * i, k = k0 + ka;
+        ra[i] = fd_ldg32(rsA, (m < g.M) & (k < g.K) ? 4u * ((unsigned)m * (unsigned)g.K + (unsigned)k) : FD_OOB);
     };
-    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) sA[buf][ka * LDA + ma + MP * i] = oka[i] ? ra[i] : 0.f;
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) {
-            float v = rb[i];
-            if (NORM) v = (v - 0.45f) / 0.225f;                    // resnet_encoder.py:94, padding stays 0
-            sB[buf][(kr + RP * i) * LDB + jn] = okb[i] ? v : 0.f;
-        }
+    auto load_b = [&](int i) __attribute__((always_inline)) {
+        const int k = k0 + kr + RP * i;                // wave-uniform
+        const int c = k / (TA * TB), t = k - c * (TA * TB);
+        const int ta = t / TB, tb = t - ta * TB;
+        int r = ry0 + ta * g.da, cc = cx0 + tb * g.db;
+        const bool inside = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
+        const int rr = reflect_idx(r, g.Hi), cr = reflect_idx(cc, g.Wi);
+        r = refl ? rr : r; cc = refl ? cr : cc;
+        const bool ok = pvalid & (k < g.K) & (refl | inside);
+        rb[i] = fd_ldg32(rsX, ok ? 4u * (nbase + (unsigned)c * (unsigned)chw + (unsigned)(r * g.Wi + cc)) : FD_OOB);
+        if (NORM) okmask = (okmask & ~(1u << i)) | (ok ? (1u << i) : 0u);
+    };
+    auto store_a = [&](int buf, int i) __attribute__((always_inline)) { sA[buf][ka * LDA + ma + MP * i] = ra[i]; };
+    auto store_b = [&](int buf, int i) __attribute__((always_inline)) {
+        float v = rb[i];
+        if (NORM) v = ((okmask >> i) & 1u) ? (v - 0.45f) / 0.225f : 0.f;          // resnet_encoder.py:94, padding stays 0
+        sB[buf][(kr + RP * i) * LDB + jn] = v;
     };
 
     f32x16 acc[WM][WN];
@@ -140,29 +130,55 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_gather_gemm(GemmArgs
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nchunk = (g.K + BK - 1) / BK;
-    load_chunk(0);
-    store_chunk(0);
+    constexpr int NK = BK / 2, LS = NK / 2;           // first LS k-steps issue the next chunk's loads, the last LS store them
+#pragma unroll
+    for (int i = 0; i < NA_LOAD; ++i) load_a(i);
+#pragma unroll
+    for (int i = 0; i < NB_LOAD; ++i) load_b(i);
+#pragma unroll
+    for (int i = 0; i < NA_LOAD; ++i) store_a(0, i);
+#pragma unroll
+    for (int i = 0; i < NB_LOAD; ++i) store_b(0, i);
     __syncthreads();
     const int arow = lane >> 5, acol = lane & 31;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < nchunk) load_chunk((ch + 1) * BK);
+        k0 = (ch + 1) * BK;                            // past the end: k >= K, every load out of range
         const float* pa = &sA[cur][arow * LDA + wave_m * 32 * WM + acol];
         const float* pb = &sB[cur][arow * LDB + wave_n * 32 * WN + acol];
+        float av[2][WM], bv[2][WN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float av[WM], bv[WN];
+        for (int i = 0; i < WM; ++i) av[0][i] = pa[i * 32];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) av[i] = pa[kk * 2 * LDA + i * 32];
+        for (int j = 0; j < WN; ++j) bv[0][j] = pb[j * 32];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bv[j] = pb[kk * 2 * LDB + j * 32];
+        for (int kk = 0; kk < NK; ++kk) {
+            const int cb = kk & 1, nb = cb ^ 1;
+            if (kk + 1 < NK) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) av[nb][i] = pa[(kk + 1) * 2 * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bv[nb][j] = pb[(kk + 1) * 2 * LDB + j * 32];
+            }
+            if (kk < LS) {
+#pragma unroll
+                for (int i = 0; i < NA_LOAD; ++i) if ((i * LS) / NA_LOAD == kk) load_a(i);
+#pragma unroll
+                for (int i = 0; i < NB_LOAD; ++i) if ((i * LS) / NB_LOAD == kk) load_b(i);
+            } else if (kk >= NK - LS) {
+#pragma unroll
+                for (int i = 0; i < NA_LOAD; ++i) if ((i * LS) / NA_LOAD == kk - (NK - LS)) store_a(cur ^ 1, i);
+#pragma unroll
+                for (int i = 0; i < NB_LOAD; ++i) if ((i * LS) / NB_LOAD == kk - (NK - LS)) store_b(cur ^ 1, i);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (ch + 1 < nchunk) store_chunk(cur ^ 1);
         __syncthreads();
     }
 
@@ -596,8 +612,8 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
     FD_REQUIRE(x && w && y, "fd_conv2d_fwd: NULL tensor");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_fwd: empty output");
-    FD_REQUIRE((long)d->N * d->Cin * d->H * d->W < (1L << 31) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 31),
-               "fd_conv2d_fwd: tensor too large for 32-bit offsets");
+    FD_REQUIRE((long)d->N * d->Cin * d->H * d->W < (1L << 29) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 29),
+               "fd_conv2d_fwd: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
     if (fast_fwd_ok(d)) {
         FD_REQUIRE(wt, "fd_conv2d_fwd: weight-layout buffer required (fd_conv2d_fwd_wt_floats)");
@@ -653,8 +669,8 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
     FD_REQUIRE(gy && w && gx && wt_base, "fd_conv2d_bwd_data: NULL tensor");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_data: empty output");
-    FD_REQUIRE((long)d->N * d->Cin * (d->H + 2) * (d->W + 2) < (1L << 31) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 31),
-               "fd_conv2d_bwd_data: tensor too large for 32-bit offsets");
+    FD_REQUIRE((long)d->N * d->Cin * (d->H + 2) * (d->W + 2) < (1L << 29) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 29),
+               "fd_conv2d_bwd_data: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
     const int KH = d->KH, KW = d->KW;
     const bool fast = fast_dgrad_ok(d);

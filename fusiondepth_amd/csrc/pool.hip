@@ -29,48 +29,56 @@ __global__ void __launch_bounds__(NT) k_maxpool_fwd(const float* __restrict__ x,
                                                     uint8_t* __restrict__ idx, long planes, int H, int W, int Ho, int Wo) {
     PLANE_LOOP(pl, r, planes, Ho * Wo) {
         const int ho = r / Wo, wo = r - ho * Wo;
-        const long i = pl * Ho * Wo + r;
         const float* p = x + pl * H * W;
-        float best = -INFINITY;
-        int bi = 0;
-        bool any = false;
+        float best = 0.f;
+        int bi = -1;
+        // branch-free: every tap is loaded from a clamped address; taps outside the image never win
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int h = ho * 2 - 1 + kh;
-            if (h < 0 || h >= H) continue;
+            const bool vh = (unsigned)h < (unsigned)H;
+            const int hc = h < 0 ? 0 : (h >= H ? H - 1 : h);
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int w = wo * 2 - 1 + kw;
-                if (w < 0 || w >= W) continue;
-                const float v = p[h * W + w];
-                if (!any || v > best || v != v) { best = v; bi = kh * 3 + kw; any = true; }
+                const bool ok = vh & ((unsigned)w < (unsigned)W);
+                const int wc = w < 0 ? 0 : (w >= W ? W - 1 : w);
+                const float v = p[hc * W + wc];
+                const bool take = ok & ((bi < 0) | (v > best) | (v != v));
+                best = take ? v : best;
+                bi = take ? kh * 3 + kw : bi;
             }
         }
-        y[i] = best;
-        idx[i] = (uint8_t)bi;
+        y[pl * Ho * Wo + r] = best;
+        idx[pl * Ho * Wo + r] = (uint8_t)bi;
     }
 }
-// gather form of the scatter-add: each input pixel checks the <=4 windows that contain it
+// Gather form of the scatter-add.  One thread owns a 2x2 block of input pixels (rows 2p, 2p+1; columns 2q, 2q+1); the only
+// pooling windows that can select them are (p, q), (p, q+1), (p+1, q), (p+1, q+1), so 4 index bytes + 4 gradients give the
+// 4 outputs with no branches and contiguous accesses across the lanes.
 __global__ void __launch_bounds__(NT) k_maxpool_bwd(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
                                                     float* __restrict__ gx, long planes, int H, int W, int Ho, int Wo) {
-    PLANE_LOOP(pl, r, planes, H * W) {
-        const int h = r / W, w = r - h * W;
-        const long i = pl * H * W + r;
+    const int Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    PLANE_LOOP(pl, r, planes, Hb * Wb) {
+        const int p = r / Wb, q = r - p * Wb;
         const float* g = gy + pl * Ho * Wo;
         const uint8_t* ix = idx + pl * Ho * Wo;
-        float s = 0.f;
-        for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {   // windows with 2ho-1 <= h <= 2ho+1
-            if (ho < 0 || ho >= Ho) continue;
-            const int kh = h - (2 * ho - 1);
-            if (kh < 0 || kh > 2) continue;
-            for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
-                if (wo < 0 || wo >= Wo) continue;
-                const int kw = w - (2 * wo - 1);
-                if (kw < 0 || kw > 2) continue;
-                if (ix[ho * Wo + wo] == kh * 3 + kw) s += g[ho * Wo + wo];
-            }
-        }
-        gx[i] = s;
+        const int p1 = p + 1 < Ho ? p + 1 : p, q1 = q + 1 < Wo ? q + 1 : q;      // clamped; masked below
+        const bool vp = p + 1 < Ho, vq = q + 1 < Wo;
+        const int i00 = ix[p * Wo + q], i01 = vq ? ix[p * Wo + q1] : 255, i10 = vp ? ix[p1 * Wo + q] : 255,
+                  i11 = (vp & vq) ? ix[p1 * Wo + q1] : 255;
+        const float g00 = g[p * Wo + q], g01 = g[p * Wo + q1], g10 = g[p1 * Wo + q], g11 = g[p1 * Wo + q1];
+        // window (p,q): taps (kh,kw) in {1,2}x{1,2} hit this block; (p,q+1): kw = 0, kh in {1,2}; (p+1,q): kh = 0, kw in {1,2};
+        // (p+1,q+1): tap 0.  Sums are taken in window raster order (p,q), (p,q+1), (p+1,q), (p+1,q+1).
+        const float o00 = (i00 == 4 ? g00 : 0.f);
+        const float o01 = (i00 == 5 ? g00 : 0.f) + (i01 == 3 ? g01 : 0.f);
+        const float o10 = (i00 == 7 ? g00 : 0.f) + (i10 == 1 ? g10 : 0.f);
+        const float o11 = (((i00 == 8 ? g00 : 0.f) + (i01 == 6 ? g01 : 0.f)) + (i10 == 2 ? g10 : 0.f)) + (i11 == 0 ? g11 : 0.f);
+        float* o = gx + pl * H * W + (2 * p) * W + 2 * q;
+        const bool h1 = 2 * p + 1 < H, w1 = 2 * q + 1 < W;
+        o[0] = o00;
+        if (w1) o[1] = o01;
+        if (h1) { o[W] = o10; if (w1) o[W + 1] = o11; }
     }
 }
 
@@ -149,6 +157,12 @@ __global__ void __launch_bounds__(NT) k_act_bwd(const float* __restrict__ y, con
 __global__ void __launch_bounds__(NT) k_axpby(const float* __restrict__ a, const float* __restrict__ b,
                                               float* __restrict__ out, long n, float alpha, float beta) {
     GRID_STRIDE(i, n) out[i] = alpha * a[i] + beta * b[i];
+}
+
+// networks/resnet_encoder.py:94  x = (input_image - 0.45) / 0.225 (a true division, as the reference rounds it)
+__global__ void __launch_bounds__(NT) k_input_normalize(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                        float mean, float std) {
+    GRID_STRIDE(i, n) y[i] = (x[i] - mean) / std;
 }
 
 // one wave per plane: out = scale * mean(plane)
@@ -234,7 +248,7 @@ extern "C" int fd_maxpool3x3s2_bwd(const float* gy, const uint8_t* idx, float* g
     FD_REQUIRE(gy && idx && gx && N > 0 && C > 0 && H > 0 && W > 0, "fd_maxpool3x3s2_bwd: bad args");
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long planes = (long)N * C;
-    hipLaunchKernelGGL(k_maxpool_bwd, plane_grid(planes, (long)H * W), dim3(NT), 0, (hipStream_t)stream, gy, idx, gx,
+    hipLaunchKernelGGL(k_maxpool_bwd, plane_grid(planes, (long)((H + 1) / 2) * ((W + 1) / 2)), dim3(NT), 0, (hipStream_t)stream, gy, idx, gx,
                        planes, H, W, Ho, Wo);
     FD_LAUNCH_CHECK("fd_maxpool3x3s2_bwd");
     return 0;
@@ -297,6 +311,13 @@ extern "C" int fd_axpby(const float* a, const float* b, float* out, long n, floa
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, a, b, out, n, alpha, beta);
     FD_LAUNCH_CHECK("fd_axpby");
+    return 0;
+}
+extern "C" int fd_input_normalize(const float* x, float* y, long n, float mean, float std, void* stream) {
+    FD_REQUIRE(x && y && n >= 0 && std != 0.f, "fd_input_normalize: bad args");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_input_normalize, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, x, y, n, mean, std);
+    FD_LAUNCH_CHECK("fd_input_normalize");
     return 0;
 }
 extern "C" int fd_spatial_mean_fwd(const float* x, float* out, long planes, long plane_size, float scale, void* stream) {

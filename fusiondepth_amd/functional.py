@@ -485,6 +485,30 @@ class _Conv2d(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None
 
 
+class _InputNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mean, std):
+        x = f32(x)
+        _need_cuda(x)
+        y = torch.empty_like(x)
+        call("fd_input_normalize", ptr(x), ptr(y), x.numel(), float(mean), float(std), stream())
+        ctx.std = float(std)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = f32(gy)
+        gx = torch.empty_like(gy)
+        call("fd_axpby", ptr(gy), ptr(gy), ptr(gx), gy.numel(), 1.0 / ctx.std, 0.0, stream())
+        return gx, None, None
+
+
+def input_normalize(x, mean=0.45, std=0.225):
+    """``(x - mean) / std`` — the encoder's input normalisation (resnet_encoder.py:94) as its own pass, so that the stem
+    convolution and its weight gradient gather plain values (the fused ``in_norm`` variant pays a division per tap)."""
+    return _InputNormalize.apply(x, mean, std)
+
+
 def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", in_norm=False):
     """act(conv2d(pad(x)) + bias) on the MFMA implicit-GEMM kernels; ``in_norm`` folds the encoder's
     (x-0.45)/0.225 into the tap loads (resnet_encoder.py:94)."""

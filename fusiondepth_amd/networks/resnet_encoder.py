@@ -130,8 +130,8 @@ class ResnetEncoder(nn.Module):
 
     def forward(self, input_image):
         e = self.encoder
-        # (x - 0.45) / 0.225 (resnet_encoder.py:94) is folded into conv1's tap loads
-        x = FD.conv2d(input_image, e.conv1.weight, None, stride=2, pad=3, in_norm=True)
+        # (x - 0.45) / 0.225 (resnet_encoder.py:94) as its own pass: the 7x7 stem then gathers plain values
+        x = FD.conv2d(FD.input_normalize(input_image), e.conv1.weight, None, stride=2, pad=3)
         f0 = FD.batch_norm(x, e.bn1, relu=True)
         f1 = e.layer1(FD.max_pool3x3s2(f0))
         f2 = e.layer2(f1)

@@ -220,6 +220,10 @@ int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, int N, int 
 int fd_upsample2x_fwd(const float* x, float* y, long planes, int h, int w, void* stream);
 int fd_upsample2x_bwd(const float* gy, float* gx, long planes, int h, int w, void* stream);
 
+/* networks/resnet_encoder.py:94  y = (x - mean) / std  elementwise (the encoder's input normalisation, 0.45 / 0.225).
+ * The same arithmetic is available fused into the stem conv through fd_conv_desc.in_norm. */
+int fd_input_normalize(const float* x, float* y, long n, float mean, float std, void* stream);
+
 /* out = a + b (feature fusion depth_decoder.py:70, pose_decoder.py:31) ; out = alpha*a + beta*b */
 int fd_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream);
 
