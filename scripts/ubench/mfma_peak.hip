@@ -43,6 +43,11 @@ void run(const char* name, int blocks, int iters) {
     hipFree(out);
 }
 int main() {
+    run<1, false>("1 acc, regs only, 1 blk/CU", 256, 2000);
+    run<2, false>("2 acc, regs only, 1 blk/CU", 256, 2000);
+    run<2, false>("2 acc, regs only, 3 blk/CU", 768, 1000);
+    run<2, true>("2 acc, LDS operands, 1 blk/CU", 256, 2000);
+    run<2, true>("2 acc, LDS operands, 3 blk/CU", 768, 1000);
     run<4, false>("4 acc, regs only", 256, 2000);
     run<4, false>("4 acc, regs only", 512, 2000);
     run<4, false>("4 acc, regs only", 1024, 1000);
