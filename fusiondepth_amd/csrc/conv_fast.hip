@@ -551,11 +551,16 @@ int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int 
 }
 
 int fast_wgrad_splits(int M, int C, int T, long Np) {
+    // Workgroups co-resident on a CU share its matrix pipes, so a launch finishes when the fullest CU does: 513 workgroups
+    // on 256 CUs (one CU with 3) take 1.5x the time of 512.  Aim at 3 per CU (what the 50 KB LDS tiles allow) and never
+    // exceed it; measured in the training step against 256 / 512 / 1024 and against a rounds-based cost model.
+    static long target = 0;
+    if (!target) { const char* e = getenv("FD_WGRAD_TARGET"); target = e ? atol(e) : 768; }
     const int bn = C >= 128 ? 128 : 64;
     const long tiles = (long)T * fd_cdiv(C, bn) * fd_cdiv(M, M > 32 ? 64 : 32);
-    long want = (512 + tiles - 1) / tiles;
+    long sp = target / tiles;
     const long maxs = (Np + 511) / 512;
-    long sp = want < maxs ? want : maxs;
+    if (sp > maxs) sp = maxs;
     if (sp < 1) sp = 1;
     if (sp > 64) sp = 64;
     return (int)sp;

@@ -6,6 +6,8 @@ torch ops on the data path.
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -411,6 +413,38 @@ def enable_direct_grad(params):
         p._fd_direct_grad = True
 
 
+# ---- weight gradients on side streams -------------------------------------------------------------------------------
+# In a conv's backward the data gradient feeds the previous layer (critical path) while the weight gradient is a leaf:
+# with this switch on (and in-place gradient accumulation, so autograd never needs the result) the wgrad kernels of a
+# module stream run on a paired side stream, concurrently with the rest of that module's backward chain.  The tensors a
+# side-stream kernel reads are kept alive until ``join_wgrad_streams`` (the caching allocator would otherwise hand their
+# memory to later kernels of the main stream).
+_WGRAD_ASYNC = [False]
+_WGRAD_STREAMS = {}
+_WGRAD_KEEPALIVE = []
+
+
+def enable_async_wgrad(on=True):
+    _WGRAD_ASYNC[0] = bool(on)
+
+
+def join_wgrad_streams():
+    """Order every side-stream weight gradient before what follows on the current stream (optimiser / all-reduce)."""
+    cur = torch.cuda.current_stream()
+    for st in _WGRAD_STREAMS.values():
+        cur.wait_stream(st)
+    _WGRAD_KEEPALIVE.clear()
+
+
+def _wgrad_stream():
+    cur = torch.cuda.current_stream()
+    st = _WGRAD_STREAMS.get(cur.cuda_stream)
+    if st is None:
+        st = _WGRAD_STREAMS[cur.cuda_stream] = torch.cuda.Stream()
+    st.wait_stream(cur)
+    return st
+
+
 def _direct_grad_target(p):
     if p is not None and getattr(p, "_fd_direct_grad", False) and p.grad is not None and p.grad.is_contiguous():
         return p.grad
@@ -479,7 +513,13 @@ class _Conv2d(torch.autograd.Function):
             gw = tw if direct else torch.empty_like(w)
             gb = (tb if direct else _empty((d.Cout,), x)) if ctx.has_bias else None
             ws = _empty((max(query("fd_conv2d_bwd_weight_ws_floats", dp), 1),), x)
-            call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
+            if direct and _WGRAD_ASYNC[0]:
+                side = _wgrad_stream()                     # ordered after everything queued so far (gy is complete)
+                with torch.cuda.stream(side):
+                    call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), 1, stream())
+                _WGRAD_KEEPALIVE.append((x, gy, ws))
+            else:
+                call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
             if direct:
                 gw = gb = None          # already accumulated in place
         return gx, gw, gb, None, None, None, None, None

@@ -95,6 +95,7 @@ class Trainer:
         self.flat = dp.FlatParameters(self.parameters_to_train)
         FD.enable_weight_cache(self.parameters_to_train)
         FD.enable_direct_grad(self.parameters_to_train)
+        FD.enable_async_wgrad(os.environ.get("FD_ASYNC_WGRAD", "0") == "1")     # opt-in; measured slower
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.adam_step_count = 0
@@ -292,9 +293,11 @@ class Trainer:
         cur = torch.cuda.current_stream()
         for st in self._streams:
             cur.wait_stream(st)
+        FD.join_wgrad_streams()          # side-stream weight gradients (ordered after their module streams were joined)
 
     def _fork(self, idx):
         """Side stream #idx, ordered after everything already queued on the current stream."""
+        idx = idx % int(os.environ.get("FD_NSTREAMS", "8"))
         while len(self._streams) <= idx:
             self._streams.append(torch.cuda.Stream())
         st = self._streams[idx]
