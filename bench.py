@@ -79,13 +79,15 @@ def roofline_probes(args, tr, batch):
     # H/4 x W/4, forward (the data-gradient launch is the same kernel with re-laid-out weights).  In the training step
     # four such streams run concurrently; the probe runs alone.
     h8, w8 = args.height // 4, args.width // 4
-    x = torch.randn(B, 64, h8, w8, device="cuda")
+    Bc = B * (tr.accumulate_step if tr.stack_microbatches else 1)      # what the step launches: the stacked micro-batches
+    x = torch.randn(Bc, 64, h8, w8, device="cuda")
     w = torch.randn(64, 64, 3, 3, device="cuda") * 0.03
+    w._fd_cache_id = -1                                  # as in the step: the (tap, channel)-major weight copy is cached
     with torch.no_grad():
         ms = graph_time_ms(lambda: FD.conv2d(x, w, None, 1, 1))
-    flops = 2.0 * B * h8 * w8 * 64 * 64 * 9
-    out["roofline"] = {"bound": "mfma", "kernel": "k_conv_fast (ResNet layer1 conv 3x3 64->64 @%dx%d, micro-batch %d, alone on the "
-                       "GPU; incl. its weight re-layout launch)" % (h8, w8, B),
+    flops = 2.0 * Bc * h8 * w8 * 64 * 64 * 9
+    out["roofline"] = {"bound": "mfma", "kernel": "k_conv_fast<2,2,1,2,32> (ResNet layer1 conv 3x3 64->64 @%dx%d, batch %d = the "
+                       "stacked micro-batches, alone on the GPU)" % (h8, w8, Bc),
                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "us_per_launch": ms * 1e3,
                        "flop_per_launch": flops}

@@ -31,6 +31,13 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, _I) for n in ("N", "Cin", "H", "W", "Cout", "KH", "KW", "stride", "pad", "pad_mode", "act", "in_norm")]
 
 
+class RelayoutJob(ctypes.Structure):
+    """Mirror of ``fd_relayout_job``."""
+    _fields_ = ([("w", ctypes.c_void_p), ("dst", ctypes.c_void_p)] +
+                [(n, _I) for n in ("Co", "Ci", "KH", "KW", "TA", "TB", "kh0", "dkh", "kw0", "dkw", "mode", "reserved")] +
+                [("n", ctypes.c_long), ("first_block", ctypes.c_long)])
+
+
 # name -> (argument kinds, restype kind)  ('p' pointer, 'i' int, 'l' long, 'f' float, 'd' double)
 SIGNATURES = {
     "fd_abi_version": ("", "i"),
@@ -67,6 +74,9 @@ SIGNATURES = {
     "fd_conv2d_bwd_data_wt_floats": ("p", "l"),
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_data": ("ppppp" "i" "pp", "i"),
+    "fd_conv2d_relayout_jobs": ("pippp", "i"),
+    "fd_relayout_plan": ("pi", "l"),
+    "fd_relayout_batch": ("pilp", "i"),
     "fd_conv2d_bwd_weight_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_weight": ("pppppp" "i" "p", "i"),
     "fd_act_bwd": ("ppplip", "i"),

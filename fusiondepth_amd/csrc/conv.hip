@@ -419,6 +419,36 @@ __global__ void k_weight_relayout(const float* __restrict__ W, float* __restrict
     }
 }
 
+// All weight re-layouts of a training step in one launch: workgroup -> (job, 1024-element slice) by binary search over the
+// jobs' first_block prefix.
+__global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* __restrict__ jobs, int njobs) {
+    const long b = blockIdx.x;
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                                   // last job with first_block <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const fd_relayout_job j = jobs[lo];
+    const long base = (b - j.first_block) * 1024;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long i = base + e * 256 + threadIdx.x;
+        if (i >= j.n) return;
+        int co, ci, a, bb;
+        if (j.mode == 2) {                              // [ci][co][a][b]
+            bb = (int)(i % j.TB); a = (int)((i / j.TB) % j.TA);
+            co = (int)((i / ((long)j.TB * j.TA)) % j.Co); ci = (int)(i / ((long)j.TB * j.TA * j.Co));
+        } else {                                        // [m][a][b][c]: mode 0 m = co, c = ci; mode 1 m = ci, c = co
+            const int Cr = j.mode ? j.Co : j.Ci;
+            const int c = (int)(i % Cr);
+            bb = (int)((i / Cr) % j.TB); a = (int)((i / ((long)Cr * j.TB)) % j.TA);
+            const int m = (int)(i / ((long)Cr * j.TB * j.TA));
+            co = j.mode ? c : m; ci = j.mode ? m : c;
+        }
+        j.dst[i] = j.w[(((long)co * j.Ci + ci) * j.KH + j.kh0 + j.dkh * a) * j.KW + j.kw0 + j.dkw * bb];
+    }
+}
+
 // Adjoint of ReflectionPad2d(1): fold the gradient on the padded grid [H+2][W+2] back onto [H][W].
 __global__ void k_reflect_fold(const float* __restrict__ gp, float* __restrict__ gx, long planes, int H, int W) {
     const int Wp = W + 2;
@@ -758,6 +788,51 @@ extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const 
             wt = wt_base + (long)(ph * 2 + pw) * wt_n;
             if (int rc = run(TA, TB, kh0, 2, kw0, 2, false)) return rc;
         }
+    return 0;
+}
+
+extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const float* w, float* wt, fd_relayout_job* jobs) {
+    if (check_desc(d, "fd_conv2d_relayout_jobs") || !w || !wt || !jobs) return 0;
+    auto fill = [&](fd_relayout_job& j, float* dst, int TA, int TB, int kh0, int dkh, int kw0, int dkw, int mode) {
+        j = fd_relayout_job{};
+        j.w = w; j.dst = dst; j.Co = d->Cout; j.Ci = d->Cin; j.KH = d->KH; j.KW = d->KW;
+        j.TA = TA; j.TB = TB; j.kh0 = kh0; j.dkh = dkh; j.kw0 = kw0; j.dkw = dkw; j.mode = mode;
+        j.n = (long)d->Cout * d->Cin * TA * TB;
+    };
+    if (kind == 0) {
+        if (!fast_fwd_ok(d)) return 0;
+        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, 0);
+        return 1;
+    }
+    const int KH = d->KH, KW = d->KW;
+    const int mode = fast_dgrad_ok(d) ? 1 : 2;
+    if (d->stride == 1) {
+        fill(jobs[0], wt, KH, KW, KH - 1, -1, KW - 1, -1, mode);
+        return 1;
+    }
+    const long wt_n = align4((long)d->Cin * d->Cout * KH * KW);
+    int n = 0;
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {                 // same enumeration as fd_conv2d_bwd_data
+            const int kh0 = (ph + d->pad) & 1, kw0 = (pw + d->pad) & 1;
+            if (kh0 >= KH || kw0 >= KW) continue;
+            const int TA = (KH - kh0 + 1) / 2, TB = (KW - kw0 + 1) / 2;
+            if ((d->H - ph + 1) / 2 <= 0 || (d->W - pw + 1) / 2 <= 0) continue;
+            fill(jobs[n++], wt + (long)(ph * 2 + pw) * wt_n, TA, TB, kh0, 2, kw0, 2, mode);
+        }
+    return n;
+}
+
+extern "C" long fd_relayout_plan(fd_relayout_job* jobs, int n) {
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) { jobs[i].first_block = blocks; blocks += (jobs[i].n + 1023) / 1024; }
+    return blocks;
+}
+
+extern "C" int fd_relayout_batch(const fd_relayout_job* jobs_dev, int n, long total_blocks, void* stream) {
+    FD_REQUIRE(jobs_dev && n > 0 && total_blocks > 0 && total_blocks < (1L << 31), "fd_relayout_batch: bad args");
+    hipLaunchKernelGGL(k_relayout_batch, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, n);
+    FD_LAUNCH_CHECK("fd_relayout_batch");
     return 0;
 }
 

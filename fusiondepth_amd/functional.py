@@ -451,7 +451,7 @@ def _direct_grad_target(p):
     return None
 
 
-def _weight_layout(w, cache_id, kind, nfloats):
+def _weight_layout(w, cache_id, kind, nfloats, desc=None):
     """-> (buffer, ready flag) for weight ``w`` and layout ``kind`` ('f' forward, 'd' data-gradient)."""
     if cache_id is None:
         return torch.empty((nfloats,), device=w.device, dtype=torch.float32), 0
@@ -464,8 +464,50 @@ def _weight_layout(w, cache_id, kind, nfloats):
         ent[0] = stamp
         return ent[1], 0
     buf = torch.empty((nfloats,), device=w.device, dtype=torch.float32)
-    _WT_CACHE[key] = [stamp, buf]
+    _WT_CACHE[key] = [stamp, buf, desc, w]
+    if _WT_PLAN[0] is not None:
+        _WT_PLAN[0] = None              # a layout the plan does not know: fall back to per-call re-layout until rebuilt
     return buf, 0
+
+
+# One-launch refresh of every cached layout (fd_relayout_batch): built once the cache is populated (after the first full
+# forward + backward), run by adam_step* right after the weights change.
+_WT_PLAN = [None]
+
+
+def build_weight_plan():
+    """Collect the re-layout jobs of every cached weight layout into a device table; returns the number of jobs."""
+    from ._lib import RelayoutJob
+    ents = [(k, e) for k, e in _WT_CACHE.items() if len(e) >= 4 and e[2] is not None]
+    if not ents:
+        _WT_PLAN[0] = None
+        return 0
+    jobs = (RelayoutJob * (4 * len(ents)))()
+    n = 0
+    for (cid, kind), e in ents:
+        n += query("fd_conv2d_relayout_jobs", ctypes.addressof(e[2]), 0 if kind == "f" else 1, ptr(e[3]), ptr(e[1]),
+                   ctypes.addressof(jobs) + n * ctypes.sizeof(RelayoutJob))
+    if n == 0:
+        _WT_PLAN[0] = None
+        return 0
+    blocks = query("fd_relayout_plan", ctypes.addressof(jobs), n)
+    raw = bytes(memoryview(jobs))[: n * ctypes.sizeof(RelayoutJob)]
+    dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(ents[0][1][1].device)
+    _WT_PLAN[0] = (dev, n, blocks, [k for k, _ in ents])
+    return n
+
+
+def refresh_weight_layouts():
+    """Re-derive every planned layout from the current weights (one launch) and mark them valid for this epoch."""
+    plan = _WT_PLAN[0]
+    if plan is None:
+        return False
+    dev, n, blocks, keys = plan
+    call("fd_relayout_batch", ptr(dev), n, blocks, stream())
+    for k in keys:
+        e = _WT_CACHE[k]
+        e[0] = (e[3]._version, _WEIGHTS_EPOCH[0], e[3].data_ptr())
+    return True
 
 
 class _Conv2d(torch.autograd.Function):
@@ -482,7 +524,7 @@ class _Conv2d(torch.autograd.Function):
         nws = query("fd_conv2d_fwd_ws_floats", ctypes.addressof(d))
         nwt = query("fd_conv2d_fwd_wt_floats", ctypes.addressof(d))
         ws = _empty((nws,), x) if nws > 0 else None
-        wt, ready = _weight_layout(w, cache_id, "f", nwt) if nwt > 0 else (None, 0)
+        wt, ready = _weight_layout(w, cache_id, "f", nwt, d) if nwt > 0 else (None, 0)
         call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), stream())
         ctx.save_for_backward(x, w, y if act != 0 else None)
         ctx.desc, ctx.has_bias, ctx.cache_id = d, bias is not None, cache_id
@@ -502,7 +544,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             ws = _empty((max(query("fd_conv2d_bwd_data_ws_floats", dp), 1),), x)
-            wt, ready = _weight_layout(w, ctx.cache_id, "d", query("fd_conv2d_bwd_data_wt_floats", dp))
+            wt, ready = _weight_layout(w, ctx.cache_id, "d", query("fd_conv2d_bwd_data_wt_floats", dp), d)
             call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(w), ptr(gx), ptr(wt), ready, ptr(ws), stream())
             if d.in_norm:   # d/dx of (x - 0.45) / 0.225
                 call("fd_axpby", ptr(gx), ptr(gx), ptr(gx), gx.numel(), 1.0 / 0.225, 0.0, stream())
@@ -790,6 +832,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
     bump_weights_epoch()
     call("fd_adam_step", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr), betas[0],
          betas[1], float(eps), bc1, bc2, float(grad_scale), stream())
+    refresh_weight_layouts()
 
 
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
@@ -797,3 +840,4 @@ def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, betas=(0.9, 0.999), e
     bump_weights_epoch()
     call("fd_adam_step_dev", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(state), betas[0],
          betas[1], float(eps), float(grad_scale), stream())
+    refresh_weight_layouts()

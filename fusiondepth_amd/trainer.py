@@ -185,8 +185,16 @@ class Trainer:
                 self.batch_idx += 1
         scale = self.grad_sync.finish() if self.world_size > 1 else 1.0
         self.optimizer_step(scale)
+        self._ensure_weight_plan()
         self.step += 1
         return losses
+
+    def _ensure_weight_plan(self):
+        """After the first full forward + backward every conv weight has its cached kernel-side layouts: collect their
+        re-layout work into one device job table, so that from now on Adam is followed by ONE re-layout launch instead of
+        ~220 small ones spread over the next step.  (Not capturable: call outside graph capture.)"""
+        if FD._WT_PLAN[0] is None and FD.build_weight_plan() > 0:
+            FD.refresh_weight_layouts()
 
     def optimizer_step(self, grad_scale=1.0):
         """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8).step(); zero_grad()  as one fused kernel.  The step
@@ -234,7 +242,10 @@ class Trainer:
             self._copy_into_static(micro_batches)
             self._last_mbs = micro_batches
         if self._graph == "warm":
-            FD.bump_weights_epoch()        # the captured step must (re)derive every weight layout at first use
+            with torch.cuda.stream(self._side):
+                self._ensure_weight_plan()     # layouts valid now; inside the graph Adam is followed by the batched refresh
+            if FD._WT_PLAN[0] is None:
+                FD.bump_weights_epoch()        # no plan: the captured step must re-derive every weight layout at first use
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self._side):
@@ -609,6 +620,8 @@ class Trainer:
                 for k, v in pretrained.items():
                     if k in model_dict:
                         model_dict[k].copy_(v)              # in place: parameters stay views of the flat buffer
+        FD.bump_weights_epoch()
+        FD.refresh_weight_layouts()       # a captured step holds no per-conv re-layout launches: refresh the cached copies now
         adam = os.path.join(folder, "adam.pth")
         if os.path.isfile(adam):
             st = torch.load(adam, map_location="cpu")

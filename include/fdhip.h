@@ -167,6 +167,27 @@ long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d);
 long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d);
 int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
                   int wt_ready, float* ws, void* stream);
+/* Batched weight re-layout.  A training step re-derives the kernel-side copy of every conv weight once per optimiser
+ * step; instead of one small launch per convolution inside fd_conv2d_fwd / fd_conv2d_bwd_data (wt_ready = 0) the caller can
+ * collect the work of all its convolutions once and run it as ONE launch after each optimiser update, then call the
+ * convolutions with wt_ready = 1.
+ *   fd_conv2d_relayout_jobs  appends to jobs[] (capacity >= 4) what the forward (kind 0) or data-gradient (kind 1) of `d`
+ *                            would re-lay-out from `w` into `wt`; returns the number of jobs (0: that path needs no copy).
+ *   fd_relayout_plan         fills the launch bookkeeping of a host array of n jobs; returns the workgroup count.
+ *   fd_relayout_batch        runs n jobs; `jobs_dev` is the planned array copied to DEVICE memory. */
+typedef struct fd_relayout_job {
+    const float* w;
+    float* dst;
+    int Co, Ci, KH, KW, TA, TB, kh0, dkh, kw0, dkw;
+    int mode;          /* 0 forward [Co][tap][Ci], 1 data-gradient [Ci][tap][Co], 2 generic data-gradient [Ci][Co][tap] */
+    int reserved;
+    long n;            /* elements */
+    long first_block;  /* set by fd_relayout_plan */
+} fd_relayout_job;
+int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const float* w, float* wt, fd_relayout_job* jobs);
+long fd_relayout_plan(fd_relayout_job* jobs_host, int n);
+int fd_relayout_batch(const fd_relayout_job* jobs_dev, int n, long total_blocks, void* stream);
+
 /* gx [N,Cin,H,W] = d/dx of sum(conv(x,w) * gy)  (gy is the gradient w.r.t. the PRE-activation output;
  * apply fd_act_bwd first when act != 0).  wt / wt_ready as in fd_conv2d_fwd (flipped / transposed layouts, one per
  * output-parity class for stride 2: fd_conv2d_bwd_data_wt_floats(d) floats); ws: fd_conv2d_bwd_data_ws_floats(d). */
