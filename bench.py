@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--batch_size", type=int, default=12, help="per-process --batch_size of the reference trainer")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: whichever of the two launch paths "
+                    "measures faster during the untimed warm-up)")
     ap.add_argument("--no_stack", action="store_true", help="run the accumulated micro-batches sequentially (reference order) "
                     "instead of as one stacked pass with grouped BatchNorm")
     ap.add_argument("--no_roofline", action="store_true")
@@ -176,13 +178,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step_fn = tr.train_step if args.eager else tr.train_step_graphed
-    for _ in range(max(args.warmup, 0 if args.eager else 2)):     # graph mode: 1 eager warm-up + 1 capture/replay
+    def timed(fn, n):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn(mbs)
+        barrier()
+        return (time.perf_counter() - t) / n
+
+    launch = "eager" if args.eager else ("graph" if args.graph else "auto")
+    if launch == "auto":
+        # Both launch paths run the same kernels on the same streams; which one keeps the GPU busier depends on the host
+        # (Python issue rate vs hipGraphLaunch cost per node).  Decide inside the untimed warm-up, identically on all ranks.
+        tr.train_step(mbs)                                   # allocator / autotune warm-up
+        t_eager = timed(tr.train_step, 2)
+        tr.train_step_graphed(mbs); tr.train_step_graphed(mbs)   # eager warm-up on the capture stream + capture
+        t_graph = timed(tr.train_step_graphed, 2)
+        if world > 1:
+            tt = torch.tensor([t_eager, t_graph], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_eager, t_graph = float(tt[0]), float(tt[1])
+        launch = "eager" if t_eager <= t_graph else "graph"
+        if rank == 0:
+            print("[bench] warm-up: eager %.2f ms/step, hipGraph replay %.2f ms/step -> %s" % (1e3 * t_eager, 1e3 * t_graph, launch),
+                  file=sys.stderr, flush=True)
+    step_fn = tr.train_step if launch == "eager" else tr.train_step_graphed
+    for _ in range(max(args.warmup, 0 if launch == "eager" else 2)):     # graph mode: 1 eager warm-up + 1 capture/replay
         step_fn(mbs)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step_fn(mbs)
+    t_host = time.perf_counter() - t0            # host time to ISSUE the steps (no sync): == dt when launch-bound
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -192,7 +219,7 @@ def main():
     images = args.steps * opt.batch_size * world
     loss_val = float(losses["loss"].detach())
     if rank == 0:
-        print("[bench] timed %d steps in %.3f s" % (args.steps, dt), file=sys.stderr, flush=True)
+        print("[bench] timed %d steps in %.3f s (host issue time %.3f s)" % (args.steps, dt, t_host), file=sys.stderr, flush=True)
     result = {
         "metric": "training images/sec (640x192, ResNet-18, 4-beam)", "value": images / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -200,7 +227,7 @@ def main():
         "config": {"workload": "ResNet-%d encoders + DepthDecoder + PoseDecoder, %dx%d, 4-beam LiDAR, --batch_size %d per GPU "
                                "(= %d accumulated micro-batches of %d), frames [0,-1,1], 4 scales, fwd+bwd+Adam"
                                % (args.num_layers, args.width, args.height, opt.batch_size, tr.accumulate_step, tr.batch_size),
-                   "global_batch": opt.batch_size * world, "parallelism": "dp%d" % world, "launch": "eager" if args.eager else "hipGraph replay",
+                   "global_batch": opt.batch_size * world, "parallelism": "dp%d" % world, "launch": "eager (4 HIP streams)" if launch == "eager" else "hipGraph replay",
                    "micro_batches": "stacked (grouped BatchNorm)" if tr.stack_microbatches else "sequential"},
         "final_loss": loss_val,
     }
