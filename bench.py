@@ -88,11 +88,19 @@ def roofline_probes(args, tr, batch):
     with torch.no_grad():
         ms = graph_time_ms(lambda: FD.conv2d(x, w, None, 1, 1))
     flops = 2.0 * Bc * h8 * w8 * 64 * 64 * 9
+    traffic = None                    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this exact kernel/shape
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_probe.json")))
+        if (Bc, h8, w8) == (12, 48, 160):
+            traffic = pmc["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     out["roofline"] = {"bound": "mfma", "kernel": "k_conv_fast<2,2,1,2,32> (ResNet layer1 conv 3x3 64->64 @%dx%d, batch %d = the "
                        "stacked micro-batches, alone on the GPU)" % (h8, w8, Bc),
                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                       "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "us_per_launch": ms * 1e3,
-                       "flop_per_launch": flops}
+                       "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                       "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_probe.md)",
+                       "us_per_launch": ms * 1e3, "flop_per_launch": flops}
     # fused loss path (HBM-bound): forward + backward kernels of the four scales
     H, W = args.height, args.width
     po = FD.PhotoOptions()
