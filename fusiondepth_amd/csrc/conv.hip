@@ -15,6 +15,7 @@
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include "conv_fast.h"
+#include "conv_narrow.h"
 
 namespace {
 
@@ -856,7 +857,8 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     if (!conv_out_shape(d, s)) return 0;
     const long wsz = (long)d->Cout * d->Cin * d->KH * d->KW;
     long slabs;
-    if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
+    if (narrow_wgrad_ok(d)) slabs = narrow_wgrad_ws_floats(d);
+    else if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
     else { const int sp = wgrad_splits(d, s); slabs = sp > 1 ? (long)sp * wsz : 0; }
     const long bias_part = (long)d->Cout * CS_SPLITS;
     if (slabs < wsz) slabs = wsz;                            // accumulate mode stages a single slab
@@ -873,7 +875,9 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
                "fd_conv2d_bwd_weight: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
     const long Np = (long)d->N * s.Ho * s.Wo;
-    if (fast_wgrad_ok(d)) {
+    if (narrow_wgrad_ok(d)) {
+        if (int rc = narrow_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
+    } else if (fast_wgrad_ok(d)) {
         FastWgradArgs f = {};
         f.dY = gy; f.X = x; f.slabs = ws;
         f.M = d->Cout; f.C = d->Cin; f.T = d->KH * d->KW; f.TB = d->KW;

@@ -1,0 +1,205 @@
+// Weight gradient of the narrow 3x3 stride-1 pad-1 convolutions of the DepthDecoder's full-resolution levels
+// (networks/depth_decoder.py:63-96: upconv(0,*) 16/32 -> 16 channels, dispconv(0/1) 16/32 -> 1): Cin in {16, 32}, Cout <= 16.
+//
+// As a GEMM this is M = Cout <= 16 rows x J = 9*Cin columns x K = N*H*W pixels: 0.1 GFLOP per megapixel of work on 190 MB
+// of operands - memory-bound.  The generic gather kernel pads M and J up to 32x128 MFMA tiles and gathers every tap
+// separately (reflect logic per element): 450-640 us per layer on the decoder's serial critical path.  Here
+//   * a workgroup stages a 4 x 64 pixel tile of dY and the matching (4+2) x (64+2) halo patch of X in LDS ONCE and forms
+//     the nine tap-shifted operands by reading the patch at shifted addresses (no 9x operand expansion);
+//   * v_mfma_f32_16x16x4_f32 fits the problem exactly: 16 (Cout) x 16 (channels of one group) outputs per tap, K = 4
+//     consecutive pixels; one wave per tile row, 9 x (Cin/16) accumulators of 4 VGPRs per wave held across all tiles;
+//   * LDS strides are = 4 (mod 64) words so the 64 lanes of an operand read (16 rows x 4 pixels) hit 64 distinct banks;
+//   * persistent workgroups (<= 512) loop over the tiles; per-workgroup partial sums go to slabs that a second kernel
+//     adds in a fixed order (deterministic, no float atomics).
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+#include "conv_narrow.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TW = 64, TH = 4;                 // pixel tile
+constexpr int PR = TH + 2, PCW = TW + 2;       // patch rows / columns
+constexpr int XRS = 68;                        // patch row stride (floats)
+constexpr int XCS = 452;                       // patch channel stride: >= PR * XRS and = 4 (mod 64)
+constexpr int YS = 260;                        // dY row stride: >= TH * TW and = 4 (mod 64)
+static_assert(XCS >= PR * XRS && XCS % 64 == 4 && YS >= TH * TW && YS % 64 == 4, "LDS strides");
+
+__device__ __forceinline__ int refl_clamp_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * n - 2 - i : i;
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);   // far-out halo positions of partial tiles: any in-range value (their dY is 0)
+}
+
+template <int CG>   // channel groups of 16
+__global__ void __launch_bounds__(256) k_wgrad_narrow(NarrowWgradArgs g) {
+    constexpr int C = 16 * CG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem;                          // [C][XCS]
+    float* sY = smem + C * XCS;                // [16][YS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsX = fd_make_rsrc(g.X), rsY = fd_make_rsrc(g.dY);
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+    const int tiles_per_img = tiles_x * tiles_y;
+    const int ntiles = g.N * tiles_per_img;
+    const unsigned hw = (unsigned)(g.H * g.W);
+
+    f32x4 acc[9][CG];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();                        // previous tile's readers are done
+        // ---- X halo patch (rows y0-1 .. y0+TH, columns x0-1 .. x0+TW) and the dY tile (rows >= M and pixels outside the
+        //      image read 0): the loads of a 16-channel group are all issued before its first LDS store (latencies overlap)
+        constexpr int NXI = (16 * PR * PCW + 255) / 256, NYI = 16 * TH * TW / 256;   // per 16-channel group (bounds the registers)
+        float vy[NYI];
+#pragma unroll
+        for (int it = 0; it < NYI; ++it) {
+            const int i = tid + it * 256;
+            const int m = i / (TH * TW), p = i - m * (TH * TW);
+            const int py = p / TW, px = p - py * TW;
+            const bool ok = (m < g.M) & (y0 + py < g.H) & (x0 + px < g.W);
+            vy[it] = fd_ldg32(rsY, ok ? 4u * (((unsigned)(n * g.M + m)) * hw + (unsigned)((y0 + py) * g.W + x0 + px)) : FD_OOB);
+        }
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+            float vx[NXI];
+#pragma unroll
+            for (int it = 0; it < NXI; ++it) {
+                const int i = tid + it * 256;
+                const int c = i / (PR * PCW), q = i - c * (PR * PCW);
+                const int pr = q / PCW, pc = q - pr * PCW;
+                const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
+                const unsigned plane = ((unsigned)(n * C + cg * 16 + c)) * hw;
+                unsigned off;
+                if (g.pad_mode == 1) {
+                    off = 4u * (plane + (unsigned)(refl_clamp_idx(yy, g.H) * g.W + refl_clamp_idx(xx, g.W)));
+                } else {
+                    const bool in = ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
+                    off = in ? 4u * (plane + (unsigned)(yy * g.W + xx)) : FD_OOB;
+                }
+                vx[it] = fd_ldg32(rsX, i < 16 * PR * PCW ? off : FD_OOB);
+            }
+            if (cg == 0) {
+#pragma unroll
+                for (int it = 0; it < NYI; ++it) {
+                    const int i = tid + it * 256;
+                    const int m = i / (TH * TW), p = i - m * (TH * TW);
+                    sY[m * YS + p] = vy[it];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NXI; ++it) {
+                const int i = tid + it * 256;
+                const int c = i / (PR * PCW), q = i - c * (PR * PCW);
+                const int pr = q / PCW, pc = q - pr * PCW;
+                if (i < 16 * PR * PCW) sX[(cg * 16 + c) * XCS + pr * XRS + pc] = vx[it];
+            }
+        }
+        __syncthreads();
+        // ---- wave `wave` owns tile row `wave`: 16 k-steps of 4 pixels
+        const float* pa = sY + li * YS + wave * TW + lk;
+        const float* pb = sX + li * XCS + wave * XRS + lk;
+#pragma unroll 2
+        for (int ks = 0; ks < TW / 4; ++ks) {
+            const float a = pa[4 * ks];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) {
+                        const float b = pb[c * 16 * XCS + dy * XRS + 4 * ks + dx];
+                        acc[dy * 3 + dx][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[dy * 3 + dx][c], 0, 0, 0);
+                    }
+        }
+    }
+    // ---- sum the four waves (fixed order) and write this workgroup's partial slab [m][c][tap]
+    float* slab = g.slabs + (size_t)blockIdx.x * g.M * C * 9;
+    float* red = smem;                          // [4 waves][CG][64 lanes][4 regs]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CG; ++c)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) red[((wave * CG + c) * 64 + lane) * 4 + rg] = acc[t][c][rg];
+        __syncthreads();
+        for (int i = tid; i < CG * 256; i += 256) {
+            const int c = i >> 8, q = i & 255, ln = q >> 2, rg = q & 3;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s += red[((w * CG + c) * 64 + ln) * 4 + rg];
+            const int m = 4 * (ln >> 4) + rg, ch = c * 16 + (ln & 15);      // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
+            if (m < g.M) slab[(m * C + ch) * 9 + t] = s;
+        }
+    }
+}
+
+// out[i] (+)= sum_z slabs[z][i], z-parallel: 8 thread groups sum contiguous z ranges, combined in group order.
+__global__ void __launch_bounds__(256) k_reduce_slabs_z(const float* __restrict__ slabs, float* __restrict__ out, int n, int nslab,
+                                                        int accumulate) {
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, zg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
+    const int per = (nslab + 7) / 8;
+    const int z0 = zg * per, z1 = z0 + per < nslab ? z0 + per : nslab;
+    float s = 0.f;
+    if (i < n)
+        for (int z = z0; z < z1; ++z) s += slabs[(size_t)z * n + i];
+    part[zg][e] = s;
+    __syncthreads();
+    if (zg == 0 && i < n) {
+        float t = accumulate ? out[i] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += part[k][e];
+        out[i] = t;
+    }
+}
+
+}  // namespace
+
+bool narrow_wgrad_ok(const fd_conv_desc* d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->in_norm && (d->Cin == 16 || d->Cin == 32) &&
+           d->Cout <= 16 && (double)d->N * d->Cin * d->H * d->W * 4.0 < 2147483648.0;
+}
+
+int narrow_wgrad_blocks(const fd_conv_desc* d) {
+    const long tiles = (long)d->N * ((d->H + TH - 1) / TH) * ((d->W + TW - 1) / TW);
+    return (int)(tiles < 512 ? tiles : 512);
+}
+
+long narrow_wgrad_ws_floats(const fd_conv_desc* d) { return (long)narrow_wgrad_blocks(d) * d->Cout * d->Cin * 9; }
+
+int narrow_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate,
+                        hipStream_t st) {
+    NarrowWgradArgs a;
+    a.X = x; a.dY = gy; a.slabs = ws; a.N = d->N; a.M = d->Cout; a.H = d->H; a.W = d->W; a.pad_mode = d->pad_mode;
+    const int blocks = narrow_wgrad_blocks(d);
+    const int cg = d->Cin / 16;
+    const size_t lds = sizeof(float) * ((size_t)d->Cin * XCS + 16 * YS);
+    if (cg == 1) {
+        hipLaunchKernelGGL(k_wgrad_narrow<1>, dim3(blocks), dim3(256), lds, st, a);
+    } else {
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_narrow<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
+        }
+        hipLaunchKernelGGL(k_wgrad_narrow<2>, dim3(blocks), dim3(256), lds, st, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_wgrad_narrow launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    const int n = d->Cout * d->Cin * 9;
+    hipLaunchKernelGGL(k_reduce_slabs_z, dim3((n + 31) / 32), dim3(256), 0, st, ws, gw, n, blocks, accumulate);
+    e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_reduce_slabs_z launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
