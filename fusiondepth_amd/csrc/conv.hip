@@ -858,6 +858,7 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     const long wsz = (long)d->Cout * d->Cin * d->KH * d->KW;
     long slabs;
     if (narrow_wgrad_ok(d)) slabs = narrow_wgrad_ws_floats(d);
+    else if (stem_wgrad_ok(d)) slabs = stem_wgrad_ws_floats(d);
     else if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
     else { const int sp = wgrad_splits(d, s); slabs = sp > 1 ? (long)sp * wsz : 0; }
     const long bias_part = (long)d->Cout * CS_SPLITS;
@@ -877,6 +878,8 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
     const long Np = (long)d->N * s.Ho * s.Wo;
     if (narrow_wgrad_ok(d)) {
         if (int rc = narrow_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
+    } else if (stem_wgrad_ok(d)) {
+        if (int rc = stem_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
     } else if (fast_wgrad_ok(d)) {
         FastWgradArgs f = {};
         f.dY = gy; f.X = x; f.slabs = ws;

@@ -12,3 +12,7 @@ bool narrow_wgrad_ok(const fd_conv_desc* d);
 long narrow_wgrad_ws_floats(const fd_conv_desc* d);
 int narrow_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate,
                         hipStream_t st);
+
+bool stem_wgrad_ok(const fd_conv_desc* d);
+long stem_wgrad_ws_floats(const fd_conv_desc* d);
+int stem_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st);

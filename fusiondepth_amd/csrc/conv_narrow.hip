@@ -164,7 +164,149 @@ __global__ void __launch_bounds__(256) k_reduce_slabs_z(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 7x7 stride-2 pad-3 ResNet stems (networks/resnet_encoder.py:92, Cin = 2 / 3 / 4 / 6 after the
+// input-channel variants of :53-76): M = 64, J = 49*Cin, K = N*Ho*Wo.  Same structure as above: a 4 x 32 output tile of dY
+// (64 rows) and the (2*4+5) x (2*32+5) input patch per channel in LDS, zero padding resolved while staging.  The MFMA
+// N axis is a block of taps: column n = (dy & 1, dx) of a row pair -> 16 columns per (row pair, channel), 49 of 64 used.
+// Wave w owns dY rows 16w .. 16w+15 and walks all 128 pixels of the tile: 4 row pairs x Cin accumulators.
+constexpr int STW = 32, STH = 4;                       // output-pixel tile
+constexpr int SPR = 2 * STH + 5, SPC = 2 * STW + 5;     // input patch rows / columns (13 x 69)
+constexpr int SXRS = 70;                               // patch row stride
+constexpr int SXCS = SPR * SXRS + 2;                   // patch channel stride (912)
+constexpr int SYS = 132;                               // dY row stride: >= 128 and = 4 (mod 64)
+static_assert(SYS >= STH * STW && SYS % 64 == 4, "stem LDS strides");
+
+template <int C>
+__global__ void __launch_bounds__(256) k_wgrad_stem(NarrowWgradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sX = smem;                          // [C][SXCS]
+    float* sY = smem + C * SXCS;               // [64][SYS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsX = fd_make_rsrc(g.X), rsY = fd_make_rsrc(g.dY);
+    const int Ho = (g.H + 6 - 7) / 2 + 1, Wo = (g.W + 6 - 7) / 2 + 1;
+    const int tiles_x = (Wo + STW - 1) / STW, tiles_y = (Ho + STH - 1) / STH;
+    const int tiles_per_img = tiles_x * tiles_y;
+    const int ntiles = g.N * tiles_per_img;
+    const unsigned hw = (unsigned)(g.H * g.W), howo = (unsigned)(Ho * Wo);
+
+    f32x4 acc[4][C];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B operand of column n = li: tap row parity li >> 3, tap column li & 7 (column 7 and row 7 are padding, never stored)
+    const int boff = (li >> 3) * SXRS + (li & 7) + 2 * lk;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int y0 = ty * STH, x0 = tx * STW;                 // output coordinates
+        const int iy0 = 2 * y0 - 3, ix0 = 2 * x0 - 3;           // input coordinates of the patch origin
+        __syncthreads();
+        constexpr int NXI = (C * SPR * SPC + 255) / 256, NYI = 64 * STH * STW / 256;
+        float vx[NXI];
+#pragma unroll
+        for (int it = 0; it < NXI; ++it) {
+            const int i = tid + it * 256;
+            const int c = i / (SPR * SPC), q = i - c * (SPR * SPC);
+            const int pr = q / SPC, pc = q - pr * SPC;
+            const int yy = iy0 + pr, xx = ix0 + pc;
+            const bool in = (i < C * SPR * SPC) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
+            vx[it] = fd_ldg32(rsX, in ? 4u * (((unsigned)(n * C + c)) * hw + (unsigned)(yy * g.W + xx)) : FD_OOB);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                            // dY in two halves of 16 loads (bounds the registers)
+            float vy[NYI / 2];
+#pragma unroll
+            for (int it = 0; it < NYI / 2; ++it) {
+                const int i = tid + (h * (NYI / 2) + it) * 256;
+                const int m = i / (STH * STW), p = i - m * (STH * STW);
+                const int py = p / STW, px = p - py * STW;
+                const bool ok = (m < g.M) & (y0 + py < Ho) & (x0 + px < Wo);
+                vy[it] = fd_ldg32(rsY, ok ? 4u * (((unsigned)(n * g.M + m)) * howo + (unsigned)((y0 + py) * Wo + x0 + px)) : FD_OOB);
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int it = 0; it < NXI; ++it) {
+                    const int i = tid + it * 256;
+                    const int c = i / (SPR * SPC), q = i - c * (SPR * SPC);
+                    const int pr = q / SPC, pc = q - pr * SPC;
+                    if (i < C * SPR * SPC) sX[c * SXCS + pr * SXRS + pc] = vx[it];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NYI / 2; ++it) {
+                const int i = tid + (h * (NYI / 2) + it) * 256;
+                const int m = i / (STH * STW), p = i - m * (STH * STW);
+                sY[m * SYS + p] = vy[it];
+            }
+        }
+        __syncthreads();
+        const float* pa = sY + (wave * 16 + li) * SYS + lk;
+#pragma unroll 1
+        for (int py = 0; py < STH; ++py) {
+#pragma unroll 2
+            for (int ks = 0; ks < STW / 4; ++ks) {
+                const float a = pa[py * STW + 4 * ks];
+                const float* pb = sX + (2 * py) * SXRS + 8 * ks + boff;     // input row 2*py + dy, column 2*(4ks + k) + dx
+#pragma unroll
+                for (int dp = 0; dp < 4; ++dp)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float b = pb[c * SXCS + 2 * dp * SXRS];
+                        acc[dp][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[dp][c], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // ---- this workgroup's partial slab [m][c][7][7]; wave w holds rows 16w..16w+15 (no cross-wave sum needed)
+    float* slab = g.slabs + (size_t)blockIdx.x * g.M * C * 49;
+#pragma unroll
+    for (int dp = 0; dp < 4; ++dp)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int m = wave * 16 + 4 * lk + rg;             // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
+                const int dy = 2 * dp + (li >> 3), dx = li & 7;
+                if (m < g.M && dy < 7 && dx < 7) slab[(m * C + c) * 49 + dy * 7 + dx] = acc[dp][c][rg];
+            }
+}
+
 }  // namespace
+
+bool stem_wgrad_ok(const fd_conv_desc* d) {
+    return d->KH == 7 && d->KW == 7 && d->stride == 2 && d->pad == 3 && d->pad_mode == 0 && !d->in_norm && d->Cout <= 64 &&
+           (d->Cin == 2 || d->Cin == 3 || d->Cin == 4 || d->Cin == 6) && (double)d->N * d->Cout * d->H * d->W < 2147483648.0;
+}
+static int stem_blocks(const fd_conv_desc* d) {
+    const int Ho = (d->H - 1) / 2 + 1, Wo = (d->W - 1) / 2 + 1;
+    const long tiles = (long)d->N * ((Ho + STH - 1) / STH) * ((Wo + STW - 1) / STW);
+    return (int)(tiles < 512 ? tiles : 512);
+}
+long stem_wgrad_ws_floats(const fd_conv_desc* d) { return (long)stem_blocks(d) * d->Cout * d->Cin * 49; }
+
+int stem_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st) {
+    NarrowWgradArgs a;
+    a.X = x; a.dY = gy; a.slabs = ws; a.N = d->N; a.M = d->Cout; a.H = d->H; a.W = d->W; a.pad_mode = 0;
+    const int blocks = stem_blocks(d);
+    const size_t lds = sizeof(float) * ((size_t)d->Cin * SXCS + 64 * SYS);
+    switch (d->Cin) {
+        case 2: hipLaunchKernelGGL(k_wgrad_stem<2>, dim3(blocks), dim3(256), lds, st, a); break;
+        case 3: hipLaunchKernelGGL(k_wgrad_stem<3>, dim3(blocks), dim3(256), lds, st, a); break;
+        case 4: hipLaunchKernelGGL(k_wgrad_stem<4>, dim3(blocks), dim3(256), lds, st, a); break;
+        default: hipLaunchKernelGGL(k_wgrad_stem<6>, dim3(blocks), dim3(256), lds, st, a); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_wgrad_stem launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    const int n = d->Cout * d->Cin * 49;
+    hipLaunchKernelGGL(k_reduce_slabs_z, dim3((n + 31) / 32), dim3(256), 0, st, ws, gw, n, blocks, accumulate);
+    e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_reduce_slabs_z launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
 
 bool narrow_wgrad_ok(const fd_conv_desc* d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->in_norm && (d->Cin == 16 || d->Cin == 32) &&

@@ -64,6 +64,10 @@ CONV_CASES = [
     (2, 256, 2, 3, 12, 1, 1, 0, "zero", "none", True, False),      # pose out
     (2, 16, 20, 28, 32, 5, 2, 2, "zero", "relu", True, False),     # PoseCNN 5x5
     (1, 64, 48, 160, 64, 3, 1, 1, "zero", "none", False, False),   # layer1 at full 192x640 resolution
+    (2, 3, 32, 48, 64, 7, 2, 3, "zero", "none", False, False),     # stems on a pre-normalised input: dedicated wgrad kernel
+    (1, 6, 30, 44, 64, 7, 2, 3, "zero", "none", False, False),
+    (2, 2, 37, 131, 64, 7, 2, 3, "zero", "none", False, False),    # ragged tiles, odd sizes
+    (3, 4, 64, 160, 64, 7, 2, 3, "zero", "none", False, False),
     (2, 32, 37, 130, 16, 3, 1, 1, "reflect", "elu", True, False),  # upconv(0,0): narrow wgrad kernel, 2 channel groups, ragged tiles
     (3, 32, 9, 70, 1, 3, 1, 1, "reflect", "sigmoid", True, False), # dispconv(1) shape class, Cout = 1
     (2, 16, 21, 67, 12, 3, 1, 1, "zero", "none", False, False),    # narrow kernel with zero padding
