@@ -386,18 +386,19 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
     }
 }
 
-// gw[m][c][t] (OIHW) = sum_z slabs[z][m][t][c]
+// gw[m][c][t] (OIHW) = sum_z slabs[z][m][t][c].  Threads enumerate the SLAB order (c fastest): the splits x n slab reads
+// are coalesced, the single n-element result is written with a T-float stride.
 __global__ void __launch_bounds__(256) k_wgrad_finish(const float* __restrict__ slabs, float* __restrict__ gw, int M, int C,
                                                       int T, int splits, int accumulate) {
     const long n = (long)M * C * T;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int t = (int)(i % T);
-        const int c = (int)((i / T) % C);
+        const int c = (int)(i % C);
+        const int t = (int)((i / C) % T);
         const int m = (int)(i / ((long)T * C));
-        const size_t src = ((size_t)m * T + t) * C + c;
-        float s = accumulate ? gw[i] : 0.f;
-        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + src];
-        gw[i] = s;
+        const size_t dst = ((size_t)m * C + c) * T + t;
+        float s = accumulate ? gw[dst] : 0.f;
+        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + i];
+        gw[dst] = s;
     }
 }
 

@@ -165,14 +165,17 @@ class Trainer:
         evaluated per micro-batch, and the other loss terms are means, so loss = sum_g loss_g / accumulate_step and its
         gradient equal the reference's accumulated values while every kernel sees twice the work per launch.
         Returns the loss dict (device tensors; nothing is synchronised here)."""
-        assert len(micro_batches) == self.accumulate_step
+        prestacked = isinstance(micro_batches, dict)       # a loader that already delivers the step's images as one batch
+        assert prestacked or len(micro_batches) == self.accumulate_step
         if self.stack_microbatches:
             self.grad_sync.arm()
-            outputs, losses = self.process_batch(self.stack_micro_batches(micro_batches), groups=self.accumulate_step)
+            stacked = micro_batches if prestacked else self.stack_micro_batches(micro_batches)
+            outputs, losses = self.process_batch(stacked, groups=self.accumulate_step)
             losses["loss"].backward()
             self._join_side_streams()
             self.batch_idx += self.accumulate_step
         else:
+            assert not prestacked, "pre-stacked input needs stack_microbatches"
             losses = None
             for i, inputs in enumerate(micro_batches):
                 last = i == self.accumulate_step - 1
