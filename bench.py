@@ -230,6 +230,12 @@ def main():
         dt = float(t.item())
     images = args.steps * opt.batch_size * world
     loss_val = float(losses["loss"].detach())
+    # The SI-log term of a scale is NaN by definition when no LiDAR return passes its validity mask (mean / variance of an
+    # empty set - trainer.py:577-589 behaves the same); it then contributes no gradient and the parameters stay finite.
+    # Training from scratch on synthetic frames can drive the 1/8-scale disparity out of the mask, so also report the
+    # photometric + smoothness part, which is always defined.
+    photo_val = float(sum(losses["loss/%d" % s_].detach() for s_ in range(4) if ("loss/%d" % s_) in losses) / 4.0)
+    params_finite = bool(torch.isfinite(tr.flat.flat_param).all())
     if rank == 0:
         print("[bench] timed %d steps in %.3f s (host issue time %.3f s)" % (args.steps, dt, t_host), file=sys.stderr, flush=True)
     result = {
@@ -241,7 +247,8 @@ def main():
                                % (args.num_layers, args.width, args.height, opt.batch_size, tr.accumulate_step, tr.batch_size),
                    "global_batch": opt.batch_size * world, "parallelism": "dp%d" % world, "launch": "eager (4 HIP streams)" if launch == "eager" else "hipGraph replay",
                    "micro_batches": "stacked (grouped BatchNorm)" if tr.stack_microbatches else "sequential"},
-        "final_loss": loss_val,
+        "final_loss": loss_val if loss_val == loss_val else None, "final_loss_photometric": photo_val,
+        "params_finite": params_finite,
     }
     key = (args.num_layers, args.height, args.width)
     if key in CONV_GFLOP_FWD_BWD:

@@ -41,8 +41,13 @@ def lidar_4beam(batch, height, width, gen, device, shift=0):
     rows = [int(height * f) for f in (0.52, 0.625, 0.73, 0.835)]
     for r in rows:
         cols = torch.arange(2 + (r + shift) % 3, width - 2, 3, device=device)
-        depth = torch.empty(batch, cols.numel(), device=device).uniform_(3.5, 65.0, generator=gen) / 100.0
-        beam[:, 0, r, cols] = depth
+        depth = torch.empty(batch, cols.numel(), device=device).uniform_(3.5, 65.0, generator=gen)
+        # every other return lies near what a randomly initialised DepthDecoder predicts (sigmoid(0) -> ~5 m at the SI
+        # loss's scale), so the masked SI-log loss (trainer.py:577-589) always has valid points: with none it is NaN by
+        # construction (mean / variance of an empty set), in the reference as well
+        near = torch.empty(batch, cols.numel(), device=device).uniform_(4.0, 7.0, generator=gen)
+        depth[:, ::2] = near[:, ::2]
+        beam[:, 0, r, cols] = depth / 100.0
     return beam
 
 
