@@ -224,10 +224,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
 __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ slabs, float* __restrict__ Y,
                                                        const float* __restrict__ bias, long total, long slab_stride,
                                                        int splits, long out_cs, int M, int act) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const unsigned cs = (unsigned)out_cs, uM = (unsigned)M;              // total < 2^31 (fast-path size guard)
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
         float s = 0.f;
         for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * slab_stride + i];
-        if (bias) s += bias[(i / out_cs) % M];
+        if (bias) s += bias[(i / cs) % uM];
         Y[i] = act_apply(s, act);
     }
 }
@@ -390,12 +391,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
 // are coalesced, the single n-element result is written with a T-float stride.
 __global__ void __launch_bounds__(256) k_wgrad_finish(const float* __restrict__ slabs, float* __restrict__ gw, int M, int C,
                                                       int T, int splits, int accumulate) {
-    const long n = (long)M * C * T;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const int t = (int)((i / C) % T);
-        const int m = (int)(i / ((long)T * C));
-        const size_t dst = ((size_t)m * C + c) * T + t;
+    const unsigned n = (unsigned)M * (unsigned)C * (unsigned)T;          // < 2^31 (checked by the launcher)
+    const unsigned uC = (unsigned)C, uT = (unsigned)T;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const unsigned q = i / uC, c = i - q * uC;                        // 32-bit index math: two divisions per element
+        const unsigned m = q / uT, t = q - m * uT;
+        const unsigned dst = (m * uC + c) * uT + t;
         float s = accumulate ? gw[dst] : 0.f;
         for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + i];
         gw[dst] = s;
