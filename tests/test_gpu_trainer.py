@@ -131,6 +131,39 @@ def test_trainer_matches_oracle_over_optimizer_steps():
     assert float((pg - po).abs().max()) <= 3 * 3 * tr.lr + 1e-6, "a parameter moved further than Adam allows"
 
 
+@pytest.mark.parametrize("layers,H,W,B", [(50, 64, 96, 2), (18, 320, 1024, 2)], ids=["C3-resnet50", "C4-1024x320"])
+def test_other_baseline_configs_match_oracle(layers, H, W, B):
+    """BASELINE.json configs 3 (ResNet-50) and 4 (1024x320) as parity cases: losses and disparities of the first forward
+    pass, then the loss after one optimiser step, against the oracle harness (same weights, inputs, tie-break noise)."""
+    opt = _opts(num_layers=layers, height=H, width=W, batch_size=B)
+    tr, ot = _make_pair(opt)
+    losses_seq = []
+    for step in range(2):
+        inp, noise = _batch(B, H, W, 700 + step)
+        ginp = {k: v.cuda() for k, v in inp.items()}
+        ginp["_noise"] = [n.cuda() for n in noise]
+        outs_o, losses_o = ot.micro_step({k: v.clone() for k, v in inp.items()}, noise)
+        if step == 0:
+            saved = {k: {n: b.clone() for n, b in m.named_buffers()} for k, m in tr.models.items()}
+            outs_g, losses_g = tr.process_batch(ginp)
+            for k in losses_o:
+                assert_close(float(losses_g[k]), float(losses_o[k]), rtol=5e-4, atol=1e-6, what="step0 " + k)
+            for s in range(4):
+                assert_close(outs_g[("disp", s)].detach().cpu().numpy(), outs_o[("disp", s)].detach().numpy(), rtol=2e-3,
+                             atol=2e-4, what="disp%d" % s)
+            tr.flat.zero_grad()
+            with torch.no_grad():
+                for k, m in tr.models.items():
+                    for n, b in m.named_buffers():
+                        b.copy_(saved[k][n])
+        lg = tr.train_step([ginp])
+        losses_seq.append((float(lg["loss"]), float(losses_o["loss"])))
+    print("loss (HIP, oracle) per step:", losses_seq)
+    assert np.isfinite(losses_seq).all()
+    assert_close(losses_seq[0][0], losses_seq[0][1], rtol=5e-4, atol=0, what="loss at step 0")
+    assert_close(losses_seq[1][0], losses_seq[1][1], rtol=1e-2, atol=0, what="loss after one optimiser step")
+
+
 def test_accumulate_semantics_batch12():
     """--batch_size 12 -> accumulate 2 x micro-batch 6, lr 1.5e-4, StepLR step 6 (trainer.py:28-41)."""
     from fusiondepth_amd.trainer import Trainer
