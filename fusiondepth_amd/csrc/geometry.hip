@@ -414,15 +414,18 @@ __global__ void k_bilinear_fwd(const float* __restrict__ x, float* __restrict__ 
                                ly * (hx * xi[y1 * Win + x0] + lx * xi[y1 * Win + x1]);
     }
 }
-// adjoint in gather form: each input pixel collects from the output pixels whose 2x2 footprint holds it
+// Adjoint in gather form: each input pixel collects from the output pixels whose 2x2 footprint holds it.  The bilinear
+// weight factorises, w(oy, ox) = wy(oy) * wx(ox): the column weights of the candidate window are computed once per
+// thread (<= MAXW = 24 candidates for upsampling ratios <= 8, the four pyramid scales), then every candidate row costs one weight + a short dot product.
 __global__ void k_bilinear_bwd(const float* __restrict__ gy, float* __restrict__ gx, int Hin, int Win, int Hout,
                                int Wout, float sh, float sw) {
+    constexpr int MAXW = 24;
     const int bc = blockIdx.y;
-    const long Pi = (long)Hin * Win;
+    const int Pi = Hin * Win;
     const float* g = gy + (long)bc * Hout * Wout;
     const int ry = (Hout + Hin - 1) / Hin, rx = (Wout + Win - 1) / Win;  // upsampling ratio (ceil)
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < Pi; p += (long)gridDim.x * blockDim.x) {
-        int iy = (int)(p / Win), ix = (int)(p % Win);
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Pi; p += gridDim.x * blockDim.x) {
+        const int iy = p / Win, ix = p - iy * Win;
         // output rows whose source interval [y0, y1] contains iy satisfy (iy-0.5)*r - 0.5 <= oy < (iy+1.5)*r - 0.5
         // (before edge clamping, which only adds rows at the borders handled by the max/min below); one extra on each side
         int oy_lo = (2 * iy - 1) * ry / 2 - 2, oy_hi = (2 * iy + 3) * ry / 2 + 1;
@@ -434,16 +437,40 @@ __global__ void k_bilinear_bwd(const float* __restrict__ gy, float* __restrict__
         oy_lo = oy_lo < 0 ? 0 : oy_lo; ox_lo = ox_lo < 0 ? 0 : ox_lo;
         oy_hi = oy_hi > Hout - 1 ? Hout - 1 : oy_hi; ox_hi = ox_hi > Wout - 1 ? Wout - 1 : ox_hi;
         float acc = 0.f;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            int y0, y1; float ly;
-            fd_bilinear_src(oy, sh, Hin, y0, y1, ly);
-            float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
-            if (wy == 0.f) continue;
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const int nx = ox_hi - ox_lo + 1;
+        if (nx <= MAXW) {
+            float wxs[MAXW];
+#pragma unroll
+            for (int k = 0; k < MAXW; ++k) {
                 int x0, x1; float lx;
+                const int ox = ox_lo + k < Wout ? ox_lo + k : Wout - 1;
                 fd_bilinear_src(ox, sw, Win, x0, x1, lx);
-                float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-                if (wx != 0.f) acc += wy * wx * g[(long)oy * Wout + ox];
+                const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                wxs[k] = k < nx ? wx : 0.f;
+            }
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                int y0, y1; float ly;
+                fd_bilinear_src(oy, sh, Hin, y0, y1, ly);
+                const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                if (wy == 0.f) continue;
+                const float* row = g + (long)oy * Wout + ox_lo;
+                // same accumulation order as the scalar form below: ox ascending, zero weights skipped
+#pragma unroll
+                for (int k = 0; k < MAXW; ++k)
+                    if (wxs[k] != 0.f) acc += wy * wxs[k] * row[k < nx ? k : 0];
+            }
+        } else {
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                int y0, y1; float ly;
+                fd_bilinear_src(oy, sh, Hin, y0, y1, ly);
+                float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                if (wy == 0.f) continue;
+                for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                    int x0, x1; float lx;
+                    fd_bilinear_src(ox, sw, Win, x0, x1, lx);
+                    float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                    if (wx != 0.f) acc += wy * wx * g[(long)oy * Wout + ox];
+                }
             }
         }
         gx[(long)bc * Pi + p] = acc;

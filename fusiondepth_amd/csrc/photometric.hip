@@ -22,6 +22,26 @@ constexpr int W1 = TW + 2, H1 = TH + 2;  // halo-1 region (SSIM window of tile p
 constexpr int W2 = TW + 4, H2 = TH + 4;  // halo-2 region (SSIM windows of halo-1 pixels, backward)
 constexpr float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
 
+// The kernels below are VALU-bound (profiles/round1_pmc_loss.md) and an IEEE fp32 division expands to ~10 instructions.
+// fdiv: v_rcp_f32 + one Newton-Markstein correction with FMAs (4 instructions) - the correctly rounded quotient except
+// in rare last-bit cases.  div9 / div3: division by a constant as multiply + FMA residual + FMA correction, which
+// reproduces IEEE division bit for bit (checked on 8M samples) - the window means and E[x^2] - mu^2 variances of the SSIM
+// cancel catastrophically, so their divisions by 9 must round exactly as the reference's AvgPool2d does.
+__device__ __forceinline__ float fdiv(float a, float b) {
+    const float rc = __builtin_amdgcn_rcpf(b);
+    const float q0 = a * rc;
+    return fmaf(fmaf(-q0, b, a), rc, q0);
+}
+__device__ __forceinline__ float frcp(float x) { return fdiv(1.0f, x); }
+__device__ __forceinline__ float div9(float x) {
+    const float q0 = x * (1.0f / 9.0f);
+    return fmaf(fmaf(-q0, 9.0f, x), 1.0f / 9.0f, q0);
+}
+__device__ __forceinline__ float div3(float x) {
+    const float q0 = x * (1.0f / 3.0f);
+    return fmaf(fmaf(-q0, 3.0f, x), 1.0f / 3.0f, q0);
+}
+
 __device__ __forceinline__ int refl_clamp(int i, int n) {
     i = i < 0 ? -i : i;
     i = i >= n ? 2 * n - 2 - i : i;
@@ -33,6 +53,7 @@ struct Cam {
     float lo, span;
     float sh, sw;  // Hs/H, Ws/W
     float eps;
+    float rw1, rh1;   // 1/(W-1), 1/(H-1)
     int H, W, Hs, Ws;
 };
 
@@ -46,6 +67,7 @@ __device__ __forceinline__ Cam make_cam(const fd_photo_cfg& c, const float* invK
     cm.sh = (float)c.Hs / (float)c.H;
     cm.sw = (float)c.Ws / (float)c.W;
     cm.eps = c.eps;
+    cm.rw1 = 1.0f / (float)(c.W - 1); cm.rh1 = 1.0f / (float)(c.H - 1);     // used for gradients only (see project)
     cm.H = c.H; cm.W = c.W; cm.Hs = c.Hs; cm.Ws = c.Ws;
     return cm;
 }
@@ -65,7 +87,7 @@ __device__ __forceinline__ float disp_up_at(const float* __restrict__ d, const C
 struct Samp {      // grid_sample(border, bilinear, align_corners=False) source position
     float gx, gy;  // normalised grid (the reference's ("sample", f, s))
     float ix, iy;  // clipped source coordinates
-    float u, v, den;
+    float u, v, den, rden;
     float X[3];    // camera point
     float ray[3];
     float depth;
@@ -76,7 +98,7 @@ struct Samp {      // grid_sample(border, bilinear, align_corners=False) source 
 
 __device__ __forceinline__ void project(const Cam& cm, const float* __restrict__ P, float dup, int y, int x, Samp& s) {
     const float fx = (float)x, fy = (float)y;
-    s.depth = 1.0f / (cm.lo + cm.span * dup);                       // layers.py:18-19
+    s.depth = frcp(cm.lo + cm.span * dup);                          // layers.py:18-19
     s.ray[0] = cm.ik[0] * fx + cm.ik[1] * fy + cm.ik[2];            // layers.py:158
     s.ray[1] = cm.ik[3] * fx + cm.ik[4] * fy + cm.ik[5];
     s.ray[2] = cm.ik[6] * fx + cm.ik[7] * fy + cm.ik[8];
@@ -85,13 +107,14 @@ __device__ __forceinline__ void project(const Cam& cm, const float* __restrict__
     const float c1 = P[4] * s.X[0] + P[5] * s.X[1] + P[6] * s.X[2] + P[7];
     const float c2 = P[8] * s.X[0] + P[9] * s.X[1] + P[10] * s.X[2] + P[11];
     s.den = c2 + cm.eps;
-    s.u = c0 / s.den;                                               // layers.py:221
-    s.v = c1 / s.den;
-    s.gx = (s.u / (float)(cm.W - 1) - 0.5f) * 2.0f;                 // layers.py:224-226
-    s.gy = (s.v / (float)(cm.H - 1) - 0.5f) * 2.0f;
+    s.rden = frcp(s.den);
+    s.u = fdiv(c0, s.den);                                          // layers.py:221
+    s.v = fdiv(c1, s.den);
+    s.gx = (fdiv(s.u, (float)(cm.W - 1)) - 0.5f) * 2.0f;            // layers.py:224-226
+    s.gy = (fdiv(s.v, (float)(cm.H - 1)) - 0.5f) * 2.0f;
     // aten GridSampler.h: unnormalize (align_corners=False) then clip_coordinates (border)
-    float ix = ((s.gx + 1.0f) * (float)cm.W - 1.0f) / 2.0f;
-    float iy = ((s.gy + 1.0f) * (float)cm.H - 1.0f) / 2.0f;
+    float ix = ((s.gx + 1.0f) * (float)cm.W - 1.0f) * 0.5f;
+    float iy = ((s.gy + 1.0f) * (float)cm.H - 1.0f) * 0.5f;
     const float xm = (float)(cm.W - 1), ym = (float)(cm.H - 1);
     s.mx = (ix <= 0.f || ix >= xm) ? 0.f : (float)cm.W * 0.5f;      // clip_coordinates_set_grad
     s.my = (iy <= 0.f || iy >= ym) ? 0.f : (float)cm.H * 0.5f;
@@ -125,28 +148,29 @@ __device__ __forceinline__ void gather3(const float* __restrict__ src, const Cam
 
 // SSIM loss value from the five 3x3 window sums (layers.py:267-281).
 __device__ __forceinline__ float ssim_from_sums(float Sx, float Sy, float Sxx, float Syy, float Sxy) {
-    const float mx = Sx / 9.0f, my = Sy / 9.0f;
-    const float sx = Sxx / 9.0f - mx * mx, sy = Syy / 9.0f - my * my, sxy = Sxy / 9.0f - mx * my;
+    const float mx = div9(Sx), my = div9(Sy);
+    const float sx = div9(Sxx) - mx * mx, sy = div9(Syy) - my * my, sxy = div9(Sxy) - mx * my;
     const float n = (2.f * mx * my + C1) * (2.f * sxy + C2);
     const float d = (mx * mx + my * my + C1) * (sx + sy + C2);
-    const float v = (1.f - n / d) / 2.f;
+    const float v = (1.f - fdiv(n, d)) * 0.5f;
     return fminf(fmaxf(v, 0.f), 1.f);
 }
 
 // d(SSIM loss)/d(mu_x, E[x^2], E[xy]) at one window; all zero where the clamp is active.
 __device__ __forceinline__ void ssim_coefs(float Sx, float Sy, float Sxx, float Syy, float Sxy, float w, float& ca,
                                            float& cb, float& cc) {
-    const float mx = Sx / 9.0f, my = Sy / 9.0f;
-    const float sx = Sxx / 9.0f - mx * mx, sy = Syy / 9.0f - my * my, sxy = Sxy / 9.0f - mx * my;
+    const float mx = div9(Sx), my = div9(Sy);
+    const float sx = div9(Sxx) - mx * mx, sy = div9(Syy) - my * my, sxy = div9(Sxy) - mx * my;
     const float A1 = 2.f * mx * my + C1, A2 = 2.f * sxy + C2;
     const float B1 = mx * mx + my * my + C1, B2 = sx + sy + C2;
     const float n = A1 * A2, d = B1 * B2;
-    const float q = n / d;
-    const float v = (1.f - q) / 2.f;
+    const float rd = frcp(d);
+    const float q = n * rd;
+    const float v = (1.f - q) * 0.5f;
     if (!(v >= 0.f && v <= 1.f)) { ca = 0.f; cb = 0.f; cc = 0.f; return; }
-    ca = w * (-my * (A2 - A1) + q * mx * (B2 - B1)) / d;
-    cb = w * q / (2.f * B2);
-    cc = -w * A1 / d;
+    ca = w * (-my * (A2 - A1) + q * mx * (B2 - B1)) * rd;
+    cb = w * q * 0.5f * frcp(B2);
+    cc = -w * A1 * rd;
 }
 
 // Per-thread column pass: for the 4 owned pixels compute, per channel, the SSIM loss and |t-p| from
@@ -185,7 +209,7 @@ __device__ __forceinline__ void column_losses(const float* __restrict__ sx, cons
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) L[i] = SSIM ? 0.85f * (ss[i] / 3.0f) + 0.15f * (l1[i] / 3.0f) : l1[i] / 3.0f;
+    for (int i = 0; i < 4; ++i) L[i] = SSIM ? 0.85f * div3(ss[i]) + 0.15f * div3(l1[i]) : div3(l1[i]);
 }
 
 struct PhotoArgs {
@@ -280,7 +304,7 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
             if (first || v < best) { best = v; bi = k; first = false; }
         }
         if (cfg.avg_reprojection && NF == 2) {
-            const float v = (Lr[0][i] + Lr[1][i]) / 2.0f;
+            const float v = (Lr[0][i] + Lr[1][i]) * 0.5f;
             if (first || v < best) { best = v; bi = NI; first = false; }
         } else {
 #pragma unroll
@@ -293,7 +317,7 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
         acc[0] += best;
         a.sel[b * P + p] = (uint8_t)bi;
         if (a.beam) {  // trainer.py:577-589
-            const float depth = (1.0f / (cm.lo + cm.span * disp_up_at(disp_b, cm, y, x))) * cfg.si_depth_scale;
+            const float depth = frcp(cm.lo + cm.span * disp_up_at(disp_b, cm, y, x)) * cfg.si_depth_scale;
             const float bd = a.beam[b * P + p] * cfg.si_beam_scale;
             if (bd > 1.f && depth < 80.f && depth > 1.f && fabsf(depth - bd) < cfg.si_threshold) {
                 const float d = logf(depth) - logf(bd);
@@ -451,6 +475,21 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
             }
             __syncthreads();
         }
+        // 3x3 box sums of the three coefficient planes for the 4 owned pixels: horizontal 3-sums of the 6 halo-1 rows
+        // slide down the column (18 LDS reads per plane instead of 36).  Pixels on the second / second-to-last row or
+        // column of the IMAGE also collect the windows reached through the reflect padding: rare, handled by fold_sum.
+        float box[3][4];
+        if (SSIM) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float* pl = s_coef + k * H1 * W1 + (ty * 4) * W1 + tx;
+                float hs[6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) hs[r] = pl[r * W1] + pl[r * W1 + 1] + pl[r * W1 + 2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) box[k][i] = hs[i] + hs[i + 1] + hs[i + 2];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int y = y0t + ty * 4 + i;
@@ -459,10 +498,13 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
                 const int o = (ty * 4 + i + 2) * W2 + tx + 2;
                 const float xv = px[o], yv = py[o];
                 if (SSIM) {
-                    const float sa = fold_sum(s_coef, y, x, y0t, x0t, H, W);
-                    const float sb = fold_sum(s_coef + H1 * W1, y, x, y0t, x0t, H, W);
-                    const float sc = fold_sum(s_coef + 2 * H1 * W1, y, x, y0t, x0t, H, W);
-                    g = (sa + 2.f * xv * sb + yv * sc) / 9.0f;
+                    float sa = box[0][i], sb = box[1][i], sc = box[2][i];
+                    if (y == 1 || y == H - 2 || x == 1 || x == W - 2) {
+                        sa = fold_sum(s_coef, y, x, y0t, x0t, H, W);
+                        sb = fold_sum(s_coef + H1 * W1, y, x, y0t, x0t, H, W);
+                        sc = fold_sum(s_coef + 2 * H1 * W1, y, x, y0t, x0t, H, W);
+                    }
+                    g = div9(sa + 2.f * xv * sb + yv * sc);
                 }
                 if (s_sel[(ty * 4 + i + 1) * W1 + tx + 1] == my_sel) {
                     const float df = yv - xv;  // |t - p|' w.r.t. p
@@ -516,9 +558,9 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
                 gix += go[c] * ((ne - nw) * (1.f - s.fy) + (se - sw) * s.fy);
                 giy += go[c] * ((sw - nw) * (1.f - s.fx) + (se - ne) * s.fx);
             }
-            const float du = gix * s.mx * 2.0f / (float)(W - 1);
-            const float dv = giy * s.my * 2.0f / (float)(H - 1);
-            const float dc0 = du / s.den, dc1 = dv / s.den, dc2 = -(du * s.u + dv * s.v) / s.den;
+            const float du = gix * s.mx * 2.0f * cm.rw1;
+            const float dv = giy * s.my * 2.0f * cm.rh1;
+            const float dc0 = du * s.rden, dc1 = dv * s.rden, dc2 = -(du * s.u + dv * s.v) * s.rden;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 gp[j] += dc0 * s.X[j]; gp[4 + j] += dc1 * s.X[j]; gp[8 + j] += dc2 * s.X[j];
@@ -543,14 +585,15 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
         const int y = y0t + ty * 4 + i;
         if (y >= H || x >= W) continue;
         const long p = (long)y * W + x;
-        const float depth = 1.0f / (cm.lo + cm.span * disp_up_at(disp_b, cm, y, x));
+        const float sdisp = cm.lo + cm.span * disp_up_at(disp_b, cm, y, x);
+        const float depth = frcp(sdisp);
         float dd = d_depth[i];
         if (a.beam) {
             const float d26 = depth * cfg.si_depth_scale;
             const float bd = a.beam[b * P + p] * cfg.si_beam_scale;
             if (bd > 1.f && d26 < 80.f && d26 > 1.f && fabsf(d26 - bd) < cfg.si_threshold) {
                 const float d = logf(d26) - logf(bd);
-                dd += k_si * (d - cfg.si_var * m1) / depth;
+                dd += k_si * (d - cfg.si_var * m1) * sdisp;
             }
         }
         a.d_up[b * P + p] = -dd * depth * depth * cm.span;
@@ -688,7 +731,7 @@ __global__ void __launch_bounds__(NT) k_ssim_bwd(const float* __restrict__ xg, c
         const float sa = fold_sum(s_coef, y, x, y0t, x0t, H, W);
         const float sb = fold_sum(s_coef + H1 * W1, y, x, y0t, x0t, H, W);
         const float sc = fold_sum(s_coef + 2 * H1 * W1, y, x, y0t, x0t, H, W);
-        gx[base + (long)y * W + x] = (sa + 2.f * s_x[o] * sb + s_y[o] * sc) / 9.0f;
+        gx[base + (long)y * W + x] = div9(sa + 2.f * s_x[o] * sb + s_y[o] * sc);
     }
 }
 
