@@ -101,9 +101,13 @@ def roofline_probes(args, tr, batch):
                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                        "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_probe.md)",
                        "us_per_launch": ms * 1e3, "flop_per_launch": flops}
-    # fused loss path (HBM-bound): forward + backward kernels of the four scales
+    # fused loss path: forward + backward kernels of the four scales at the batch the step launches (stacked micro-batches,
+    # SI-log statistics per micro-batch).  Reported against the HBM roofline as the north star asks; the PMC passes in
+    # profiles/round1_pmc_loss.md show the fused kernels are bound by the vector ALU (1 000 / 2 400 lane-instructions per
+    # pixel against 42-44 compulsory bytes), not by HBM.
     H, W = args.height, args.width
     po = FD.PhotoOptions()
+    B, G = Bc, (tr.accumulate_step if tr.stack_microbatches else 1)
     tgt = batch[("color", 0, 0)]
     srcs = [batch[("color", -1, 0)], batch[("color", 1, 0)]]
     ident = tr.identity_losses(batch, 0)
@@ -116,13 +120,13 @@ def roofline_probes(args, tr, batch):
         tot = 0
         for s in range(4):
             photo, si = FD.photo_loss(disps[s], [I, I], batch[("K", 0)], batch[("inv_K", 0)], srcs, tgt, ident, noise,
-                                      batch["4beam"], po)[:2]
+                                      batch["4beam"], po, False, G)[:2]
             tot = tot + photo + si
         tot.backward()
     ms = graph_time_ms(loss_fwd_bwd, launches=5)
     byts = LOSS_BYTES_PER_PIXEL * H * W * B
     out["roofline_loss_path"] = {"bound": "hbm", "kernel": "k_photo_fwd + k_photo_bwd x 4 scales (+ finalize / upsample-adjoint "
-                                 "/ projection-matrix launches), micro-batch %d" % B,
+                                 "/ projection-matrix launches), batch %d" % B,
                                  "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "us_per_launch": ms * 1e3,
                                  "bytes_per_launch": byts}
@@ -256,7 +260,7 @@ def main():
         result["step_mfma_frac"] = tf / PEAK_FP32_MFMA_TFLOPS
         result["step_conv_tflops_per_gpu"] = tf
     if rank == 0 and not args.no_roofline:
-        result.update(roofline_probes(args, tr, mbs[0]))
+        result.update(roofline_probes(args, tr, eager_in if tr.stack_microbatches else mbs[0]))
         print("[bench] roofline probes done", file=sys.stderr, flush=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args)
