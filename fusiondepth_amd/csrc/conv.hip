@@ -420,9 +420,20 @@ __global__ void k_weight_relayout(const float* __restrict__ W, float* __restrict
     }
 }
 
-// All weight re-layouts of a training step in one launch: workgroup -> (job, 1024-element slice) by binary search over the
-// jobs' first_block prefix.
+// All weight re-layouts of a training step in one launch: workgroup -> (job, unit) by binary search over the jobs'
+// first_block prefix.  For kernels up to 3x3 a unit is a 32 (Cout) x 32 (Cin) tile staged through LDS: the source rows
+// W[co][ci0..ci0+31][kh][kw] are contiguous (coalesced reads) and every destination layout has a contiguous run of 32
+// along Cin (forward) or Cout (data gradient), so both sides move full 128-byte lines (the per-element gather read with a
+// 36-byte stride: 9x the L2 traffic).  Larger kernels (5x5 PoseCNN) keep the per-element path, 1024 elements per unit.
+constexpr int RL_TILE = 32;
+__host__ __device__ inline bool relayout_tiled(int KH, int KW) { return KH * KW <= 9; }
+__host__ __device__ inline long relayout_units(const fd_relayout_job& j) {
+    if (relayout_tiled(j.KH, j.KW)) return (long)((j.Co + RL_TILE - 1) / RL_TILE) * ((j.Ci + RL_TILE - 1) / RL_TILE);
+    return (j.n + 1023) / 1024;
+}
+
 __global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* __restrict__ jobs, int njobs) {
+    __shared__ float tile[RL_TILE][RL_TILE * 9 + 1];
     const long b = blockIdx.x;
     int lo = 0, hi = njobs - 1;
     while (lo < hi) {                                   // last job with first_block <= b
@@ -430,23 +441,63 @@ __global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* _
         if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
     }
     const fd_relayout_job j = jobs[lo];
-    const long base = (b - j.first_block) * 1024;
+    const unsigned u = (unsigned)(b - j.first_block);
+    const unsigned TA = (unsigned)j.TA, TB = (unsigned)j.TB, Co = (unsigned)j.Co, Ci = (unsigned)j.Ci;
+    if (relayout_tiled(j.KH, j.KW)) {
+        const unsigned KK = (unsigned)(j.KH * j.KW), T = TA * TB;
+        const unsigned tiles_ci = (Ci + RL_TILE - 1) / RL_TILE;
+        const unsigned co0 = (u / tiles_ci) * RL_TILE, ci0 = (u % tiles_ci) * RL_TILE;
+        const unsigned nco = Co - co0 < RL_TILE ? Co - co0 : RL_TILE, nci = Ci - ci0 < RL_TILE ? Ci - ci0 : RL_TILE;
+        const unsigned row = nci * KK;                   // contiguous source floats per output channel
+        for (unsigned i = threadIdx.x; i < nco * row; i += 256) {
+            const unsigned r = i / row, q = i - r * row;
+            tile[r][q] = j.w[((size_t)(co0 + r) * Ci + ci0) * KK + q];
+        }
+        __syncthreads();
+        if (j.mode == 0) {                               // dst[(co * T + t) * Ci + ci], ci fastest
+            for (unsigned i = threadIdx.x; i < nco * T * nci; i += 256) {
+                const unsigned c = i % nci, q = i / nci, t = q % T, r = q / T;
+                const unsigned a = t / TB, bb = t - a * TB;
+                const unsigned tap = (unsigned)(j.kh0 + j.dkh * (int)a) * (unsigned)j.KW + (unsigned)(j.kw0 + j.dkw * (int)bb);
+                j.dst[((size_t)(co0 + r) * T + t) * Ci + ci0 + c] = tile[r][c * KK + tap];
+            }
+        } else if (j.mode == 1) {                        // dst[(ci * T + t) * Co + co], co fastest
+            for (unsigned i = threadIdx.x; i < nci * T * nco; i += 256) {
+                const unsigned r = i % nco, q = i / nco, t = q % T, c = q / T;
+                const unsigned a = t / TB, bb = t - a * TB;
+                const unsigned tap = (unsigned)(j.kh0 + j.dkh * (int)a) * (unsigned)j.KW + (unsigned)(j.kw0 + j.dkw * (int)bb);
+                j.dst[((size_t)(ci0 + c) * T + t) * Co + co0 + r] = tile[r][c * KK + tap];
+            }
+        } else {                                         // dst[((ci * Co + co) * TA + a) * TB + b], taps fastest
+            for (unsigned i = threadIdx.x; i < nci * nco * T; i += 256) {
+                const unsigned t = i % T, q = i / T, r = q % nco, c = q / nco;
+                const unsigned a = t / TB, bb = t - a * TB;
+                const unsigned tap = (unsigned)(j.kh0 + j.dkh * (int)a) * (unsigned)j.KW + (unsigned)(j.kw0 + j.dkw * (int)bb);
+                j.dst[((size_t)(ci0 + c) * Co + co0 + r) * T + t] = tile[r][c * KK + tap];
+            }
+        }
+        return;
+    }
+    const unsigned base = u * 1024u;                     // a job has < 2^31 elements: 32-bit index math
+    const unsigned n = (unsigned)j.n;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const long i = base + e * 256 + threadIdx.x;
-        if (i >= j.n) return;
-        int co, ci, a, bb;
+        const unsigned i = base + e * 256u + threadIdx.x;
+        if (i >= n) return;
+        unsigned co, ci, a, bb;
         if (j.mode == 2) {                              // [ci][co][a][b]
-            bb = (int)(i % j.TB); a = (int)((i / j.TB) % j.TA);
-            co = (int)((i / ((long)j.TB * j.TA)) % j.Co); ci = (int)(i / ((long)j.TB * j.TA * j.Co));
+            unsigned q = i / TB; bb = i - q * TB;
+            unsigned q2 = q / TA; a = q - q2 * TA;
+            ci = q2 / Co; co = q2 - ci * Co;
         } else {                                        // [m][a][b][c]: mode 0 m = co, c = ci; mode 1 m = ci, c = co
-            const int Cr = j.mode ? j.Co : j.Ci;
-            const int c = (int)(i % Cr);
-            bb = (int)((i / Cr) % j.TB); a = (int)((i / ((long)Cr * j.TB)) % j.TA);
-            const int m = (int)(i / ((long)Cr * j.TB * j.TA));
+            const unsigned Cr = j.mode ? Co : Ci;
+            unsigned q = i / Cr; const unsigned c = i - q * Cr;
+            unsigned q2 = q / TB; bb = q - q2 * TB;
+            const unsigned m = q2 / TA; a = q2 - m * TA;
             co = j.mode ? c : m; ci = j.mode ? m : c;
         }
-        j.dst[i] = j.w[(((long)co * j.Ci + ci) * j.KH + j.kh0 + j.dkh * a) * j.KW + j.kw0 + j.dkw * bb];
+        j.dst[i] = j.w[((co * Ci + ci) * (unsigned)j.KH + (unsigned)(j.kh0 + j.dkh * (int)a)) * (unsigned)j.KW +
+                       (unsigned)(j.kw0 + j.dkw * (int)bb)];
     }
 }
 
@@ -826,7 +877,7 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
 
 extern "C" long fd_relayout_plan(fd_relayout_job* jobs, int n) {
     long blocks = 0;
-    for (int i = 0; i < n; ++i) { jobs[i].first_block = blocks; blocks += (jobs[i].n + 1023) / 1024; }
+    for (int i = 0; i < n; ++i) { jobs[i].first_block = blocks; blocks += relayout_units(jobs[i]); }
     return blocks;
 }
 
