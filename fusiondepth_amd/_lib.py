@@ -92,6 +92,8 @@ SIGNATURES = {
     "fd_upsample2x_bwd": ("ppliip", "i"),
     "fd_axpby": ("ppplffp", "i"),
     "fd_input_normalize": ("pplffp", "i"),
+    "fd_combine_losses_fwd": ("pppifpp", "i"),
+    "fd_combine_losses_bwd": ("pifpp", "i"),
     "fd_spatial_mean_fwd": ("ppllfp", "i"),
     "fd_spatial_mean_bwd": ("ppllfp", "i"),
     "fd_depth_errors": ("pplppp", "i"),

@@ -159,3 +159,50 @@ extern "C" int fd_smooth_bwd(const float* disp, const float* img, const float* g
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// trainer.py:569-596: loss_s = photo_s + w * smooth_s / 2^s;  total = (sum_s loss_s + sum_s si_s) / n_scales.
+// The reference does this with ~10 scalar tensor ops per scale (and as many in the backward pass); here one tiny kernel
+// each way, on the loss path's serial section.
+struct CombineArgs { const float* photo[4]; const float* smooth[4]; const float* si[4]; };
+namespace {
+__global__ void k_combine_losses(CombineArgs a, int n, float w, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    for (int s = 0; s < n; ++s) {                       // same operation order as the reference's Python loop
+        const float loss = a.photo[s][0] + w * a.smooth[s][0] / (float)(1 << s);
+        total = total + loss;
+        out[s] = loss;
+        if (a.si[s]) total = total + a.si[s][0];
+    }
+    out[n] = total / (float)n;
+}
+__global__ void k_combine_losses_bwd(const float* __restrict__ g, int n, float w, float* __restrict__ grads) {
+    const int s = threadIdx.x;
+    if (blockIdx.x != 0 || s >= n) return;
+    const float gt = g[0] / (float)n;
+    grads[s] = gt;                                      // d total / d photo_s
+    grads[n + s] = gt * w / (float)(1 << s);            // d total / d smooth_s
+    grads[2 * n + s] = gt;                              // d total / d si_s
+}
+}  // namespace
+
+extern "C" int fd_combine_losses_fwd(const float* const* photo, const float* const* smooth, const float* const* si, int n_scales,
+                                     float smooth_weight, float* out, void* stream) {
+    FD_REQUIRE(photo && smooth && si && out && n_scales >= 1 && n_scales <= 4, "fd_combine_losses_fwd: bad args");
+    CombineArgs a = {};
+    for (int s = 0; s < n_scales; ++s) {
+        FD_REQUIRE(photo[s] && smooth[s], "fd_combine_losses_fwd: NULL loss term at scale %d", s);
+        a.photo[s] = photo[s]; a.smooth[s] = smooth[s]; a.si[s] = si[s];
+    }
+    hipLaunchKernelGGL(k_combine_losses, dim3(1), dim3(64), 0, (hipStream_t)stream, a, n_scales, smooth_weight, out);
+    FD_LAUNCH_CHECK("fd_combine_losses_fwd");
+    return 0;
+}
+extern "C" int fd_combine_losses_bwd(const float* g_total, int n_scales, float smooth_weight, float* grads, void* stream) {
+    FD_REQUIRE(g_total && grads && n_scales >= 1 && n_scales <= 4, "fd_combine_losses_bwd: bad args");
+    hipLaunchKernelGGL(k_combine_losses_bwd, dim3(1), dim3(64), 0, (hipStream_t)stream, g_total, n_scales, smooth_weight, grads);
+    FD_LAUNCH_CHECK("fd_combine_losses_bwd");
+    return 0;
+}
+

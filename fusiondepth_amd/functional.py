@@ -245,6 +245,38 @@ def normalized_smooth_loss(disp, img):
     return _SmoothLoss.apply(disp, img, True)
 
 
+class _CombineLosses(torch.autograd.Function):
+    """trainer.py:569-596 on device scalars: (loss_0..loss_{n-1}, total) = f(photo_s, smooth_s, si_s)."""
+
+    @staticmethod
+    def forward(ctx, weight, n, *terms):
+        photo, smooth, si = terms[:n], terms[n:2 * n], terms[2 * n:]
+        P = ctypes.c_void_p * n
+        arr = [P(*[ptr(f32(t).reshape(1)) if t is not None else None for t in group]) for group in (photo, smooth, si)]
+        out = _empty((n + 1,), photo[0])
+        call("fd_combine_losses_fwd", ctypes.addressof(arr[0]), ctypes.addressof(arr[1]), ctypes.addressof(arr[2]), n,
+             float(weight), ptr(out), stream())
+        ctx.n, ctx.weight = n, float(weight)
+        ctx.has = [t is not None for t in terms]
+        return tuple(out[i] for i in range(n + 1))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = ctx.n
+        g_total = gs[n]
+        grads = _empty((3 * n,), g_total)
+        call("fd_combine_losses_bwd", ptr(f32(g_total).reshape(1)), n, ctx.weight, ptr(grads), stream())
+        return (None, None) + tuple(grads[i] if ctx.has[i] else None for i in range(3 * n))
+
+
+def combine_losses(photo, smooth, si, smooth_weight):
+    """-> ([loss_s], total) for lists of 0-dim device tensors (``si`` entries may be None).  Only ``total`` carries a
+    gradient (the per-scale values are logging outputs, as in the reference)."""
+    n = len(photo)
+    out = _CombineLosses.apply(float(smooth_weight), n, *(list(photo) + list(smooth) + list(si)))
+    return [o.detach() for o in out[:n]], out[n]
+
+
 # ------------------------------------------------------------------------------------ LiDAR -------
 def scatter_2channel(beam, roi=(76, 190, 2, 638), expand=2):
     """gen2channel.py:60-117 on the GPU.  beam [B,1,H,W] (or [H,W]) -> [B,2,H,W]."""

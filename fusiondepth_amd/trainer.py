@@ -545,16 +545,28 @@ class Trainer:
     def compute_losses(self, inputs, outputs):
         """trainer.py:490-596: per scale  loss = min-reprojection mean + smoothness/2^s ; total += loss + si_loss."""
         losses = {}
+        scales = list(self.opt.scales)
+        photo, si, smooth = [], [], []
+        for scale in scales:
+            p, s_ = outputs[("photo", scale)]
+            photo.append(p); si.append(s_)
+            smooth.append(FD.normalized_smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)]))
+        if scales == list(range(len(scales))) and len(scales) == self.num_scales and len(scales) <= 4:
+            per_scale, total = FD.combine_losses(photo, smooth, si, self.opt.disparity_smoothness)     # one kernel each way
+            for scale in scales:
+                losses["loss/{}".format(scale)] = per_scale[scale]
+                if si[scale] is not None:
+                    losses["loss/si_loss{}".format(scale)] = si[scale]
+            losses["loss"] = total
+            return losses
         total_loss = 0
-        for scale in self.opt.scales:
-            photo, si = outputs[("photo", scale)]
-            smooth = FD.normalized_smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)])
-            loss = photo + self.opt.disparity_smoothness * smooth / (2 ** scale)
+        for i, scale in enumerate(scales):
+            loss = photo[i] + self.opt.disparity_smoothness * smooth[i] / (2 ** scale)
             total_loss = total_loss + loss
             losses["loss/{}".format(scale)] = loss
-            if si is not None:
-                total_loss = total_loss + si
-                losses["loss/si_loss{}".format(scale)] = si
+            if si[i] is not None:
+                total_loss = total_loss + si[i]
+                losses["loss/si_loss{}".format(scale)] = si[i]
         losses["loss"] = total_loss / self.num_scales
         return losses
 

@@ -241,6 +241,13 @@ int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, int N, int 
 int fd_upsample2x_fwd(const float* x, float* y, long planes, int h, int w, void* stream);
 int fd_upsample2x_bwd(const float* gy, float* gx, long planes, int h, int w, void* stream);
 
+/* trainer.py:569-596  loss_s = photo_s + w * smooth_s / 2^s ;  total = (sum_s loss_s + sum_s si_s) / n_scales  on device
+ * scalars (photo / smooth / si: n_scales host arrays of device pointers to one float; si[s] may be NULL).
+ * out[0..n-1] = loss_s, out[n] = total.  bwd: grads[0..n-1] = d total/d photo_s, [n..2n-1] = d/d smooth_s, [2n..3n-1] = d/d si_s. */
+int fd_combine_losses_fwd(const float* const* photo, const float* const* smooth, const float* const* si, int n_scales,
+                          float smooth_weight, float* out, void* stream);
+int fd_combine_losses_bwd(const float* g_total, int n_scales, float smooth_weight, float* grads, void* stream);
+
 /* networks/resnet_encoder.py:94  y = (x - mean) / std  elementwise (the encoder's input normalisation, 0.45 / 0.225).
  * The same arithmetic is available fused into the stem conv through fd_conv_desc.in_norm. */
 int fd_input_normalize(const float* x, float* y, long n, float mean, float std, void* stream);
