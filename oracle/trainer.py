@@ -169,6 +169,23 @@ def process_batch(opt, models, inputs, noise=None):
     return outputs, compute_losses(opt, inputs, outputs, noise)
 
 
+def compute_depth_losses(depth_pred, depth_gt):
+    """Reference: trainer.py:598-630 — monitoring metrics of the scale-0 depth against sparse ground truth: bilinear resize
+    to the ground-truth size, clamp to [1e-3, 80], Garg/Eigen crop rows 153..370 / cols 44..1196 of valid (> 0) pixels,
+    median scaling, clamp again, layers.compute_depth_errors.  Returns the 7 metrics (abs_rel, sq_rel, rms, log_rms, a1-3)."""
+    import torch.nn.functional as F
+    from . import layers as OL
+    gh, gw = depth_gt.shape[2:]
+    pred = torch.clamp(F.interpolate(depth_pred, [gh, gw], mode="bilinear", align_corners=False), 1e-3, 80).detach()
+    mask = depth_gt > 0
+    crop = torch.zeros_like(mask)
+    crop[:, :, 153:371, 44:1197] = 1
+    mask = mask * crop
+    gt, pr = depth_gt[mask], pred[mask]
+    pr = torch.clamp(pr * (torch.median(gt) / torch.median(pr)), min=1e-3, max=80)
+    return [float(v) for v in OL.compute_depth_errors(gt, pr)]
+
+
 def trainable_parameters(models):
     """trainer.py:71-127 order: encoder, beam_encoder, beam_encoder_pose, depth, pose_encoder, pose."""
     params = []

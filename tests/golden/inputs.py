@@ -113,3 +113,14 @@ def fill_params(module, seed):
                 v = rng.randn(*shape) * 0.01
             t.copy_(torch.from_numpy(v.astype(np.float32)))
     return module
+
+
+def depth_eval_inputs(seed, B, H, W, gt_h=375, gt_w=1242):
+    """Sparse ground-truth depth [B,1,375,1242] (about 5 % valid, metres) and a dense prediction [B,1,H,W] for the
+    monitoring metrics of trainer.py:598-630."""
+    rng = np.random.RandomState(seed)
+    gt = rng.uniform(1.5, 70.0, size=(B, 1, gt_h, gt_w)).astype(np.float32)
+    gt[rng.rand(B, 1, gt_h, gt_w) > 0.05] = 0.0
+    pred = rng.uniform(0.5, 90.0, size=(B, 1, H, W)).astype(np.float32)
+    return gt, pred
+

@@ -295,6 +295,18 @@ def gold_scatter(get2ch):
     save("scatter_192x640", **out)
 
 
+def gold_depth_losses(RL, RT):
+    """trainer.py:598-630 (Garg crop, median scaling, clamp, compute_depth_errors) run as an unbound Trainer method."""
+    from types import SimpleNamespace
+    B, H, W = 2, 192, 640
+    gt, pred = gin.depth_eval_inputs(707, B, H, W)
+    ns = SimpleNamespace(depth_metric_names=["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"])
+    losses = {}
+    RT.Trainer.compute_depth_losses(ns, {"depth_gt": torch.from_numpy(gt)}, {("depth", 0, 0): torch.from_numpy(pred)}, losses)
+    save("depth_losses_b2_192x640", seed=np.array(707), metrics=np.array([float(losses[m]) for m in ns.depth_metric_names],
+                                                                           dtype=np.float64))
+
+
 def gold_options():
     """Flag surface of the reference's argparse (options.py:9-480): name -> default/type/choices/action."""
     import json
@@ -323,6 +335,7 @@ def main():
     gold_losses(RL, RT, "losses_nossim_noautomask_b2_64x96", 606, 2, 64, 96, full_arrays=False,
                 opt_over=dict(no_ssim=True, disable_automasking=True))
     gold_scatter(get2ch)
+    gold_depth_losses(RL, RT)
 
 
 if __name__ == "__main__":

@@ -164,6 +164,20 @@ def test_other_baseline_configs_match_oracle(layers, H, W, B):
     assert_close(losses_seq[1][0], losses_seq[1][1], rtol=1e-2, atol=0, what="loss after one optimiser step")
 
 
+def test_depth_monitoring_metrics_vs_reference_golden(golden):
+    """Trainer.compute_depth_losses (device-side resize / crop / median scaling / metrics kernel) against the metrics the
+    reference's own Trainer.compute_depth_losses produced on the same inputs (tests/golden/make_golden.py)."""
+    g = golden("depth_losses_b2_192x640")
+    gt, pred = gin.depth_eval_inputs(int(g["seed"]), 2, 192, 640)
+    opt = _opts(height=192, width=640)
+    from fusiondepth_amd.trainer import Trainer
+    tr = Trainer(opt, verbose=False)
+    losses = {}
+    tr.compute_depth_losses({"depth_gt": torch.from_numpy(gt).cuda()}, {("depth", 0, 0): torch.from_numpy(pred).cuda()}, losses)
+    got = [float(losses[m]) for m in tr.depth_metric_names]
+    assert_close(got, g["metrics"], rtol=2e-5, atol=0, what="depth metrics vs reference")
+
+
 def test_accumulate_semantics_batch12():
     """--batch_size 12 -> accumulate 2 x micro-batch 6, lr 1.5e-4, StepLR step 6 (trainer.py:28-41)."""
     from fusiondepth_amd.trainer import Trainer

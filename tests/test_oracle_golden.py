@@ -255,3 +255,13 @@ def test_derived_hparams_match_reference_rules():
     assert abs(hp.learning_rate - 1.5e-4) < 1e-12
     hp = OT.derived_hparams(5)
     assert (hp.accumulate_step, hp.micro_batch) == (1, 5)
+
+
+def test_depth_monitoring_metrics_match_reference(golden):
+    """oracle.trainer.compute_depth_losses == the reference's Trainer.compute_depth_losses (trainer.py:598-630)."""
+    from oracle import trainer as OT
+    g = golden("depth_losses_b2_192x640")
+    gt, pred = gin.depth_eval_inputs(int(g["seed"]), 2, 192, 640)
+    got = OT.compute_depth_losses(torch.from_numpy(pred), torch.from_numpy(gt))
+    np.testing.assert_allclose(got, g["metrics"], rtol=1e-6, atol=0)
+
