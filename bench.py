@@ -202,6 +202,7 @@ def main():
         barrier()
         return (time.perf_counter() - t) / n
 
+    barrier(); barrier()          # the first collective builds the communicator (seconds): keep it out of every measurement
     launch = "eager" if args.eager else ("graph" if args.graph else "auto")
     if launch == "auto":
         # Both launch paths run the same kernels on the same streams; which one keeps the GPU busier depends on the host

@@ -119,10 +119,15 @@ class GradientSynchronizer:
         """After backward: reduce buckets whose hooks never fired (unused parameters, e.g. the ResNet ``fc``)
         and wait for everything.  Returns the factor that turns the summed gradient into the mean."""
         if self.world > 1 and self.armed:
-            for b in range(len(self.buckets)):
-                self._launch(b)
-            for h in self.handles:
-                h.wait()
+            if not any(self.launched):
+                # no hook fired (the trainer's kernels accumulate gradients in place, autograd never sees them): the whole
+                # flat buffer goes out as ONE all-reduce - the largest message the ring over xGMI can get
+                dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                for b in range(len(self.buckets)):
+                    self._launch(b)
+                for h in self.handles:
+                    h.wait()
         self.armed = False
         return 1.0 / self.world
 
