@@ -9,15 +9,23 @@
 // reflect-pad halo) in LDS and produces the per-tile partial sums directly.  HBM-bound by design:
 // compulsory traffic per scale is disp_s + target + 2 sources + LiDAR (+ 1 byte/pixel argmin).
 //
-// Thread layout: 256 threads = 4 waves; thread (tx = tid&63, ty = tid>>6) owns the 4 vertically
-// adjacent pixels (ty*4 .. ty*4+3, tx) of the tile, so lanes of a wave touch consecutive x (coalesced
-// HBM rows, conflict-free LDS rows) and the 3x3 box sums slide down the column.
+// Thread layout: NT threads = NT/64 waves; thread (tx = tid&63, ty = tid>>6) owns the PPT = 16/(NT/64) vertically
+// adjacent pixels (ty*PPT .. ty*PPT+PPT-1, tx) of the tile, so lanes of a wave touch consecutive x (coalesced
+// HBM rows, conflict-free LDS rows) and the 3x3 box sums slide down the column.  The kernels are bound by the vector
+// ALU and by the latency of their dependent gathers (profiles/round1_pmc_loss.md); 8 waves x 2 pixels per tile keeps 24
+// waves per CU resident against 12 with 4 x 4.
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 
 namespace {
 
-constexpr int TW = 64, TH = 16, NT = 256;
+constexpr int TW = 64, TH = 16;
+#ifndef FD_PHOTO_NT
+#define FD_PHOTO_NT 512      // measured at batch 12: 256 -> 65 / 209 us (fwd / bwd), 512 -> 61 / 173, 1024 -> 87 / 214
+#endif
+constexpr int NT = FD_PHOTO_NT;          // threads per 16x64 tile
+constexpr int NWV = NT / 64;              // waves per tile
+constexpr int PPT = TH / NWV;             // vertically adjacent pixels owned by a thread (4 at 256 threads, 2 at 512)
 constexpr int W1 = TW + 2, H1 = TH + 2;  // halo-1 region (SSIM window of tile pixels)
 constexpr int W2 = TW + 4, H2 = TH + 4;  // halo-2 region (SSIM windows of halo-1 pixels, backward)
 constexpr float C1 = (float)(0.01 * 0.01), C2 = (float)(0.03 * 0.03);
@@ -178,17 +186,19 @@ __device__ __forceinline__ void ssim_coefs(float Sx, float Sy, float Sxx, float 
 // (plane row stride WS).  Returns 0.85*mean_c ssim + 0.15*mean_c l1 (or mean_c l1).
 template <int WS, int HALO, bool SSIM>
 __device__ __forceinline__ void column_losses(const float* __restrict__ sx, const float* __restrict__ sy, int plane,
-                                              int tx, int ty, float (&L)[4]) {
-    float ss[4] = {0.f, 0.f, 0.f, 0.f}, l1[4] = {0.f, 0.f, 0.f, 0.f};
+                                              int tx, int ty, float (&L)[PPT]) {
+    float ss[PPT], l1[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) { ss[i] = 0.f; l1[i] = 0.f; }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float* px = sx + c * plane;
         const float* py = sy + c * plane;
         if (SSIM) {
-            float hx[6], hy[6], hxx[6], hyy[6], hxy[6];
+            float hx[PPT + 2], hy[PPT + 2], hxx[PPT + 2], hyy[PPT + 2], hxy[PPT + 2];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const int o = (ty * 4 + r + HALO - 1) * WS + tx + HALO - 1;
+            for (int r = 0; r < PPT + 2; ++r) {
+                const int o = (ty * PPT + r + HALO - 1) * WS + tx + HALO - 1;
                 const float x0 = px[o], x1 = px[o + 1], x2 = px[o + 2];
                 const float y0 = py[o], y1 = py[o + 1], y2 = py[o + 2];
                 hx[r] = x0 + x1 + x2; hy[r] = y0 + y1 + y2;
@@ -197,19 +207,19 @@ __device__ __forceinline__ void column_losses(const float* __restrict__ sx, cons
                 hxy[r] = x0 * y0 + x1 * y1 + x2 * y2;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < PPT; ++i)
                 ss[i] += ssim_from_sums(hx[i] + hx[i + 1] + hx[i + 2], hy[i] + hy[i + 1] + hy[i + 2],
                                         hxx[i] + hxx[i + 1] + hxx[i + 2], hyy[i] + hyy[i + 1] + hyy[i + 2],
                                         hxy[i] + hxy[i + 1] + hxy[i + 2]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int o = (ty * 4 + i + HALO) * WS + tx + HALO;
+        for (int i = 0; i < PPT; ++i) {
+            const int o = (ty * PPT + i + HALO) * WS + tx + HALO;
             l1[i] += fabsf(py[o] - px[o]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) L[i] = SSIM ? 0.85f * div3(ss[i]) + 0.15f * div3(l1[i]) : div3(l1[i]);
+    for (int i = 0; i < PPT; ++i) L[i] = SSIM ? 0.85f * div3(ss[i]) + 0.15f * div3(l1[i]) : div3(l1[i]);
 }
 
 struct PhotoArgs {
@@ -227,7 +237,7 @@ template <bool SSIM>
 __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
     __shared__ float s_tgt[3 * H1 * W1];
     __shared__ float s_pred[3 * H1 * W1];
-    __shared__ float s_red[4 * 4];
+    __shared__ float s_red[NWV * 4];
     const fd_photo_cfg& cfg = a.cfg;
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int x0t = blockIdx.x * TW, y0t = blockIdx.y * TH, b = blockIdx.z;
@@ -243,12 +253,12 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
         s_tgt[i] = t[0]; s_tgt[H1 * W1 + i] = t[P]; s_tgt[2 * H1 * W1 + i] = t[2 * P];
     }
 
-    float Lr[2][4];
+    float Lr[2][PPT];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
         if (f >= NF) {   // NF is workgroup-uniform, so the barriers below stay convergent
 #pragma unroll
-            for (int i = 0; i < 4; ++i) Lr[f][i] = 0.f;
+            for (int i = 0; i < PPT; ++i) Lr[f][i] = 0.f;
             continue;
         }
         const float* Pf = a.P + ((long)b * NF + f) * 12;
@@ -291,8 +301,8 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
     const int NI = a.ident ? (cfg.avg_reprojection ? 1 : NF) : 0;
     const int x = x0t + tx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0t + ty * 4 + i;
+    for (int i = 0; i < PPT; ++i) {
+        const int y = y0t + ty * PPT + i;
         if (y >= H || x >= W) continue;
         const long p = (long)y * W + x;
         float best = 0.f;
@@ -325,7 +335,7 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
             }
         }
     }
-    const float s = fd_block_sum_n<4, 4>(acc, s_red);
+    const float s = fd_block_sum_n<4, NWV>(acc, s_red);
     if (tid < 4) {
         const long blk = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         a.ws[blk * 4 + tid] = s;
@@ -419,7 +429,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     __shared__ float s_pred[3 * H2 * W2];
     __shared__ float s_coef[3 * H1 * W1];
     __shared__ uint8_t s_sel[H1 * W1];
-    __shared__ float s_red[4 * 24];
+    __shared__ float s_red[NWV * 24];
     const fd_photo_cfg& cfg = a.cfg;
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int x0t = blockIdx.x * TW, y0t = blockIdx.y * TH, b = blockIdx.z;
@@ -445,14 +455,16 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
         s_sel[i] = (py >= 0 && py < H && px >= 0 && px < W) ? a.sel[b * P + (long)py * W + px] : (uint8_t)255;
     }
 
-    float d_depth[4] = {0.f, 0.f, 0.f, 0.f};
+    float d_depth[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) d_depth[i] = 0.f;
     float gP0[12], gP1[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { gP0[i] = 0.f; gP1[i] = 0.f; }
 
     // d(loss)/d(pred channel c) for the 4 owned pixels; `c` is a compile-time constant so that every
     // register array below is statically indexed.
-    auto channel_grad = [&](const int c, const int my_sel, float (&dp)[4]) __attribute__((always_inline)) {
+    auto channel_grad = [&](const int c, const int my_sel, float (&dp)[PPT]) __attribute__((always_inline)) {
         const float* px = s_pred + c * H2 * W2;
         const float* py = s_tgt + c * H2 * W2;
         if (SSIM) {
@@ -478,24 +490,24 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
         // 3x3 box sums of the three coefficient planes for the 4 owned pixels: horizontal 3-sums of the 6 halo-1 rows
         // slide down the column (18 LDS reads per plane instead of 36).  Pixels on the second / second-to-last row or
         // column of the IMAGE also collect the windows reached through the reflect padding: rare, handled by fold_sum.
-        float box[3][4];
+        float box[3][PPT];
         if (SSIM) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float* pl = s_coef + k * H1 * W1 + (ty * 4) * W1 + tx;
-                float hs[6];
+                const float* pl = s_coef + k * H1 * W1 + (ty * PPT) * W1 + tx;
+                float hs[PPT + 2];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) hs[r] = pl[r * W1] + pl[r * W1 + 1] + pl[r * W1 + 2];
+                for (int r = 0; r < PPT + 2; ++r) hs[r] = pl[r * W1] + pl[r * W1 + 1] + pl[r * W1 + 2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) box[k][i] = hs[i] + hs[i + 1] + hs[i + 2];
+                for (int i = 0; i < PPT; ++i) box[k][i] = hs[i] + hs[i + 1] + hs[i + 2];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int y = y0t + ty * 4 + i;
+        for (int i = 0; i < PPT; ++i) {
+            const int y = y0t + ty * PPT + i;
             float g = 0.f;
             if (y < H && x < W) {
-                const int o = (ty * 4 + i + 2) * W2 + tx + 2;
+                const int o = (ty * PPT + i + 2) * W2 + tx + 2;
                 const float xv = px[o], yv = py[o];
                 if (SSIM) {
                     float sa = box[0][i], sb = box[1][i], sc = box[2][i];
@@ -506,7 +518,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
                     }
                     g = div9(sa + 2.f * xv * sb + yv * sc);
                 }
-                if (s_sel[(ty * 4 + i + 1) * W1 + tx + 1] == my_sel) {
+                if (s_sel[(ty * PPT + i + 1) * W1 + tx + 1] == my_sel) {
                     const float df = yv - xv;  // |t - p|' w.r.t. p
                     const float sg = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f);
                     g += sg * g_photo * wfrm * ((SSIM ? 0.15f : 1.0f) / 3.0f);
@@ -535,15 +547,15 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
             s_pred[i] = pr[0]; s_pred[H2 * W2 + i] = pr[1]; s_pred[2 * H2 * W2 + i] = pr[2];
         }
         __syncthreads();
-        float dp0[4], dp1[4], dp2[4];
+        float dp0[PPT], dp1[PPT], dp2[PPT];
         channel_grad(0, my_sel, dp0);
         channel_grad(1, my_sel, dp1);
         channel_grad(2, my_sel, dp2);
 
         // grid_sample backward (w.r.t. the grid) -> projection -> depth, and gP
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int y = y0t + ty * 4 + i;
+        for (int i = 0; i < PPT; ++i) {
+            const int y = y0t + ty * PPT + i;
             if (y >= H || x >= W) continue;
             if (dp0[i] == 0.f && dp1[i] == 0.f && dp2[i] == 0.f) continue;
             Samp s;
@@ -581,8 +593,8 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     const float n_valid = a.stats[8 + 4 * grp], m1 = a.stats[9 + 4 * grp], var = a.stats[10 + 4 * grp];
     const float k_si = a.beam ? a.g[1] / (float)cfg.groups * 0.1f / (sqrtf(var) * n_valid) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0t + ty * 4 + i;
+    for (int i = 0; i < PPT; ++i) {
+        const int y = y0t + ty * PPT + i;
         if (y >= H || x >= W) continue;
         const long p = (long)y * W + x;
         const float sdisp = cm.lo + cm.span * disp_up_at(disp_b, cm, y, x);
@@ -601,7 +613,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     float gPa[24];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { gPa[i] = gP0[i]; gPa[12 + i] = gP1[i]; }
-    const float s = fd_block_sum_n<24, 4>(gPa, s_red);
+    const float s = fd_block_sum_n<24, NWV>(gPa, s_red);
     if (tid < 24) {
         const long blk = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
         a.part[blk * 24 + tid] = s;
@@ -648,12 +660,12 @@ __global__ void __launch_bounds__(NT) k_reproj_map(const float* __restrict__ pre
         }
     }
     __syncthreads();
-    float L[4];
+    float L[PPT];
     column_losses<W1, 1, SSIM>(s_x, s_y, H1 * W1, tx, ty, L);
     const int x = x0t + tx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0t + ty * 4 + i;
+    for (int i = 0; i < PPT; ++i) {
+        const int y = y0t + ty * PPT + i;
         if (y < H && x < W) out[b * out_bs + (long)y * W + x] = L[i];
     }
 }
@@ -674,15 +686,15 @@ __global__ void __launch_bounds__(NT) k_ssim_fwd(const float* __restrict__ xg, c
     __syncthreads();
     const int x = x0t + tx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0t + ty * 4 + i;
+    for (int i = 0; i < PPT; ++i) {
+        const int y = y0t + ty * PPT + i;
         if (y >= H || x >= W) continue;
         float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Syy = 0.f, Sxy = 0.f;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const float xv = s_x[(ty * 4 + i + dy) * W1 + tx + dx], yv = s_y[(ty * 4 + i + dy) * W1 + tx + dx];
+                const float xv = s_x[(ty * PPT + i + dy) * W1 + tx + dx], yv = s_y[(ty * PPT + i + dy) * W1 + tx + dx];
                 Sx += xv; Sy += yv; Sxx += xv * xv; Syy += yv * yv; Sxy += xv * yv;
             }
         out[base + (long)y * W + x] = ssim_from_sums(Sx, Sy, Sxx, Syy, Sxy);
@@ -724,10 +736,10 @@ __global__ void __launch_bounds__(NT) k_ssim_bwd(const float* __restrict__ xg, c
     __syncthreads();
     const int x = x0t + tx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int y = y0t + ty * 4 + i;
+    for (int i = 0; i < PPT; ++i) {
+        const int y = y0t + ty * PPT + i;
         if (y >= H || x >= W) continue;
-        const int o = (ty * 4 + i + 2) * W2 + tx + 2;
+        const int o = (ty * PPT + i + 2) * W2 + tx + 2;
         const float sa = fold_sum(s_coef, y, x, y0t, x0t, H, W);
         const float sb = fold_sum(s_coef + H1 * W1, y, x, y0t, x0t, H, W);
         const float sc = fold_sum(s_coef + 2 * H1 * W1, y, x, y0t, x0t, H, W);
