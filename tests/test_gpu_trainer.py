@@ -131,9 +131,11 @@ def test_trainer_matches_oracle_over_optimizer_steps():
     assert float((pg - po).abs().max()) <= 3 * 3 * tr.lr + 1e-6, "a parameter moved further than Adam allows"
 
 
-@pytest.mark.parametrize("layers,H,W,B", [(50, 64, 96, 2), (18, 320, 1024, 2)], ids=["C3-resnet50", "C4-1024x320"])
+@pytest.mark.parametrize("layers,H,W,B", [(50, 64, 96, 2), (18, 320, 1024, 2), (18, 352, 1216, 1)],
+                         ids=["C3-resnet50", "C4-1024x320", "completor-1216x352"])
 def test_other_baseline_configs_match_oracle(layers, H, W, B):
-    """BASELINE.json configs 3 (ResNet-50) and 4 (1024x320) as parity cases: losses and disparities of the first forward
+    """BASELINE.json configs 3 (ResNet-50) and 4 (1024x320), and the completor's 1216x352 resolution (completor.py:31-34;
+    widths / heights that are not powers of two times the tile sizes), as parity cases: losses and disparities of the first forward
     pass, then the loss after one optimiser step, against the oracle harness (same weights, inputs, tie-break noise)."""
     opt = _opts(num_layers=layers, height=H, width=W, batch_size=B)
     tr, ot = _make_pair(opt)
