@@ -74,6 +74,12 @@ SIGNATURES = {
     "fd_conv2d_bwd_data_wt_floats": ("p", "l"),
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_data": ("ppppp" "i" "pp", "i"),
+    "fd_conv2d_fwd_pair_ws_floats": ("p", "l"),
+    "fd_conv2d_fwd_pair": ("ppppppp" "i" "pp", "i"),
+    "fd_conv2d_bwd_data_pair_ws_floats": ("p", "l"),
+    "fd_conv2d_bwd_data_pair": ("ppppppp" "i" "pp", "i"),
+    "fd_conv2d_bwd_weight_pair_ws_floats": ("p", "l"),
+    "fd_conv2d_bwd_weight_pair": ("pppppp" "i" "p", "i"),
     "fd_conv2d_relayout_jobs": ("pippp", "i"),
     "fd_relayout_plan": ("pi", "l"),
     "fd_relayout_batch": ("pilp", "i"),

@@ -63,8 +63,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     const int cpt = g.C / BKC;                  // chunks per tap
     const int nchunk_all = g.T * cpt;
     // split-K: this workgroup handles chunks [ch_lo, ch_hi)
-    const int per_split = (nchunk_all + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int ch_lo = blockIdx.z * per_split;
+    const int nsplit = (int)gridDim.z / g.siblings;          // gridDim.z = siblings * splits
+    const int sib = (int)blockIdx.z / nsplit, zs = (int)blockIdx.z - sib * nsplit;
+    const int per_split = (nchunk_all + nsplit - 1) / nsplit;
+    const int ch_lo = zs * per_split;
     const int ch_hi = ch_lo + per_split < nchunk_all ? ch_lo + per_split : nchunk_all;
 
     // ---- activation loader: fixed pixel column, channel rows kr + RP*i
@@ -85,7 +87,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     // ---- weight loader: float4 column a4 of row ar + A_ROWS_PER_PASS*i
     const int a4 = tid % A_V4_PER_ROW, ar = tid / A_V4_PER_ROW;
 
-    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(g.A), rsX = fd_make_rsrc(g.X);
+    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(sib ? g.A1 : g.A),
+                                 rsX = fd_make_rsrc(g.X + (size_t)sib * g.Nb * g.C * chw);
     float4 ra[NA_LOAD];
     float rb[NB_LOAD];
     // state of the chunk being fetched (set by prep_chunk, consumed by the load/store slices); byte offsets
@@ -193,8 +196,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     }
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
-    const bool final_pass = gridDim.z == 1;
-    float* Y = final_pass ? g.Y : g.slabs + (size_t)blockIdx.z * g.slab_stride;
+    const bool final_pass = nsplit == 1;
+    float* Y = final_pass ? g.Y + (size_t)sib * g.Nb * g.out_ns : g.slabs + (size_t)blockIdx.z * g.slab_stride;
+    const float* bias = sib ? g.bias1 : g.bias;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const long p = p0 + wave_n * 32 * WN + j * 32 + acol;
@@ -211,7 +215,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
                 if (m < g.M) {
                     float v = acc[i][j][r];
                     if (final_pass) {
-                        if (g.bias) v += g.bias[m];
+                        if (bias) v += bias[m];
                         v = act_apply(v, g.act);
                     }
                     yo[(long)m * g.out_cs] = v;
@@ -257,7 +261,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
     const int plane = g.NY * g.NX;
     const long Np = (long)g.Nb * plane;
     const unsigned chw = (unsigned)(g.Hi * g.Wi);
-    const long pbeg = (long)blockIdx.z * g.pix_per_split;
+    const int nsplit = (int)gridDim.z / g.siblings;
+    const int sib = (int)blockIdx.z / nsplit, zs = (int)blockIdx.z - sib * nsplit;
+    const long pbeg = (long)zs * g.pix_per_split;
     long pend = pbeg + g.pix_per_split;
     if (pend > Np) pend = Np;
 
@@ -265,7 +271,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
     const int ncol = g.C - c0 < BN ? g.C - c0 : BN;          // valid channel columns of this tile
     const int nrow = g.M - m0 < BM ? g.M - m0 : BM;
 
-    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY), rsX = fd_make_rsrc(g.X);
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY + (size_t)sib * g.Nb * g.dy_ns),
+                                 rsX = fd_make_rsrc(g.X + (size_t)sib * g.Nb * g.C * chw);
     float ra[NA_LOAD], rb[NB_LOAD];
     // Byte offsets of this thread's dY rows / X channels.  Rows past the tile's valid range are clamped to the last valid
     // one: their products land in accumulator rows / columns the epilogue never stores.
@@ -431,6 +438,7 @@ void launch_cfg(const FastGemmArgs& a, int splits, hipStream_t st) {
     const long Np = (long)a.Nb * a.NY * a.NX;
     const int gx = fd_cdiv(Np, BN), gy = fd_cdiv(a.M, BM);
     FastGemmArgs g = a;
+    if (g.siblings < 1) g.siblings = 1;
     g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
     const size_t lds = sizeof(float) * 2 * BKC * ((BM + 1) + BN);
     auto kern = k_conv_fast<WAVES_M, WAVES_N, WM, WN, BKC>;
@@ -439,7 +447,7 @@ void launch_cfg(const FastGemmArgs& a, int splits, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(64 * WAVES_M * WAVES_N), lds, st, g);
+    hipLaunchKernelGGL(kern, dim3(gx, gy, splits * g.siblings), dim3(64 * WAVES_M * WAVES_N), lds, st, g);
 }
 
 }  // namespace
@@ -496,7 +504,7 @@ FastChoice choose_config(const FastGemmArgs& a) {
         const long tiles = (long)fd_cdiv(Np, bn[c]) * fd_cdiv(a.M, bm[c]);
         const int max_split = can_split ? (nchunk / 4 > 0 ? (nchunk / 4 < 16 ? nchunk / 4 : 16) : 1) : 1;
         for (int sp = 1; sp <= max_split; ++sp) {
-            const long blocks = tiles * sp;
+            const long blocks = tiles * sp * (a.siblings > 1 ? a.siblings : 1);
             const double rounds = (double)((blocks + 255) / 256);
             const double per_block = ((double)nchunk / sp) * t_chunk[c] * scale + t_fixed;
             double t = rounds * per_block;
@@ -513,7 +521,7 @@ long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out) {
     if (probe.slab_stride <= 0) probe.slab_stride = probe.out_total > 0 ? probe.out_total : 1;   // sizing query
     const FastChoice ch = choose_config(probe);
     if (splits_out) *splits_out = ch.splits;
-    return ch.splits > 1 ? (long)ch.splits * a.out_total : 0;
+    return ch.splits > 1 ? (long)ch.splits * a.out_total * (a.siblings > 1 ? a.siblings : 1) : 0;
 }
 
 int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
@@ -534,10 +542,13 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_conv_fast launch failed: %s", hipGetErrorString(e)); return (int)e; }
     if (splits > 1) {
-        hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(a.out_total)), dim3(256), 0, st, a.slabs, a.Y, a.bias, a.out_total,
-                           a.slab_stride, splits, a.out_cs, a.M, a.act);
-        e = hipGetLastError();
-        if (e != hipSuccess) { fd_set_error("k_splitk_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
+        for (int sib = 0; sib < (a.siblings > 1 ? a.siblings : 1); ++sib) {
+            hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(a.out_total)), dim3(256), 0, st,
+                               a.slabs + (size_t)sib * splits * a.slab_stride, a.Y + (size_t)sib * a.Nb * a.out_ns,
+                               sib ? a.bias1 : a.bias, a.out_total, a.slab_stride, splits, a.out_cs, a.M, a.act);
+            e = hipGetLastError();
+            if (e != hipSuccess) { fd_set_error("k_splitk_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
     }
     return 0;
 }
@@ -552,7 +563,7 @@ int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int 
     return 0;
 }
 
-int fast_wgrad_splits(int M, int C, int T, long Np) {
+int fast_wgrad_splits(int M, int C, int T, long Np, int siblings) {
     // Workgroups co-resident on a CU share its matrix pipes, so a launch finishes when the fullest CU does: 513 workgroups
     // on 256 CUs (one CU with 3) take 1.5x the time of 512.  Aim at 3 per CU (what the 50 KB LDS tiles allow) and never
     // exceed it; measured in the training step against 256 / 512 / 1024 and against a rounds-based cost model.
@@ -560,7 +571,7 @@ int fast_wgrad_splits(int M, int C, int T, long Np) {
     if (!target) { const char* e = getenv("FD_WGRAD_TARGET"); target = e ? atol(e) : 768; }
     const int bn = C >= 128 ? 128 : 64;
     const long tiles = (long)T * fd_cdiv(C, bn) * fd_cdiv(M, M > 32 ? 64 : 32);
-    long sp = target / tiles;
+    long sp = target / (tiles * (siblings > 1 ? siblings : 1));
     const long maxs = (Np + 511) / 512;
     if (sp > maxs) sp = maxs;
     if (sp < 1) sp = 1;
@@ -568,8 +579,10 @@ int fast_wgrad_splits(int M, int C, int T, long Np) {
     return (int)sp;
 }
 
-int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st) {
+int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st, float* gw1) {
     FastWgradArgs g = a;
+    if (g.siblings < 1) g.siblings = 1;
+    const int nsib = g.siblings;
     const long Np = (long)a.Nb * a.NY * a.NX;
     if ((double)a.Nb * a.C * a.Hi * a.Wi * 4.0 >= 2147483648.0 || (double)a.Nb * (double)a.dy_ns * 4.0 >= 2147483648.0) {
         fd_set_error("conv wgrad: tensor exceeds the 2 GiB addressing range of the fast path"); return -1;
@@ -579,7 +592,7 @@ int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumul
     g.pix_per_split = pps;
     auto go = [&](auto kern, int BM, int BN) {
         const size_t lds = sizeof(float) * 2 * 32 * ((BM + 1) + (BN + 1));
-        dim3 grid(a.T * fd_cdiv(a.C, BN), fd_cdiv(a.M, BM), splits);
+        dim3 grid(a.T * fd_cdiv(a.C, BN), fd_cdiv(a.M, BM), splits * nsib);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);
     };
     if (a.M <= 32) go(k_wgrad_fast<1, 4, 1, 1>, 32, 128);
@@ -588,8 +601,11 @@ int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumul
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_wgrad_fast launch failed: %s", hipGetErrorString(e)); return (int)e; }
     const long n = (long)a.M * a.C * a.T;
-    hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks(n)), dim3(256), 0, st, a.slabs, gw, a.M, a.C, a.T, splits, accumulate);
-    e = hipGetLastError();
-    if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    for (int sib = 0; sib < nsib; ++sib) {
+        hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks(n)), dim3(256), 0, st, a.slabs + (size_t)sib * splits * n, sib ? gw1 : gw,
+                           a.M, a.C, a.T, splits, accumulate);
+        e = hipGetLastError();
+        if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
     return 0;
 }

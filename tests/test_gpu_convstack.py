@@ -423,3 +423,37 @@ def test_grouped_batchnorm_equals_separate_passes(FD, N, C, H, W, G, res):
     relclose(cpu(bn_g.running_mean), cpu(bn_o.running_mean), "running_mean after %d in-order updates" % G)
     relclose(cpu(bn_g.running_var), cpu(bn_o.running_var), "running_var after %d in-order updates" % G)
     assert int(bn_g.num_batches_tracked) == int(bn_o.num_batches_tracked) == G
+
+
+def test_paired_encoders_equal_separate_passes(NW):
+    """networks.paired_forward (one launch per conv for two sibling encoders) == the two encoders run on their own: features,
+    parameter gradients and BatchNorm running statistics, per sibling, to rounding of the split-K / slab summation order."""
+    import copy
+    torch.manual_seed(11)
+    B, H, W = 4, 64, 96
+    enc_a = NW.ResnetEncoder(18, False).cuda()
+    enc_b = NW.ResnetEncoder(18, False, beam_encoder=True).cuda()
+    ref_a, ref_b = copy.deepcopy(enc_a), copy.deepcopy(enc_b)
+    xa, xb = torch.rand(B, 3, H, W, device="cuda"), torch.rand(B, 2, H, W, device="cuda")
+    cots = [torch.randn(B, c, H >> (i + 1), W >> (i + 1), device="cuda") for i, c in enumerate((64, 64, 128, 256, 512))]
+
+    def run(fn, ea, eb):
+        fa, fb = fn(ea, eb)
+        loss = sum((f * c).sum() for f, c in zip(fa, cots)) + sum((f * c).sum() * 0.5 for f, c in zip(fb, cots))
+        loss.backward()
+        return fa, fb
+
+    fa, fb = run(lambda ea, eb: NW.paired_forward(ea, eb, xa, xb), enc_a, enc_b)
+    ga, gb = run(lambda ea, eb: (ea(xa), eb(xb)), ref_a, ref_b)
+    for got, want, nm in ((fa, ga, "a"), (fb, gb, "b")):
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert_close(g.detach().cpu().numpy(), w.detach().cpu().numpy(), rtol=1e-5, atol=1e-5, what="feature %s%d" % (nm, i))
+    for e, r, nm in ((enc_a, ref_a, "a"), (enc_b, ref_b, "b")):
+        for (n, p), (_, q) in zip(e.named_parameters(), r.named_parameters()):
+            if q.grad is None:
+                assert p.grad is None
+                continue
+            scale = float(q.grad.abs().max()) + 1e-12
+            assert_close(p.grad.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale, what="grad %s %s" % (nm, n))
+        for (n, p), (_, q) in zip(e.named_buffers(), r.named_buffers()):
+            assert_close(p.float().cpu().numpy(), q.float().cpu().numpy(), rtol=1e-5, atol=1e-6, what="buffer %s %s" % (nm, n))
