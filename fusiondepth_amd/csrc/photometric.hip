@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
         if (a.beam) {  // trainer.py:577-589
             const float depth = frcp(cm.lo + cm.span * disp_up_at(disp_b, cm, y, x)) * cfg.si_depth_scale;
             const float bd = a.beam[b * P + p] * cfg.si_beam_scale;
-            if (bd > 1.f && depth < 80.f && depth > 1.f && fabsf(depth - bd) < cfg.si_threshold) {
+            if (bd > cfg.si_lo && depth < 80.f && depth > cfg.si_lo && fabsf(depth - bd) < cfg.si_threshold) {
                 const float d = logf(depth) - logf(bd);
                 acc[1] += 1.f; acc[2] += d; acc[3] += d * d;
             }
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
         if (a.beam) {
             const float d26 = depth * cfg.si_depth_scale;
             const float bd = a.beam[b * P + p] * cfg.si_beam_scale;
-            if (bd > 1.f && d26 < 80.f && d26 > 1.f && fabsf(d26 - bd) < cfg.si_threshold) {
+            if (bd > cfg.si_lo && d26 < 80.f && d26 > cfg.si_lo && fabsf(d26 - bd) < cfg.si_threshold) {
                 const float d = logf(d26) - logf(bd);
                 dd += k_si * (d - cfg.si_var * m1) * sdisp;
             }

@@ -1,0 +1,219 @@
+"""HIP-backed ``Refiner`` — the training step of the reference's ``refiner.py`` (BASELINE.json config 5)
+on the same kernels as the trainer's hot path.
+
+The trained depth / pose networks are frozen (eval-mode BatchNorm, ``torch.no_grad`` for the depth branch); a second decoder,
+``refine2d_decoder`` = DepthDecoder(road=True, catxy, deep), is trained.  Per scale it receives the coarse disparity rescaled
+to the sparse LiDAR's metric scale (median ratio inside the crop), the pseudo-3D ``Cat_xy`` coordinates and the max-pooled
+2-channel LiDAR map (refiner.py:316-348); its output goes through the trainer's fused warp + SSIM/L1 + min-reprojection
+kernel, whose masked scale-invariant log term is pointed at the dense GDC depth ``inputs["inf_gdc"]`` with the refiner's
+constants (refiner.py:557-563: mask lower bound 1e-3, no 26x / 100x scaling, factor 10 * gdc_loss_weight [* 4]).
+
+Reference map: refiner.py:299-382 process_batch, :383-448 predict_poses, :487-541 generate_images_pred, :557-563 siloss,
+:592-693 compute_losses, :80-167 model set / Adam.  Glue that is not arithmetic of the hot path (2x2 ceil-mode max-pooling of
+three small maps, the masked medians, the bilinear down-sampling of 1/depth) uses ATen ops on the GPU.
+"""
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+
+from . import dp
+from . import functional as FD
+from . import networks
+from .layers import disp_to_depth
+from .trainer import Trainer, derived_hparams
+
+REFINER_MODEL_ORDER = ["encoder", "beam_encoder", "beam_encoder_pose", "depth", "pose_encoder", "pose", "refine2d_decoder"]
+
+
+class Refiner(Trainer):
+    """Same method names as the reference's ``Refiner``; batches are dicts with the reference's keys (+ ``"inf_gdc"``)."""
+
+    def __init__(self, options, device=None, verbose=True):
+        self.opt = options
+        if self.opt.no_cuda or not torch.cuda.is_available():
+            raise RuntimeError("fusiondepth_amd.Refiner needs an MI355X: there is no CPU path (use oracle/ for CPU checks)")
+        self.opt.clone_gdc, self.opt.refine_2d = True, True                                   # refiner.py:29-30
+        self.device = torch.device(device if device is not None else "cuda")
+        self.rank, self.world_size = 0, 1
+        self.materialize_outputs = False
+        vram = torch.cuda.get_device_properties(self.device).total_memory / 1024 ** 3
+        hp = derived_hparams(self.opt, vram)                                                  # refiner.py:32-45 (same rule)
+        self.opt.num_epochs = hp["num_epochs"]
+        self.accumulate_step, self.learning_rate = hp["accumulate_step"], hp["learning_rate"]
+        self.scheduler_step_size, self.batch_size = hp["scheduler_step_size"], hp["micro_batch"]
+        self.eval_scales = self.opt.scales
+        assert self.opt.height % 32 == 0 and self.opt.width % 32 == 0, "'height' / 'width' must be multiples of 32"
+        assert self.opt.frame_ids[0] == 0, "frame_ids must start with 0"
+        if self.opt.use_stereo or self.opt.predictive_mask or self.opt.pose_model_type != "separate_resnet" or \
+                self.opt.v1_multiscale or self.opt.train_entire_net or not self.opt.beam_encoder:
+            raise NotImplementedError("Refiner: only the default path (frozen nets, separate_resnet pose net, beam encoder, "
+                                      "full-resolution sampling) is implemented")
+        self.num_scales = len(self.opt.scales)
+        self.num_input_frames = len(self.opt.frame_ids)
+        self.num_pose_frames = 2 if self.opt.pose_model_input == "pairs" else self.num_input_frames
+        self.use_pose_net = True
+
+        m = {}                                                                                # refiner.py:80-160
+        m["encoder"] = networks.ResnetEncoder(self.opt.num_layers, False, cat4beam_to_color=self.opt.cat_4beam_to_color,
+                                              cat2channel=self.opt.cat2start)
+        m["beam_encoder"] = networks.ResnetEncoder(self.opt.num_layers, False, beam_encoder=True)
+        m["beam_encoder_pose"] = networks.ResnetEncoder(self.opt.num_layers, False, num_input_images=self.num_pose_frames,
+                                                        beam_encoder=True)
+        m["depth"] = networks.DepthDecoder(m["encoder"].num_ch_enc, self.opt.scales, cat2end=self.opt.cat2end)
+        m["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, False, num_input_images=self.num_pose_frames)
+        m["pose"] = networks.PoseDecoder(m["pose_encoder"].num_ch_enc, num_input_features=1, num_frames_to_predict_for=2)
+        m["refine2d_decoder"] = networks.DepthDecoder(m["encoder"].num_ch_enc, self.opt.scales, road=True,
+                                                      catxy=(self.opt.catxy == "true"), deep=(self.opt.refine2d_deep == "true"))
+        self.models = {k: m[k].to(self.device) for k in REFINER_MODEL_ORDER}
+        self.parameters_to_train = list(self.models["refine2d_decoder"].parameters())          # refiner.py:148-160
+        for k, net in self.models.items():
+            if k != "refine2d_decoder":
+                for p in net.parameters():
+                    p.requires_grad_(False)          # frozen: no data gradient is propagated into them either
+
+        self.flat = dp.FlatParameters(self.parameters_to_train)
+        FD.enable_weight_cache(self.parameters_to_train)
+        FD.enable_direct_grad(self.parameters_to_train)
+        self.exp_avg = torch.zeros_like(self.flat.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
+        self.adam_step_count = 0
+        self.lr = self.learning_rate
+        self.adam_state = torch.tensor([0.0, self.lr], device=self.device)
+        self._graph, self._streams = None, []
+        self.parallel_streams = False
+        self.pair_siblings = self._pair_depth = self._pair_pose = False
+        self.stack_microbatches = False
+        self._groups = 1
+        self.grad_sync = dp.GradientSynchronizer(self.flat, 1)
+        self.photo_options = FD.PhotoOptions(self.opt.min_depth, self.opt.max_depth, self.opt.no_ssim, self.opt.avg_reprojection,
+                                             self.opt.gdc_loss_threshold, self.opt.si_var, si_depth_scale=1.0,
+                                             si_beam_scale=1.0, si_lo=1e-3)
+        self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
+        self.epoch, self.step, self.batch_idx = 0, 0, 0
+        self.best = 10.0
+        self.start_time = time.time()
+        self.set_train()
+        self.flat.zero_grad()
+        if verbose:
+            n = sum(p.numel() for p in self.parameters_to_train)
+            print("fusiondepth_amd.Refiner: training refine2d_decoder, %d parameters (%.1f MB fp32), lr %.3g" % (n, n * 4 / 1e6, self.lr))
+
+    def set_train(self):
+        """refiner.py:80-160: the depth / pose networks stay in eval mode; only the refine decoder trains."""
+        for k, net in self.models.items():
+            net.train() if k == "refine2d_decoder" else net.eval()
+
+    # ------------------------------------------------------------------------------------------------
+    def refine_inputs(self, inputs, outputs):
+        """refiner.py:316-348."""
+        opt = self.opt
+        beam, two_cha = inputs["4beam"], inputs["2channel"]
+        disp_0 = outputs[("disp", 0)]
+        res = {}
+        mask = beam > 0
+        crop = torch.zeros_like(mask)
+        crop[:, :, 78:190, 23:617] = 1
+        mask = mask * crop
+        beam_med = torch.median(beam[mask] * 100.0)
+        for scale in opt.scales:
+            if opt.refine_a0 != "true":
+                disp = outputs[("disp", scale)]
+            else:
+                disp = disp_0
+                disp_0 = F.max_pool2d(disp_0, 2, ceil_mode=True)
+            disp640 = FD.bilinear_upsample(disp, (opt.height, opt.width)) if disp.shape[2] != opt.height else disp
+            depth = disp_to_depth(disp640, opt.min_depth, opt.max_depth)[1]
+            depth = depth * (beam_med / torch.median(depth[mask]))
+            scaled_disp = (F.interpolate(1 / depth, disp.shape[2:], mode="bilinear", align_corners=False) - 0.01) / 9.9
+            if scale != 0:
+                two_cha = F.max_pool2d(two_cha, 2, ceil_mode=True)
+            if opt.catxy == "true":
+                for _ in range(scale):
+                    depth = F.max_pool2d(depth, 2, ceil_mode=True)
+                xyz = FD.cat_xy(depth, inputs[("inv_K", scale)])
+                res[("disp", scale)] = torch.cat([scaled_disp, xyz, two_cha], 1)
+            else:
+                res[("disp", scale)] = torch.cat([scaled_disp, two_cha], 1)
+        return res
+
+    def process_batch(self, inputs, val=False):
+        """refiner.py:299-382 (train_entire_net=False)."""
+        for key, ipt in inputs.items():
+            if torch.is_tensor(ipt) and ipt.device != self.device:
+                inputs[key] = ipt.to(self.device)
+        with torch.no_grad():
+            features = self.models["encoder"](inputs["color_aug", 0, 0])
+            beam_features = self.models["beam_encoder"](inputs["2channel"])
+            if self.opt.refine_depthnet_with_beam == "true":
+                outputs = dict(self.models["depth"](features, beam_features=beam_features))
+            else:
+                outputs = dict(self.models["depth"](features))
+            outputs.update(self.refine_inputs(inputs, outputs))
+        if self.use_pose_net and not val:
+            with torch.no_grad():                     # frozen pose networks (reference: eval mode, not in the optimiser)
+                outputs.update(self.predict_poses(inputs, features))
+        losses = {"loss": 0.0}
+        n_iter = self.opt.refine_iter
+        for it in range(n_iter):
+            offset = self.models["refine2d_decoder"](features, beam_features=beam_features, depth_maps=outputs,
+                                                     tanh=self.opt.refine_offset)
+            for s in self.opt.scales:
+                outputs[("disp", s)] = offset[("disp", s)]
+            self.generate_images_pred(inputs, outputs, [0] if val else self.opt.frame_ids)
+            if not val:
+                gama = (1.0 if n_iter == 1 else self.opt.refine_iter_gama) ** (n_iter - it)
+                losses = self.compute_losses(inputs, outputs, losses, gama=gama)
+        return outputs, losses
+
+    def generate_images_pred(self, inputs, outputs, frame_ids):
+        """refiner.py:487-541 fused with the per-pixel part of compute_losses; the SI term is the GDC loss (compute_losses)."""
+        fids = [f for f in frame_ids[1:]]
+        if not fids:
+            for scale in self.opt.scales:
+                disp = FD.bilinear_upsample(outputs[("disp", scale)], (self.opt.height, self.opt.width))
+                outputs[("depth", 0, scale)] = disp_to_depth(disp, self.opt.min_depth, self.opt.max_depth)[1]
+            return
+        automask = not self.opt.disable_automasking
+        ident = self.identity_losses(inputs, 0) if automask else None
+        noise_in = inputs.get("_noise")
+        for scale in self.opt.scales:
+            noise = None
+            if ident is not None:
+                noise = noise_in[scale] if noise_in is not None else torch.randn(ident.shape, device=ident.device)
+            use_gdc = (not self.opt.gdc_loss_only_on_scale_0) or scale == 0
+            Ts = [outputs[("cam_T_cam", 0, f)] for f in fids]
+            srcs = [inputs[("color", f, 0)] for f in fids]
+            photo, si, sel, depth, sample, color = FD.photo_loss(
+                outputs[("disp", scale)], Ts, inputs[("K", 0)], inputs[("inv_K", 0)], srcs, inputs[("color", 0, 0)], ident, noise,
+                inputs["inf_gdc"] if use_gdc else None, self.photo_options, self.materialize_outputs, 1)
+            outputs[("photo", scale)] = (photo, si if use_gdc else None)
+            if automask:
+                outputs["identity_selection/{}".format(scale)] = (sel > ident.shape[1] - 1).float()
+
+    def compute_losses(self, inputs, outputs, losses, gama=1.0, frame_ids=None):
+        """refiner.py:592-693.  The fused kernel's SI term is 0.1 * sqrt(var); the refiner's is 10 * sqrt(var) * weight [* 4]."""
+        total = 0
+        for scale in self.opt.scales:
+            photo, si = outputs[("photo", scale)]
+            smooth = FD.normalized_smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)])
+            loss = photo + self.opt.disparity_smoothness * smooth / (2 ** scale)
+            total = total + loss
+            losses["loss/gama{}_scale{}".format(gama, scale)] = loss
+            if si is not None:
+                gdc_loss = si * (100.0 * self.opt.gdc_loss_weight * (4.0 if self.opt.gdc_loss_only_on_scale_0 else 1.0))
+                total = total + gdc_loss
+                losses["loss/gdc_scale{}".format(scale)] = gdc_loss
+        total = total / self.num_scales
+        losses["loss"] = losses["loss"] + total * gama
+        return losses
+
+    def train_step(self, inputs):
+        """One optimiser step of refiner.py:262-297 (accumulate_step == 1: batch sizes <= 8)."""
+        outputs, losses = self.process_batch(inputs)
+        losses["loss"].backward()
+        self.optimizer_step(1.0)
+        self._ensure_weight_plan()
+        self.step += 1
+        return losses

@@ -118,6 +118,8 @@ typedef struct {
     float si_var;           /* opt.si_var */
     float eps;              /* Project3D eps 1e-7 */
     int groups;             /* number of stacked micro-batches (>= 1) */
+    float si_lo;            /* lower bound of the SI-loss mask: target > si_lo && pred > si_lo  (1.0 in trainer.py:584-586,
+                               1e-3 in refiner.py:561-562) */
 } fd_photo_cfg;
 
 long fd_photo_ws_floats(int B, int H, int W);

@@ -124,3 +124,40 @@ def depth_eval_inputs(seed, B, H, W, gt_h=375, gt_w=1242):
     pred = rng.uniform(0.5, 90.0, size=(B, 1, H, W)).astype(np.float32)
     return gt, pred
 
+
+def refiner_inputs(seed, B, H, W):
+    """Inputs of one refiner step: the trainer batch + a dense "GDC" depth map (metres) + LiDAR maps made by the oracle's
+    scatter (shared by the generator and the tests)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle import scatter as OS
+    inp, rng = batch_inputs(seed, B, H, W)
+    roi = (76, 190, 2, 638)
+    for i, f in enumerate((0, -1, 1)):
+        beam = lidar_4beam(np.random.RandomState(seed + 10 + i), B, H, W)
+        beam = np.where(beam > 0, 0.035 + (beam - 0.05) * (0.035 / 0.6), 0).astype(np.float32)     # ~3.5-7 m returns
+        two = np.stack([np.stack(OS.scatter_2channel_c(beam[b, 0], roi)) for b in range(B)])
+        inp[("2channel", f, 0)] = torch.from_numpy(two)
+        if f == 0:
+            inp["2channel"] = torch.from_numpy(two)
+            inp["4beam"] = torch.from_numpy(beam)
+    # dense "GDC" depth in the units of the refined prediction (disp ~ 0.5 -> depth ~ 0.2), so that the SI-log mask
+    # |pred - target| < gdc_loss_threshold (refiner.py:561-562) is well populated
+    inp["inf_gdc"] = torch.from_numpy(np.random.RandomState(seed + 77).uniform(0.05, 1.5, size=(B, 1, H, W)).astype(np.float32))
+    noise = [torch.from_numpy(np.random.RandomState(seed + 50 + s).randn(B, 2, H, W).astype(np.float32)) for s in range(4)]
+    return inp, noise
+
+
+def refiner_models(module_table, seed=5):
+    """The seven networks of refiner.py:80-160 with seeded weights (tests rebuild the same state from the seeds).  The
+    refine decoder's four disparity heads are scaled down so that sigmoid(.) stays away from saturation: with raw random
+    weights the refined disparity spans [1e-8, 1] (depth 0.1 .. 100 m), almost every warp lands on the image border and the
+    gradient is carried by a few hundred pixels whose argmin / clamp branches flip with the last bit of rounding."""
+    for k, net in module_table.items():
+        fill_params(net, 300 + len(k) + seed)
+        net.train() if k == "refine2d_decoder" else net.eval()
+    with torch.no_grad():
+        for name, t in module_table["refine2d_decoder"].state_dict().items():
+            if name.split(".")[1] in ("10", "11", "12", "13"):
+                t.mul_(0.02)
+    return module_table

@@ -23,6 +23,7 @@ import torch.nn as nn
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("FD_REFERENCE", "/root/reference")
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))     # repo root: the oracle package
 import inputs as gin  # noqa: E402
 
 
@@ -307,6 +308,55 @@ def gold_depth_losses(RL, RT):
                                                                            dtype=np.float64))
 
 
+def gold_refiner(RL, DD, PD):
+    """refiner.py:299-382 + :592-693 run as unbound Refiner methods.  The ResNet trunks are oracle.networks' (torchvision is
+    not installed); decoders, Cat_xy, projection, SSIM and every loss line are the reference's own code."""
+    import copy
+    from types import SimpleNamespace
+    import refiner as RF
+    from oracle import networks as ON
+    B, H, W = 1, 192, 640
+    opt = copy.deepcopy(RF.opts)
+    opt.height, opt.width, opt.batch_size = H, W, B
+    opt.refine_2d, opt.clone_gdc, opt.train_entire_net = True, True, False
+    enc = ON.ResnetEncoder(18, False)
+    models = {"encoder": enc, "beam_encoder": ON.ResnetEncoder(18, False, beam_encoder=True),
+              "beam_encoder_pose": ON.ResnetEncoder(18, False, num_input_images=2, beam_encoder=True),
+              "depth": DD.DepthDecoder(enc.num_ch_enc, opt.scales),
+              "pose_encoder": ON.ResnetEncoder(18, False, num_input_images=2),
+              "pose": PD.PoseDecoder(enc.num_ch_enc, num_input_features=1, num_frames_to_predict_for=2),
+              "refine2d_decoder": DD.DepthDecoder(enc.num_ch_enc, opt.scales, road=True, catxy=(opt.catxy == "true"),
+                                                  deep=(opt.refine2d_deep == "true"))}
+    gin.refiner_models(models)
+    ns = SimpleNamespace(opt=opt, models=models, device=torch.device("cpu"), batch_size=B, eval_scales=opt.scales,
+                         num_scales=len(opt.scales), num_pose_frames=2, use_pose_net=True, ssim=RL.SSIM(),
+                         backproject_depth={}, project_3d={}, catxy={})
+    for s in opt.scales:
+        h, w = H // 2 ** s, W // 2 ** s
+        ns.backproject_depth[s] = RL.BackprojectDepth(B, h, w)
+        ns.project_3d[s] = RL.Project3D(B, h, w)
+        ns.catxy["False", s] = RL.Cat_xy(B, h, w)
+    for name in ("predict_poses", "generate_images_pred", "compute_reprojection_loss", "siloss", "compute_losses"):
+        setattr(ns, name, (lambda f: (lambda *a, **k: f(ns, *a, **k)))(getattr(RF.Refiner, name)))
+    inp, noise = gin.refiner_inputs(808, B, H, W)
+    torch.manual_seed(4242)
+    rec = [torch.randn(B, 2, H, W) for _ in opt.scales]      # what compute_losses will draw (scale order)
+    torch.manual_seed(4242)
+    outputs, losses = RF.Refiner.process_batch(ns, {k: v.clone() for k, v in inp.items()})
+    params = list(models["refine2d_decoder"].parameters())
+    grads = torch.autograd.grad(losses["loss"], params, allow_unused=True)
+    out = {"noise_seed": np.array(4242), "noise_head": npy(rec[0]).reshape(-1)[:16]}
+    for k, v in losses.items():
+        out["L/" + k.replace("/", "_")] = np.array(float(v.detach()) if torch.is_tensor(v) else float(v), dtype=np.float64)
+    for s in opt.scales:
+        out["disp%d" % s] = npy(outputs[("disp", s)])
+        out["depth%d_sub" % s] = npy(outputs[("depth", 0, s)])[:, :, ::16, ::16]
+    for (n, p), g in zip(models["refine2d_decoder"].named_parameters(), grads):
+        if g is not None:
+            put_grad(out, "g/" + n, g)
+    save("refiner_b1_192x640", **out)
+
+
 def gold_options():
     """Flag surface of the reference's argparse (options.py:9-480): name -> default/type/choices/action."""
     import json
@@ -336,6 +386,7 @@ def main():
                 opt_over=dict(no_ssim=True, disable_automasking=True))
     gold_scatter(get2ch)
     gold_depth_losses(RL, RT)
+    gold_refiner(RL, DD, PD)
 
 
 if __name__ == "__main__":

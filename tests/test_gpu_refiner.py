@@ -1,0 +1,69 @@
+"""GPU parity of the HIP-backed Refiner (BASELINE.json config 5 / SURVEY.md §8f rank 1) against the golden produced by the
+reference's own Refiner.process_batch / compute_losses, and against the CPU oracle over optimiser steps."""
+import numpy as np
+import pytest
+import torch
+
+import inputs as gin
+from conftest import assert_close, check_grad_compact
+from oracle import refiner as OR
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(B=1, H=192, W=640):
+    from fusiondepth_amd.options import MonodepthOptions
+    from fusiondepth_amd.refiner import Refiner
+    o = MonodepthOptions().parse(["--num_layers", "18", "--weights_init", "scratch", "--batch_size", str(B),
+                                  "--height", str(H), "--width", str(W)])
+    rf = Refiner(o, verbose=False)
+    oopt = OR.default_opt(batch_size=B, height=H, width=W, learning_rate=o.learning_rate)
+    omodels = gin.refiner_models(OR.build_models(oopt, 0))
+    with torch.no_grad():
+        for k, m in omodels.items():
+            for name, t in rf.models[k].state_dict().items():
+                t.copy_(m.state_dict()[name])
+    return rf, oopt, omodels
+
+
+def test_refiner_step_vs_reference_golden(golden):
+    g = golden("refiner_b1_192x640")
+    B, H, W = 1, 192, 640
+    rf, oopt, _ = _make(B, H, W)
+    inp, _ = gin.refiner_inputs(808, B, H, W)
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = [torch.randn(B, 2, H, W) for _ in range(4)]
+    np.testing.assert_array_equal(noise[0].numpy().reshape(-1)[:16], g["noise_head"])
+    ginp = {k: v.cuda() for k, v in inp.items()}
+    ginp["_noise"] = [n.cuda() for n in noise]
+    outputs, losses = rf.process_batch(ginp)
+    for k, v in losses.items():
+        assert_close(float(v.detach()), float(g["L/" + k.replace("/", "_")]), rtol=2e-4, atol=1e-7, what=k)
+    for s in range(4):
+        assert_close(outputs[("disp", s)].detach().cpu().numpy(), g["disp%d" % s], rtol=1e-3, atol=1e-4, what="refined disp%d" % s)
+    losses["loss"].backward()
+    for n, p in rf.models["refine2d_decoder"].named_parameters():
+        if ("g/" + n) in g or ("g/" + n + "@sum") in g:
+            check_grad_compact(g, "g/" + n, p.grad.cpu().numpy(), rtol=2e-3, atol=1e-5)
+
+
+def test_refiner_trains_like_the_oracle():
+    """Three Adam steps of the refine decoder: loss trajectory vs the oracle harness (same init, inputs, noise)."""
+    B, H, W = 1, 192, 640
+    rf, oopt, omodels = _make(B, H, W)
+    opt_o = torch.optim.Adam(omodels["refine2d_decoder"].parameters(), rf.lr)
+    traj = []
+    for step in range(3):
+        inp, noise = gin.refiner_inputs(820 + step, B, H, W)
+        ginp = {k: v.cuda() for k, v in inp.items()}
+        ginp["_noise"] = [n.cuda() for n in noise]
+        _, lo = OR.process_batch(oopt, omodels, inp, noise)
+        opt_o.zero_grad()
+        lo["loss"].backward()
+        opt_o.step()
+        lg = rf.train_step(ginp)
+        traj.append((float(lg["loss"]), float(lo["loss"])))
+    print("refiner loss (HIP, oracle):", traj)
+    assert np.isfinite(traj).all()
+    assert_close(traj[0][0], traj[0][1], rtol=2e-4, atol=0, what="refiner loss at step 0")
+    assert_close([t[0] for t in traj], [t[1] for t in traj], rtol=5e-3, atol=0, what="refiner loss trajectory")

@@ -265,3 +265,29 @@ def test_depth_monitoring_metrics_match_reference(golden):
     got = OT.compute_depth_losses(torch.from_numpy(pred), torch.from_numpy(gt))
     np.testing.assert_allclose(got, g["metrics"], rtol=1e-6, atol=0)
 
+
+def test_refiner_step_matches_reference(golden):
+    """oracle.refiner.process_batch (refine inputs, refine decoder, warp, photometric + GDC SI-log loss) == the reference's
+    Refiner.process_batch / compute_losses (refiner.py:299-382, 592-693) on the same weights, inputs and noise."""
+    from oracle import refiner as OR
+    g = golden("refiner_b1_192x640")
+    B, H, W = 1, 192, 640
+    opt = OR.default_opt(batch_size=B)
+    models = gin.refiner_models(OR.build_models(opt, 0))
+    inp, _ = gin.refiner_inputs(808, B, H, W)
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = [torch.randn(B, 2, H, W) for _ in opt.scales]
+    np.testing.assert_array_equal(noise[0].numpy().reshape(-1)[:16], g["noise_head"])
+    outputs, losses = OR.process_batch(opt, models, inp, noise)
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), float(g["L/" + k.replace("/", "_")]), rtol=2e-6, atol=1e-9, err_msg=k)
+    for s in opt.scales:
+        np.testing.assert_allclose(outputs[("disp", s)].detach().numpy(), g["disp%d" % s], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(outputs[("depth", 0, s)].detach().numpy()[:, :, ::16, ::16], g["depth%d_sub" % s], rtol=1e-5,
+                                   atol=1e-5)
+    params = dict(models["refine2d_decoder"].named_parameters())
+    grads = torch.autograd.grad(losses["loss"], list(params.values()), allow_unused=True)
+    for (n, _), gr in zip(params.items(), grads):
+        if gr is not None:
+            check_grad_compact(g, "g/" + n, gr, rtol=2e-4)
+
