@@ -65,3 +65,151 @@ extern "C" int fd_scatter_2channel(const float* beam, float* out, int B, int H, 
     FD_LAUNCH_CHECK("fd_scatter_2channel");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// LiDAR rasterisation upstream of the scatter: Velodyne points -> z-buffered sparse depth image -> padded -> 2x2 max-pool
+// -> "4beam" input.  Reference: kitti_utils.py:40-102 generate_depth_map, datasets/kitti_dataset.py:93-117 get_4beam,
+// datasets/mono_dataset.py:193-198.  All arithmetic in float64 like the reference's numpy code; np.round = rint (ties to
+// even).  The reference's duplicate handling is reproduced exactly (oracle/rasterize.py spells it out): a pixel holds the
+// depth of the LAST point that hit it unless its `sub2ind` index (row * (W - 1) + col - 1) is shared by several points, in
+// which case the pixel of the FIRST such point gets their minimum - and that index is also shared between column 0 of
+// row r and column W - 1 of row r - 1.  Per-pixel min depth / first index / last index come from integer atomics (order
+// independent), so the result is deterministic.
+namespace {
+
+__device__ __forceinline__ unsigned long long zkey(double z) {              // order-preserving map double -> u64
+    const unsigned long long b = (unsigned long long)__double_as_longlong(z);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double zunkey(unsigned long long k) {
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct RasterWs {
+    unsigned long long* zmin;   // [im_h * im_w]
+    unsigned* first;            // [im_h * im_w]
+    unsigned* last;             // [im_h * im_w]
+    double* zs;                 // [n_points]
+    double* depth;              // [im_h * im_w]
+};
+
+__global__ void k_raster_init(RasterWs w, long npix) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+        w.zmin[i] = ~0ull; w.first[i] = 0xFFFFFFFFu; w.last[i] = 0u;
+    }
+}
+
+__global__ void k_raster_points(const float* __restrict__ pts, int n, const double* __restrict__ P, int im_h, int im_w, RasterWs w) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double x = (double)pts[4 * i], y = (double)pts[4 * i + 1], z = (double)pts[4 * i + 2];
+        if (!(x >= 0.0)) continue;                                         // kitti_utils.py:62
+        // kitti_utils.py:65 np.dot(P_velo2im, velo.T): homogeneous coordinate 1.0
+        const double c0 = fma(P[3], 1.0, fma(P[2], z, fma(P[1], y, P[0] * x)));
+        const double c1 = fma(P[7], 1.0, fma(P[6], z, fma(P[5], y, P[4] * x)));
+        const double c2 = fma(P[11], 1.0, fma(P[10], z, fma(P[9], y, P[8] * x)));
+        const double u = rint(c0 / c2) - 1.0, v = rint(c1 / c2) - 1.0;     // :66, :73-74
+        w.zs[i] = c2;
+        if (!(u >= 0.0 && v >= 0.0 && u < (double)im_w && v < (double)im_h)) continue;
+        const long pix = (long)v * im_w + (long)u;
+        atomicMin(&w.zmin[pix], zkey(c2));
+        atomicMin(&w.first[pix], (unsigned)i);
+        atomicMax(&w.last[pix], (unsigned)i);
+    }
+}
+
+__global__ void k_raster_resolve(RasterWs w, int im_h, int im_w) {
+    const long npix = (long)im_h * im_w;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(p / im_w), c = (int)(p - (long)r * im_w);
+        double d = 0.0;
+        if (w.first[p] != 0xFFFFFFFFu) {
+            d = zunkey(w.zmin[p]);                                         // all points of this pixel share one sub2ind value
+            // partner pixel with the same sub2ind value: (r, 0) <-> (r - 1, W - 1)
+            long q = -1;
+            if (im_w > 1 && c == 0 && r >= 1) q = (long)(r - 1) * im_w + (im_w - 1);
+            else if (im_w > 1 && c == im_w - 1 && r + 1 < im_h) q = (long)(r + 1) * im_w;
+            if (q >= 0 && w.first[q] != 0xFFFFFFFFu) {
+                if (w.first[p] < w.first[q]) {                             // this pixel holds the group's first point: group minimum
+                    const double dq = zunkey(w.zmin[q]);
+                    d = dq < d ? dq : d;
+                } else {
+                    d = w.zs[w.last[p]];                                   // untouched by the duplicate pass: last point wins
+                }
+            }
+            if (d < 0.0) d = 0.0;                                          // kitti_utils.py:86
+        }
+        w.depth[p] = d;
+    }
+}
+
+// pad (top / left; optional 2-row crop) to the target shape, 2x2 max-pool with ceil_mode, float32, / 100
+__global__ void k_raster_pool(const double* __restrict__ depth, int im_h, int im_w, int pad_top, int pad_left, int crop_top,
+                              int tgt_h, int tgt_w, float* __restrict__ out, int out_h, int out_w) {
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < out_h * out_w; o += gridDim.x * blockDim.x) {
+        const int oy = o / out_w, ox = o - oy * out_w;
+        double m = -1.0 / 0.0;
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) {
+                const int ty = 2 * oy + dy, tx = 2 * ox + dx;
+                if (ty >= tgt_h || tx >= tgt_w) continue;                  // ceil_mode: partial windows
+                const int sy = ty + crop_top - pad_top, sx = tx - pad_left;
+                const double v = (sy >= 0 && sy < im_h && sx >= 0 && sx < im_w) ? depth[(long)sy * im_w + sx] : 0.0;
+                m = v > m ? v : m;
+            }
+        out[o] = (float)m / 100.0f;
+    }
+}
+
+inline size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+}  // namespace
+
+extern "C" long fd_velo_rasterize_ws_bytes(int n_points, int im_h, int im_w) {
+    if (n_points < 0 || im_h <= 0 || im_w <= 0) return 0;
+    const size_t npix = (size_t)im_h * im_w;
+    return (long)(align256(npix * 8) + 2 * align256(npix * 4) + align256((size_t)(n_points > 0 ? n_points : 1) * 8) + align256(npix * 8));
+}
+
+extern "C" int fd_velo_rasterize(const float* points, int n_points, const double* P_velo2im, int im_h, int im_w, int target_h,
+                                 int target_w, float* beam_out, double* depth_full, void* ws, void* stream) {
+    FD_REQUIRE(points && P_velo2im && beam_out && ws && n_points >= 0 && im_h > 0 && im_w > 0 && target_h > 0 && target_w > 0,
+               "fd_velo_rasterize: bad args");
+    FD_REQUIRE(target_w >= im_w, "fd_velo_rasterize: target width %d < image width %d (the reference pads, never crops, columns)",
+               target_w, im_w);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)im_h * im_w;
+    char* b = (char*)ws;
+    RasterWs w;
+    w.zmin = (unsigned long long*)b; b += align256(npix * 8);
+    w.first = (unsigned*)b; b += align256(npix * 4);
+    w.last = (unsigned*)b; b += align256(npix * 4);
+    w.zs = (double*)b; b += align256((size_t)(n_points > 0 ? n_points : 1) * 8);
+    w.depth = (double*)b;
+    hipLaunchKernelGGL(k_raster_init, dim3(fd_cdiv((long)npix, 256)), dim3(256), 0, st, w, (long)npix);
+    FD_LAUNCH_CHECK("fd_velo_rasterize(init)");
+    if (n_points > 0) {
+        hipLaunchKernelGGL(k_raster_points, dim3(fd_cdiv(n_points, 256)), dim3(256), 0, st, points, n_points, P_velo2im, im_h, im_w, w);
+        FD_LAUNCH_CHECK("fd_velo_rasterize(points)");
+    }
+    hipLaunchKernelGGL(k_raster_resolve, dim3(fd_cdiv((long)npix, 256)), dim3(256), 0, st, w, im_h, im_w);
+    FD_LAUNCH_CHECK("fd_velo_rasterize(resolve)");
+    if (depth_full) {
+        if (hipMemcpyAsync(depth_full, w.depth, npix * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            fd_set_error("fd_velo_rasterize: copy of the full-resolution depth failed");
+            return -1;
+        }
+    }
+    // kitti_utils.py:88-101: rows are padded on top by |target_h - im_h| (and 2 rows cropped when the target is shorter),
+    // columns split the padding left / right
+    const int ypad = target_h > im_h ? target_h - im_h : im_h - target_h;
+    const int crop = target_h < im_h ? 2 : 0;
+    const int padded_h = im_h + ypad - crop;
+    FD_REQUIRE(padded_h >= 1, "fd_velo_rasterize: empty padded image");
+    const int xpad1 = (target_w - im_w) / 2;
+    const int out_h = (padded_h + 1) / 2, out_w = (target_w + 1) / 2;
+    hipLaunchKernelGGL(k_raster_pool, dim3(fd_cdiv((long)out_h * out_w, 256)), dim3(256), 0, st, w.depth, im_h, im_w, ypad, xpad1, crop,
+                       padded_h, target_w, beam_out, out_h, out_w);
+    FD_LAUNCH_CHECK("fd_velo_rasterize(pool)");
+    return 0;
+}
+

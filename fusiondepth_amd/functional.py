@@ -291,6 +291,24 @@ def scatter_2channel(beam, roi=(76, 190, 2, 638), expand=2):
     return out[0] if squeeze else out
 
 
+def velo_rasterize(points, P_velo2im, im_h, im_w, shape=(384, 1280), return_full=False):
+    """Velodyne scan -> "4beam" network input (kitti_utils.py:40-102 + kitti_dataset.py:93-117 + mono_dataset.py:193-198).
+    ``points``: [N,4] float32 CUDA; ``P_velo2im``: 3x4 (numpy / tensor, float64).  Returns the [shape/2] float32 map
+    (metres / 100) and, optionally, the full-resolution float64 depth image."""
+    points = f32(points)
+    _need_cuda(points)
+    P = torch.as_tensor(P_velo2im, dtype=torch.float64).reshape(12).to(points.device).contiguous()
+    n = points.shape[0]
+    ypad = abs(shape[0] - im_h)
+    padded_h = im_h + ypad - (2 if shape[0] < im_h else 0)
+    out = torch.empty(((padded_h + 1) // 2, (shape[1] + 1) // 2), device=points.device, dtype=torch.float32)
+    full = torch.empty((im_h, im_w), device=points.device, dtype=torch.float64) if return_full else None
+    ws = torch.empty((query("fd_velo_rasterize_ws_bytes", n, im_h, im_w),), device=points.device, dtype=torch.uint8)
+    call("fd_velo_rasterize", points.data_ptr(), n, P.data_ptr(), im_h, im_w, int(shape[0]), int(shape[1]), out.data_ptr(),
+         full.data_ptr() if full is not None else None, ws.data_ptr(), stream())
+    return (out, full) if return_full else out
+
+
 def scaled_roi(H, W):
     """ROI of gen2channel.py:64-65 (rows 76..189, cols 2..637 of 192x640) scaled to another size."""
     return (max(int(round(76 * H / 192)), 2), min(int(round(190 * H / 192)), H - 2), 2, W - 2)

@@ -161,3 +161,36 @@ def refiner_models(module_table, seed=5):
             if name.split(".")[1] in ("10", "11", "12", "13"):
                 t.mul_(0.02)
     return module_table
+
+
+def lidar_scan(seed, n_points=6000, im_h=375, im_w=1242):
+    """A synthetic Velodyne scan (float32 [N,4]: forward, left, up, reflectance) and a KITTI-like velodyne -> image
+    projection (float64 [3,4]).  Includes points behind the camera, points outside the image, clusters that pile up on
+    single pixels and points forced onto the first / last image column of adjacent rows (the reference's sub2ind quirk)."""
+    rng = np.random.RandomState(seed)
+    fwd = rng.uniform(-5.0, 70.0, n_points)
+    left = rng.uniform(-25.0, 25.0, n_points)
+    up = rng.uniform(-2.5, 1.5, n_points)
+    velo = np.stack([fwd, left, up, rng.rand(n_points)], 1).astype(np.float32)
+    velo[:400, :3] = velo[400:800, :3] * np.float32(1.0003)          # near-duplicates: many pixels get 2+ points
+    K = np.array([[721.5377, 0.0, 609.5593, 44.85728], [0.0, 721.5377, 172.854, 0.2163791], [0.0, 0.0, 1.0, 0.002745884]])
+    R = np.eye(4)
+    c, s_ = np.cos(0.01), np.sin(0.01)
+    R[:3, :3] = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+    velo2cam = np.array([[7.533745e-03, -9.999714e-01, -6.166020e-04, -4.069766e-03],
+                         [1.480249e-02, 7.280733e-04, -9.998902e-01, -7.631618e-02],
+                         [9.998621e-01, 7.523790e-03, 1.480755e-02, -2.717806e-01], [0.0, 0.0, 0.0, 1.0]])
+    P = np.dot(np.dot(K, R), velo2cam)                       # kitti_utils.py:57, same association
+    # points whose projection lands exactly on column 0 / column W-1 of adjacent rows
+    Pi = np.linalg.pinv(np.vstack([P, [0, 0, 0, 1.0]]))
+    extra = []
+    for r in (100, 101, 102, 200):
+        for col, zz in ((0, 12.0), (im_w - 1, 9.0), (0, 7.5)):
+            uvw = np.array([(col + 1.0) * zz, (r + 1.0 - (col != 0)) * zz, zz, 1.0])
+            x = Pi @ uvw
+            extra.append([x[0] / x[3], x[1] / x[3], x[2] / x[3], 0.5])
+    velo = np.concatenate([velo, np.array(extra, dtype=np.float32)], 0)
+    lidar_scan.calib = dict(P_rect_02=K, R_rect_00=R[:3, :3].copy(), R=velo2cam[:3, :3].copy(), T=velo2cam[:3, 3].copy(),
+                            S_rect_02=np.array([float(im_w), float(im_h)]))
+    return velo, P
+

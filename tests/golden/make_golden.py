@@ -357,6 +357,31 @@ def gold_refiner(RL, DD, PD):
     save("refiner_b1_192x640", **out)
 
 
+def gold_rasterize():
+    """kitti_utils.generate_depth_map (:40-102) on a synthetic scan written as the reference's on-disk formats (Velodyne .bin,
+    calib_cam_to_cam.txt / calib_velo_to_cam.txt), then kitti_dataset.get_4beam's pad + 2x2 ceil max-pool + / 100."""
+    import tempfile
+    import torch.nn.functional as F
+    np.int = int                                     # kitti_utils.py:76 uses the alias removed in numpy 1.24
+    import kitti_utils as KU
+    velo, P = gin.lidar_scan(3)
+    cal = gin.lidar_scan.calib
+    fmt = lambda a: " ".join("%.17g" % v for v in np.asarray(a, dtype=np.float64).reshape(-1))
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "calib_cam_to_cam.txt"), "w") as f:
+            f.write("S_rect_02: %s\nR_rect_00: %s\nP_rect_02: %s\n" % (fmt(cal["S_rect_02"]), fmt(cal["R_rect_00"]), fmt(cal["P_rect_02"])))
+        with open(os.path.join(d, "calib_velo_to_cam.txt"), "w") as f:
+            f.write("R: %s\nT: %s\n" % (fmt(cal["R"]), fmt(cal["T"])))
+        velo.tofile(os.path.join(d, "scan.bin"))
+        full = KU.generate_depth_map(d, os.path.join(d, "scan.bin"), 2)
+        padded = KU.generate_depth_map(d, os.path.join(d, "scan.bin"), 2, shape=[384, 1280])
+    beam = F.max_pool2d(torch.tensor(padded).unsqueeze(0), 2, ceil_mode=True).squeeze().numpy()
+    beam = torch.from_numpy(np.expand_dims(beam, 0).astype(np.float32)) / 100.0          # mono_dataset.py:196-198
+    ys, xs = np.nonzero(full)
+    save("rasterize_scan3", seed=np.array(3), full_rows=ys.astype(np.int32), full_cols=xs.astype(np.int32), full_vals=full[ys, xs],
+         beam=beam.numpy()[0])
+
+
 def gold_options():
     """Flag surface of the reference's argparse (options.py:9-480): name -> default/type/choices/action."""
     import json
@@ -387,6 +412,7 @@ def main():
     gold_scatter(get2ch)
     gold_depth_losses(RL, RT)
     gold_refiner(RL, DD, PD)
+    gold_rasterize()
 
 
 if __name__ == "__main__":

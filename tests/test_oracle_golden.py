@@ -291,3 +291,34 @@ def test_refiner_step_matches_reference(golden):
         if gr is not None:
             check_grad_compact(g, "g/" + n, gr, rtol=2e-4)
 
+
+
+def test_rasterize_matches_reference(golden):
+    """oracle.rasterize (kitti_utils.generate_depth_map + get_4beam restated) == the reference's output, bit for bit."""
+    from oracle import rasterize as OR
+    g = golden("rasterize_scan3")
+    velo, P = gin.lidar_scan(int(g["seed"]))
+    full = OR.depth_image(velo, P, 375, 1242)
+    want = np.zeros((375, 1242))
+    want[g["full_rows"], g["full_cols"]] = g["full_vals"]
+    assert np.array_equal(full, want)
+    # the scan exercises both duplicate rules: pixels hit more than once, and the (r, 0) / (r - 1, W - 1) index collision
+    col, row, _ = OR.project_points(velo, P, 375, 1242)
+    pix = row * 1242 + col
+    assert np.unique(pix).size < pix.size
+    assert ((col == 0) & (row == 101)).any() and ((col == 1241) & (row == 100)).any()
+    beam = OR.four_beam(velo, P, 375, 1242)
+    assert beam.dtype == np.float32 and beam.shape == (192, 640)
+    assert np.array_equal(beam, g["beam"])
+
+
+def test_rasterize_edge_cases():
+    from oracle import rasterize as OR
+    _, P = gin.lidar_scan(3)
+    empty = np.zeros((0, 4), np.float32)
+    assert not OR.depth_image(empty, P, 375, 1242).any()
+    behind = np.array([[-5.0, 0.0, 0.0, 0.0]], np.float32)
+    assert not OR.depth_image(behind, P, 375, 1242).any()
+    # crop branch (target shorter than the image): 2 rows dropped after top padding (kitti_utils.py:97-99)
+    d = OR.pad_to_shape(np.ones((375, 1242)), (352, 1280))
+    assert d.shape == (375 + 23 - 2, 1280)
