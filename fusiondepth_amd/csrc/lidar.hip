@@ -172,7 +172,7 @@ extern "C" long fd_velo_rasterize_ws_bytes(int n_points, int im_h, int im_w) {
 
 extern "C" int fd_velo_rasterize(const float* points, int n_points, const double* P_velo2im, int im_h, int im_w, int target_h,
                                  int target_w, float* beam_out, double* depth_full, void* ws, void* stream) {
-    FD_REQUIRE(points && P_velo2im && beam_out && ws && n_points >= 0 && im_h > 0 && im_w > 0 && target_h > 0 && target_w > 0,
+    FD_REQUIRE((points || n_points == 0) && P_velo2im && beam_out && ws && n_points >= 0 && im_h > 0 && im_w > 0 && target_h > 0 && target_w > 0,
                "fd_velo_rasterize: bad args");
     FD_REQUIRE(target_w >= im_w, "fd_velo_rasterize: target width %d < image width %d (the reference pads, never crops, columns)",
                target_w, im_w);
