@@ -23,7 +23,7 @@ class PhotoCfg(ctypes.Structure):
                 ("B", _I), ("H", _I), ("W", _I), ("Hs", _I), ("Ws", _I), ("NF", _I),
                 ("use_ssim", _I), ("avg_reprojection", _I),
                 ("si_depth_scale", _F), ("si_beam_scale", _F), ("si_threshold", _F), ("si_var", _F), ("eps", _F),
-                ("groups", _I), ("si_lo", _F)]
+                ("groups", _I), ("si_lo", _F), ("si_mode", _I)]
 
 
 class ConvDesc(ctypes.Structure):

@@ -329,7 +329,9 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
         if (a.beam) {  // trainer.py:577-589
             const float depth = frcp(cm.lo + cm.span * disp_up_at(disp_b, cm, y, x)) * cfg.si_depth_scale;
             const float bd = a.beam[b * P + p] * cfg.si_beam_scale;
-            if (bd > cfg.si_lo && depth < 80.f && depth > cfg.si_lo && fabsf(depth - bd) < cfg.si_threshold) {
+            if (cfg.si_mode == 1) {  // completor.py:718-723 (--completion_l1loss): masked L1, no |pred - beam| gate
+                if (bd > cfg.si_lo && depth < 80.f && depth > cfg.si_lo) { acc[1] += 1.f; acc[2] += fabsf(depth - bd); }
+            } else if (bd > cfg.si_lo && depth < 80.f && depth > cfg.si_lo && fabsf(depth - bd) < cfg.si_threshold) {
                 const float d = logf(depth) - logf(bd);
                 acc[1] += 1.f; acc[2] += d; acc[3] += d * d;
             }
@@ -348,7 +350,8 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
 //   out[0] = mean over ALL pixels of the min-reprojection loss     out[4] = mean over groups of si_loss_g
 //   out[8 + 4g ..] = n_valid_g, mean(d)_g, var_g, si_loss_g
 __global__ void __launch_bounds__(256) k_photo_finalize(const float* __restrict__ ws, int tiles_per_group, int groups,
-                                                        float count, float si_var, int have_beam, float* __restrict__ out) {
+                                                        float count, float si_var, int have_beam, int si_mode,
+                                                        float* __restrict__ out) {
     __shared__ float s_red[4 * 4];
     __shared__ float tot[4];
     const int g = blockIdx.x;
@@ -365,7 +368,7 @@ __global__ void __launch_bounds__(256) k_photo_finalize(const float* __restrict_
         const float var = m2 - si_var * (m1 * m1);
         float* o = out + 8 + 4 * g;
         o[0] = n; o[1] = m1; o[2] = var;
-        o[3] = have_beam ? sqrtf(var) * 0.1f : 0.f;
+        o[3] = have_beam ? (si_mode == 1 ? m1 * 0.001f : sqrtf(var) * 0.1f) : 0.f;
         out[8 + 4 * groups + g] = tot[0];           // per-group sum of the min-reprojection loss
     }
 }
@@ -592,6 +595,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     const int grp = b / (cfg.B / cfg.groups);
     const float n_valid = a.stats[8 + 4 * grp], m1 = a.stats[9 + 4 * grp], var = a.stats[10 + 4 * grp];
     const float k_si = a.beam ? a.g[1] / (float)cfg.groups * 0.1f / (sqrtf(var) * n_valid) : 0.f;
+    const float k_l1 = a.beam ? a.g[1] / (float)cfg.groups * 0.001f / n_valid * cfg.si_depth_scale : 0.f;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int y = y0t + ty * PPT + i;
@@ -603,7 +607,9 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
         if (a.beam) {
             const float d26 = depth * cfg.si_depth_scale;
             const float bd = a.beam[b * P + p] * cfg.si_beam_scale;
-            if (bd > cfg.si_lo && d26 < 80.f && d26 > cfg.si_lo && fabsf(d26 - bd) < cfg.si_threshold) {
+            if (cfg.si_mode == 1) {
+                if (bd > cfg.si_lo && d26 < 80.f && d26 > cfg.si_lo) dd += d26 > bd ? k_l1 : (d26 < bd ? -k_l1 : 0.f);
+            } else if (bd > cfg.si_lo && d26 < 80.f && d26 > cfg.si_lo && fabsf(d26 - bd) < cfg.si_threshold) {
                 const float d = logf(d26) - logf(bd);
                 dd += k_si * (d - cfg.si_var * m1) * sdisp;
             }
@@ -758,6 +764,7 @@ int check_cfg(const fd_photo_cfg* c, const char* who) {
     FD_REQUIRE(c->groups >= 1 && c->groups <= 16 && c->B % c->groups == 0, "%s: batch %d not divisible into %d groups", who, c->B,
                c->groups);
     FD_REQUIRE(c->min_depth > 0 && c->max_depth > c->min_depth, "%s: bad depth range", who);
+    FD_REQUIRE(c->si_mode == 0 || c->si_mode == 1, "%s: si_mode must be 0 (SI-log) or 1 (masked L1), got %d", who, c->si_mode);
     return 0;
 }
 
@@ -787,7 +794,7 @@ extern "C" int fd_photo_fwd(const fd_photo_cfg* cfg, const float* disp, const fl
     FD_LAUNCH_CHECK("fd_photo_fwd");
     const float count = (float)cfg->B * (float)cfg->H * (float)cfg->W;
     hipLaunchKernelGGL(k_photo_finalize, dim3(cfg->groups), dim3(256), 0, st, ws,
-                       (int)(tile_count(cfg->B, cfg->H, cfg->W) / cfg->groups), cfg->groups, count, cfg->si_var, beam ? 1 : 0, out);
+                       (int)(tile_count(cfg->B, cfg->H, cfg->W) / cfg->groups), cfg->groups, count, cfg->si_var, beam ? 1 : 0, cfg->si_mode, out);
     FD_LAUNCH_CHECK("fd_photo_finalize");
     hipLaunchKernelGGL(k_photo_finalize2, dim3(1), dim3(64), 0, st, out, cfg->groups, count);
     FD_LAUNCH_CHECK("fd_photo_finalize2");

@@ -319,12 +319,13 @@ class PhotoOptions:
     """The option subset the fused loss reads (options.py:64-71,111-125,242-330)."""
 
     def __init__(self, min_depth=0.1, max_depth=100.0, no_ssim=False, avg_reprojection=False, si_threshold=2.0,
-                 si_var=0.3, si_depth_scale=26.0, si_beam_scale=100.0, si_lo=1.0):
+                 si_var=0.3, si_depth_scale=26.0, si_beam_scale=100.0, si_lo=1.0, si_mode=0):
         self.min_depth, self.max_depth = float(min_depth), float(max_depth)
         self.no_ssim, self.avg_reprojection = bool(no_ssim), bool(avg_reprojection)
         self.si_threshold, self.si_var = float(si_threshold), float(si_var)
         self.si_depth_scale, self.si_beam_scale = float(si_depth_scale), float(si_beam_scale)
         self.si_lo = float(si_lo)
+        self.si_mode = int(si_mode)       # 0 SI-log, 1 masked L1 (completor.py:718-723)
 
 
 def _photo_cfg(po, B, H, W, Hs, Ws, NF, groups=1):
@@ -337,6 +338,7 @@ def _photo_cfg(po, B, H, W, Hs, Ws, NF, groups=1):
     c.si_depth_scale, c.si_beam_scale = po.si_depth_scale, po.si_beam_scale
     c.si_threshold, c.si_var, c.eps = po.si_threshold, po.si_var, PROJECT_EPS
     c.si_lo = getattr(po, "si_lo", 1.0)
+    c.si_mode = getattr(po, "si_mode", 0)
     return c
 
 

@@ -48,7 +48,7 @@ class Trainer:
         self.materialize_outputs = materialize_outputs
 
         vram = torch.cuda.get_device_properties(self.device).total_memory / 1024 ** 3      # trainer.py:30-35
-        hp = derived_hparams(self.opt, vram)
+        hp = self._derived_hparams(vram)
         self.opt.num_epochs = hp["num_epochs"]                                                # trainer.py:28
         self.accumulate_step = hp["accumulate_step"]
         self.learning_rate = hp["learning_rate"]
@@ -62,7 +62,7 @@ class Trainer:
         if self.opt.use_stereo or self.opt.predictive_mask or self.opt.pose_model_type == "shared":
             raise NotImplementedError("stereo / predictive_mask / shared pose encoder are ablations outside the hot path "
                                       "(SURVEY.md §8); supported: separate_resnet and posecnn pose nets")
-        if self.opt.v1_multiscale and self.opt.trainer_siloss == "true":
+        if self.opt.v1_multiscale and self._lidar_term()[0]:
             raise NotImplementedError("--v1_multiscale together with the LiDAR SI loss is not supported by the fused kernel "
                                       "(the SI term is evaluated at the sampling resolution); pass --trainer_siloss false")
         self.num_scales = len(self.opt.scales)
@@ -72,16 +72,17 @@ class Trainer:
 
         # ---- networks (trainer.py:66-127) --------------------------------------------------------------
         pre = self.opt.weights_init == "pretrained"
+        depth_layers, pose_layers = self._encoder_layers()
         m = {}
-        m["encoder"] = networks.ResnetEncoder(self.opt.num_layers, pre, cat4beam_to_color=self.opt.cat_4beam_to_color,
+        m["encoder"] = networks.ResnetEncoder(depth_layers, pre, cat4beam_to_color=self.opt.cat_4beam_to_color,
                                               cat2channel=self.opt.cat2start)
         if self.opt.beam_encoder:
-            m["beam_encoder"] = networks.ResnetEncoder(self.opt.num_layers, pre, beam_encoder=True)
-            m["beam_encoder_pose"] = networks.ResnetEncoder(self.opt.num_layers, pre, num_input_images=self.num_pose_frames,
+            m["beam_encoder"] = networks.ResnetEncoder(depth_layers, pre, beam_encoder=True)
+            m["beam_encoder_pose"] = networks.ResnetEncoder(pose_layers, pre, num_input_images=self.num_pose_frames,
                                                             beam_encoder=True)
         m["depth"] = networks.DepthDecoder(m["encoder"].num_ch_enc, self.opt.scales, cat2end=self.opt.cat2end)
         if self.opt.pose_model_type == "separate_resnet":
-            m["pose_encoder"] = networks.ResnetEncoder(self.opt.num_layers, pre, num_input_images=self.num_pose_frames)
+            m["pose_encoder"] = networks.ResnetEncoder(pose_layers, pre, num_input_images=self.num_pose_frames)
             m["pose"] = networks.PoseDecoder(m["pose_encoder"].num_ch_enc, num_input_features=1, num_frames_to_predict_for=2)
         elif self.opt.pose_model_type == "posecnn":
             m["pose"] = networks.PoseCNN(self.num_input_frames if self.opt.pose_model_input == "all" else 2)
@@ -123,7 +124,8 @@ class Trainer:
             self.backproject_depth[scale] = BackprojectDepth(self.batch_size, h, w)
             self.project_3d[scale] = Project3D(self.batch_size, h, w)
         self.photo_options = FD.PhotoOptions(self.opt.min_depth, self.opt.max_depth, self.opt.no_ssim,
-                                             self.opt.avg_reprojection, self.opt.gdc_loss_threshold, self.opt.si_var)
+                                             self.opt.avg_reprojection, self.opt.gdc_loss_threshold, self.opt.si_var,
+                                             si_mode=self._lidar_term()[1])
         self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
         self.epoch, self.step, self.batch_idx = 0, 0, 0
         self.best = 10.0
@@ -134,6 +136,21 @@ class Trainer:
             n = sum(p.numel() for p in self.parameters_to_train)
             print("fusiondepth_amd.Trainer: %d parameters (%.1f MB fp32), accumulating %d steps, single batch size = %d, "
                   "lr %.3g, %d rank(s)" % (n, n * 4 / 1e6, self.accumulate_step, self.batch_size, self.lr, world_size))
+
+    # ---- what the sibling drivers of the reference (completor.py) configure differently -----------------
+    def _derived_hparams(self, vram_gib):
+        return derived_hparams(self.opt, vram_gib)
+
+    def _encoder_layers(self):
+        """(ResNet depth of the depth / beam encoders, of the pose / beam-pose encoders)."""
+        return self.opt.num_layers, self.opt.num_layers
+
+    def _lidar_term(self):
+        """(scales at which the LiDAR loss is evaluated, fd_photo_cfg.si_mode, name of the entry in ``losses``)
+        trainer.py:569-589."""
+        if self.opt.trainer_siloss != "true":
+            return [], 0, "si_loss"
+        return (list(self.opt.scales) if self.opt.trainer_siloss_all_scale else [0]), 0, "si_loss"
 
     # ------------------------------------------------------------------------------------------------
     def set_train(self):
@@ -513,7 +530,7 @@ class Trainer:
                 outputs[("depth", 0, scale)] = disp_to_depth(disp, self.opt.min_depth, self.opt.max_depth)[1]
             return
         automask = not self.opt.disable_automasking
-        use_si = self.opt.trainer_siloss == "true"
+        si_scales = self._lidar_term()[0]
         ident0 = self.identity_losses(inputs, 0) if (automask and not self.opt.v1_multiscale) else None
         noise_in = inputs.get("_noise")               # injected tie-break noise (tests); else drawn like trainer.py:551-552
         for scale in self.opt.scales:
@@ -525,7 +542,7 @@ class Trainer:
             noise = None
             if ident is not None:
                 noise = noise_in[scale] if noise_in is not None else torch.randn(ident.shape, device=ident.device)
-            beam = inputs["4beam"] if (use_si and (self.opt.trainer_siloss_all_scale or scale == 0) and src_s == 0) else None
+            beam = inputs["4beam"] if (scale in si_scales and src_s == 0) else None
             if self.opt.pose_model_type == "posecnn":
                 # trainer.py:450-460: PoseCNN translations are rescaled by the mean inverse depth of this scale
                 disp_up = outputs[("disp", scale)]
@@ -565,6 +582,7 @@ class Trainer:
         """trainer.py:490-596: per scale  loss = min-reprojection mean + smoothness/2^s ; total += loss + si_loss."""
         losses = {}
         scales = list(self.opt.scales)
+        lidar_name = self._lidar_term()[2]
         photo, si, smooth = [], [], []
         for scale in scales:
             p, s_ = outputs[("photo", scale)]
@@ -575,7 +593,7 @@ class Trainer:
             for scale in scales:
                 losses["loss/{}".format(scale)] = per_scale[scale]
                 if si[scale] is not None:
-                    losses["loss/si_loss{}".format(scale)] = si[scale]
+                    losses["loss/{}{}".format(lidar_name, scale)] = si[scale]
             losses["loss"] = total
             return losses
         total_loss = 0
@@ -585,7 +603,7 @@ class Trainer:
             losses["loss/{}".format(scale)] = loss
             if si[i] is not None:
                 total_loss = total_loss + si[i]
-                losses["loss/si_loss{}".format(scale)] = si[i]
+                losses["loss/{}{}".format(lidar_name, scale)] = si[i]
         losses["loss"] = total_loss / self.num_scales
         return losses
 

@@ -120,6 +120,9 @@ typedef struct {
     int groups;             /* number of stacked micro-batches (>= 1) */
     float si_lo;            /* lower bound of the SI-loss mask: target > si_lo && pred > si_lo  (1.0 in trainer.py:584-586,
                                1e-3 in refiner.py:561-562) */
+    int si_mode;            /* LiDAR term: 0 = scale-invariant log loss * 0.1 (trainer.py:577-589, completor.py:699-716),
+                               1 = masked L1 * 0.001 without the |pred - beam| gate (completor.py:718-723, --completion_l1loss);
+                               out[8+4g+1] then holds mean |pred - beam| */
 } fd_photo_cfg;
 
 long fd_photo_ws_floats(int B, int H, int W);

@@ -382,6 +382,56 @@ def gold_rasterize():
          beam=beam.numpy()[0])
 
 
+def gold_completor(RL):
+    """completor.py:428-476 generate_images_pred + :546-726 compute_losses + :728-762 compute_depth_losses run as unbound
+    Completor methods at the completion resolution (1216x352): default flags (SI-log at scale 0 only), the all-scale switch,
+    and the masked-L1 alternative."""
+    import copy
+    from types import SimpleNamespace
+    import completor as CP
+    B, H, W = 1, 352, 1216
+    names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
+    out = {"seed": np.array(808)}
+    for tag, over in (("default", {}), ("allscale", dict(completion_siloss_all_scale="true")),
+                      ("l1", dict(completion_siloss=False, completion_l1loss=True))):
+        opt = copy.deepcopy(CP.opts)
+        opt.height, opt.width, opt.batch_size = H, W, B
+        for k, v in over.items():
+            setattr(opt, k, v)
+        ns = SimpleNamespace(opt=opt, num_scales=len(opt.scales), ssim=RL.SSIM(), backproject_depth={}, project_3d={},
+                             l1loss=nn.L1Loss(), depth_metric_names=names)
+        for s in opt.scales:
+            ns.backproject_depth[s] = RL.BackprojectDepth(B, H // 2 ** s, W // 2 ** s)
+            ns.project_3d[s] = RL.Project3D(B, H // 2 ** s, W // 2 ** s)
+        ns.compute_reprojection_loss = lambda pred, target, ns=ns: CP.Completor.compute_reprojection_loss(ns, pred, target)
+        inp, rng = gin.batch_inputs(808, B, H, W)
+        disp = gin.disp_pyramid(rng, B, H, W)
+        outputs, leaves = {}, []
+        for s in range(4):
+            outputs[("disp", s)] = disp[("disp", s)].clone().requires_grad_(True)
+            leaves.append(outputs[("disp", s)])
+        for f in (-1, 1):
+            aa, tr = gin.small_poses(rng, B)
+            outputs[("cam_T_cam", 0, f)] = RL.transformation_from_parameters(aa, tr, invert=(f < 0)).detach()
+        CP.Completor.generate_images_pred(ns, inp, outputs, opt.frame_ids)
+        torch.manual_seed(1808)
+        losses = CP.Completor.compute_losses(ns, inp, outputs)
+        grads = torch.autograd.grad(losses["loss"], leaves)
+        for k, v in losses.items():
+            out[tag + "/L/" + k.replace("/", "_")] = np.array(float(v.detach()), dtype=np.float64)
+        for s in range(4):
+            put_grad(out, tag + "/g_disp%d" % s, grads[s])
+        out[tag + "/siloss_weight_after"] = np.array(opt.completion_siloss_weight)
+    # monitoring metrics: ground truth at the network resolution (KITTI completion crops), with and without the Garg crop
+    gt, pred = gin.depth_eval_inputs(809, 2, H, W, gt_h=H, gt_w=W)
+    for tag, crop in (("nocrop", False), ("crop", True)):
+        ns = SimpleNamespace(opt=SimpleNamespace(completion_eigen_crop=crop), depth_metric_names=names)
+        m = {}
+        CP.Completor.compute_depth_losses(ns, {"depth_gt": torch.from_numpy(gt)}, {("depth", 0, 0): torch.from_numpy(pred)}, m)
+        out["metrics_" + tag] = np.array([float(m[n]) for n in names], dtype=np.float64)
+    save("completor_b1_352x1216", **out)
+
+
 def gold_options():
     """Flag surface of the reference's argparse (options.py:9-480): name -> default/type/choices/action."""
     import json
@@ -413,6 +463,7 @@ def main():
     gold_depth_losses(RL, RT)
     gold_refiner(RL, DD, PD)
     gold_rasterize()
+    gold_completor(RL)
 
 
 if __name__ == "__main__":

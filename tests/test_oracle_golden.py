@@ -322,3 +322,57 @@ def test_rasterize_edge_cases():
     # crop branch (target shorter than the image): 2 rows dropped after top padding (kitti_utils.py:97-99)
     d = OR.pad_to_shape(np.ones((375, 1242)), (352, 1280))
     assert d.shape == (375 + 23 - 2, 1280)
+
+
+def _completor_case(seed, B, H, W, **over):
+    from oracle import completor as OC
+    opt = OC.default_opt(height=H, width=W, batch_size=B, **over)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp = gin.disp_pyramid(rng, B, H, W)
+    outputs, leaves = {}, []
+    for s in range(4):
+        outputs[("disp", s)] = disp[("disp", s)].clone().requires_grad_(True)
+        leaves.append(outputs[("disp", s)])
+    for f in (-1, 1):
+        aa, tr = gin.small_poses(rng, B)
+        outputs[("cam_T_cam", 0, f)] = OL.transformation_from_parameters(aa, tr, invert=(f < 0)).detach()
+    torch.manual_seed(1000 + seed)
+    noise = [torch.randn(B, 2, H, W) for _ in range(4)]
+    OT.generate_images_pred(opt, inp, outputs)
+    losses = OC.compute_losses(opt, inp, outputs, noise)
+    return opt, losses, torch.autograd.grad(losses["loss"], leaves)
+
+
+def check_stored_grad(g, key, got, rtol, atol_rel):
+    """Compare against a gradient stored by make_golden.put_grad (whole, or sum / L2 / every-97th sample)."""
+    got = np.asarray(got)
+    if key in g:
+        assert_close(got, g[key], rtol=rtol, atol=atol_rel * np.abs(g[key]).max(), what=key)
+        return
+    s97 = g[key + "@s97"]
+    assert_close(got.reshape(-1)[::97], s97, rtol=rtol, atol=atol_rel * np.abs(s97).max(), what=key + " sample")
+    assert_close(np.sqrt((got.astype(np.float64) ** 2).sum()), g[key + "@l2"], rtol=max(rtol, 1e-5), atol=0, what=key + " L2")
+
+
+@pytest.mark.parametrize("tag,over", [("default", {}), ("allscale", dict(completion_siloss_all_scale="true")),
+                                      ("l1", dict(completion_siloss=False, completion_l1loss=True))])
+def test_completor_losses_match_reference(golden, tag, over):
+    """oracle.completor == reference Completor.generate_images_pred + compute_losses at 1216x352 (SI-log at scale 0, the
+    all-scale switch, the masked-L1 alternative)."""
+    g = golden("completor_b1_352x1216")
+    opt, losses, grads = _completor_case(int(g["seed"]), 1, 352, 1216, **over)
+    keys = {k[len(tag) + 3:] for k in g if k.startswith(tag + "/L/")}
+    assert keys == {k.replace("/", "_") for k in losses}
+    for k, v in losses.items():
+        assert_close(float(v), g[tag + "/L/" + k.replace("/", "_")], rtol=2e-6, atol=1e-8, what=k)
+    for s in range(4):
+        check_stored_grad(g, tag + "/g_disp%d" % s, npy(grads[s]), 1e-5, 1e-6)
+
+
+def test_completor_depth_metrics_match_reference(golden):
+    from oracle import completor as OC
+    g = golden("completor_b1_352x1216")
+    gt, pred = gin.depth_eval_inputs(809, 2, 352, 1216, gt_h=352, gt_w=1216)
+    for tag, crop in (("nocrop", False), ("crop", True)):
+        m = OC.compute_depth_losses(OC.default_opt(completion_eigen_crop=crop), torch.from_numpy(pred), torch.from_numpy(gt))
+        assert_close(m, g["metrics_" + tag], rtol=1e-5, atol=0, what="completor metrics " + tag)
