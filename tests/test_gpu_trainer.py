@@ -317,3 +317,40 @@ def test_stacked_microbatches_equal_sequential_accumulation():
     # the sequential path reports the LAST micro-batch's losses, the stacked path the mean over micro-batches
     tr2 = Trainer(_opts(batch_size=10), verbose=False)
     assert tr2.stack_microbatches
+
+
+def test_val_loop_and_best_checkpoint_bookkeeping(tmp_path):
+    """trainer.py:390-423: eval-mode depth-only forward over the validation batches, mean metrics, best de/abs_rel
+    remembered and saved as weights_best (+ weights_absrel<N> below 0.080)."""
+    import os
+    from oracle import layers as OL
+    B, H, W = 1, 64, 96
+    opt = _opts(batch_size=B, log_dir=str(tmp_path))
+    tr, ot = _make_pair(opt)
+    batches = []
+    for i in range(2):
+        inp, _ = _batch(B, H, W, 970 + i)
+        gt, _p = gin.depth_eval_inputs(980 + i, B, H, W)               # KITTI-sized ground truth [B,1,375,1242]
+        inp["depth_gt"] = torch.from_numpy(gt)
+        batches.append({k: v.cuda() for k, v in inp.items()})
+    losses = tr.val(batches)
+    for m in ot.models.values():
+        m.eval()
+    want = np.zeros(7)
+    with torch.no_grad():
+        for b in batches:
+            cb = {k: v.cpu() for k, v in b.items()}
+            outs = ot.models["depth"](ot.models["encoder"](cb[("color_aug", 0, 0)]),
+                                      beam_features=ot.models["beam_encoder"](cb["2channel"]))
+            disp = torch.nn.functional.interpolate(outs[("disp", 0)], [H, W], mode="bilinear", align_corners=False)
+            want += np.array(OT.compute_depth_losses(OL.disp_to_depth(disp, 0.1, 100.0)[1], cb["depth_gt"]))
+    want /= 2
+    assert_close([float(losses[n]) for n in tr.depth_metric_names], want, rtol=2e-3, atol=0, what="val metrics")
+    assert tr.best == float(losses["de/abs_rel"]) < 10.0
+    assert [os.path.basename(p) for p in tr.last_saved][:1] == ["weights_best"]
+    assert os.path.isfile(os.path.join(tr.last_saved[0], "encoder.pth")) and os.path.isfile(os.path.join(tr.last_saved[0], "adam.pth"))
+    absrel = round(float(losses["de/abs_rel"]) * 1000)
+    assert (len(tr.last_saved) == 2) == (absrel < 80)
+    assert all(m.training for m in tr.models.values())
+    tr.val(batches)
+    assert tr.last_saved == []                                          # not strictly better: nothing saved
