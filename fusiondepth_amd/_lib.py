@@ -75,7 +75,7 @@ SIGNATURES = {
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_data": ("ppppp" "i" "pp", "i"),
     "fd_velo_rasterize_ws_bytes": ("iii", "l"),
-    "fd_velo_rasterize": ("pipiiiipppp", "i"),
+    "fd_velo_rasterize": ("pipiiiiipppp", "i"),
     "fd_conv2d_fwd_pair_ws_floats": ("p", "l"),
     "fd_conv2d_fwd_pair": ("ppppppp" "i" "pp", "i"),
     "fd_conv2d_bwd_data_pair_ws_floats": ("p", "l"),

@@ -100,7 +100,8 @@ __global__ void k_raster_init(RasterWs w, long npix) {
     }
 }
 
-__global__ void k_raster_points(const float* __restrict__ pts, int n, const double* __restrict__ P, int im_h, int im_w, RasterWs w) {
+__global__ void k_raster_points(const float* __restrict__ pts, int n, const double* __restrict__ P, int im_h, int im_w, int vel_depth,
+                                RasterWs w) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const double x = (double)pts[4 * i], y = (double)pts[4 * i + 1], z = (double)pts[4 * i + 2];
         if (!(x >= 0.0)) continue;                                         // kitti_utils.py:62
@@ -109,10 +110,11 @@ __global__ void k_raster_points(const float* __restrict__ pts, int n, const doub
         const double c1 = fma(P[7], 1.0, fma(P[6], z, fma(P[5], y, P[4] * x)));
         const double c2 = fma(P[11], 1.0, fma(P[10], z, fma(P[9], y, P[8] * x)));
         const double u = rint(c0 / c2) - 1.0, v = rint(c1 / c2) - 1.0;     // :66, :73-74
-        w.zs[i] = c2;
+        const double depth = vel_depth ? x : c2;                             // kitti_utils.py:68-69: forward distance instead of z
+        w.zs[i] = depth;
         if (!(u >= 0.0 && v >= 0.0 && u < (double)im_w && v < (double)im_h)) continue;
         const long pix = (long)v * im_w + (long)u;
-        atomicMin(&w.zmin[pix], zkey(c2));
+        atomicMin(&w.zmin[pix], zkey(depth));
         atomicMin(&w.first[pix], (unsigned)i);
         atomicMax(&w.last[pix], (unsigned)i);
     }
@@ -143,7 +145,17 @@ __global__ void k_raster_resolve(RasterWs w, int im_h, int im_w) {
     }
 }
 
-// pad (top / left; optional 2-row crop) to the target shape, 2x2 max-pool with ceil_mode, float32, / 100
+// pad (top / left; optional 2-row crop) to the target shape: the float64 image generate_depth_map(shape=...) returns
+__global__ void k_raster_pad(const double* __restrict__ depth, int im_h, int im_w, int pad_top, int pad_left, int crop_top, int tgt_h,
+                             int tgt_w, double* __restrict__ out) {
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < (long)tgt_h * tgt_w; o += (long)gridDim.x * blockDim.x) {
+        const int ty = (int)(o / tgt_w), tx = (int)(o - (long)ty * tgt_w);
+        const int sy = ty + crop_top - pad_top, sx = tx - pad_left;
+        out[o] = (sy >= 0 && sy < im_h && sx >= 0 && sx < im_w) ? depth[(long)sy * im_w + sx] : 0.0;
+    }
+}
+
+// the same padding, then 2x2 max-pool with ceil_mode, float32, / 100
 __global__ void k_raster_pool(const double* __restrict__ depth, int im_h, int im_w, int pad_top, int pad_left, int crop_top,
                               int tgt_h, int tgt_w, float* __restrict__ out, int out_h, int out_w) {
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < out_h * out_w; o += gridDim.x * blockDim.x) {
@@ -170,10 +182,11 @@ extern "C" long fd_velo_rasterize_ws_bytes(int n_points, int im_h, int im_w) {
     return (long)(align256(npix * 8) + 2 * align256(npix * 4) + align256((size_t)(n_points > 0 ? n_points : 1) * 8) + align256(npix * 8));
 }
 
-extern "C" int fd_velo_rasterize(const float* points, int n_points, const double* P_velo2im, int im_h, int im_w, int target_h,
-                                 int target_w, float* beam_out, double* depth_full, void* ws, void* stream) {
-    FD_REQUIRE((points || n_points == 0) && P_velo2im && beam_out && ws && n_points >= 0 && im_h > 0 && im_w > 0 && target_h > 0 && target_w > 0,
+extern "C" int fd_velo_rasterize(const float* points, int n_points, const double* P_velo2im, int im_h, int im_w, int vel_depth,
+                                 int target_h, int target_w, float* beam_out, double* depth_out, void* ws, void* stream) {
+    FD_REQUIRE((points || n_points == 0) && P_velo2im && (beam_out || depth_out) && ws && n_points >= 0 && im_h > 0 && im_w > 0,
                "fd_velo_rasterize: bad args");
+    if (target_h <= 0 || target_w <= 0) { target_h = im_h; target_w = im_w; }   // shape=None: no padding
     FD_REQUIRE(target_w >= im_w, "fd_velo_rasterize: target width %d < image width %d (the reference pads, never crops, columns)",
                target_w, im_w);
     hipStream_t st = (hipStream_t)stream;
@@ -188,17 +201,12 @@ extern "C" int fd_velo_rasterize(const float* points, int n_points, const double
     hipLaunchKernelGGL(k_raster_init, dim3(fd_cdiv((long)npix, 256)), dim3(256), 0, st, w, (long)npix);
     FD_LAUNCH_CHECK("fd_velo_rasterize(init)");
     if (n_points > 0) {
-        hipLaunchKernelGGL(k_raster_points, dim3(fd_cdiv(n_points, 256)), dim3(256), 0, st, points, n_points, P_velo2im, im_h, im_w, w);
+        hipLaunchKernelGGL(k_raster_points, dim3(fd_cdiv(n_points, 256)), dim3(256), 0, st, points, n_points, P_velo2im, im_h, im_w,
+                           vel_depth, w);
         FD_LAUNCH_CHECK("fd_velo_rasterize(points)");
     }
     hipLaunchKernelGGL(k_raster_resolve, dim3(fd_cdiv((long)npix, 256)), dim3(256), 0, st, w, im_h, im_w);
     FD_LAUNCH_CHECK("fd_velo_rasterize(resolve)");
-    if (depth_full) {
-        if (hipMemcpyAsync(depth_full, w.depth, npix * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) {
-            fd_set_error("fd_velo_rasterize: copy of the full-resolution depth failed");
-            return -1;
-        }
-    }
     // kitti_utils.py:88-101: rows are padded on top by |target_h - im_h| (and 2 rows cropped when the target is shorter),
     // columns split the padding left / right
     const int ypad = target_h > im_h ? target_h - im_h : im_h - target_h;
@@ -206,10 +214,16 @@ extern "C" int fd_velo_rasterize(const float* points, int n_points, const double
     const int padded_h = im_h + ypad - crop;
     FD_REQUIRE(padded_h >= 1, "fd_velo_rasterize: empty padded image");
     const int xpad1 = (target_w - im_w) / 2;
-    const int out_h = (padded_h + 1) / 2, out_w = (target_w + 1) / 2;
-    hipLaunchKernelGGL(k_raster_pool, dim3(fd_cdiv((long)out_h * out_w, 256)), dim3(256), 0, st, w.depth, im_h, im_w, ypad, xpad1, crop,
-                       padded_h, target_w, beam_out, out_h, out_w);
-    FD_LAUNCH_CHECK("fd_velo_rasterize(pool)");
+    if (depth_out) {
+        hipLaunchKernelGGL(k_raster_pad, dim3(fd_cdiv((long)padded_h * target_w, 256)), dim3(256), 0, st, w.depth, im_h, im_w, ypad, xpad1,
+                           crop, padded_h, target_w, depth_out);
+        FD_LAUNCH_CHECK("fd_velo_rasterize(pad)");
+    }
+    if (beam_out) {
+        const int out_h = (padded_h + 1) / 2, out_w = (target_w + 1) / 2;
+        hipLaunchKernelGGL(k_raster_pool, dim3(fd_cdiv((long)out_h * out_w, 256)), dim3(256), 0, st, w.depth, im_h, im_w, ypad, xpad1, crop,
+                           padded_h, target_w, beam_out, out_h, out_w);
+        FD_LAUNCH_CHECK("fd_velo_rasterize(pool)");
+    }
     return 0;
 }
-

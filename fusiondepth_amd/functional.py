@@ -291,22 +291,32 @@ def scatter_2channel(beam, roi=(76, 190, 2, 638), expand=2):
     return out[0] if squeeze else out
 
 
-def velo_rasterize(points, P_velo2im, im_h, im_w, shape=(384, 1280), return_full=False):
+def padded_rows(im_h, target_h):
+    """Rows of generate_depth_map(shape=[target_h, .]) (kitti_utils.py:88-101): top padding, 2 rows cropped if shorter."""
+    return im_h + abs(target_h - im_h) - (2 if target_h < im_h else 0)
+
+
+def velo_rasterize(points, P_velo2im, im_h, im_w, shape=(384, 1280), return_full=False, vel_depth=False, beam=True):
     """Velodyne scan -> "4beam" network input (kitti_utils.py:40-102 + kitti_dataset.py:93-117 + mono_dataset.py:193-198).
-    ``points``: [N,4] float32 CUDA; ``P_velo2im``: 3x4 (numpy / tensor, float64).  Returns the [shape/2] float32 map
-    (metres / 100) and, optionally, the full-resolution float64 depth image."""
+    ``points``: [N,4] float32 CUDA; ``P_velo2im``: 3x4 (numpy / tensor, float64); ``shape``: the reference's ``shape`` argument
+    (None: no padding).  Returns the pooled float32 map (metres / 100) and / or, with ``return_full``, the float64 image
+    ``generate_depth_map`` returns."""
     points = f32(points)
     _need_cuda(points)
     P = torch.as_tensor(P_velo2im, dtype=torch.float64).reshape(12).to(points.device).contiguous()
     n = points.shape[0]
-    ypad = abs(shape[0] - im_h)
-    padded_h = im_h + ypad - (2 if shape[0] < im_h else 0)
-    out = torch.empty(((padded_h + 1) // 2, (shape[1] + 1) // 2), device=points.device, dtype=torch.float32)
-    full = torch.empty((im_h, im_w), device=points.device, dtype=torch.float64) if return_full else None
+    th, tw = (int(shape[0]), int(shape[1])) if shape is not None else (im_h, im_w)
+    ph = padded_rows(im_h, th)
+    out = torch.empty(((ph + 1) // 2, (tw + 1) // 2), device=points.device, dtype=torch.float32) if beam else None
+    full = torch.empty((ph, tw), device=points.device, dtype=torch.float64) if return_full else None
+    if out is None and full is None:
+        raise ValueError("velo_rasterize: nothing to return")
     ws = torch.empty((query("fd_velo_rasterize_ws_bytes", n, im_h, im_w),), device=points.device, dtype=torch.uint8)
-    call("fd_velo_rasterize", points.data_ptr(), n, P.data_ptr(), im_h, im_w, int(shape[0]), int(shape[1]), out.data_ptr(),
-         full.data_ptr() if full is not None else None, ws.data_ptr(), stream())
-    return (out, full) if return_full else out
+    call("fd_velo_rasterize", points.data_ptr(), n, P.data_ptr(), im_h, im_w, 1 if vel_depth else 0, th, tw,
+         out.data_ptr() if out is not None else None, full.data_ptr() if full is not None else None, ws.data_ptr(), stream())
+    if out is not None and full is not None:
+        return out, full
+    return out if out is not None else full
 
 
 def scaled_roi(H, W):

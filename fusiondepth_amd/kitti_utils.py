@@ -1,0 +1,108 @@
+"""Host mirror of the reference ``kitti_utils.py`` and of the LiDAR preprocessing around it, on the HIP kernels.
+
+Same function names, arguments and return types as the reference (file formats included), so its dataset classes and its
+offline ``gen2channel.py`` script can call these instead:
+
+  * ``load_velodyne_points`` / ``read_calib_file``            kitti_utils.py:8-30   (on-disk formats: Velodyne ``.bin`` =
+    float32 x 4 per point; ``calib_*.txt`` = ``key: v0 v1 ...`` lines)
+  * ``generate_depth_map(calib_dir, velo_filename, cam, vel_depth, shape)``   kitti_utils.py:40-102  -> float64 numpy image
+  * ``get_4beam`` / ``get_4beam_2channel`` / ``gen2channel``  kitti_dataset.py:93-117, gen2channel.py:42-58,60-117,122-183
+    (writes ``<idx>_<side>_<flip>.npy`` float32 [2,192,640], the files ``KITTIDataset.load_4beam_2channel`` reads).
+
+Parsing the two text files and the 3x4 matrix product stay on the host in float64 exactly as the reference computes them;
+projection, z-buffer, padding, pooling and the 2-channel scatter run on the GPU (``fd_velo_rasterize``,
+``fd_scatter_2channel``) and are bit-exact against the reference (tests/test_gpu_rasterize.py).  No CPU fallback.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import functional as FD
+
+
+def load_velodyne_points(filename):
+    """kitti_utils.py:8-11."""
+    points = np.fromfile(filename, dtype=np.float32).reshape(-1, 4)
+    points[:, 3] = 1.0  # homogeneous
+    return points
+
+
+def read_calib_file(path):
+    """kitti_utils.py:14-30: ``key: value`` lines; values made only of float characters become float64 arrays."""
+    float_chars = set("0123456789.e+- ")
+    data = {}
+    with open(path, "r") as f:
+        for line in f.readlines():
+            key, value = line.split(":", 1)
+            value = value.strip()
+            data[key] = value
+            if float_chars.issuperset(value):
+                try:
+                    data[key] = np.array(list(map(float, value.split(" "))))
+                except ValueError:
+                    pass
+    return data
+
+
+def velo_to_image(calib_dir, cam=2):
+    """kitti_utils.py:43-57 -> (P_velo2im [3,4] float64, (im_h, im_w))."""
+    cam2cam = read_calib_file(os.path.join(calib_dir, "calib_cam_to_cam.txt"))
+    velo2cam = read_calib_file(os.path.join(calib_dir, "calib_velo_to_cam.txt"))
+    velo2cam = np.hstack((velo2cam["R"].reshape(3, 3), velo2cam["T"][..., np.newaxis]))
+    velo2cam = np.vstack((velo2cam, np.array([0, 0, 0, 1.0])))
+    im_shape = cam2cam["S_rect_02"][::-1].astype(np.int32)
+    R_cam2rect = np.eye(4)
+    R_cam2rect[:3, :3] = cam2cam["R_rect_00"].reshape(3, 3)
+    P_rect = cam2cam["P_rect_0" + str(cam)].reshape(3, 4)
+    return np.dot(np.dot(P_rect, R_cam2rect), velo2cam), (int(im_shape[0]), int(im_shape[1]))
+
+
+def _device_scan(velo_filename, device):
+    return torch.from_numpy(load_velodyne_points(velo_filename)).to(device)
+
+
+def generate_depth_map(calib_dir, velo_filename, cam=2, vel_depth=False, shape=None, device="cuda"):
+    """kitti_utils.py:40-102."""
+    P, (im_h, im_w) = velo_to_image(calib_dir, cam)
+    full = FD.velo_rasterize(_device_scan(velo_filename, device), P, im_h, im_w, shape, return_full=True, vel_depth=vel_depth,
+                             beam=False)
+    return full.cpu().numpy()
+
+
+def get_4beam_device(calib_dir, velo_filename, cam=2, do_flip=False, device="cuda"):
+    """kitti_dataset.py:93-110 + mono_dataset.py:196-198 on the device: [192,640] float32, metres / 100."""
+    P, (im_h, im_w) = velo_to_image(calib_dir, cam)
+    beam = FD.velo_rasterize(_device_scan(velo_filename, device), P, im_h, im_w, (384, 1280))
+    return torch.flip(beam, dims=[1]).contiguous() if do_flip else beam
+
+
+def get_4beam(calib_dir, velo_filename, cam=2, do_flip=False, device="cuda"):
+    """gen2channel.py:42-58: the pooled map in metres (float64 numpy, before the / 100)."""
+    P, (im_h, im_w) = velo_to_image(calib_dir, cam)
+    full = FD.velo_rasterize(_device_scan(velo_filename, device), P, im_h, im_w, (384, 1280), return_full=True, beam=False)
+    pooled = torch.nn.functional.max_pool2d(full[None], 2, ceil_mode=True)[0].cpu().numpy()
+    return np.fliplr(pooled) if do_flip else pooled
+
+
+def get_4beam_2channel(fourbeam, height=192, width=640, expand=2):
+    """gen2channel.py:60-117: [H,W] map (metres / 100) -> (expanded_depth, confidence_map), device tensors."""
+    fourbeam = torch.as_tensor(fourbeam, dtype=torch.float32)
+    if not fourbeam.is_cuda:
+        fourbeam = fourbeam.cuda()
+    two = FD.scatter_2channel(fourbeam.contiguous(), FD.scaled_roi(height, width), expand)
+    return two[0], two[1]
+
+
+def gen2channel(calib_dir, velo_filename, out_path, idx, side, regenerate=True, device="cuda"):
+    """gen2channel.py:122-183 for one split line: writes ``<idx>_<side>_False.npy`` and ``<idx>_<side>_True.npy``
+    (float32 [2,192,640]: expanded depth, confidence) under ``out_path``; returns the two paths."""
+    side_map = {"2": 2, "3": 3, "l": 2, "r": 3}
+    os.makedirs(out_path, exist_ok=True)
+    paths = [os.path.join(out_path, "{}_{}_{}.npy".format(idx, side, flip)) for flip in (False, True)]
+    if not regenerate and all(os.path.isfile(p) for p in paths):
+        return paths
+    for flip, path in zip((False, True), paths):
+        beam = get_4beam_device(calib_dir, velo_filename, side_map[side], flip, device)
+        np.save(path, FD.scatter_2channel(beam).cpu().numpy())
+    return paths

@@ -306,13 +306,15 @@ int fd_scatter_2channel(const float* beam, float* out, int B, int H, int W, int 
 
 /* LiDAR rasterisation (the step upstream of the scatter): kitti_utils.py:40-102 generate_depth_map + kitti_dataset.py:93-117
  * get_4beam + mono_dataset.py:193-198.  points [n][4] float32 (forward, left, up, reflectance), P_velo2im 3x4 float64 (device),
- * image im_h x im_w  ->  z-buffered sparse depth (float64, optional output depth_full [im_h][im_w]), padded to
- * target_h x target_w as the reference pads (384 x 1280), 2x2 ceil-mode max-pool, float32, / 100:
- * beam_out [ceil(padded_h / 2)][ceil(target_w / 2)] = the "4beam" network input.  Bit-exact vs the reference incl. its duplicate
- * rule (oracle/rasterize.py).  ws: fd_velo_rasterize_ws_bytes bytes. */
+ * image im_h x im_w  ->  z-buffered sparse depth (float64; vel_depth != 0 stores the forward distance instead of the camera z,
+ * kitti_utils.py:68-69), padded / cropped to target_h x target_w exactly as generate_depth_map(shape=[target_h, target_w]) does
+ * (target_h <= 0: shape=None).  Outputs, either may be NULL:
+ *   depth_out [padded_h][target_w] float64 = the function's return value  (padded_h = im_h + |target_h - im_h| - (2 if target_h < im_h))
+ *   beam_out  [ceil(padded_h / 2)][ceil(target_w / 2)] float32 = 2x2 ceil-mode max-pool of it / 100 = the "4beam" network input.
+ * Bit-exact vs the reference incl. its duplicate rule (oracle/rasterize.py).  ws: fd_velo_rasterize_ws_bytes bytes. */
 long fd_velo_rasterize_ws_bytes(int n_points, int im_h, int im_w);
-int fd_velo_rasterize(const float* points, int n_points, const double* P_velo2im, int im_h, int im_w, int target_h, int target_w,
-                      float* beam_out, double* depth_full, void* ws, void* stream);
+int fd_velo_rasterize(const float* points, int n_points, const double* P_velo2im, int im_h, int im_w, int vel_depth, int target_h,
+                      int target_w, float* beam_out, double* depth_out, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,12 +13,14 @@ round-half-even, the "- 1" MATLAB offset, bounds test) with the duplicate handli
 import numpy as np
 
 
-def project_points(velo, P_velo2im, im_h, im_w):
-    """kitti_utils.py:59-72: -> (col, row, z) of the points that land inside the image, in point order."""
+def project_points(velo, P_velo2im, im_h, im_w, vel_depth=False):
+    """kitti_utils.py:59-72: -> (col, row, depth) of the points that land inside the image, in point order."""
     velo = velo[velo[:, 0] >= 0, :].copy()
     velo[:, 3] = 1.0
     pts = np.dot(P_velo2im, velo.T).T
     pts[:, :2] = pts[:, :2] / pts[:, 2][..., np.newaxis]
+    if vel_depth:                                         # kitti_utils.py:68-69
+        pts[:, 2] = velo[:, 0]
     pts[:, 0] = np.round(pts[:, 0]) - 1
     pts[:, 1] = np.round(pts[:, 1]) - 1
     ok = (pts[:, 0] >= 0) & (pts[:, 1] >= 0) & (pts[:, 0] < im_w) & (pts[:, 1] < im_h)
@@ -26,9 +28,9 @@ def project_points(velo, P_velo2im, im_h, im_w):
     return pts[:, 0].astype(np.int64), pts[:, 1].astype(np.int64), pts[:, 2]
 
 
-def depth_image(velo, P_velo2im, im_h, im_w):
+def depth_image(velo, P_velo2im, im_h, im_w, vel_depth=False):
     """kitti_utils.py:74-86: sparse depth [im_h, im_w] (float64)."""
-    col, row, z = project_points(velo, P_velo2im, im_h, im_w)
+    col, row, z = project_points(velo, P_velo2im, im_h, im_w, vel_depth)
     depth = np.zeros((im_h, im_w))
     depth[row, col] = z                                   # last point wins
     inds = row * (im_w - 1) + col - 1                     # the reference's sub2ind

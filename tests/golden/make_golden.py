@@ -375,11 +375,16 @@ def gold_rasterize():
         velo.tofile(os.path.join(d, "scan.bin"))
         full = KU.generate_depth_map(d, os.path.join(d, "scan.bin"), 2)
         padded = KU.generate_depth_map(d, os.path.join(d, "scan.bin"), 2, shape=[384, 1280])
+        vd = KU.generate_depth_map(d, os.path.join(d, "scan.bin"), 2, True)                      # vel_depth
+        crop = KU.generate_depth_map(d, os.path.join(d, "scan.bin"), 2, shape=[352, 1280])       # shorter target: crop branch
     beam = F.max_pool2d(torch.tensor(padded).unsqueeze(0), 2, ceil_mode=True).squeeze().numpy()
     beam = torch.from_numpy(np.expand_dims(beam, 0).astype(np.float32)) / 100.0          # mono_dataset.py:196-198
     ys, xs = np.nonzero(full)
+    vy, vx = np.nonzero(vd)
+    cy, cx = np.nonzero(crop)
     save("rasterize_scan3", seed=np.array(3), full_rows=ys.astype(np.int32), full_cols=xs.astype(np.int32), full_vals=full[ys, xs],
-         beam=beam.numpy()[0])
+         beam=beam.numpy()[0], vd_rows=vy.astype(np.int32), vd_cols=vx.astype(np.int32), vd_vals=vd[vy, vx],
+         crop_shape=np.array(crop.shape), crop_rows=cy.astype(np.int32), crop_cols=cx.astype(np.int32), crop_vals=crop[cy, cx])
 
 
 def gold_completor(RL):

@@ -12,11 +12,27 @@ import inputs as gin  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _run(velo, P, im_h=375, im_w=1242, shape=(384, 1280)):
+def _run(velo, P, im_h=375, im_w=1242, shape=(384, 1280), vel_depth=False):
+    """-> (4-beam map for ``shape``, unpadded full-resolution float64 depth image)."""
     import fusiondepth_amd.functional as FD
-    beam, full = FD.velo_rasterize(torch.from_numpy(velo).cuda(), P, im_h, im_w, shape, return_full=True)
+    pts = torch.from_numpy(velo).cuda()
+    beam = FD.velo_rasterize(pts, P, im_h, im_w, shape, vel_depth=vel_depth)
+    full = FD.velo_rasterize(pts, P, im_h, im_w, None, return_full=True, beam=False, vel_depth=vel_depth)
     torch.cuda.synchronize()
     return beam.cpu().numpy(), full.cpu().numpy()
+
+
+def _write_kitti_files(d, velo):
+    """The scan and its calibration in the reference's on-disk formats (kitti_utils.py:8-30, 43-57)."""
+    cal = gin.lidar_scan.calib
+    fmt = lambda a: " ".join("%.17g" % v for v in np.asarray(a, dtype=np.float64).reshape(-1))
+    with open(os.path.join(d, "calib_cam_to_cam.txt"), "w") as f:
+        f.write("calib_time: 09-Jan-2012 13:57:47\nS_rect_02: %s\nR_rect_00: %s\nP_rect_02: %s\n"
+                % (fmt(cal["S_rect_02"]), fmt(cal["R_rect_00"]), fmt(cal["P_rect_02"])))
+    with open(os.path.join(d, "calib_velo_to_cam.txt"), "w") as f:
+        f.write("R: %s\nT: %s\n" % (fmt(cal["R"]), fmt(cal["T"])))
+    velo.tofile(os.path.join(d, "scan.bin"))
+    return os.path.join(d, "scan.bin")
 
 
 def test_rasterize_matches_reference_golden(golden):
@@ -37,6 +53,8 @@ def test_rasterize_matches_oracle(seed, n, shape):
     beam, full = _run(velo, P, shape=shape)
     assert np.array_equal(full, OR.depth_image(velo, P, 375, 1242))
     assert np.array_equal(beam, OR.four_beam(velo, P, 375, 1242, shape))
+    _, full_vd = _run(velo, P, shape=shape, vel_depth=True)
+    assert np.array_equal(full_vd, OR.depth_image(velo, P, 375, 1242, vel_depth=True))
 
 
 def test_rasterize_is_deterministic_and_order_rule_holds():
@@ -70,3 +88,54 @@ def test_rasterize_feeds_the_scatter(golden):
     two = FD.scatter_2channel(beam).cpu().numpy()
     depth, conf = OS.scatter_2channel_c(g["beam"])
     assert np.array_equal(two[0], depth) and np.array_equal(two[1], conf)
+
+
+def _sparse(shape, rows, cols, vals):
+    a = np.zeros(tuple(shape))
+    a[rows, cols] = vals
+    return a
+
+
+def test_generate_depth_map_from_kitti_files_vs_reference_golden(golden, tmp_path):
+    """fusiondepth_amd.kitti_utils.generate_depth_map reading the reference's file formats == the reference's own
+    generate_depth_map on the same files: default, shape=[384,1280], vel_depth=True, and the crop branch (shape=[352,1280])."""
+    from fusiondepth_amd import kitti_utils as KU
+    g = golden("rasterize_scan3")
+    velo, P = gin.lidar_scan(int(g["seed"]))
+    scan = _write_kitti_files(str(tmp_path), velo)
+    P_file, im = KU.velo_to_image(str(tmp_path), 2)
+    assert im == (375, 1242) and np.array_equal(P_file, P)
+    assert KU.read_calib_file(os.path.join(str(tmp_path), "calib_cam_to_cam.txt"))["calib_time"] == "09-Jan-2012 13:57:47"
+    full = _sparse((375, 1242), g["full_rows"], g["full_cols"], g["full_vals"])
+    got = KU.generate_depth_map(str(tmp_path), scan, 2)
+    assert got.dtype == np.float64 and np.array_equal(got, full)
+    padded = KU.generate_depth_map(str(tmp_path), scan, 2, shape=[384, 1280])
+    assert padded.shape == (384, 1280) and np.array_equal(padded[9:, 19:19 + 1242], full) and not padded[:9].any()
+    assert np.array_equal(KU.generate_depth_map(str(tmp_path), scan, 2, True), _sparse((375, 1242), g["vd_rows"], g["vd_cols"], g["vd_vals"]))
+    crop = KU.generate_depth_map(str(tmp_path), scan, 2, shape=[352, 1280])
+    assert np.array_equal(crop, _sparse(g["crop_shape"], g["crop_rows"], g["crop_cols"], g["crop_vals"]))
+    # get_4beam (gen2channel.py:42-58: metres, before the / 100) and its flipped twin
+    pooled = KU.get_4beam(str(tmp_path), scan, 2, False)
+    assert np.array_equal(pooled.astype(np.float32) / np.float32(100.0), g["beam"])
+    assert np.array_equal(KU.get_4beam(str(tmp_path), scan, 2, True), np.fliplr(pooled))
+
+
+def test_gen2channel_writes_the_npy_files_the_dataset_reads(golden, tmp_path):
+    """gen2channel.py:122-183: <idx>_<side>_False.npy / _True.npy, float32 [2,192,640] == oracle scatter of the reference's
+    4-beam map (and of its left-right flip)."""
+    from fusiondepth_amd import kitti_utils as KU
+    from oracle import scatter as OS
+    g = golden("rasterize_scan3")
+    velo, _ = gin.lidar_scan(int(g["seed"]))
+    scan = _write_kitti_files(str(tmp_path), velo)
+    out = os.path.join(str(tmp_path), "2channel")
+    paths = KU.gen2channel(str(tmp_path), scan, out, 7, "l")
+    assert [os.path.basename(p) for p in paths] == ["7_l_False.npy", "7_l_True.npy"]
+    for p, beam in zip(paths, (g["beam"], np.ascontiguousarray(np.fliplr(g["beam"])))):
+        two = np.load(p)
+        assert two.dtype == np.float32 and two.shape == (2, 192, 640)
+        d, c = OS.scatter_2channel_c(beam)
+        assert np.array_equal(two[0], d) and np.array_equal(two[1], c)
+    stamp = os.path.getmtime(paths[0])
+    KU.gen2channel(str(tmp_path), scan, out, 7, "l", regenerate=False)          # both files exist: left alone
+    assert os.path.getmtime(paths[0]) == stamp

@@ -310,6 +310,13 @@ def test_rasterize_matches_reference(golden):
     beam = OR.four_beam(velo, P, 375, 1242)
     assert beam.dtype == np.float32 and beam.shape == (192, 640)
     assert np.array_equal(beam, g["beam"])
+    # vel_depth=True (forward distance instead of camera z) and the crop branch of the padding (target shorter than the image)
+    want = np.zeros((375, 1242))
+    want[g["vd_rows"], g["vd_cols"]] = g["vd_vals"]
+    assert np.array_equal(OR.depth_image(velo, P, 375, 1242, vel_depth=True), want)
+    want = np.zeros(tuple(g["crop_shape"]))
+    want[g["crop_rows"], g["crop_cols"]] = g["crop_vals"]
+    assert np.array_equal(OR.pad_to_shape(full, (352, 1280)), want)
 
 
 def test_rasterize_edge_cases():
