@@ -105,6 +105,7 @@ SIGNATURES = {
     "fd_spatial_mean_fwd": ("ppllfp", "i"),
     "fd_spatial_mean_bwd": ("ppllfp", "i"),
     "fd_depth_errors": ("pplppp", "i"),
+    "fd_post_process_disparity": ("ppplii" "p", "i"),
     "fd_adam_step": ("ppppl" "fffffff" "p", "i"),
     "fd_adam_step_dev": ("ppppl" "p" "ffff" "p", "i"),
 }

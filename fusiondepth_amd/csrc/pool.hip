@@ -365,3 +365,36 @@ extern "C" int fd_adam_step_dev(float* param, const float* grad, float* exp_avg,
     FD_LAUNCH_CHECK("fd_adam_step_dev");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// evaluate_depth.py:62-70 batch_post_process_disparity: blend of the disparity of an image and of its mirrored twin
+// (Monodepth-v1 post-processing).  float32 disparities, float64 ramp masks and result, exactly the reference's
+// numpy expression (np.linspace(0, 1, w): i * (1 / (w - 1)), last element 1; no fused multiply-adds).
+namespace {
+#pragma clang fp contract(off)
+__global__ void k_post_process_disparity(const float* __restrict__ l_disp, const float* __restrict__ r_disp, double* __restrict__ out,
+                                         long planes, int H, int W) {
+    const double step = 1.0 / (double)(W - 1);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < planes * H * W; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int xr = W - 1 - x;
+        const double lx = (x == W - 1) ? 1.0 : (double)x * step;
+        const double lr = (xr == W - 1) ? 1.0 : (double)xr * step;
+        double a = 20.0 * (lx - 0.05), b = 20.0 * (lr - 0.05);
+        a = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);
+        b = b < 0.0 ? 0.0 : (b > 1.0 ? 1.0 : b);
+        const double l_mask = 1.0 - a, r_mask = 1.0 - b;
+        const float l = l_disp[i], r = r_disp[i];
+        const float m = 0.5f * (l + r);
+        out[i] = (r_mask * (double)l + l_mask * (double)r) + ((1.0 - l_mask) - r_mask) * (double)m;
+    }
+}
+}  // namespace
+
+extern "C" int fd_post_process_disparity(const float* l_disp, const float* r_disp, double* out, long planes, int H, int W, void* stream) {
+    FD_REQUIRE(l_disp && r_disp && out && planes > 0 && H > 0 && W > 1, "fd_post_process_disparity: bad args");
+    hipLaunchKernelGGL(k_post_process_disparity, dim3(fd_cdiv(planes * H * W, 256) > 4096 ? 4096 : fd_cdiv(planes * H * W, 256)),
+                       dim3(256), 0, (hipStream_t)stream, l_disp, r_disp, out, planes, H, W);
+    FD_LAUNCH_CHECK("fd_post_process_disparity");
+    return 0;
+}

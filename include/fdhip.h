@@ -283,6 +283,10 @@ int fd_spatial_mean_bwd(const float* gout, float* gx, long planes, long plane_si
  * abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3.  ws: 7*256 floats. */
 int fd_depth_errors(const float* gt, const float* pred, long n, float* out, float* ws, void* stream);
 
+/* evaluate_depth.py:62-70 batch_post_process_disparity(l_disp, r_disp): l_disp / r_disp [planes][H][W] float32 (r_disp = the
+ * prediction for the mirrored image, already flipped back) -> out [planes][H][W] float64, bit-exact vs the numpy expression. */
+int fd_post_process_disparity(const float* l_disp, const float* r_disp, double* out, long planes, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------ optimiser ------------------ */
 
 /* torch.optim.Adam step (trainer.py:129,247) over a flat parameter segment:

@@ -194,3 +194,22 @@ def lidar_scan(seed, n_points=6000, im_h=375, im_w=1242):
                             S_rect_02=np.array([float(im_w), float(im_h)]))
     return velo, P
 
+
+
+def eval_pairs(seed):
+    """Matched (ground truth, prediction) depth vectors in metres for evaluate_depth.compute_errors: float32, 1-D."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for n, noise in ((5000, 0.05), (20011, 0.3), (37, 1.0)):
+        gt = rng.uniform(1.0, 80.0, n).astype(np.float32)
+        pred = np.clip(gt * np.exp(rng.randn(n) * noise), 1e-3, 80).astype(np.float32)
+        out.append((gt, pred))
+    return out
+
+
+def disp_pair(seed, B, H, W):
+    """Disparities of an image batch and of its mirrored twin (already flipped back), float32 [B,H,W]."""
+    rng = np.random.RandomState(seed)
+    l = rng.uniform(0.01, 0.9, (B, H, W)).astype(np.float32)
+    r = (l * rng.uniform(0.8, 1.2, (B, H, W))).astype(np.float32)
+    return l, r

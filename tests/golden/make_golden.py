@@ -437,6 +437,25 @@ def gold_completor(RL):
     save("completor_b1_352x1216", **out)
 
 
+def gold_evaluate():
+    """evaluate_depth.py:42-60 compute_errors and :62-70 batch_post_process_disparity, lifted out of the script by name (the
+    module itself imports cv2 / matplotlib / the dataset stack and runs a whole evaluation at import-free call time only)."""
+    src = open(os.path.join(REF, "evaluate_depth.py")).read()
+    fns = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in ("compute_errors", "batch_post_process_disparity")]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "evaluate_depth.py", "exec"), ns)
+    out = {"seed": np.array(4242)}
+    for i, (gt, pred) in enumerate(gin.eval_pairs(4242)):
+        out["errors%d" % i] = np.array(ns["compute_errors"](gt, pred), dtype=np.float64)
+    l, r = gin.disp_pair(4243, 2, 192, 640)
+    pp = ns["batch_post_process_disparity"](l, r)
+    assert pp.dtype == np.float64
+    out["pp_sub"] = pp[:, ::7, ::3].copy()
+    out["pp_edges"] = np.concatenate([pp[:, :, :40], pp[:, :, -40:]], 2)[:, ::16].copy()
+    out["pp_sum"] = np.array(pp.sum())
+    save("evaluate_metrics", **out)
+
+
 def gold_options():
     """Flag surface of the reference's argparse (options.py:9-480): name -> default/type/choices/action."""
     import json
@@ -469,6 +488,7 @@ def main():
     gold_refiner(RL, DD, PD)
     gold_rasterize()
     gold_completor(RL)
+    gold_evaluate()
 
 
 if __name__ == "__main__":

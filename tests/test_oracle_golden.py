@@ -383,3 +383,20 @@ def test_completor_depth_metrics_match_reference(golden):
     for tag, crop in (("nocrop", False), ("crop", True)):
         m = OC.compute_depth_losses(OC.default_opt(completion_eigen_crop=crop), torch.from_numpy(pred), torch.from_numpy(gt))
         assert_close(m, g["metrics_" + tag], rtol=1e-5, atol=0, what="completor metrics " + tag)
+
+
+def test_evaluate_metric_core_matches_reference(golden):
+    """oracle.evaluate.compute_errors / batch_post_process_disparity == the reference's own functions (evaluate_depth.py:42-70)."""
+    from oracle import evaluate as OE
+    g = golden("evaluate_metrics")
+    for i, (gt, pred) in enumerate(gin.eval_pairs(int(g["seed"]))):
+        assert_close(np.array(OE.compute_errors(gt, pred), dtype=np.float64), g["errors%d" % i], rtol=1e-7, atol=0, what="errors%d" % i)
+    l, r = gin.disp_pair(4243, 2, 192, 640)
+    pp = OE.batch_post_process_disparity(l, r)
+    assert np.array_equal(pp[:, ::7, ::3], g["pp_sub"])
+    assert np.array_equal(np.concatenate([pp[:, :, :40], pp[:, :, -40:]], 2)[:, ::16], g["pp_edges"])
+    # the resize restatement: identity at equal size, exact on a linear ramp in the interior, edge replication outside
+    ramp = np.tile(np.arange(8, dtype=np.float32), (4, 1))
+    assert np.array_equal(OE.resize_bilinear(ramp, 4, 8), ramp)
+    up = OE.resize_bilinear(ramp, 8, 16)
+    assert np.allclose(up[0, 1:-1], (np.arange(16)[1:-1] + 0.5) / 2 - 0.5) and up[0, 0] == 0 and up[0, -1] == 7
