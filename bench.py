@@ -204,6 +204,10 @@ def main():
 
     barrier(); barrier()          # the first collective builds the communicator (seconds): keep it out of every measurement
     launch = "eager" if args.eager else ("graph" if args.graph else "auto")
+    if launch == "auto" and world > 1:
+        # Multi-process runs keep to the eager path: it measured faster than hipGraph replay on one GPU (profiles/README.md),
+        # and a capture that fails on one rank only would leave the others waiting in the next collective.
+        launch = "eager"
     if launch == "auto":
         # Both launch paths run the same kernels on the same streams; which one keeps the GPU busier depends on the host
         # (Python issue rate vs hipGraphLaunch cost per node).  Decide inside the untimed warm-up, identically on all ranks.
