@@ -248,7 +248,7 @@ def main():
     if rank == 0:
         print("[bench] timed %d steps in %.3f s (host issue time %.3f s)" % (args.steps, dt, t_host), file=sys.stderr, flush=True)
     result = {
-        "metric": "training images/sec (640x192, ResNet-18, 4-beam)", "value": images / dt, "unit": "images/s",
+        "metric": "training images/sec (%dx%d, ResNet-%d, 4-beam)" % (args.width, args.height, args.num_layers), "value": images / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "ResNet-%d encoders + DepthDecoder + PoseDecoder, %dx%d, 4-beam LiDAR, --batch_size %d per GPU "
