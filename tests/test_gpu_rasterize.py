@@ -139,3 +139,23 @@ def test_gen2channel_writes_the_npy_files_the_dataset_reads(golden, tmp_path):
     stamp = os.path.getmtime(paths[0])
     KU.gen2channel(str(tmp_path), scan, out, 7, "l", regenerate=False)          # both files exist: left alone
     assert os.path.getmtime(paths[0]) == stamp
+
+
+@pytest.mark.parametrize("n_points", [100, 200])
+def test_random_sample_scans_r100_r200(n_points):
+    """BASELINE config 5's sparse inputs: `random100` / `random200` scans (gen2channel.py:17-24, --random_sample) hold 100 / 200
+    Velodyne returns instead of 4 beams; the rasterise -> scatter chain is the same and must stay bit-exact on such maps."""
+    import fusiondepth_amd.functional as FD
+    from oracle import rasterize as OR
+    from oracle import scatter as OS
+    rng = np.random.RandomState(n_points)
+    _, P = gin.lidar_scan(3)
+    velo = np.stack([rng.uniform(4.0, 60.0, n_points), rng.uniform(-12.0, 12.0, n_points), rng.uniform(-1.6, 0.2, n_points),
+                     rng.rand(n_points)], 1).astype(np.float32)
+    beam = FD.velo_rasterize(torch.from_numpy(velo).cuda(), P, 375, 1242)
+    want_beam = OR.four_beam(velo, P, 375, 1242)
+    assert 0 < (want_beam > 0).sum() <= n_points
+    assert np.array_equal(beam.cpu().numpy(), want_beam)
+    two = FD.scatter_2channel(beam).cpu().numpy()
+    d, c = OS.scatter_2channel_c(want_beam)
+    assert np.array_equal(two[0], d) and np.array_equal(two[1], c)
