@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no_stack", action="store_true", help="run the accumulated micro-batches sequentially (reference order) "
                     "instead of as one stacked pass with grouped BatchNorm")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--probe_only", action="store_true", help="run only the roofline probes (no training steps) and print their "
+                    "JSON: the command profiled for profiles/*probe_kernel_stats*.md, so that rocprofv3's per-kernel average "
+                    "covers the probe launches alone")
     return ap.parse_args()
 
 
@@ -193,6 +196,11 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.probe_only:
+        if rank == 0:
+            print(json.dumps(roofline_probes(args, tr, eager_in if tr.stack_microbatches else mbs[0])))
+        return
 
     def timed(fn, n):
         barrier()
