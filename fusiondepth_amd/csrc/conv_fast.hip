@@ -457,12 +457,20 @@ namespace {
 // ~ceil(blocks / 256) block-times: pick the configuration whose block count fills the 256 CUs most evenly
 // (measured: 360 blocks of 128x128 leave 30 % of the chip idle, 720 blocks of 64x128 do not).
 struct FastChoice { int cfg; int splits; };   // cfg 0: 128x128, 1: 64x128, 2: 32x256
-int g_policy = -1;   // 0: cost model for an otherwise idle GPU; 1: efficiency first (the trainer runs 4 streams concurrently)
+int g_policy = -1;   // 0: fill rule (default); 1: largest tile, split only tiny grids; 2: the earlier cost model
 int policy() {
     if (g_policy < 0) { const char* e = getenv("FD_CONV_POLICY"); g_policy = e ? atoi(e) : 0; }
     return g_policy;
 }
 FastChoice choose_config(const FastGemmArgs& a) {
+    if (const char* f = getenv("FD_CONV_FORCE")) {        // tuning aid (scripts/conv_cfg_sweep.py): "cfg,splits", read per call
+        int c = -1, sp = 1;
+        if (sscanf(f, "%d,%d", &c, &sp) == 2 && c >= 0 && c <= 2 && sp >= 1) {
+            const bool ok_c = (c == 0 && a.M > 64) || (c == 1 && a.M > 32) || c == 2;
+            const bool can = a.osy == 1 && a.osx == 1 && a.slab_stride > 0;
+            if (ok_c) return {c, can ? sp : 1};
+        }
+    }
     if (policy() == 1) {
         // Largest tile that M allows (best MFMA : LDS ratio); split K only when even the concurrent streams of the training
         // step cannot fill the chip (< 64 tiles), and keep >= 8 chunks per split.
@@ -486,8 +494,23 @@ FastChoice choose_config(const FastGemmArgs& a) {
     const int nchunk = a.T * (a.C / bkc);
     const bool can_split = a.osy == 1 && a.osx == 1 && a.slab_stride > 0;
     const int bm[3] = {128, 64, 32}, bn[3] = {128, 128, 256};
-    // measured model (scripts/conv_ksweep.py): a launch takes ceil(blocks/256) "block times"; a block time is
-    // chunks * t_chunk + t_fixed (prologue, first-chunk latency, epilogue); split-K adds a slab write + finish pass.
+    if (policy() == 0) {
+        // Measured rule (scripts/conv_cfg_sweep.py, every ResNet / decoder shape at batch 12 and 24): the 64x128 tile (32x256 for
+        // <= 32 output channels) with split-K chosen so that tiles x splits comes closest to, without exceeding, the 768
+        // workgroups the chip holds (3 per CU) wins or ties everywhere: 720 = 720x1 = 360x2 = 180x4, 768 = 96x8 = 48x16.
+        const int c = a.M > 32 ? 1 : 2;
+        const long tiles = (long)fd_cdiv(Np, bn[c]) * fd_cdiv(a.M, bm[c]) * (a.siblings > 1 ? a.siblings : 1);
+        int sp = 1;
+        if (can_split && tiles < 768) {
+            sp = (int)(768 / tiles);
+            const int cap = nchunk / 4 > 0 ? (nchunk / 4 < 16 ? nchunk / 4 : 16) : 1;
+            if (sp > cap) sp = cap;
+            if (sp < 1) sp = 1;
+        }
+        return {c, sp};
+    }
+    // policy 2: the earlier measured cost model (kept for A/B runs): a launch takes ceil(blocks/256) "block times"; a block time
+    // is chunks * t_chunk + t_fixed (prologue, first-chunk latency, epilogue); split-K adds a slab write + finish pass.
     static double t_chunk[3] = {2.4, 1.2, 1.3}, t_fixed = 5.0;                 // microseconds
     static bool tuned = false;
     if (!tuned) {                                                                // FD_CONV_MODEL="t128,t64,t32,tfixed" (tuning aid)
