@@ -444,7 +444,7 @@ void launch_cfg(const FastGemmArgs& a, int splits, hipStream_t st) {
     auto kern = k_conv_fast<WAVES_M, WAVES_N, WM, WN, BKC>;
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KiB of dynamic LDS
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(gx, gy, splits * g.siblings), dim3(64 * WAVES_M * WAVES_N), lds, st, g);

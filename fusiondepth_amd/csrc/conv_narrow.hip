@@ -332,7 +332,7 @@ int narrow_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, 
     } else {
         static bool attr = false;
         if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_narrow<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_narrow<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr = true;
         }
         hipLaunchKernelGGL(k_wgrad_narrow<2>, dim3(blocks), dim3(256), lds, st, a);
