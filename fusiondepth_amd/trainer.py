@@ -87,7 +87,8 @@ class Trainer:
         elif self.opt.pose_model_type == "posecnn":
             m["pose"] = networks.PoseCNN(self.num_input_frames if self.opt.pose_model_input == "all" else 2)
         self.models = {k: m[k].to(self.device) for k in MODEL_ORDER if k in m}
-        dp.broadcast_module_state(self.models.values())
+        if world_size > 1:
+            dp.broadcast_module_state(self.models.values())
         self.parameters_to_train = []
         for k in self.models:
             self.parameters_to_train += list(self.models[k].parameters())
