@@ -461,6 +461,23 @@ __global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* _
                 const unsigned tap = (unsigned)(j.kh0 + j.dkh * (int)a) * (unsigned)j.KW + (unsigned)(j.kw0 + j.dkw * (int)bb);
                 j.dst[((size_t)(co0 + r) * T + t) * Ci + ci0 + c] = tile[r][c * KK + tap];
             }
+        } else if (j.mode == 3) {                        // Winograd U[t][co][ky][ci] (conv_wino.hip), ci fastest
+            const size_t n = (size_t)Co * 3 * Ci;
+            for (unsigned i = threadIdx.x; i < nco * 3 * nci; i += 256) {
+                const unsigned c = i % nci, q = i / nci, ky = q % 3, r = q / 3;
+                const float g0 = tile[r][c * 9 + ky * 3], g1 = tile[r][c * 9 + ky * 3 + 1], g2 = tile[r][c * 9 + ky * 3 + 2];
+                float* o = j.dst + ((size_t)(co0 + r) * 3 + ky) * Ci + ci0 + c;
+                o[0] = g0; o[n] = 0.5f * (g0 + g1 + g2); o[2 * n] = 0.5f * (g0 - g1 + g2); o[3 * n] = g2;
+            }
+        } else if (j.mode == 4) {                        // Winograd U of the data gradient: [t][ci][ky][co] of the flipped kernel
+            const size_t n = (size_t)Ci * 3 * Co;
+            for (unsigned i = threadIdx.x; i < nci * 3 * nco; i += 256) {
+                const unsigned r = i % nco, q = i / nco, ky = q % 3, c = q / 3;
+                const unsigned row = (2 - ky) * 3;
+                const float g0 = tile[r][c * 9 + row + 2], g1 = tile[r][c * 9 + row + 1], g2 = tile[r][c * 9 + row];
+                float* o = j.dst + ((size_t)(ci0 + c) * 3 + ky) * Co + co0 + r;
+                o[0] = g0; o[n] = 0.5f * (g0 + g1 + g2); o[2 * n] = 0.5f * (g0 - g1 + g2); o[3 * n] = g2;
+            }
         } else if (j.mode == 1) {                        // dst[(ci * T + t) * Co + co], co fastest
             for (unsigned i = threadIdx.x; i < nci * T * nco; i += 256) {
                 const unsigned r = i % nco, q = i / nco, t = q % T, c = q / T;
@@ -661,6 +678,22 @@ inline bool fast_fwd_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->
 inline bool fast_dgrad_ok(const fd_conv_desc* d) { return d->Cout % 16 == 0; }
 inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && d->Cin >= 64 && !d->in_norm; }   // narrow layers: a (tap, channel) tile would be mostly padding
 
+// 1-D Winograd F(2,3) path (conv_wino.hip): 3x3 stride-1 pad-1 convs with >= 64 output channels (its tile is 64 channels tall).
+// FD_WINO=0 keeps everything on the direct implicit GEMM (A/B runs).
+bool wino_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FD_WINO"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+inline bool wino_use_fwd(const fd_conv_desc* d) { return wino_enabled() && wino_fwd_ok(d) && d->Cout >= 64; }
+// the data gradient of a zero-padded 3x3 stride-1 conv is the same kind of conv over dY (channels swapped, kernel flipped)
+inline bool wino_dgrad_desc(const fd_conv_desc* d, fd_conv_desc& g) {
+    if (!(wino_enabled() && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0)) return false;
+    g = *d;
+    g.Cin = d->Cout; g.Cout = d->Cin; g.act = 0; g.in_norm = 0;
+    return wino_fwd_ok(&g) && g.Cout >= 64;
+}
+
 void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
     f = FastGemmArgs{};
     f.M = d->Cout; f.C = d->Cin; f.T = d->KH * d->KW; f.TB = d->KW; f.K = f.T * f.C;
@@ -676,6 +709,7 @@ void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
 
 extern "C" long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d) {
     if (!d || !fast_fwd_ok(d)) return 0;
+    if (wino_use_fwd(d)) return align4(wino_wt_floats(d->Cout, d->Cin));
     return align4((long)d->Cout * d->Cin * d->KH * d->KW);
 }
 
@@ -683,6 +717,7 @@ extern "C" long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s) || !fast_fwd_ok(d)) return 0;
+    if (wino_use_fwd(d)) return wino_ws_floats(d);
     FastGemmArgs f;
     fill_fwd_args(d, s, f);
     return fast_splitk_slab_floats(f, nullptr);
@@ -699,6 +734,11 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
     hipStream_t st = (hipStream_t)stream;
     if (fast_fwd_ok(d)) {
         FD_REQUIRE(wt, "fd_conv2d_fwd: weight-layout buffer required (fd_conv2d_fwd_wt_floats)");
+        if (wino_use_fwd(d)) {
+            if (!wt_ready)
+                if (int rc = wino_weight_launch(w, wt, d->Cout, d->Cin, 0, st)) return rc;
+            return wino_conv_launch(d, x, wt, bias, y, ws, st);
+        }
         FastGemmArgs f;
         fill_fwd_args(d, s, f);
         if (!wt_ready)
@@ -727,7 +767,7 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
 extern "C" long fd_conv2d_fwd_pair_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
-    if (!conv_out_shape(d, s) || !fast_fwd_ok(d)) return fd_conv2d_fwd_ws_floats(d);
+    if (!conv_out_shape(d, s) || !fast_fwd_ok(d) || wino_use_fwd(d)) return fd_conv2d_fwd_ws_floats(d);
     FastGemmArgs f;
     fill_fwd_args(d, s, f);
     f.siblings = 2;
@@ -741,7 +781,7 @@ extern "C" int fd_conv2d_fwd_pair(const fd_conv_desc* d, const float* x, const f
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_fwd_pair: empty output");
     const size_t xin = (size_t)d->N * d->Cin * d->H * d->W, yout = (size_t)d->N * d->Cout * s.Ho * s.Wo;
-    if (!fast_fwd_ok(d)) {                                   // no paired kernel for this shape: two launches
+    if (!fast_fwd_ok(d) || wino_use_fwd(d)) {                // no paired kernel for this shape: two launches
         if (int rc = fd_conv2d_fwd(d, x, w0, nullptr, y, wt0, wt_ready, ws, stream)) return rc;
         return fd_conv2d_fwd(d, x + xin, w1, nullptr, y + yout, wt1, wt_ready, ws, stream);
     }
@@ -760,6 +800,8 @@ extern "C" int fd_conv2d_fwd_pair(const fd_conv_desc* d, const float* x, const f
 
 extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
     if (!d) return 0;
+    fd_conv_desc g;
+    if (wino_dgrad_desc(d, g)) return align4(wino_wt_floats(g.Cout, g.Cin));
     return (d->stride == 1 ? 1 : 4) * align4((long)d->Cin * d->Cout * d->KH * d->KW);
 }
 
@@ -767,6 +809,10 @@ extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s)) return 0;
+    {
+        fd_conv_desc g;
+        if (wino_dgrad_desc(d, g)) return wino_ws_floats(&g);
+    }
     const long wt = 0;
     const long padded = d->pad_mode == 1 ? align4((long)d->N * d->Cin * (d->H + 2) * (d->W + 2)) : 0;
     long slabs = 0;
@@ -793,7 +839,8 @@ extern "C" long fd_conv2d_bwd_data_pair_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s)) return 0;
-    if (!(fast_dgrad_ok(d) && d->pad_mode == 0)) return fd_conv2d_bwd_data_ws_floats(d);
+    fd_conv_desc gw;
+    if (!(fast_dgrad_ok(d) && d->pad_mode == 0) || wino_dgrad_desc(d, gw)) return fd_conv2d_bwd_data_ws_floats(d);
     long slabs = 0;
     if (d->stride == 1) {
         FastGemmArgs f = {};
@@ -810,7 +857,8 @@ extern "C" int fd_conv2d_bwd_data_pair(const fd_conv_desc* d, const float* gy, c
     FD_REQUIRE(gy && w0 && w1 && gx && wt0 && wt1, "fd_conv2d_bwd_data_pair: NULL tensor");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_data_pair: empty output");
-    if (!(fast_dgrad_ok(d) && d->pad_mode == 0)) {           // no paired kernel for this shape: two launches
+    fd_conv_desc gw;
+    if (!(fast_dgrad_ok(d) && d->pad_mode == 0) || wino_dgrad_desc(d, gw)) {   // no paired kernel for this shape: two launches
         const size_t xin = (size_t)d->N * d->Cin * d->H * d->W, yout = (size_t)d->N * d->Cout * s.Ho * s.Wo;
         if (int rc = fd_conv2d_bwd_data(d, gy, w0, gx, wt0, wt_ready, ws, stream)) return rc;
         return fd_conv2d_bwd_data(d, gy + yout, w1, gx + xin, wt1, wt_ready, ws, stream);
@@ -828,6 +876,14 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
                "fd_conv2d_bwd_data: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
     const int KH = d->KH, KW = d->KW;
+    {
+        fd_conv_desc gd;
+        if (siblings == 1 && wino_dgrad_desc(d, gd)) {
+            if (!wt_ready)
+                if (int rc = wino_weight_launch(w, wt_base, gd.Cout, gd.Cin, 1, st)) return rc;
+            return wino_conv_launch(&gd, gy, wt_base, nullptr, gx, ws, st);
+        }
+    }
     const bool fast = fast_dgrad_ok(d);
     const long wt_n = align4((long)d->Cin * d->Cout * KH * KW);
     float* wt = wt_base;                       // per parity class: wt_base + class * wt_n
@@ -933,10 +989,14 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
     };
     if (kind == 0) {
         if (!fast_fwd_ok(d)) return 0;
-        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, 0);
+        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? 3 : 0);
         return 1;
     }
     const int KH = d->KH, KW = d->KW;
+    {
+        fd_conv_desc gd;
+        if (wino_dgrad_desc(d, gd)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, 4); return 1; }
+    }
     const int mode = fast_dgrad_ok(d) ? 1 : 2;
     if (d->stride == 1) {
         fill(jobs[0], wt, KH, KW, KH - 1, -1, KW - 1, -1, mode);

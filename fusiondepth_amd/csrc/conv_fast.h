@@ -1,6 +1,7 @@
 // Internal interface between conv.hip (C-ABI entry points, shape logic) and conv_fast.hip (fast-path kernels).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "../../include/fdhip.h"
 
 struct FastGemmArgs {
     const float* A;      // [M][T][C] re-laid-out weights
@@ -45,3 +46,14 @@ int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int 
                          int dkw, int mode, hipStream_t st);
 int fast_wgrad_splits(int M, int C, int T, long Np, int siblings = 1);
 int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st, float* gw1 = nullptr);
+
+// Y[i] = act(sum_z slabs[z][i] + bias[channel(i)]) - the deterministic split-K epilogue (also used by conv_wino.hip)
+int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, long total, long slab_stride, int splits, long out_cs,
+                              int M, int act, hipStream_t st);
+
+// conv_wino.hip: 3x3 stride-1 convolutions through the 1-D Winograd F(2,3) transform
+bool wino_fwd_ok(const fd_conv_desc* d);
+long wino_wt_floats(int M, int C);
+long wino_ws_floats(const fd_conv_desc* d);
+int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStream_t st);
+int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st);

@@ -576,6 +576,15 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
     return 0;
 }
 
+int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, long total, long slab_stride, int splits, long out_cs,
+                              int M, int act, hipStream_t st) {
+    hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(total)), dim3(256), 0, st, slabs, Y, bias, total, slab_stride, splits, out_cs, M,
+                       act);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_splitk_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh,
                          int kw0, int dkw, int mode, hipStream_t st) {
     const long n = (long)Co * Ci * TA * TB;

@@ -1,0 +1,301 @@
+// 3x3 stride-1 convolutions with the Winograd F(2,3) transform along x (1-D), on the FP32 MFMA.
+//
+// For an output pair (x, x+1) = (2j, 2j+1) of row y and each of the three kernel rows ky, the four inputs d0..d3 at columns
+// 2j-1 .. 2j+2 of row y+ky-1 become  V = (d0-d2, d1+d2, d2-d1, d1-d3); the kernel row (g0,g1,g2) becomes
+// U = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) once per optimiser step; then with  M_t = sum_{c,ky} U_t V_t  (4 independent GEMMs, M = Cout,
+// N = pixel PAIRS, K = 3*Cin)  the two outputs are  M0+M1+M2  and  M1-M2-M3.  6 multiplies per output instead of 9: the matrix
+// pipe - the resource that bounds the training step - does 1.5x less work for the same convolution; the transform
+// arithmetic (4 adds per 4 loaded values, 4 adds per 2 outputs) rides in the loader / epilogue.  Coefficients are +-1 and 1/2, so
+// the fp32 rounding error stays within a few ulps of the direct sum (tests: 1e-5 of the output scale).
+//
+// Kernel shape: 256 threads = 4 waves, wave t owns component t and a 64 (channels) x 64 (pairs) accumulator block = 2x2 MFMA
+// 32x32x2 tiles (4 MFMAs per 4 LDS operand reads); a chunk is 16 input channels of one kernel row; LDS double-buffered
+// (66 KB -> 2 workgroups per CU); the four component blocks meet in LDS for the output transform; split-K over the (ky, channel)
+// chunks writes partial OUTPUTS to the usual slabs (the transform is linear), finished by k_splitk_finish.
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+#include "conv_fast.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 fd_ldg64(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float wino_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    if (act == 3) return 1.0f / (1.0f + expf(-v));
+    if (act == 4) return tanhf(v);
+    return v;
+}
+
+constexpr int WBM = 64, WBN = 64, WBKC = 16, WNT = 256;
+constexpr int LDU = WBM + 1, LDV = WBN, LDM = WBN + 1;
+constexpr int W_BUF_FLOATS = 4 * WBKC * (LDU + LDV);          // one operand buffer (all four components)
+constexpr int W_LDS_FLOATS = (2 * W_BUF_FLOATS > 4 * WBM * LDM) ? 2 * W_BUF_FLOATS : 4 * WBM * LDM;
+
+// U[t][m][ky][c] from W[m][c][ky][kx] (forward) or, for the data gradient (flip = 1: a conv over dY with the spatially flipped,
+// channel-transposed kernel), from W[c][m][2-ky][2-kx].
+__global__ void k_wino_weight(const float* __restrict__ w, float* __restrict__ U, int M, int C, int flip) {
+    const long n = (long)M * 3 * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int ky = (int)((i / C) % 3);
+        const int m = (int)(i / (3L * C));
+        float g0, g1, g2;
+        if (!flip) {
+            const float* p = w + (((long)m * C + c) * 3 + ky) * 3;
+            g0 = p[0]; g1 = p[1]; g2 = p[2];
+        } else {
+            const float* p = w + (((long)c * M + m) * 3 + (2 - ky)) * 3;
+            g0 = p[2]; g1 = p[1]; g2 = p[0];
+        }
+        U[i] = g0;
+        U[n + i] = 0.5f * (g0 + g1 + g2);
+        U[2 * n + i] = 0.5f * (g0 - g1 + g2);
+        U[3 * n + i] = g2;
+    }
+}
+
+struct WinoArgs {
+    const float* U; const float* X; float* Y; const float* bias; float* slabs;
+    long slab_stride;
+    int M, C, Nb, H, W;
+    int pad_mode, act;
+};
+
+__global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, comp = tid >> 6;       // wave index = Winograd component
+    const int W2 = g.W >> 1;
+    const long plane2 = (long)g.H * W2, Np = (long)g.Nb * plane2;
+    const unsigned hw = (unsigned)(g.H * g.W);
+    const int m0 = blockIdx.y * WBM;
+    const long p0 = (long)blockIdx.x * WBN;
+    const int cpt = g.C / WBKC, nchunk_all = 3 * cpt;
+    const int nsplit = (int)gridDim.z, zs = (int)blockIdx.z;
+    const int per_split = (nchunk_all + nsplit - 1) / nsplit;
+    const int ch_lo = zs * per_split;
+    const int ch_hi = ch_lo + per_split < nchunk_all ? ch_lo + per_split : nchunk_all;
+
+    // ---- activation loader: this thread always fetches pair jn of the tile, channel rows kr + 4 i
+    const int jn = tid & 63;
+    const int kr = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long pg = p0 + jn;
+    const bool pvalid = pg < Np;
+    int y0, j0;
+    unsigned nbase;
+    {
+        const long pp = pvalid ? pg : 0;
+        const int n = (int)(pp / plane2);
+        const int rem = (int)(pp - (long)n * plane2);
+        y0 = rem / W2; j0 = rem - y0 * W2;
+        nbase = (unsigned)n * (unsigned)g.C * hw;
+    }
+    const bool refl = g.pad_mode == 1;
+    const bool left_edge = j0 == 0, right_edge = 2 * j0 + 2 >= g.W;
+    // ---- weight loader: float4 a4 (of the chunk's 16 channels) of row ar, for each component
+    const int a4 = tid & 3, ar = tid >> 2;
+    int mrow = m0 + ar;
+    mrow = mrow < g.M ? mrow : g.M - 1;                                  // rows >= M are never stored
+    const unsigned u_comp = 4u * (unsigned)g.M * 3u * (unsigned)g.C;     // bytes between components
+    const __amdgpu_buffer_rsrc_t rsU = fd_make_rsrc(g.U), rsX = fd_make_rsrc(g.X);
+
+    float4 ru[4];
+    f32x2 rmid[4];
+    float rl[4], rr[4];
+    unsigned u_off = FD_OOB, mid_off = FD_OOB, l_off = FD_OOB, r_off = FD_OOB;
+    const unsigned c_step = 4u * 4u * hw;                                // 4 channel rows further
+    int pc_ky, pc_c0;
+    { pc_ky = ch_lo / cpt; pc_c0 = (ch_lo - pc_ky * cpt) * WBKC; }
+    auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
+        u_off = live ? 4u * (((unsigned)mrow * 3u + (unsigned)pc_ky) * (unsigned)g.C + (unsigned)pc_c0 + 4u * a4) : FD_OOB;
+        int r = y0 + pc_ky - 1;
+        const bool inb = (unsigned)r < (unsigned)g.H;
+        if (refl) r = r < 0 ? -r : (r >= g.H ? 2 * g.H - 2 - r : r);
+        const bool ok = pvalid & live & (refl | inb);
+        const unsigned base = 4u * (nbase + (unsigned)(pc_c0 + kr) * hw + (unsigned)(r * g.W + 2 * j0));
+        mid_off = ok ? base : FD_OOB;
+        l_off = (ok & !left_edge) ? base - 4u : FD_OOB;
+        r_off = (ok & !right_edge) ? base + 8u : FD_OOB;
+        pc_c0 += WBKC;
+        if (pc_c0 >= g.C) { pc_c0 = 0; ++pc_ky; }
+    };
+    auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off == FD_OOB ? FD_OOB : u_off + (unsigned)t * u_comp); };
+    auto load_v = [&](int i) __attribute__((always_inline)) {
+        const unsigned s = (unsigned)i * c_step;
+        rmid[i] = fd_ldg64(rsX, mid_off == FD_OOB ? FD_OOB : mid_off + s);
+        rl[i] = fd_ldg32(rsX, l_off == FD_OOB ? FD_OOB : l_off + s);
+        rr[i] = fd_ldg32(rsX, r_off == FD_OOB ? FD_OOB : r_off + s);
+    };
+    auto store_u = [&](int buf, int t) __attribute__((always_inline)) {
+        float* q = smem + buf * W_BUF_FLOATS + t * WBKC * LDU + (4 * a4) * LDU + ar;
+        q[0] = ru[t].x; q[LDU] = ru[t].y; q[2 * LDU] = ru[t].z; q[3 * LDU] = ru[t].w;
+    };
+    auto store_v = [&](int buf, int i) __attribute__((always_inline)) {
+        const float d1 = rmid[i].x, d2 = rmid[i].y;
+        const float d0 = (refl & left_edge) ? d2 : rl[i];               // reflect: column -1 is column 1, column W is column W-2
+        const float d3 = (refl & right_edge) ? d1 : rr[i];
+        float* q = smem + buf * W_BUF_FLOATS + 4 * WBKC * LDU + (kr + 4 * i) * LDV + jn;
+        q[0] = d0 - d2;
+        q[WBKC * LDV] = d1 + d2;
+        q[2 * WBKC * LDV] = d2 - d1;
+        q[3 * WBKC * LDV] = d1 - d3;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int NK = WBKC / 2;       // 8 MFMA k-steps per chunk
+    constexpr int LS = NK / 2;         // loads in the first 4 k-steps, LDS stores in the last 4
+    const int arow = lane >> 5, acol = lane & 31;
+    if (ch_lo < ch_hi) {
+        prep_chunk(true);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) load_u(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_v(i);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store_u(0, t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_v(0, i);
+        __syncthreads();
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+            const int cur = (ch - ch_lo) & 1;
+            prep_chunk(ch + 1 < ch_hi);
+            const float* pa = smem + cur * W_BUF_FLOATS + comp * WBKC * LDU + arow * LDU + acol;
+            const float* pb = smem + cur * W_BUF_FLOATS + 4 * WBKC * LDU + comp * WBKC * LDV + arow * LDV + acol;
+            float av[2][2], bv[2][2];
+            av[0][0] = pa[0]; av[0][1] = pa[32]; bv[0][0] = pb[0]; bv[0][1] = pb[32];
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk + 1 < NK) {
+                    av[nb][0] = pa[(kk + 1) * 2 * LDU]; av[nb][1] = pa[(kk + 1) * 2 * LDU + 32];
+                    bv[nb][0] = pb[(kk + 1) * 2 * LDV]; bv[nb][1] = pb[(kk + 1) * 2 * LDV + 32];
+                }
+                if (kk < LS) { load_u(kk); load_v(kk); }
+                else { store_u(cur ^ 1, kk - LS); store_v(cur ^ 1, kk - LS); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform through LDS: sM[t][m][pair]
+    float* sM = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                sM[(comp * WBM + m) * LDM + j * 32 + acol] = acc[i][j][r];
+            }
+    __syncthreads();
+    if (!pvalid) return;
+    const bool final_pass = nsplit == 1;
+    float* Y = final_pass ? g.Y : g.slabs + (size_t)zs * g.slab_stride;
+    {
+        const int n = (int)(pg / plane2);
+        float* yo = Y + ((long)n * g.M) * hw + (long)y0 * g.W + 2 * j0;
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            const int ml = kr + 4 * t, m = m0 + ml;
+            if (m >= g.M) break;
+            const float M0 = sM[(0 * WBM + ml) * LDM + jn], M1 = sM[(1 * WBM + ml) * LDM + jn];
+            const float M2 = sM[(2 * WBM + ml) * LDM + jn], M3 = sM[(3 * WBM + ml) * LDM + jn];
+            f32x2 o;
+            o.x = (M0 + M1) + M2;
+            o.y = (M1 - M2) - M3;
+            if (final_pass) {
+                const float b = g.bias ? g.bias[m] : 0.f;
+                o.x = wino_act(o.x + b, g.act); o.y = wino_act(o.y + b, g.act);
+            }
+            *reinterpret_cast<f32x2*>(yo + (long)m * hw) = o;
+        }
+    }
+}
+
+inline int wino_splits(const fd_conv_desc* d, int M, int C) {
+    const long tiles = (long)fd_cdiv((long)d->N * d->H * (d->W / 2), WBN) * fd_cdiv(M, WBM);
+    const int nchunk = 3 * (C / WBKC);
+    int sp = 1;
+    static long target = 0;
+    if (!target) { const char* e = getenv("FD_WINO_TARGET"); target = e ? atol(e) : 768; }     // measured best (scripts/wino_probe.py)
+    if (tiles < target) {
+        sp = (int)(target / tiles);
+        const int cap = nchunk / 3 > 0 ? (nchunk / 3 < 16 ? nchunk / 3 : 16) : 1;
+        if (sp > cap) sp = cap;
+        if (sp < 1) sp = 1;
+    }
+    return sp;
+}
+
+}  // namespace
+
+bool wino_fwd_ok(const fd_conv_desc* d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 16 == 0 && d->W % 2 == 0 && !d->in_norm &&
+           (long)d->Cout * 3 * d->Cin * 4 * 4 < 2147483648L;
+}
+long wino_wt_floats(int M, int C) { return 4L * M * 3 * C; }
+long wino_ws_floats(const fd_conv_desc* d) {
+    const int sp = wino_splits(d, d->Cout, d->Cin);
+    return sp > 1 ? (long)sp * d->N * d->Cout * d->H * d->W : 0;
+}
+int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStream_t st) {
+    const long n = (long)M * 3 * C;
+    hipLaunchKernelGGL(k_wino_weight, dim3(fd_cdiv(n, 256) > 4096 ? 4096 : fd_cdiv(n, 256)), dim3(256), 0, st, w, U, M, C, flip);
+    FD_LAUNCH_CHECK("wino weight transform");
+    return 0;
+}
+// y = act(conv3x3(x; U) + bias); d describes the convolution being computed (for a data gradient: Cin / Cout already swapped).
+int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st) {
+    WinoArgs g = {};
+    g.U = U; g.X = x; g.Y = y; g.bias = bias; g.slabs = ws;
+    g.M = d->Cout; g.C = d->Cin; g.Nb = d->N; g.H = d->H; g.W = d->W;
+    g.pad_mode = d->pad_mode; g.act = d->act;
+    const long out_total = (long)d->N * d->Cout * d->H * d->W;
+    g.slab_stride = out_total;
+    const int sp = wino_splits(d, d->Cout, d->Cin);
+    if (sp > 1 && !ws) { fd_set_error("wino conv: split-K workspace missing"); return -1; }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int gx = fd_cdiv((long)d->N * d->H * (d->W / 2), WBN), gy = fd_cdiv(d->Cout, WBM);
+    hipLaunchKernelGGL(k_conv_wino, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+    FD_LAUNCH_CHECK("k_conv_wino");
+    if (sp > 1) return fast_splitk_finish_launch(ws, y, bias, out_total, out_total, sp, (long)d->H * d->W, d->Cout, d->act, st);
+    return 0;
+}
+
+// ---- probe entry points (scripts/wino_probe.py, tests): the Winograd path on its own
+extern "C" long fd_conv3x3_wino_wt_floats(const fd_conv_desc* d) { return (d && wino_fwd_ok(d)) ? wino_wt_floats(d->Cout, d->Cin) : 0; }
+extern "C" long fd_conv3x3_wino_ws_floats(const fd_conv_desc* d) { return (d && wino_fwd_ok(d)) ? wino_ws_floats(d) : 0; }
+extern "C" int fd_conv3x3_wino_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
+                                   int wt_ready, float* ws, void* stream) {
+    FD_REQUIRE(d && x && w && y && wt, "fd_conv3x3_wino_fwd: NULL argument");
+    FD_REQUIRE(wino_fwd_ok(d), "fd_conv3x3_wino_fwd: needs a 3x3 stride-1 pad-1 convolution with Cin %% 16 == 0 and an even width");
+    hipStream_t st = (hipStream_t)stream;
+    if (!wt_ready)
+        if (int rc = wino_weight_launch(w, wt, d->Cout, d->Cin, 0, st)) return rc;
+    return wino_conv_launch(d, x, wt, bias, y, ws, st);
+}

@@ -308,6 +308,15 @@ int fd_adam_step_dev(float* param, const float* grad, float* exp_avg, float* exp
 int fd_scatter_2channel(const float* beam, float* out, int B, int H, int W, int r0, int r1, int c0, int c1, int expand,
                         void* stream);
 
+/* 3x3 stride-1 pad-1 convolution (nn.Conv2d / layers.Conv3x3 as above) through the 1-D Winograd F(2,3) transform: 1.5x fewer
+ * MFMA cycles than the direct implicit GEMM.  Needs Cin % 16 == 0 and an even width (fd_conv3x3_wino_wt_floats returns 0
+ * otherwise).  `wt` receives the transformed weights [4][Cout][3][Cin]; pass wt_ready = 1 to reuse them.  fd_conv2d_fwd routes
+ * eligible convolutions here by itself; these entry points expose the path on its own (probes, tests). */
+long fd_conv3x3_wino_wt_floats(const fd_conv_desc* d);
+long fd_conv3x3_wino_ws_floats(const fd_conv_desc* d);
+int fd_conv3x3_wino_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt, int wt_ready,
+                        float* ws, void* stream);
+
 /* LiDAR rasterisation (the step upstream of the scatter): kitti_utils.py:40-102 generate_depth_map + kitti_dataset.py:93-117
  * get_4beam + mono_dataset.py:193-198.  points [n][4] float32 (forward, left, up, reflectance), P_velo2im 3x4 float64 (device),
  * image im_h x im_w  ->  z-buffered sparse depth (float64; vel_depth != 0 stores the forward distance instead of the camera z,
