@@ -457,3 +457,83 @@ def test_paired_encoders_equal_separate_passes(NW):
             assert_close(p.grad.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale, what="grad %s %s" % (nm, n))
         for (n, p), (_, q) in zip(e.named_buffers(), r.named_buffers()):
             assert_close(p.float().cpu().numpy(), q.float().cpu().numpy(), rtol=1e-5, atol=1e-6, what="buffer %s %s" % (nm, n))
+
+
+# ------------------------------------------------------------------------------------------------ Winograd F(2,3) path
+def _wino_conv(x, w, bias, reflect, act=0):
+    import ctypes
+    from fusiondepth_amd import _lib
+    N, C, H, W = x.shape
+    d = _lib.ConvDesc(N, C, H, W, w.shape[0], 3, 3, 1, 1, 1 if reflect else 0, act, 0)
+    nwt = _lib.query("fd_conv3x3_wino_wt_floats", ctypes.byref(d))
+    assert nwt == 4 * w.shape[0] * 3 * C
+    y = torch.empty(N, w.shape[0], H, W, device="cuda")
+    wt = torch.empty(nwt, device="cuda")
+    ws = torch.empty(max(_lib.query("fd_conv3x3_wino_ws_floats", ctypes.byref(d)), 1), device="cuda")
+    _lib.call("fd_conv3x3_wino_fwd", ctypes.byref(d), x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+              y.data_ptr(), wt.data_ptr(), 0, ws.data_ptr(), _lib.stream())
+    return y
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,reflect,act", [
+    (2, 64, 64, 48, 160, False, 0),      # layer1 shape, no split
+    (1, 256, 256, 12, 40, False, 1),     # few tiles: split-K slabs + finish (bias + ReLU applied there)
+    (2, 96, 80, 7, 10, False, 0),        # 80 output channels (partial channel tile), odd height, pairs < one tile
+    (1, 128, 64, 24, 80, True, 2),       # reflect padding (decoder ConvBlock), ELU
+    (3, 16, 64, 5, 6, True, 0),          # 16 input channels = a single chunk per kernel row
+])
+def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act):
+    """conv_wino.hip through its own entry point against torch float64 conv2d: error within a few fp32 ulps of the output scale,
+    i.e. no worse than the direct implicit GEMM (transform coefficients are +-1 and 1/2)."""
+    torch.manual_seed(N * 1000 + Ci)
+    x = torch.randn(N, Ci, H, W, device="cuda")
+    w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
+    b = torch.randn(Co, device="cuda")
+    xp = F.pad(x.double(), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    ref = F.conv2d(xp, w.double(), b.double())
+    ref = {0: ref, 1: F.relu(ref), 2: F.elu(ref)}[act]
+    got = _wino_conv(x, w, b, reflect, act)
+    relclose(cpu(got), cpu(ref.float()), "winograd conv", rtol=1e-5, arel=3e-6)
+
+
+def test_winograd_refuses_ineligible_shapes():
+    import ctypes
+    from fusiondepth_amd import _lib
+    for desc in (_lib.ConvDesc(1, 64, 8, 9, 64, 3, 3, 1, 1, 0, 0, 0),      # odd width
+                 _lib.ConvDesc(1, 24, 8, 8, 64, 3, 3, 1, 1, 0, 0, 0),      # Cin not a multiple of 16
+                 _lib.ConvDesc(1, 64, 8, 8, 64, 3, 3, 2, 1, 0, 0, 0)):     # stride 2
+        assert _lib.query("fd_conv3x3_wino_wt_floats", ctypes.byref(desc)) == 0
+    d = _lib.ConvDesc(1, 64, 8, 9, 64, 3, 3, 1, 1, 0, 0, 0)
+    t = torch.zeros(64 * 64 * 9 * 2, device="cuda")
+    with pytest.raises(RuntimeError):
+        _lib.call("fd_conv3x3_wino_fwd", ctypes.byref(d), t.data_ptr(), t.data_ptr(), None, t.data_ptr(), t.data_ptr(), 0, None,
+                  _lib.stream())
+
+
+def test_winograd_routing_forward_and_data_gradient_match_torch():
+    """FD.conv2d routes eligible 3x3 convs to the Winograd kernel (forward and zero-pad data gradient); values and both
+    gradients against torch autograd in float64, and the batched weight re-layout (modes 3 / 4) against the per-call transform."""
+    import fusiondepth_amd.functional as FD
+    torch.manual_seed(5)
+    x = torch.randn(2, 64, 12, 40, device="cuda", requires_grad=True)
+    w = torch.nn.Parameter(torch.randn(128, 64, 3, 3, device="cuda") * 0.05)
+    FD.enable_weight_cache([w])
+    y = FD.conv2d(x, w, None, 1, 1)
+    gy = torch.randn_like(y)
+    gx, gw = torch.autograd.grad(y, [x, w], gy)
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, 1, 1)
+    gxd, gwd = torch.autograd.grad(yd, [xd, wd], gy.double())
+    relclose(cpu(y), cpu(yd.float()), "y", rtol=1e-5, arel=3e-6)
+    relclose(cpu(gx), cpu(gxd.float()), "dx (Winograd data gradient)", rtol=1e-5, arel=3e-6)
+    relclose(cpu(gw), cpu(gwd.float()), "dw", rtol=1e-4, arel=1e-5)
+    # change the weights, refresh every cached layout in one batched launch, recompute: must equal a fresh per-call transform
+    assert FD.build_weight_plan() >= 2
+    with torch.no_grad():
+        w.mul_(1.5)
+    FD.bump_weights_epoch()
+    assert FD.refresh_weight_layouts()
+    y2 = FD.conv2d(x, w, None, 1, 1)
+    gx2 = torch.autograd.grad(y2, x, gy)[0]
+    relclose(cpu(y2), cpu(1.5 * y), "y after batched re-layout", rtol=1e-6, arel=1e-6)
+    relclose(cpu(gx2), cpu(1.5 * gx), "dx after batched re-layout", rtol=1e-6, arel=1e-6)
