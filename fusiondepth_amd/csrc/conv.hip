@@ -685,6 +685,15 @@ bool wino_enabled() {
     if (on < 0) { const char* e = getenv("FD_WINO"); on = e ? atoi(e) : 1; }
     return on != 0;
 }
+inline bool wino_use_wgrad(const fd_conv_desc* d) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FD_WINO_WGRAD"); on = e ? atoi(e) : 1; }
+    // layer1's 64x64 weight (3 tiles x 256 pixel-splits) is 10 % slower than the direct kernel when run alone and still the
+    // better choice inside the step (449.6 vs 442 images/s): what the step is short of is MFMA cycles, not launch latency
+    static long min_cc = -1;
+    if (min_cc < 0) { const char* e = getenv("FD_WINO_WGRAD_MIN"); min_cc = e ? atol(e) : 0; }
+    return on != 0 && wino_enabled() && wino_wgrad_ok(d) && (long)d->Cin * d->Cout >= min_cc;
+}
 inline bool wino_use_fwd(const fd_conv_desc* d) { return wino_enabled() && wino_fwd_ok(d) && d->Cout >= 64; }
 // the data gradient of a zero-padded 3x3 stride-1 conv is the same kind of conv over dY (channels swapped, kernel flipped)
 inline bool wino_dgrad_desc(const fd_conv_desc* d, fd_conv_desc& g) {
@@ -1050,6 +1059,7 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     long slabs;
     if (narrow_wgrad_ok(d)) slabs = narrow_wgrad_ws_floats(d);
     else if (stem_wgrad_ok(d)) slabs = stem_wgrad_ws_floats(d);
+    else if (wino_use_wgrad(d)) slabs = wino_wgrad_ws_floats(d);
     else if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
     else { const int sp = wgrad_splits(d, s); slabs = sp > 1 ? (long)sp * wsz : 0; }
     const long bias_part = (long)d->Cout * CS_SPLITS;
@@ -1061,7 +1071,7 @@ extern "C" long fd_conv2d_bwd_weight_pair_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s)) return 0;
-    if (!fast_wgrad_ok(d) || narrow_wgrad_ok(d) || stem_wgrad_ok(d)) return fd_conv2d_bwd_weight_ws_floats(d);
+    if (!fast_wgrad_ok(d) || narrow_wgrad_ok(d) || stem_wgrad_ok(d) || wino_use_wgrad(d)) return fd_conv2d_bwd_weight_ws_floats(d);
     const long wsz = (long)d->Cout * d->Cin * d->KH * d->KW;
     return 2L * fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo, 2) * wsz;
 }
@@ -1074,7 +1084,7 @@ extern "C" int fd_conv2d_bwd_weight_pair(const fd_conv_desc* d, const float* x, 
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_weight_pair: empty output");
     const size_t xin = (size_t)d->N * d->Cin * d->H * d->W, yout = (size_t)d->N * d->Cout * s.Ho * s.Wo;
-    if (!fast_wgrad_ok(d) || narrow_wgrad_ok(d) || stem_wgrad_ok(d)) {      // no paired kernel for this shape: two launches
+    if (!fast_wgrad_ok(d) || narrow_wgrad_ok(d) || stem_wgrad_ok(d) || wino_use_wgrad(d)) {      // no paired kernel: two launches
         if (int rc = fd_conv2d_bwd_weight(d, x, gy, gw0, nullptr, ws, accumulate, stream)) return rc;
         return fd_conv2d_bwd_weight(d, x + xin, gy + yout, gw1, nullptr, ws, accumulate, stream);
     }
@@ -1105,6 +1115,8 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
         if (int rc = narrow_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
     } else if (stem_wgrad_ok(d)) {
         if (int rc = stem_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
+    } else if (wino_use_wgrad(d)) {
+        if (int rc = wino_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
     } else if (fast_wgrad_ok(d)) {
         FastWgradArgs f = {};
         f.dY = gy; f.X = x; f.slabs = ws;

@@ -576,6 +576,13 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
     return 0;
 }
 
+int fast_wgrad_finish_launch(const float* slabs, float* gw, int M, int C, int T, int splits, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks((long)M * C * T)), dim3(256), 0, st, slabs, gw, M, C, T, splits, accumulate);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, long total, long slab_stride, int splits, long out_cs,
                               int M, int act, hipStream_t st) {
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(total)), dim3(256), 0, st, slabs, Y, bias, total, slab_stride, splits, out_cs, M,

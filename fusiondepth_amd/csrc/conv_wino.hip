@@ -244,6 +244,167 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[m][c][ky][kx] = sum over pixels dY[m][y][x] * X[c][y+ky-1][x+kx-1].  Per pixel pair (dy0, dy1) and the same four inputs
+// d0..d3 as the forward, the transposed F(2,3) algorithm needs 4 products instead of 6:
+//   P = (dy0, dy0+dy1, dy0-dy1, dy1),  Q = (d0-d2, d1+d2, d2-d1, d1-d3)  (Q is the forward's input transform),
+//   M_t = sum_pairs P_t Q_t   (4 GEMMs, M = Cout, N = Cin, K = pixel pairs),
+//   dW[kx=0] = M0 + (M1+M2)/2,  dW[1] = (M1-M2)/2,  dW[2] = (M1+M2)/2 - M3.
+// One workgroup = (64 output channels) x (64 input channels) x one kernel row ky x a slice of the pairs; wave t owns component t.
+// Slices write [split][m][ky*3+kx][c] slabs, reduced in fixed order by k_wgrad_finish (deterministic).
+struct WinoWgradArgs {
+    const float* dY; const float* X; float* slabs;
+    int M, C, Nb, H, W;
+    int pad_mode;
+    long pairs_per_split;
+};
+constexpr int WGP = 16;                                          // pairs per chunk (GEMM-K 16 -> 8 MFMA k-steps)
+constexpr int WG_BUF_FLOATS = 4 * WGP * (LDU + LDU);             // A: [4][16][65], B: [4][16][65]
+constexpr int WG_LDS_FLOATS = (2 * WG_BUF_FLOATS > 4 * WBM * LDM) ? 2 * WG_BUF_FLOATS : 4 * WBM * LDM;
+
+__global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, comp = tid >> 6;
+    const int W2 = g.W >> 1;
+    const long plane2 = (long)g.H * W2, Np = (long)g.Nb * plane2;
+    const unsigned hw = (unsigned)(g.H * g.W);
+    const int ctiles = (g.C + WBN - 1) / WBN;
+    const int ky = blockIdx.x / ctiles, c0 = (blockIdx.x - ky * ctiles) * WBN;
+    const int m0 = blockIdx.y * WBM;
+    const long pp_lo = (long)blockIdx.z * g.pairs_per_split;
+    const long pp_hi = pp_lo + g.pairs_per_split < Np ? pp_lo + g.pairs_per_split : Np;
+    const int nchunk = pp_hi > pp_lo ? (int)((pp_hi - pp_lo + WGP - 1) / WGP) : 0;
+
+    // loader: pair p of the chunk, rows rw + 16 i (dY rows = output channels, X rows = input channels)
+    const int p = tid & 15, rw = tid >> 4;
+    unsigned a_row[4], b_row[4];                                 // element offsets of the 4 channel rows (clamped: never stored)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + rw + 16 * i; m = m < g.M ? m : g.M - 1;
+        int c = c0 + rw + 16 * i; c = c < g.C ? c : g.C - 1;
+        a_row[i] = (unsigned)m * hw; b_row[i] = (unsigned)c * hw;
+    }
+    const bool refl = g.pad_mode == 1;
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY), rsX = fd_make_rsrc(g.X);
+    f32x2 ra[4], rmid[4];
+    float rl[4], rr[4];
+    unsigned a_off = FD_OOB, mid_off = FD_OOB, l_off = FD_OOB, r_off = FD_OOB;
+    bool e_left = false, e_right = false;
+    long pc = pp_lo;                                             // first pair of the chunk being prepared
+    auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
+        const long pg = pc + p;
+        const bool ok = live & (pg < pp_hi);
+        const long pq = ok ? pg : 0;
+        const int n = (int)(pq / plane2);
+        const int rem = (int)(pq - (long)n * plane2);
+        const int y = rem / W2, j = rem - y * W2;
+        a_off = ok ? 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(y * g.W + 2 * j)) : FD_OOB;
+        int r = y + ky - 1;
+        const bool inb = (unsigned)r < (unsigned)g.H;
+        if (refl) r = r < 0 ? -r : (r >= g.H ? 2 * g.H - 2 - r : r);
+        const bool okb = ok & (refl | inb);
+        const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(r * g.W + 2 * j));
+        e_left = j == 0; e_right = 2 * j + 2 >= g.W;
+        mid_off = okb ? base : FD_OOB;
+        l_off = (okb & !e_left) ? base - 4u : FD_OOB;
+        r_off = (okb & !e_right) ? base + 8u : FD_OOB;
+        pc += WGP;
+    };
+    // the edge flags belong to the chunk whose registers are in flight: latch them with the loads
+    bool s_left = false, s_right = false;
+    auto load_row = [&](int i) __attribute__((always_inline)) {
+        ra[i] = fd_ldg64(rsY, a_off == FD_OOB ? FD_OOB : a_off + 4u * a_row[i]);
+        rmid[i] = fd_ldg64(rsX, mid_off == FD_OOB ? FD_OOB : mid_off + 4u * b_row[i]);
+        rl[i] = fd_ldg32(rsX, l_off == FD_OOB ? FD_OOB : l_off + 4u * b_row[i]);
+        rr[i] = fd_ldg32(rsX, r_off == FD_OOB ? FD_OOB : r_off + 4u * b_row[i]);
+    };
+    auto store_row = [&](int buf, int i) __attribute__((always_inline)) {
+        float* qa = smem + buf * WG_BUF_FLOATS + p * LDU + rw + 16 * i;
+        const float y0 = ra[i].x, y1 = ra[i].y;
+        qa[0] = y0; qa[WGP * LDU] = y0 + y1; qa[2 * WGP * LDU] = y0 - y1; qa[3 * WGP * LDU] = y1;
+        const float d1 = rmid[i].x, d2 = rmid[i].y;
+        const float d0 = (refl & s_left) ? d2 : rl[i];
+        const float d3 = (refl & s_right) ? d1 : rr[i];
+        float* qb = smem + buf * WG_BUF_FLOATS + 4 * WGP * LDU + p * LDU + rw + 16 * i;
+        qb[0] = d0 - d2; qb[WGP * LDU] = d1 + d2; qb[2 * WGP * LDU] = d2 - d1; qb[3 * WGP * LDU] = d1 - d3;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    constexpr int NK = WGP / 2, LS = NK / 2;
+    const int arow = lane >> 5, acol = lane & 31;
+    if (nchunk > 0) {
+        prep_chunk(true);
+        s_left = e_left; s_right = e_right;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_row(i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_row(0, i);
+        __syncthreads();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int cur = ch & 1;
+            prep_chunk(ch + 1 < nchunk);
+            s_left = e_left; s_right = e_right;
+            const float* pa = smem + cur * WG_BUF_FLOATS + comp * WGP * LDU + arow * LDU + acol;
+            const float* pb = pa + 4 * WGP * LDU;
+            float av[2][2], bv[2][2];
+            av[0][0] = pa[0]; av[0][1] = pa[32]; bv[0][0] = pb[0]; bv[0][1] = pb[32];
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk + 1 < NK) {
+                    av[nb][0] = pa[(kk + 1) * 2 * LDU]; av[nb][1] = pa[(kk + 1) * 2 * LDU + 32];
+                    bv[nb][0] = pb[(kk + 1) * 2 * LDU]; bv[nb][1] = pb[(kk + 1) * 2 * LDU + 32];
+                }
+                if (kk < LS) load_row(kk);
+                else store_row(cur ^ 1, kk - LS);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform through LDS: sM[t][m][c] -> slab[z][m][ky*3 + kx][c]
+    float* sM = smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                sM[(comp * WBM + m) * LDM + j * 32 + acol] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int cl = tid & 63, c = c0 + cl;
+    if (c >= g.C) return;
+    float* slab = g.slabs + (size_t)blockIdx.z * ((size_t)g.M * 9 * g.C);
+#pragma unroll 4
+    for (int t = 0; t < 16; ++t) {
+        const int ml = (tid >> 6) + 4 * t, m = m0 + ml;
+        if (m >= g.M) break;
+        const float M0 = sM[(0 * WBM + ml) * LDM + cl], M1 = sM[(1 * WBM + ml) * LDM + cl];
+        const float M2 = sM[(2 * WBM + ml) * LDM + cl], M3 = sM[(3 * WBM + ml) * LDM + cl];
+        const float h = 0.5f * (M1 + M2);
+        float* o = slab + ((size_t)m * 9 + ky * 3) * g.C + c;
+        o[0] = M0 + h;
+        o[g.C] = 0.5f * (M1 - M2);
+        o[2 * (size_t)g.C] = h - M3;
+    }
+}
+
 inline int wino_splits(const fd_conv_desc* d, int M, int C) {
     const long tiles = (long)fd_cdiv((long)d->N * d->H * (d->W / 2), WBN) * fd_cdiv(M, WBM);
     const int nchunk = 3 * (C / WBKC);
@@ -310,3 +471,42 @@ extern "C" int fd_conv3x3_wino_fwd(const fd_conv_desc* d, const float* x, const 
         if (int rc = wino_weight_launch(w, wt, d->Cout, d->Cin, 0, st)) return rc;
     return wino_conv_launch(d, x, wt, bias, y, ws, st);
 }
+
+// ---- weight gradient
+bool wino_wgrad_ok(const fd_conv_desc* d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 16 == 0 && d->Cin >= 64 && d->Cout >= 64 &&
+           d->W % 2 == 0 && !d->in_norm;
+}
+int wino_wgrad_splits(const fd_conv_desc* d) {
+    const long tiles = 3L * fd_cdiv(d->Cin, WBN) * fd_cdiv(d->Cout, WBM);
+    const long Np = (long)d->N * d->H * (d->W / 2);
+    static long target = 0;
+    if (!target) { const char* e = getenv("FD_WINO_WGRAD_TARGET"); target = e ? atol(e) : 768; }
+    long sp = target / tiles;
+    const long maxs = (Np + 4 * WGP - 1) / (4 * WGP);          // at least 4 chunks per split
+    if (sp > maxs) sp = maxs;
+    if (sp < 1) sp = 1;
+    if (sp > 512) sp = 512;
+    return (int)sp;
+}
+long wino_wgrad_ws_floats(const fd_conv_desc* d) { return (long)wino_wgrad_splits(d) * d->Cout * 9 * d->Cin; }
+int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st) {
+    WinoWgradArgs g = {};
+    g.dY = gy; g.X = x; g.slabs = ws;
+    g.M = d->Cout; g.C = d->Cin; g.Nb = d->N; g.H = d->H; g.W = d->W; g.pad_mode = d->pad_mode;
+    const int sp = wino_wgrad_splits(d);
+    const long Np = (long)d->N * d->H * (d->W / 2);
+    long pps = (Np + sp - 1) / sp;
+    pps = (pps + WGP - 1) / WGP * WGP;
+    g.pairs_per_split = pps;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_wgrad_wino, dim3(3 * fd_cdiv(d->Cin, WBN), fd_cdiv(d->Cout, WBM), sp), dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st,
+                       g);
+    FD_LAUNCH_CHECK("k_wgrad_wino");
+    return fast_wgrad_finish_launch(ws, gw, d->Cout, d->Cin, 9, sp, accumulate, st);
+}
+
