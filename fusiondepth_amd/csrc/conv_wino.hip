@@ -70,6 +70,7 @@ struct WinoArgs {
     long slab_stride;
     int M, C, Nb, H, W;
     int pad_mode, act;
+    int xcd_swizzle;     // consecutive pixel tiles (vertical neighbours share input rows) go to the same XCD / L2
 };
 
 __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
@@ -79,7 +80,9 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     const long plane2 = (long)g.H * W2, Np = (long)g.Nb * plane2;
     const unsigned hw = (unsigned)(g.H * g.W);
     const int m0 = blockIdx.y * WBM;
-    const long p0 = (long)blockIdx.x * WBN;
+    int bx = blockIdx.x;
+    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    const long p0 = (long)bx * WBN;
     const int cpt = g.C / WBKC, nchunk_all = 3 * cpt;
     const int nsplit = (int)gridDim.z, zs = (int)blockIdx.z;
     const int per_split = (nchunk_all + nsplit - 1) / nsplit;
@@ -257,6 +260,7 @@ struct WinoWgradArgs {
     int M, C, Nb, H, W;
     int pad_mode;
     long pairs_per_split;
+    int slice_major;     // 1: grid x = pixel slice (XCD-aligned), z = (ky, c tile); 0: x = (ky, c tile), z = slice
 };
 constexpr int WGP = 16;                                          // pairs per chunk (GEMM-K 16 -> 8 MFMA k-steps)
 constexpr int WG_BUF_FLOATS = 4 * WGP * (LDU + LDU);             // A: [4][16][65], B: [4][16][65]
@@ -268,10 +272,14 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     const int W2 = g.W >> 1;
     const long plane2 = (long)g.H * W2, Np = (long)g.Nb * plane2;
     const unsigned hw = (unsigned)(g.H * g.W);
+    // grid (default): x = (kernel row, input-channel tile), y = output-channel tile, z = pixel slice.  The alternative
+    // (slice_major: x = slice with the slice count a multiple of 8, so that all workgroups of a slice share an XCD / L2) measured
+    // slightly slower in the training step and is kept as a tuning switch (FD_WINO_WGRAD_MAP=1).
     const int ctiles = (g.C + WBN - 1) / WBN;
-    const int ky = blockIdx.x / ctiles, c0 = (blockIdx.x - ky * ctiles) * WBN;
+    const int bt = g.slice_major ? blockIdx.z : blockIdx.x, bs = g.slice_major ? blockIdx.x : blockIdx.z;
+    const int ky = bt / ctiles, c0 = (bt - ky * ctiles) * WBN;
     const int m0 = blockIdx.y * WBM;
-    const long pp_lo = (long)blockIdx.z * g.pairs_per_split;
+    const long pp_lo = (long)bs * g.pairs_per_split;
     const long pp_hi = pp_lo + g.pairs_per_split < Np ? pp_lo + g.pairs_per_split : Np;
     const int nchunk = pp_hi > pp_lo ? (int)((pp_hi - pp_lo + WGP - 1) / WGP) : 0;
 
@@ -390,7 +398,7 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     __syncthreads();
     const int cl = tid & 63, c = c0 + cl;
     if (c >= g.C) return;
-    float* slab = g.slabs + (size_t)blockIdx.z * ((size_t)g.M * 9 * g.C);
+    float* slab = g.slabs + (size_t)bs * ((size_t)g.M * 9 * g.C);
 #pragma unroll 4
     for (int t = 0; t < 16; ++t) {
         const int ml = (tid >> 6) + 4 * t, m = m0 + ml;
@@ -453,6 +461,7 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         attr_set = true;
     }
     const int gx = fd_cdiv((long)d->N * d->H * (d->W / 2), WBN), gy = fd_cdiv(d->Cout, WBM);
+    g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
     hipLaunchKernelGGL(k_conv_wino, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
     FD_LAUNCH_CHECK("k_conv_wino");
     if (sp > 1) return fast_splitk_finish_launch(ws, y, bias, out_total, out_total, sp, (long)d->H * d->W, d->Cout, d->act, st);
@@ -485,8 +494,9 @@ int wino_wgrad_splits(const fd_conv_desc* d) {
     long sp = target / tiles;
     const long maxs = (Np + 4 * WGP - 1) / (4 * WGP);          // at least 4 chunks per split
     if (sp > maxs) sp = maxs;
-    if (sp < 1) sp = 1;
     if (sp > 512) sp = 512;
+    if (sp >= 8) sp &= ~7L;                                     // XCD alignment, see k_wgrad_wino
+    if (sp < 1) sp = 1;
     return (int)sp;
 }
 long wino_wgrad_ws_floats(const fd_conv_desc* d) { return (long)wino_wgrad_splits(d) * d->Cout * 9 * d->Cin; }
@@ -504,7 +514,11 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_wgrad_wino, dim3(3 * fd_cdiv(d->Cin, WBN), fd_cdiv(d->Cout, WBM), sp), dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st,
+    static int slice_major = -1;
+    if (slice_major < 0) { const char* e = getenv("FD_WINO_WGRAD_MAP"); slice_major = e ? atoi(e) : 0; }     // measured: 450-452 (0) vs 447-449 (1) images/s
+    g.slice_major = slice_major;
+    const int nt = 3 * fd_cdiv(d->Cin, WBN);
+    hipLaunchKernelGGL(k_wgrad_wino, slice_major ? dim3(sp, fd_cdiv(d->Cout, WBM), nt) : dim3(nt, fd_cdiv(d->Cout, WBM), sp), dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st,
                        g);
     FD_LAUNCH_CHECK("k_wgrad_wino");
     return fast_wgrad_finish_launch(ws, gw, d->Cout, d->Cin, 9, sp, accumulate, st);
