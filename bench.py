@@ -80,9 +80,11 @@ def roofline_probes(args, tr, batch):
     from fusiondepth_amd import functional as FD
     out = {}
     B = tr.batch_size
-    # dominant kernel: the 3x3 convolutions of the ResNet trunks (k_conv_fast).  Probe = layer1's 64->64 conv at
-    # H/4 x W/4, forward (the data-gradient launch is the same kernel with re-laid-out weights).  In the training step
-    # four such streams run concurrently; the probe runs alone.
+    # dominant kernel: the 3x3 stride-1 convolutions of the ResNet trunks (k_conv_wino, the 1-D Winograd F(2,3) MFMA kernel).
+    # Probe = layer1's 64->64 conv at H/4 x W/4, forward (the data-gradient launch is the same kernel with transformed flipped
+    # weights).  `achieved` divides the ALGORITHMIC flops of the convolution (2*Cout*Cin*9 per output pixel) by the
+    # launch time; the kernel itself issues 2/3 of them as MFMA work (6 multiplies per output instead of 9), `mfma_flop_per_launch`.
+    # In the training step four such streams run concurrently; the probe runs alone.
     h8, w8 = args.height // 4, args.width // 4
     Bc = B * (tr.accumulate_step if tr.stack_microbatches else 1)      # what the step launches: the stacked micro-batches
     x = torch.randn(Bc, 64, h8, w8, device="cuda")
@@ -93,17 +95,17 @@ def roofline_probes(args, tr, batch):
     flops = 2.0 * Bc * h8 * w8 * 64 * 64 * 9
     traffic = None                    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this exact kernel/shape
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_probe.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_probe_wino.json")))
         if (Bc, h8, w8) == (12, 48, 160):
             traffic = pmc["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
-    out["roofline"] = {"bound": "mfma", "kernel": "k_conv_fast<2,2,1,2,32> (ResNet layer1 conv 3x3 64->64 @%dx%d, batch %d = the "
-                       "stacked micro-batches, alone on the GPU)" % (h8, w8, Bc),
+    out["roofline"] = {"bound": "mfma", "kernel": "k_conv_wino (ResNet layer1 conv 3x3 64->64 @%dx%d, batch %d = the "
+                       "stacked micro-batches, alone on the GPU; Winograd F(2,3): algorithmic flops, 2/3 of them executed)" % (h8, w8, Bc),
                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                       "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_probe.md)",
-                       "us_per_launch": ms * 1e3, "flop_per_launch": flops}
+                       "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_probe_wino.md)",
+                       "us_per_launch": ms * 1e3, "flop_per_launch": flops, "mfma_flop_per_launch": flops * 2.0 / 3.0}
     # fused loss path: forward + backward kernels of the four scales at the batch the step launches (stacked micro-batches,
     # SI-log statistics per micro-batch).  Reported against the HBM roofline as the north star asks; the PMC passes in
     # profiles/round1_pmc_loss.md show the fused kernels are bound by the vector ALU (1 000 / 2 400 lane-instructions per

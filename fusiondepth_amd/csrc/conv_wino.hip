@@ -36,11 +36,9 @@ __device__ __forceinline__ float wino_act(float v, int act) {
 constexpr int WBM = 64, WBN = 64, WBKC = 16, WNT = 256;
 constexpr int LDU = WBM + 1, LDV = WBN, LDM = WBN + 1;
 constexpr int W_BUF_FLOATS = 4 * WBKC * (LDU + LDV);          // one operand buffer (all four components)
-#ifndef FD_WINO_NBUF
-#define FD_WINO_NBUF 2
-#endif
-constexpr int W_NBUF = FD_WINO_NBUF;                             // 2: double-buffered operands (66 KB, 2 workgroups / CU); 1: 33 KB
-constexpr int W_LDS_FLOATS = (W_NBUF * W_BUF_FLOATS > 4 * WBM * LDM) ? W_NBUF * W_BUF_FLOATS : 4 * WBM * LDM;
+// double-buffered operands: 66 KB -> 2 workgroups per CU.  (A single-buffered variant - 33 KB, 4 per CU, two barriers per chunk - and a
+// one-chunk-deep register pipeline both measured the same: neither occupancy nor load latency is what limits this kernel.)
+constexpr int W_LDS_FLOATS = (2 * W_BUF_FLOATS > 4 * WBM * LDM) ? 2 * W_BUF_FLOATS : 4 * WBM * LDM;
 
 // U[t][m][ky][c] from W[m][c][ky][kx] (forward) or, for the data gradient (flip = 1: a conv over dY with the spatially flipped,
 // channel-transposed kernel), from W[c][m][2-ky][2-kx].
@@ -177,7 +175,7 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
         for (int i = 0; i < 4; ++i) store_v(0, i);
         __syncthreads();
         for (int ch = ch_lo; ch < ch_hi; ++ch) {
-            const int cur = W_NBUF == 2 ? (ch - ch_lo) & 1 : 0;
+            const int cur = (ch - ch_lo) & 1;
             prep_chunk(ch + 1 < ch_hi);
             const float* pa = smem + cur * W_BUF_FLOATS + comp * WBKC * LDU + arow * LDU + acol;
             const float* pb = smem + cur * W_BUF_FLOATS + 4 * WBKC * LDU + comp * WBKC * LDV + arow * LDV + acol;
@@ -191,7 +189,7 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
                     bv[nb][0] = pb[(kk + 1) * 2 * LDV]; bv[nb][1] = pb[(kk + 1) * 2 * LDV + 32];
                 }
                 if (kk < LS) { load_u(kk); load_v(kk); }
-                else if (W_NBUF == 2) { store_u(cur ^ 1, kk - LS); store_v(cur ^ 1, kk - LS); }
+                else { store_u(cur ^ 1, kk - LS); store_v(cur ^ 1, kk - LS); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -201,13 +199,6 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
-            if (W_NBUF == 1) {                   // single buffer: everyone is done reading it, refill from the prefetch registers
-#pragma unroll
-                for (int t = 0; t < 4; ++t) store_u(0, t);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) store_v(0, i);
-                __syncthreads();
-            }
         }
     }
 
