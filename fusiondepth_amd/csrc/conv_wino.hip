@@ -37,7 +37,8 @@ constexpr int WBM = 64, WBN = 64, WBKC = 16, WNT = 256;
 constexpr int LDU = WBM + 1, LDV = WBN, LDM = WBN + 1;
 constexpr int W_BUF_FLOATS = 4 * WBKC * (LDU + LDV);          // one operand buffer (all four components)
 // double-buffered operands: 66 KB -> 2 workgroups per CU.  (A single-buffered variant - 33 KB, 4 per CU, two barriers per chunk - and a
-// one-chunk-deep register pipeline both measured the same: neither occupancy nor load latency is what limits this kernel.)
+// one-chunk-deep register pipeline both measured the same; an 8-channel-chunk variant - 33 KB, 3 per CU - was 2-5 % faster alone
+// and 2 % slower inside the training step, where its extra resident waves take CUs from the other streams' kernels.)
 constexpr int W_LDS_FLOATS = (2 * W_BUF_FLOATS > 4 * WBM * LDM) ? 2 * W_BUF_FLOATS : 4 * WBM * LDM;
 
 // U[t][m][ky][c] from W[m][c][ky][kx] (forward) or, for the data gradient (flip = 1: a conv over dY with the spatially flipped,
