@@ -231,7 +231,13 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
     const unsigned cs = (unsigned)out_cs, uM = (unsigned)M;              // total < 2^31 (fast-path size guard)
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * slab_stride + i];
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {                        // fixed order, four loads in flight
+            const float a0 = slabs[(size_t)z * slab_stride + i], a1 = slabs[(size_t)(z + 1) * slab_stride + i];
+            const float a2 = slabs[(size_t)(z + 2) * slab_stride + i], a3 = slabs[(size_t)(z + 3) * slab_stride + i];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; z < splits; ++z) s += slabs[(size_t)z * slab_stride + i];
         if (bias) s += bias[(i / cs) % uM];
         Y[i] = act_apply(s, act);
     }
@@ -405,7 +411,14 @@ __global__ void __launch_bounds__(256) k_wgrad_finish(const float* __restrict__ 
         const unsigned m = q / uT, t = q - m * uT;
         const unsigned dst = (m * uC + c) * uT + t;
         float s = accumulate ? gw[dst] : 0.f;
-        for (int z = 0; z < splits; ++z) s += slabs[(size_t)z * n + i];
+        // fixed summation order (z ascending); four loads in flight per thread: the pass is latency-bound otherwise
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {
+            const float a0 = slabs[(size_t)z * n + i], a1 = slabs[(size_t)(z + 1) * n + i];
+            const float a2 = slabs[(size_t)(z + 2) * n + i], a3 = slabs[(size_t)(z + 3) * n + i];
+            s += a0; s += a1; s += a2; s += a3;
+        }
+        for (; z < splits; ++z) s += slabs[(size_t)z * n + i];
         gw[dst] = s;
     }
 }
