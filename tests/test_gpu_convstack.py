@@ -537,3 +537,31 @@ def test_winograd_routing_forward_and_data_gradient_match_torch():
     gx2 = torch.autograd.grad(y2, x, gy)[0]
     relclose(cpu(y2), cpu(1.5 * y), "y after batched re-layout", rtol=1e-6, arel=1e-6)
     relclose(cpu(gx2), cpu(1.5 * gx), "dx after batched re-layout", rtol=1e-6, arel=1e-6)
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,mode", [
+    (2, 64, 64, 24, 80, "zero"),        # 3 tiles x many pixel slices
+    (1, 96, 80, 7, 10, "zero"),         # partial channel tiles on both sides, 35 pairs (< one slice of 64)
+    (2, 128, 64, 12, 40, "reflect"),    # decoder ConvBlock: reflect padding
+    (3, 64, 128, 5, 6, "reflect"),      # edges everywhere: every pair touches a border
+])
+def test_winograd_weight_gradient_vs_float64_reference(N, Ci, Co, H, W, mode):
+    """k_wgrad_wino (transposed F(2,3): 4 products per pixel pair and kernel row) through FD.conv2d's backward, against torch
+    float64 autograd; also accumulation into an existing gradient (the trainer's direct-gradient mode)."""
+    import fusiondepth_amd.functional as FD
+    torch.manual_seed(Ci + Co)
+    x = torch.randn(N, Ci, H, W, device="cuda")
+    w = torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05)
+    y = FD.conv2d(x, w, None, 1, 1, mode)
+    gy = torch.randn_like(y)
+    gw = torch.autograd.grad(y, w, gy)[0]
+    xd = F.pad(x.double(), (1, 1, 1, 1), mode="reflect" if mode == "reflect" else "constant")
+    wd = w.detach().double().requires_grad_(True)
+    gwd = torch.autograd.grad(F.conv2d(xd, wd), wd, gy.double())[0]
+    relclose(cpu(gw), cpu(gwd.float()), "dw (Winograd weight gradient)", rtol=1e-5, arel=3e-6)
+    # direct accumulation into a pre-existing .grad (fd_conv2d_bwd_weight accumulate = 1)
+    w.grad = torch.ones_like(w)
+    FD.enable_direct_grad([w])
+    y2 = FD.conv2d(x, w, None, 1, 1, mode)
+    y2.backward(gy)
+    relclose(cpu(w.grad), cpu(gwd.float() + 1.0), "accumulated dw", rtol=1e-5, arel=3e-6)
