@@ -513,9 +513,11 @@ FastChoice choose_config(const FastGemmArgs& a) {
         // workgroups the chip holds (3 per CU) wins or ties everywhere: 720 = 720x1 = 360x2 = 180x4, 768 = 96x8 = 48x16.
         const int c = a.M > 32 ? 1 : 2;
         const long tiles = (long)fd_cdiv(Np, bn[c]) * fd_cdiv(a.M, bm[c]) * (a.siblings > 1 ? a.siblings : 1);
+        static long fill = 0;
+        if (!fill) { const char* e = getenv("FD_CONV_TARGET"); fill = e ? atol(e) : 768; }
         int sp = 1;
-        if (can_split && tiles < 768) {
-            sp = (int)(768 / tiles);
+        if (can_split && tiles < fill) {
+            sp = (int)(fill / tiles);
             const int cap = nchunk / 4 > 0 ? (nchunk / 4 < 16 ? nchunk / 4 : 16) : 1;
             if (sp > cap) sp = cap;
             if (sp < 1) sp = 1;

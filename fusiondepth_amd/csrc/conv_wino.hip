@@ -410,7 +410,7 @@ inline int wino_splits(const fd_conv_desc* d, int M, int C) {
     const int nchunk = 3 * (C / WBKC);
     int sp = 1;
     static long target = 0;
-    if (!target) { const char* e = getenv("FD_WINO_TARGET"); target = e ? atol(e) : 768; }     // measured best (scripts/wino_probe.py)
+    if (!target) { const char* e = getenv("FD_WINO_TARGET"); target = e ? atol(e) : 384; }     // alone on the GPU 768 is best; inside the step 256-384 (less slab traffic)
     if (tiles < target) {
         sp = (int)(target / tiles);
         const int cap = nchunk / 3 > 0 ? (nchunk / 3 < 16 ? nchunk / 3 : 16) : 1;
@@ -482,7 +482,7 @@ int wino_wgrad_splits(const fd_conv_desc* d) {
     const long tiles = 3L * fd_cdiv(d->Cin, WBN) * fd_cdiv(d->Cout, WBM);
     const long Np = (long)d->N * d->H * (d->W / 2);
     static long target = 0;
-    if (!target) { const char* e = getenv("FD_WINO_WGRAD_TARGET"); target = e ? atol(e) : 768; }
+    if (!target) { const char* e = getenv("FD_WINO_WGRAD_TARGET"); target = e ? atol(e) : 384; }     // in-step optimum (768: -1 %)
     long sp = target / tiles;
     const long maxs = (Np + 4 * WGP - 1) / (4 * WGP);          // at least 4 chunks per split
     if (sp > maxs) sp = maxs;
