@@ -129,17 +129,50 @@ class ResnetEncoder(nn.Module):
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
-    def forward(self, input_image):
+    def forward_steps(self, input_image):
+        """The forward pass as a generator that yields after the stem and after every residual block, so that a caller can
+        advance several encoders in turn (``interleaved_forward``).  ``self.features`` is set when it is exhausted."""
         e = self.encoder
         # (x - 0.45) / 0.225 (resnet_encoder.py:94) as its own pass: the 7x7 stem then gathers plain values
         x = FD.conv2d(FD.input_normalize(input_image), e.conv1.weight, None, stride=2, pad=3)
         f0 = FD.batch_norm(x, e.bn1, relu=True)
-        f1 = e.layer1(FD.max_pool3x3s2(f0))
-        f2 = e.layer2(f1)
-        f3 = e.layer3(f2)
-        f4 = e.layer4(f3)
-        self.features = [f0, f1, f2, f3, f4]
+        yield
+        feats = [f0]
+        x = FD.max_pool3x3s2(f0)
+        for li in range(1, 5):
+            for blk in getattr(e, "layer%d" % li):
+                x = blk(x)
+                yield
+            feats.append(x)
+        self.features = feats
+
+    def forward(self, input_image):
+        for _ in self.forward_steps(input_image):
+            pass
         return self.features
+
+
+def interleaved_forward(jobs):
+    """Advance several independent encoders block by block in round-robin order.  ``jobs``: list of (encoder, input, stream or
+    None, BatchNorm groups).  The four encoders of a training step run on four HIP streams, but one Python thread issues them: issued
+    one after the other, stream k only starts once the k-1 encoders before it have been issued in full, and - because autograd
+    replays nodes in reverse creation order - the backward passes are issued one whole encoder at a time as well, the largest
+    (first issued) last.  Issued in turns, all streams have work from the first block on, in both directions."""
+    gens = [enc.forward_steps(x) for enc, x, _, _ in jobs]
+    alive = list(range(len(jobs)))
+    while alive:
+        for i in list(alive):
+            enc, _, st, groups = jobs[i]
+            with FD.bn_groups(groups):
+                try:
+                    if st is None:
+                        next(gens[i])
+                    else:
+                        with torch.cuda.stream(st):
+                            next(gens[i])
+                except StopIteration:
+                    alive.remove(i)
+    return [enc.features for enc, _, _, _ in jobs]
 
 
 # ------------------------------------------------------------------------------------------------------------------------

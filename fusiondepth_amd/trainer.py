@@ -112,6 +112,8 @@ class Trainer:
         self.pair_siblings = mode != "0"
         self._pair_depth, self._pair_pose = mode in ("1", "depth"), mode in ("1", "pose")
         self.stack_microbatches = True
+        # the four encoders issued block by block in turns instead of one after the other (networks.interleaved_forward)
+        self.interleave_encoders = os.environ.get("FD_INTERLEAVE", "1") != "0"
         self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)
         if self.opt.train_load_weights_folder is not None:
             self.load_model()
@@ -374,12 +376,15 @@ class Trainer:
         pose_out = None
         if groups > 1 and not par:
             raise NotImplementedError("stacked micro-batches need the separate_resnet pose path; set stack_microbatches=False")
-        if par:
+        interleave = (par and self.interleave_encoders and self.opt.beam_encoder and not self.opt.cat2end and not self.pair_siblings)
+        if par and not interleave:
             pose_out = self._launch_pose_encoders(inputs)          # side streams, joined in predict_poses
         beam_features = None
         pair = (par and self._pair_depth and self.opt.beam_encoder and not self.opt.cat2end
                 and enc_in.shape[0] == inputs["2channel"].shape[0] and self.models["encoder"].training)
-        if pair:
+        if interleave:
+            features, beam_features, pose_out = self._encoders_interleaved(inputs, enc_in, groups)
+        elif pair:
             # RGB and LiDAR depth encoders: same architecture and batch -> one launch per convolution for both
             with FD.bn_groups(groups):
                 features, beam_features = networks.paired_forward(self.models["encoder"], self.models["beam_encoder"], enc_in,
@@ -421,17 +426,8 @@ class Trainer:
         per-pass batch statistics and the order of the running-statistics updates are those of the two separate passes,
         but every kernel sees twice the pixels (layer4: 1 440 instead of 720) and half the launches are issued."""
         fids = self.opt.frame_ids[1:]
-        orders = [(f, 0) if f < 0 else (0, f) for f in fids]
         G = self._groups
-        Bg = inputs["color_aug", 0, 0].shape[0] // G
-
-        def stack(key):
-            # reference pass order: for each micro-batch g, for each source frame f  (trainer.py:237-248 + 336-351)
-            pairs = [torch.cat([inputs[key, i, 0] for i in o], 1) for o in orders]
-            if G == 1:
-                return torch.cat(pairs, 0)
-            return torch.cat([p[g * Bg:(g + 1) * Bg] for g in range(G) for p in pairs], 0)
-
+        stack = lambda key: self._stack_pose_inputs(inputs, key)
         res = {}
         st_rgb = self._fork(1)
         if self._pair_pose and self.opt.beam_encoder and self.models["pose_encoder"].training:
@@ -451,6 +447,35 @@ class Trainer:
                     bf = self.models["beam_encoder_pose"](stack("2channel"))
         res["stacked"] = (pf, st_rgb, bf, st_beam)
         return res
+
+    def _stack_pose_inputs(self, inputs, key):
+        """The (source, target) frame pairs of all source frames stacked along the batch axis, in the reference's pass order:
+        for each micro-batch g, for each source frame f  (trainer.py:237-248 + 336-351)."""
+        fids = self.opt.frame_ids[1:]
+        orders = [(f, 0) if f < 0 else (0, f) for f in fids]
+        G = self._groups
+        Bg = inputs["color_aug", 0, 0].shape[0] // G
+        pairs = [torch.cat([inputs[key, i, 0] for i in o], 1) for o in orders]
+        if G == 1:
+            return torch.cat(pairs, 0)
+        return torch.cat([p[g * Bg:(g + 1) * Bg] for g in range(G) for p in pairs], 0)
+
+    def _encoders_interleaved(self, inputs, enc_in, groups):
+        """All four encoder modules of the step, each on its own stream, issued block by block in turns
+        (networks.interleaved_forward) -> (features, beam_features, pose_out for predict_poses)."""
+        nf = len(self.opt.frame_ids[1:])
+        st_rgb, st_beam, st_lidar = self._fork(1), self._fork(2), self._fork(0)
+        with torch.cuda.stream(st_rgb):
+            pose_in = self._stack_pose_inputs(inputs, "color_aug")
+        with torch.cuda.stream(st_beam):
+            beam_pose_in = self._stack_pose_inputs(inputs, "2channel")
+        jobs = [(self.models["pose_encoder"], pose_in, st_rgb, groups * nf),
+                (self.models["beam_encoder_pose"], beam_pose_in, st_beam, groups * nf),
+                (self.models["beam_encoder"], inputs["2channel"], st_lidar, groups),
+                (self.models["encoder"], enc_in, None, groups)]
+        pf, bf, beam_features, features = networks.interleaved_forward(jobs)
+        self._join(st_lidar, beam_features)
+        return features, beam_features, {"stacked": (pf, st_rgb, bf, st_beam)}
 
     def predict_poses(self, inputs, features, precomputed=None):
         """trainer.py:321-388.  ``precomputed``: encoder features already launched on side streams."""
