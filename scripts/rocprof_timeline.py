@@ -45,3 +45,21 @@ for i, dt in alone.items():
 print("time spent as the ONLY kernel in flight, by kernel:")
 for n, dt in sorted(byname.items(), key=lambda kv: -kv[1])[:18]:
     print("  %-72s %6.2f ms" % (n, dt / 1e6))
+
+# coarse timeline: per millisecond of the step, the average number of kernels in flight and the kernels that cover it
+print("per-ms timeline (avg kernels in flight | top kernels by covered time):")
+nb = int((t1 - t0) / 1e6) + 1
+cover = [defaultdict(float) for _ in range(nb)]
+for r in ev:
+    a, b = r[1], r[2]
+    n = re.sub(r"\(anonymous namespace\)::", "", r[0]); n = re.sub(r"^void ", "", n); n = re.sub(r"[<(].*$", "", n)[:18]
+    k = int((a - t0) / 1e6)
+    while a < b and k < nb:
+        edge = t0 + (k + 1) * 1e6
+        seg = min(b, edge) - a
+        cover[k][n] += seg
+        a = edge; k += 1
+for k in range(nb):
+    tot_k = sum(cover[k].values())
+    top = sorted(cover[k].items(), key=lambda kv: -kv[1])[:4]
+    print("  %2d ms  %.2f  %s" % (k, tot_k / 1e6, "  ".join("%s %.2f" % (n, v / 1e6) for n, v in top)))
