@@ -565,3 +565,40 @@ def test_winograd_weight_gradient_vs_float64_reference(N, Ci, Co, H, W, mode):
     y2 = FD.conv2d(x, w, None, 1, 1, mode)
     y2.backward(gy)
     relclose(cpu(w.grad), cpu(gwd.float() + 1.0), "accumulated dw", rtol=1e-5, arel=3e-6)
+
+
+def test_interleaved_encoders_equal_sequential_passes():
+    """networks.interleaved_forward (four encoders advanced block by block in turns, each on its own stream) returns exactly what
+    four sequential forward calls return, and autograd through it gives the same parameter gradients."""
+    from fusiondepth_amd import networks
+    import fusiondepth_amd.functional as FD
+    torch.manual_seed(3)
+    specs = [dict(num_input_images=2), dict(num_input_images=2, beam_encoder=True), dict(beam_encoder=True), dict()]
+    encs = [networks.ResnetEncoder(18, False, **kw).cuda().train() for kw in specs]
+    xs = [torch.rand(2, e.encoder.conv1.weight.shape[1], 64, 96, device="cuda") for e in encs]
+    seq = []
+    for e, x in zip(encs, xs):
+        saved = {n: b.clone() for n, b in e.named_buffers()}
+        feats = e(x)
+        loss = sum(f.square().mean() for f in feats)
+        grads = torch.autograd.grad(loss, list(e.parameters()), allow_unused=True)
+        seq.append(([f.detach().clone() for f in feats], grads))
+        with torch.no_grad():
+            for n, b in e.named_buffers():
+                b.copy_(saved[n])                     # running statistics back to the start for the second pass
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(), None]
+    for st in streams[:3]:
+        st.wait_stream(torch.cuda.current_stream())
+    outs = networks.interleaved_forward([(e, x, st, 1) for e, x, st in zip(encs, xs, streams)])
+    for st in streams[:3]:
+        torch.cuda.current_stream().wait_stream(st)
+    for (feats_s, grads_s), feats_i, e in zip(seq, outs, encs):
+        for a, b in zip(feats_s, feats_i):
+            assert torch.equal(a, b.detach())
+        loss = sum(f.square().mean() for f in feats_i)
+        grads_i = torch.autograd.grad(loss, list(e.parameters()), allow_unused=True)
+        torch.cuda.synchronize()
+        for ga, gb in zip(grads_s, grads_i):
+            assert (ga is None) == (gb is None)
+            if ga is not None:
+                assert torch.equal(ga, gb)
