@@ -15,6 +15,7 @@
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include "conv_fast.h"
+#include <stdio.h>
 #include "conv_narrow.h"
 
 namespace {
@@ -678,6 +679,13 @@ inline bool fast_fwd_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->
 inline bool fast_dgrad_ok(const fd_conv_desc* d) { return d->Cout % 16 == 0; }
 inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && d->Cin >= 64 && !d->in_norm; }   // narrow layers: a (tap, channel) tile would be mostly padding
 
+// FD_CONV_LOG=1: one stderr line per convolution call (which kernel family it was routed to) - a tuning aid
+void conv_log(const char* what, const char* path, const fd_conv_desc* d) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FD_CONV_LOG"); on = e ? atoi(e) : 0; }
+    if (on) fprintf(stderr, "FDCONV %s %s N=%d Cin=%d H=%d W=%d Cout=%d K=%d s=%d pad_mode=%d\n", what, path, d->N, d->Cin, d->H, d->W, d->Cout, d->KH,
+                    d->stride, d->pad_mode);
+}
 // 1-D Winograd F(2,3) path (conv_wino.hip): 3x3 stride-1 pad-1 convs with >= 64 output channels (its tile is 64 channels tall).
 // FD_WINO=0 keeps everything on the direct implicit GEMM (A/B runs).
 bool wino_enabled() {
@@ -744,10 +752,12 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
     if (fast_fwd_ok(d)) {
         FD_REQUIRE(wt, "fd_conv2d_fwd: weight-layout buffer required (fd_conv2d_fwd_wt_floats)");
         if (wino_use_fwd(d)) {
+            conv_log("fwd", "wino", d);
             if (!wt_ready)
                 if (int rc = wino_weight_launch(w, wt, d->Cout, d->Cin, 0, st)) return rc;
             return wino_conv_launch(d, x, wt, bias, y, ws, st);
         }
+        conv_log("fwd", "direct", d);
         FastGemmArgs f;
         fill_fwd_args(d, s, f);
         if (!wt_ready)
@@ -887,6 +897,7 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
     const int KH = d->KH, KW = d->KW;
     {
         fd_conv_desc gd;
+        conv_log("dgrad", (siblings == 1 && wino_dgrad_desc(d, gd)) ? "wino" : "direct", d);
         if (siblings == 1 && wino_dgrad_desc(d, gd)) {
             if (!wt_ready)
                 if (int rc = wino_weight_launch(w, wt_base, gd.Cout, gd.Cin, 1, st)) return rc;
@@ -1111,6 +1122,7 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
                "fd_conv2d_bwd_weight: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
     const long Np = (long)d->N * s.Ho * s.Wo;
+    conv_log("wgrad", narrow_wgrad_ok(d) ? "narrow" : stem_wgrad_ok(d) ? "stem" : wino_use_wgrad(d) ? "wino" : fast_wgrad_ok(d) ? "direct" : "generic", d);
     if (narrow_wgrad_ok(d)) {
         if (int rc = narrow_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
     } else if (stem_wgrad_ok(d)) {
