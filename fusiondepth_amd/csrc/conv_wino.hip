@@ -131,12 +131,12 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
         pc_c0 += WBKC;
         if (pc_c0 >= g.C) { pc_c0 = 0; ++pc_ky; }
     };
-    auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off == FD_OOB ? FD_OOB : u_off + (unsigned)t * u_comp); };
+    auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off + (unsigned)t * u_comp); };   // FD_OOB + (< 2^31) stays out of range
     auto load_v = [&](int i) __attribute__((always_inline)) {
         const unsigned s = (unsigned)i * c_step;
-        rmid[i] = fd_ldg64(rsX, mid_off == FD_OOB ? FD_OOB : mid_off + s);
-        rl[i] = fd_ldg32(rsX, l_off == FD_OOB ? FD_OOB : l_off + s);
-        rr[i] = fd_ldg32(rsX, r_off == FD_OOB ? FD_OOB : r_off + s);
+        rmid[i] = fd_ldg64(rsX, mid_off + s);                             // an FD_OOB base + (offset < 2^31) is still >= 2^31: reads 0
+        rl[i] = fd_ldg32(rsX, l_off + s);
+        rr[i] = fd_ldg32(rsX, r_off + s);
     };
     auto store_u = [&](int buf, int t) __attribute__((always_inline)) {
         float* q = smem + buf * W_BUF_FLOATS + t * WBKC * LDU + (4 * a4) * LDU + ar;
@@ -313,10 +313,10 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     // the edge flags belong to the chunk whose registers are in flight: latch them with the loads
     bool s_left = false, s_right = false;
     auto load_row = [&](int i) __attribute__((always_inline)) {
-        ra[i] = fd_ldg64(rsY, a_off == FD_OOB ? FD_OOB : a_off + 4u * a_row[i]);
-        rmid[i] = fd_ldg64(rsX, mid_off == FD_OOB ? FD_OOB : mid_off + 4u * b_row[i]);
-        rl[i] = fd_ldg32(rsX, l_off == FD_OOB ? FD_OOB : l_off + 4u * b_row[i]);
-        rr[i] = fd_ldg32(rsX, r_off == FD_OOB ? FD_OOB : r_off + 4u * b_row[i]);
+        ra[i] = fd_ldg64(rsY, a_off + 4u * a_row[i]);                     // FD_OOB + (< 2^31) stays out of range
+        rmid[i] = fd_ldg64(rsX, mid_off + 4u * b_row[i]);
+        rl[i] = fd_ldg32(rsX, l_off + 4u * b_row[i]);
+        rr[i] = fd_ldg32(rsX, r_off + 4u * b_row[i]);
     };
     auto store_row = [&](int buf, int i) __attribute__((always_inline)) {
         float* qa = smem + buf * WG_BUF_FLOATS + p * LDU + rw + 16 * i;
