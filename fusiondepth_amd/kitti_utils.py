@@ -106,3 +106,37 @@ def gen2channel(calib_dir, velo_filename, out_path, idx, side, regenerate=True, 
         beam = get_4beam_device(calib_dir, velo_filename, side_map[side], flip, device)
         np.save(path, FD.scatter_2channel(beam).cpu().numpy())
     return paths
+
+
+# export_gt_depth.py:57-131: which scan of a split line feeds the ground-truth / sparse-input depth map
+_SPLIT_SCAN_DIR = {"eigen": "velodyne_points/data", "demo_gt": "velodyne_points/data", "demo": "4beam", "r100": "random100",
+                   "r200": "random200", "1beam": "1beam", "2beam": "2beam", "3beam": "3beam", "4beam": "4beam", "8beam": "8beam",
+                   "16beam": "16beam"}
+_SPLIT_OUTPUT = {"r100": "r100.npz", "r200": "r200.npz", "demo": "4beam.npz", "eigen": "gt_depths.npz", "demo_gt": "gt_depths.npz"}
+
+
+def export_gt_depths(data_path, lines, split, output_path=None, device="cuda"):
+    """export_gt_depth.py:29-131 for the Velodyne-based splits: one ``generate_depth_map(calib_dir, scan, 2, True)`` (vel_depth)
+    per split line ``"<date>/<drive> <frame> <side>"``, float32, saved as ``np.savez_compressed(output, data=...)`` - the
+    ``gt_depths.npz`` / ``4beam.npz`` / ``r100.npz`` files ``evaluate_depth.py`` loads.  Returns the list of maps.
+    (``eigen_benchmark`` reads PNGs and the ``detec*`` splits need OpenCV to find the calibration: not covered.)"""
+    if split not in _SPLIT_SCAN_DIR:
+        raise ValueError("export_gt_depths: split %r is not Velodyne-based (supported: %s)" % (split, sorted(_SPLIT_SCAN_DIR)))
+    gt_depths = []
+    for line in lines:
+        folder, frame_id, _ = line.split()
+        calib_dir = os.path.join(data_path, folder.split("/")[0])
+        velo_filename = os.path.join(data_path, folder, _SPLIT_SCAN_DIR[split], "{:010d}.bin".format(int(frame_id)))
+        gt_depths.append(generate_depth_map(calib_dir, velo_filename, 2, True, device=device).astype(np.float32))
+    if output_path is not None:
+        same = all(g.shape == gt_depths[0].shape for g in gt_depths)
+        data = np.array(gt_depths) if same else np.array(gt_depths, dtype=object)       # drives differ in image size
+        np.savez_compressed(output_path, data=data)
+    return gt_depths
+
+
+def split_output_name(split):
+    """export_gt_depth.py:116-127: file name the split's maps are saved under."""
+    if split in ("1beam", "2beam", "3beam", "4beam", "8beam", "16beam"):
+        return "{}.npz".format(split)
+    return _SPLIT_OUTPUT.get(split, "gt_depths.npz")

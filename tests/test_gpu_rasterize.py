@@ -159,3 +159,35 @@ def test_random_sample_scans_r100_r200(n_points):
     two = FD.scatter_2channel(beam).cpu().numpy()
     d, c = OS.scatter_2channel_c(want_beam)
     assert np.array_equal(two[0], d) and np.array_equal(two[1], c)
+
+
+def test_export_gt_depths_from_a_kitti_tree(tmp_path):
+    """export_gt_depth.py: split lines -> vel_depth maps (float32) -> gt_depths.npz / r200.npz, on a synthetic KITTI tree."""
+    from fusiondepth_amd import kitti_utils as KU
+    from oracle import rasterize as OR
+    root = str(tmp_path)
+    date, drive = "2011_09_26", "2011_09_26/2011_09_26_drive_0002_sync"
+    os.makedirs(os.path.join(root, drive, "velodyne_points/data"))
+    os.makedirs(os.path.join(root, drive, "random200"))
+    scans = {}
+    for frame, seed in ((69, 31), (54, 32)):
+        velo, P = gin.lidar_scan(seed, n_points=4000)
+        scans[frame] = (velo, P)
+        _write_kitti_files(os.path.join(root, date), velo)                 # calib files live in the date folder
+        velo.tofile(os.path.join(root, drive, "velodyne_points/data", "%010d.bin" % frame))
+        velo[:200].tofile(os.path.join(root, drive, "random200", "%010d.bin" % frame))
+    lines = ["%s %010d l" % (drive, 69), "%s %010d l" % (drive, 54)]
+    out = os.path.join(root, KU.split_output_name("eigen"))
+    maps = KU.export_gt_depths(root, lines, "eigen", out)
+    data = np.load(out)["data"]
+    assert data.dtype == np.float32 and data.shape == (2, 375, 1242)
+    for m, frame in zip(maps, (69, 54)):
+        velo, P = scans[frame]
+        want = OR.depth_image(velo, P, 375, 1242, vel_depth=True).astype(np.float32)
+        assert np.array_equal(m, want)
+    assert np.array_equal(data[1], maps[1])
+    sparse = KU.export_gt_depths(root, lines[:1], "r200", os.path.join(root, KU.split_output_name("r200")))
+    want = OR.depth_image(scans[69][0][:200], scans[69][1], 375, 1242, vel_depth=True).astype(np.float32)
+    assert np.array_equal(sparse[0], want) and KU.split_output_name("r200") == "r200.npz" and KU.split_output_name("4beam") == "4beam.npz"
+    with pytest.raises(ValueError):
+        KU.export_gt_depths(root, lines, "eigen_benchmark")
