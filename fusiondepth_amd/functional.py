@@ -924,7 +924,11 @@ class _UpCat(torch.autograd.Function):
         gs = _empty((N, Cs, 2 * h, 2 * w), g) if need_s else None
         g3 = _empty((N, C3, 2 * h, 2 * w), g) if ctx.has[2] and ctx.needs_input_grad[3] else None
         call("fd_upcat_bwd", ptr(g), ptr(ga), ptr(gs), ptr(g3), N, Ca, Cs, C3, h, w, stream())
-        return ga, gs if ctx.has[0] else None, gs if ctx.has[1] else None, g3
+        # skip and skip_add come from encoders that run their backward on DIFFERENT streams.  Handing both the same tensor is
+        # a race: autograd may accumulate a second incoming gradient into it in place on one stream while the other stream's
+        # kernels still read it (seen as run-to-run different encoder gradients under GPU contention).  One owner each.
+        both = ctx.has[0] and ctx.has[1] and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+        return ga, gs if ctx.has[0] else None, (gs.clone() if both else gs) if ctx.has[1] else None, g3
 
 
 def upsample_concat(a, skip=None, skip_add=None, extra=None):
@@ -966,7 +970,8 @@ class _Add(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g, g
+        # the two operands belong to encoders on different streams: separate gradient tensors (see _UpCat.backward)
+        return g, (g.clone() if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] else g)
 
 
 def add(a, b):

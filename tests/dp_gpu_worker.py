@@ -67,6 +67,16 @@ def main():
         res["solo_max_abs_diff"] = float(d.max())
         res["solo_rel_l2"] = float(d.norm() / solo.flat.flat_param.norm())
         res["moved"] = float((p - init).abs().max())
+        # which tensors differ most (diagnostics when the comparison fails)
+        worst = []
+        names = [(k, n) for k, m in solo.models.items() for n, _ in m.named_parameters()]
+        for (k, n), q, o in zip(names, solo.parameters_to_train, solo.flat.offsets):
+            dd = float(d[o:o + q.numel()].max())
+            if dd > 1e-6:
+                worst.append(("%s.%s" % (k, n), dd))
+        worst.sort(key=lambda t: -t[1])
+        res["worst"] = worst[:12]
+        res["n_bad_tensors"] = len(worst)
     with open(out_path + ".%d" % rank, "w") as f:
         json.dump(res, f)
     dist.barrier()
