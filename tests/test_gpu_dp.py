@@ -13,12 +13,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(tmp_path, mode):
+def _run(tmp_path, mode, extra_env=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = str(tmp_path / ("dp_" + mode))
     env = dict(os.environ, FD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "dp_gpu_worker.py"), out, mode]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
@@ -26,10 +27,13 @@ def _run(tmp_path, mode):
     return [json.load(open(out + ".%d" % k)) for k in range(2)]
 
 
-def test_two_ranks_same_batch_equal_single_process(tmp_path):
+@pytest.mark.parametrize("interleave", ["0", "1"])
+def test_two_ranks_same_batch_equal_single_process(tmp_path, interleave):
     """Both ranks see the same batch: mean of two identical gradients = the gradient, so two DP steps must land on the
-    single-process parameters (up to the rounding of (g + g) / 2 inside Adam) and the replicas must stay bit-identical."""
-    r0, r1 = _run(tmp_path, "same")
+    single-process parameters (up to the rounding of (g + g) / 2 inside Adam) and the replicas must stay bit-identical.
+    Two processes contending for one GPU also make this a race detector: with the encoders issued in turns (interleave = 1) it
+    caught a gradient tensor shared by two streams (functional._UpCat.backward)."""
+    r0, r1 = _run(tmp_path, "same", {"FD_INTERLEAVE": interleave})
     for r in (r0, r1):
         assert r["same_init"] and r["replicas_equal"] and r["finite"]
     assert r0["losses"] == r1["losses"]
