@@ -354,3 +354,42 @@ def test_val_loop_and_best_checkpoint_bookkeeping(tmp_path):
     assert all(m.training for m in tr.models.values())
     tr.val(batches)
     assert tr.last_saved == []                                          # not strictly better: nothing saved
+
+
+@pytest.mark.parametrize("interleave", [False, True])
+def test_gradients_are_run_to_run_identical_under_gpu_contention(interleave):
+    """Every kernel is deterministic, so repeating forward + backward on the same weights must give bit-identical gradients -
+    unless two streams race.  A background stream keeps the GPU busy with unrelated work of varying size to shake the timing
+    (this is how a gradient tensor shared by two encoder streams was caught; see functional._UpCat.backward)."""
+    B, H, W = 2, 64, 96
+    opt = _opts(batch_size=B)
+    from fusiondepth_amd.trainer import Trainer
+    tr = Trainer(opt, verbose=False)
+    tr.interleave_encoders = interleave
+    inp, noise = _batch(B, H, W, 990)
+    ginp = {k: v.cuda() for k, v in inp.items()}
+    ginp["_noise"] = [n.cuda() for n in noise]
+    saved = {k: {n: b.clone() for n, b in m.named_buffers()} for k, m in tr.models.items()}
+    bg = torch.cuda.Stream()
+    junk = [torch.randn(s, s, device="cuda") for s in (256, 1024, 2048, 3072)]
+    ref = None
+    for rep in range(6):
+        with torch.no_grad():
+            for k, m in tr.models.items():
+                for n, b in m.named_buffers():
+                    b.copy_(saved[k][n])
+        tr.flat.zero_grad()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(bg):
+            for i in range(20 + 7 * rep):
+                junk[(i + rep) % 4] @ junk[(i + rep) % 4]
+        outputs, losses = tr.process_batch(ginp, groups=tr.accumulate_step)
+        losses["loss"].backward()
+        tr._join_side_streams()
+        torch.cuda.synchronize()
+        g = tr.flat.flat_grad.clone()
+        if ref is None:
+            ref = g
+            assert float(g.abs().max()) > 0
+        else:
+            assert torch.equal(g, ref), "repetition %d: %d gradient entries differ" % (rep, int((g != ref).sum()))
