@@ -67,3 +67,29 @@ def test_refiner_trains_like_the_oracle():
     assert np.isfinite(traj).all()
     assert_close(traj[0][0], traj[0][1], rtol=2e-4, atol=0, what="refiner loss at step 0")
     assert_close([t[0] for t in traj], [t[1] for t in traj], rtol=5e-3, atol=0, what="refiner loss trajectory")
+
+
+def test_refiner_steps_are_reproducible_under_gpu_contention():
+    """Two optimiser steps of the refiner from the same state, repeated with different background GPU load: bit-identical
+    refine-decoder parameters (the refiner drives frozen encoders on side streams, a median-scaling pass and the fused loss)."""
+    B, H, W = 1, 192, 640
+    batches = []
+    for step in range(2):
+        inp, noise = gin.refiner_inputs(840 + step, B, H, W)
+        g = {k: v.cuda() for k, v in inp.items()}
+        g["_noise"] = [n.cuda() for n in noise]
+        batches.append(g)
+    bg = torch.cuda.Stream()
+    junk = [torch.randn(s, s, device="cuda") for s in (768, 2048)]
+    finals = []
+    for run in range(3):
+        rf, _, _ = _make(B, H, W)
+        for step, b in enumerate(batches):
+            with torch.cuda.stream(bg):
+                for i in range(8 + 9 * run + 2 * step):
+                    junk[i % 2] @ junk[i % 2]
+            rf.train_step({k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in b.items()})
+        torch.cuda.synchronize()
+        finals.append(torch.cat([p.detach().reshape(-1) for p in rf.models["refine2d_decoder"].parameters()]).clone())
+        del rf
+    assert torch.equal(finals[0], finals[1]) and torch.equal(finals[0], finals[2])
