@@ -423,6 +423,30 @@ __global__ void __launch_bounds__(256) k_wgrad_finish(const float* __restrict__ 
     }
 }
 
+// The same reduction for 3x3 kernels with both sides coalesced: a workgroup owns (output channel m, 32 input channels); thread
+// (t, c) sums slab rows [m][t][c0 + c] over the slices (128-byte rows), the 9 x 32 block is transposed through LDS, and the
+// 288 results leave as one contiguous run of gw[m][c0 .. c0 + 31][0 .. 8] (the generic kernel writes single floats 36 bytes apart).
+__global__ void __launch_bounds__(288) k_wgrad_finish9(const float* __restrict__ slabs, float* __restrict__ gw, int M, int C,
+                                                       int splits, int accumulate) {
+    __shared__ float tile[9][33];
+    const int m = blockIdx.y, c0 = blockIdx.x * 32;
+    const int t = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const size_t n = (size_t)M * 9 * C;
+    const float* p = slabs + ((size_t)m * 9 + t) * C + c0 + c;
+    float s = 0.f;
+    int z = 0;
+    for (; z + 4 <= splits; z += 4) {                              // fixed order, four loads in flight
+        const float a0 = p[(size_t)z * n], a1 = p[(size_t)(z + 1) * n], a2 = p[(size_t)(z + 2) * n], a3 = p[(size_t)(z + 3) * n];
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; z < splits; ++z) s += p[(size_t)z * n];
+    tile[t][c] = s;
+    __syncthreads();
+    const int j = threadIdx.x, cc = j / 9, tt = j - cc * 9;
+    float* o = gw + ((size_t)m * C + c0) * 9 + j;
+    *o = (accumulate ? *o : 0.f) + tile[tt][cc];
+}
+
 // A2[m][(a,b)][c]:  mode 0 (forward)  A2[co][t][ci] = W[co][ci][kh0+dkh*a][kw0+dkw*b]
 //                   mode 1 (dgrad)    A2[ci][t][co] = W[co][ci][kh0+dkh*a][kw0+dkw*b]
 __global__ void __launch_bounds__(256) k_weight_relayout_tc(const float* __restrict__ W, float* __restrict__ A2, int Co,
@@ -592,6 +616,12 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
 }
 
 int fast_wgrad_finish_launch(const float* slabs, float* gw, int M, int C, int T, int splits, int accumulate, hipStream_t st) {
+    if (T == 9 && C % 32 == 0) {
+        hipLaunchKernelGGL(k_wgrad_finish9, dim3(C / 32, M), dim3(288), 0, st, slabs, gw, M, C, splits, accumulate);
+        hipError_t e9 = hipGetLastError();
+        if (e9 != hipSuccess) { fd_set_error("k_wgrad_finish9 launch failed: %s", hipGetErrorString(e9)); return (int)e9; }
+        return 0;
+    }
     hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks((long)M * C * T)), dim3(256), 0, st, slabs, gw, M, C, T, splits, accumulate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
@@ -655,11 +685,8 @@ int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumul
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_wgrad_fast launch failed: %s", hipGetErrorString(e)); return (int)e; }
     const long n = (long)a.M * a.C * a.T;
-    for (int sib = 0; sib < nsib; ++sib) {
-        hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks(n)), dim3(256), 0, st, a.slabs + (size_t)sib * splits * n, sib ? gw1 : gw,
-                           a.M, a.C, a.T, splits, accumulate);
-        e = hipGetLastError();
-        if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
-    }
+    for (int sib = 0; sib < nsib; ++sib)
+        if (int rc = fast_wgrad_finish_launch(a.slabs + (size_t)sib * splits * n, sib ? gw1 : gw, a.M, a.C, a.T, splits, accumulate, st))
+            return rc;
     return 0;
 }
