@@ -234,6 +234,11 @@ def main():
             print("[bench] warm-up: eager %.2f ms/step, hipGraph replay %.2f ms/step -> %s" % (1e3 * t_eager, 1e3 * t_graph, launch),
                   file=sys.stderr, flush=True)
     step_fn = (lambda _: tr.train_step(eager_in)) if launch == "eager" else tr.train_step_graphed
+    # two extra untimed steps of the chosen path, so that the caching allocator, the weight-layout caches and the batched
+    # re-layout plan (built after the first step; re-derived when the trial above switched between the two launch paths) are
+    # in their steady state before the W warm-up steps even when W is 0 or 1
+    for _ in range(2):
+        step_fn(mbs)
     for _ in range(max(args.warmup, 0 if launch == "eager" else 2)):     # graph mode: 1 eager warm-up + 1 capture/replay
         step_fn(mbs)
     barrier()
