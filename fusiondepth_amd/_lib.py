@@ -12,6 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfdhip.so")
 ABI_VERSION = 1
+PHOTO_OUT_FLOATS = 96        # FD_PHOTO_OUT_FLOATS
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F, "d": _D}
@@ -24,6 +25,12 @@ class PhotoCfg(ctypes.Structure):
                 ("use_ssim", _I), ("avg_reprojection", _I),
                 ("si_depth_scale", _F), ("si_beam_scale", _F), ("si_threshold", _F), ("si_var", _F), ("eps", _F),
                 ("groups", _I), ("si_lo", _F), ("si_mode", _I)]
+
+
+class PhotoMsCfg(ctypes.Structure):
+    """Mirror of ``fd_photo_ms_cfg``."""
+    _fields_ = [("base", PhotoCfg), ("n_scales", _I), ("Hs", _I * 4), ("Ws", _I * 4), ("beam_mask", ctypes.c_uint),
+                ("rows_per_strip", _I)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -64,6 +71,9 @@ SIGNATURES = {
     "fd_photo_fwd": ("p" * 16, "i"),
     "fd_photo_bwd_ws_floats": ("iii", "l"),
     "fd_photo_bwd": ("pppppppp" "i" "pppppp", "i"),
+    "fd_photo_ms_ws_floats": ("p", "l"),
+    "fd_photo_ms_fwd": ("p" * 14, "i"),
+    "fd_photo_ms_bwd": ("p" * 11, "i"),
     "fd_smooth_ws_floats": ("iii", "l"),
     "fd_smooth_fwd": ("ppppiiiip", "i"),
     "fd_smooth_bwd": ("pppppiiiip", "i"),

@@ -26,10 +26,17 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _file_flags(src):
+    """Per-file compiler flags: a leading ``// FD_HIPCC_FLAGS: ...`` line of the source."""
+    with open(src) as fh:
+        first = fh.readline()
+    return first.split(":", 1)[1].split() if first.startswith("// FD_HIPCC_FLAGS:") else []
+
+
 def _compile(src, headers, force):
     obj = os.path.join(OBJ_DIR, os.path.basename(src).replace(".hip", ".o"))
     if force or _newer(obj, [src] + headers):
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + _file_flags(src) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stdout))

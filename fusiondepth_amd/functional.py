@@ -430,6 +430,109 @@ def photo_loss(disp, T_list, K, inv_K, src_list, target, ident=None, noise=None,
                             int(groups))
 
 
+def photo_ms_supported(po, n_src, materialize=False):
+    """Configurations the multi-scale kernel (csrc/photometric_ms.hip) covers; the rest stays on the per-scale kernels."""
+    return n_src == 2 and not po.no_ssim and not po.avg_reprojection and not materialize
+
+
+class _PhotoLossMS(torch.autograd.Function):
+    """All pyramid scales of generate_images_pred + the photometric / LiDAR part of compute_losses in ONE launch that also
+    produces the unit-cotangent gradients (``fd_photo_ms_fwd``); the backward only scales them (``fd_photo_ms_bwd``).
+
+    Returns (photo_0..photo_{S-1}, si_0..si_{S-1}, sel[S,B,H,W])."""
+
+    @staticmethod
+    def forward(ctx, T0, T1, K, inv_K, src0, src1, target, ident, noise, beam, po, groups, beam_scales, rows, *disps):
+        S = len(disps)
+        disps = [f32(d) for d in disps]
+        K, inv_K, target, src0, src1 = f32(K), f32(inv_K), f32(target), f32(src0), f32(src1)
+        _need_cuda(disps[0], K, inv_K, target, src0, src1)
+        B = disps[0].shape[0]
+        H, W = target.shape[2:]
+        Ts = [f32(T0), f32(T1)]
+        P = _empty((B, 2, 3, 4), target)
+        for f in range(2):
+            call("fd_proj_matrix_fwd", ptr(K), ptr(Ts[f]), P.data_ptr() + f * 48, 24, B, stream())
+        ident = f32(ident) if ident is not None else None
+        beam = f32(beam) if beam is not None else None
+        if noise is not None and ident is not None:
+            noise = [f32(n) for n in noise]            # S tensors [B,2,H,W] (or the S slices of one [S,B,2,H,W] tensor)
+        else:
+            noise = None
+        cfg = _lib.PhotoMsCfg()
+        cfg.base = _photo_cfg(po, B, H, W, H, W, 2, groups)
+        cfg.n_scales = S
+        for s in range(S):
+            cfg.Hs[s], cfg.Ws[s] = disps[s].shape[2], disps[s].shape[3]
+        cfg.beam_mask = sum(1 << s for s in beam_scales if s < S) if beam is not None else 0
+        cfg.rows_per_strip = int(rows)
+        need_grad = any(ctx.needs_input_grad[i] for i in (0, 1)) or any(ctx.needs_input_grad[14:])
+        sel = _empty((S, B, H, W), target, torch.uint8)
+        d1 = _empty((S, B, H, W), target) if need_grad else None
+        ws = _empty((query("fd_photo_ms_ws_floats", ctypes.addressof(cfg)),), target)
+        out = _empty((S * _lib.PHOTO_OUT_FLOATS,), target)
+        PP = ctypes.c_void_p * 4
+        disp_arr = PP(*[ptr(d) for d in disps])
+        noise_arr = PP(*[ptr(n) for n in noise]) if noise is not None else None
+        src_arr = (ctypes.c_void_p * 2)(ptr(src0), ptr(src1))
+        call("fd_photo_ms_fwd", ctypes.addressof(cfg), ctypes.addressof(disp_arr), ptr(inv_K), ptr(P), ctypes.addressof(src_arr),
+             ptr(target), ptr(ident), ctypes.addressof(noise_arr) if noise_arr is not None else None, ptr(beam), ptr(sel),
+             ptr(d1), ptr(ws), ptr(out), stream())
+        ctx.save_for_backward(K, out, ws, beam, *disps)
+        ctx.d1, ctx.cfg, ctx.S = d1, cfg, S
+        ctx.mark_non_differentiable(sel)
+        photo = tuple(out[s * _lib.PHOTO_OUT_FLOATS] for s in range(S))
+        si = tuple(out[s * _lib.PHOTO_OUT_FLOATS + 4] for s in range(S))
+        return photo + si + (sel,)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        K, stats, ws, beam = ctx.saved_tensors[:4]
+        disps = ctx.saved_tensors[4:]
+        S, cfg, d1 = ctx.S, ctx.cfg, ctx.d1
+        if d1 is None:
+            raise RuntimeError("photo_loss_ms: backward called although no input required a gradient in forward")
+        B, H, W = cfg.base.B, cfg.base.H, cfg.base.W
+        PP = ctypes.c_void_p * 4
+
+        keep = [f32(g).reshape(1) if g is not None else None for g in grads[:2 * S]]
+        gp_arr = PP(*[ptr(g) for g in keep[:S]])
+        gs_arr = PP(*[ptr(g) for g in keep[S:2 * S]])
+        d_disps = [torch.empty_like(d) for d in disps]
+        dd_arr = PP(*[ptr(d) for d in d_disps])
+        disp_arr = PP(*[ptr(d) for d in disps])
+        gP = _empty((B, 2, 3, 4), stats)
+        call("fd_photo_ms_bwd", ctypes.addressof(cfg), ctypes.addressof(disp_arr), ptr(beam), ptr(stats), ctypes.addressof(gp_arr),
+             ctypes.addressof(gs_arr), ptr(d1), ptr(ws), ctypes.addressof(dd_arr), ptr(gP), stream())
+        gTs = []
+        for f in range(2):
+            if ctx.needs_input_grad[f]:
+                gT = _empty((B, 4, 4), stats)
+                call("fd_proj_matrix_bwd", ptr(K), gP.data_ptr() + f * 48, 24, ptr(gT), B, stream())
+                gTs.append(gT)
+            else:
+                gTs.append(None)
+        return (gTs[0], gTs[1]) + (None,) * 12 + tuple(d_disps)
+
+
+def photo_loss_ms(disps, T_list, K, inv_K, src_list, target, ident=None, noise=None, beam=None, beam_scales=(), po=None,
+                  groups=1, rows_per_strip=0):
+    """Fused loss of ALL scales (two source frames).  ``noise``: S tensors [B,2,H,W] (or one [S,B,2,H,W] tensor) or None;
+    ``beam_scales``: the scales that carry the LiDAR term.  Returns ([photo_s], [si_s or None], sel[S,B,H,W])."""
+    po = po or PhotoOptions()
+    S = len(disps)
+    if not photo_ms_supported(po, len(src_list)):
+        raise RuntimeError("photo_loss_ms: unsupported configuration (use photo_loss per scale)")
+    res = _PhotoLossMS.apply(T_list[0], T_list[1], K, inv_K, src_list[0], src_list[1], target, ident, noise, beam, po,
+                             int(groups), tuple(beam_scales), int(rows_per_strip), *disps)
+    photo, si, sel = list(res[:S]), list(res[S:2 * S]), res[2 * S]
+    if beam is None:
+        si = [None] * S
+    else:
+        si = [si[s] if s in beam_scales else None for s in range(S)]
+    return photo, si, sel
+
+
 # ------------------------------------------------------------------------------------ conv stack --
 ACT = {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3, "tanh": 4}
 PAD_MODE = {"zero": 0, "reflect": 1}

@@ -138,6 +138,35 @@ int fd_photo_bwd(const fd_photo_cfg* cfg, const float* disp, const float* inv_K,
                  const float* const* src, const float* target, const float* beam, const uint8_t* sel, int has_ident,
                  const float* stats, const float* g, float* d_disp, float* gP, float* ws, void* stream);
 
+/* ---- all pyramid scales in one launch, value + unit-cotangent gradient in the same pass ------------------------------
+ * Replaces the per-scale loop of trainer.py:425-474 (generate_images_pred) + trainer.py:509-567, 577-589 (compute_losses)
+ * for the default configuration: two source frames, SSIM + L1, per-frame minimum (automasking on or off), SI-log or masked
+ * L1 LiDAR term on any subset of the scales.  The flag variants (--no_ssim, --avg_reprojection, one source frame, the
+ * materialised ("depth"|"sample"|"color", f, s) outputs) stay on fd_photo_fwd / fd_photo_bwd.
+ *   cfg.base      as for fd_photo_fwd (Hs / Ws ignored: per-scale sizes are cfg.Hs[] / cfg.Ws[]); NF must be 2
+ *   disp[s]       [B,1,Hs[s],Ws[s]]      noise[s]  [B,2,H,W] or NULL (the array itself may be NULL)
+ *   ident         [B,2,H,W] or NULL      beam      [B,1,H,W] or NULL; cfg.beam_mask bit s = scale s carries the LiDAR term
+ *   sel           [S,B,H,W] u8 out       d1        [S,B,H,W] out: d out[s][0] / d disp_up, or NULL to skip every gradient
+ *   ws            fd_photo_ms_ws_floats(cfg) floats; must stay untouched until fd_photo_ms_bwd has run
+ *   out           [S][FD_PHOTO_OUT_FLOATS], each laid out like fd_photo_fwd's `out`
+ * fd_photo_ms_bwd: g_photo[s] / g_si[s] = device pointers to dL/d out[s][0] / dL/d out[s][4] (NULL = 0); d1 is read only;
+ * d_disp[s] [B,1,Hs[s],Ws[s]] out (H / Hs[s] == W / Ws[s] must be an integer <= 16);
+ * gP [B,2,3,4] out = sum over scales of g_photo[s] * d out[s][0] / d P. */
+typedef struct {
+    fd_photo_cfg base;
+    int n_scales;            /* 1..4 */
+    int Hs[4], Ws[4];
+    unsigned beam_mask;
+    int rows_per_strip;      /* image rows a wave streams through; 0 = default */
+} fd_photo_ms_cfg;
+long fd_photo_ms_ws_floats(const fd_photo_ms_cfg* cfg);
+int fd_photo_ms_fwd(const fd_photo_ms_cfg* cfg, const float* const* disp, const float* inv_K, const float* P,
+                    const float* const* src, const float* target, const float* ident, const float* const* noise,
+                    const float* beam, uint8_t* sel, float* d1, float* ws, float* out, void* stream);
+int fd_photo_ms_bwd(const fd_photo_ms_cfg* cfg, const float* const* disp, const float* beam, const float* stats,
+                    const float* const* g_photo, const float* const* g_si, float* d1, const float* ws,
+                    float* const* d_disp, float* gP, void* stream);
+
 /* layers.py:235-248 get_smooth_loss on the mean-normalised disparity (trainer.py:569-571):
  * out[0] = get_smooth_loss(disp/(mean_hw(disp)+1e-7), img).  ws: fd_smooth_ws_floats(B,H,W). */
 long fd_smooth_ws_floats(int B, int H, int W);

@@ -309,6 +309,94 @@ def test_fused_photo_loss_vs_reference_golden(FD, golden):
     assert_close(got[5], g["g_T1"], rtol=1e-3, atol=5e-4 * np.abs(g["g_T1"]).max(), what="g T+1 vs reference")
 
 
+def _hip_photo_terms_ms(FD, opt, inp, disp, Ts, noise, rows=0, beam_scales=(0, 1, 2, 3)):
+    po = FD.PhotoOptions(opt.min_depth, opt.max_depth, opt.no_ssim, opt.avg_reprojection, opt.gdc_loss_threshold, opt.si_var)
+    fids = opt.frame_ids[1:]
+    target = dev(inp[("color", 0, 0)])
+    srcs = [dev(inp[("color", f, 0)]) for f in fids]
+    ident = None
+    if not opt.disable_automasking:
+        ident = torch.cat([FD.reprojection_loss_map(s, target, not opt.no_ssim) for s in srcs], 1)
+    K, inv_K, beam = dev(inp[("K", 0)]), dev(inp[("inv_K", 0)]), dev(inp["4beam"])
+    nz = [dev(noise[s]) for s in opt.scales] if ident is not None else None
+    return FD.photo_loss_ms([disp[s] for s in opt.scales], [Ts[f] for f in fids], K, inv_K, srcs, target, ident, nz, beam,
+                            beam_scales, po, 1, rows)
+
+
+@pytest.mark.parametrize("seed,B,H,W,rows,over", [
+    (404, 2, 64, 96, 0, {}),
+    (404, 2, 64, 96, 7, {}),                      # ragged strips: 64 = 9 x 7 + 1
+    (31, 2, 48, 200, 16, {}),                     # several strips in x (200 = 3 x 60 + 20) and y
+    (505, 1, 192, 640, 0, {}),                    # full size
+    (909, 2, 32, 184, 0, {}),                     # four owned columns in the last strip
+    (606, 2, 64, 96, 0, dict(disable_automasking=True)),
+])
+def test_multiscale_photo_loss_vs_oracle(FD, seed, B, H, W, rows, over):
+    """fd_photo_ms_fwd / fd_photo_ms_bwd (all scales in one launch, gradient produced in the forward pass) against the
+    oracle's generate_images_pred + compute_losses (trainer.py:425-589) on the same seeded inputs."""
+    opt = OT.default_opt(height=H, width=W, **over)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp0 = gin.disp_pyramid(rng, B, H, W)
+    poses = {f: gin.small_poses(rng, B) for f in (-1, 1)}
+    T0 = {f: OL.transformation_from_parameters(*poses[f], invert=(f < 0)) for f in (-1, 1)}
+    noise = [torch.from_numpy(np.random.RandomState(1000 + seed + s).randn(B, 2, H, W).astype(np.float32)) for s in range(4)]
+    d_o = {s: disp0[("disp", s)].clone().requires_grad_(True) for s in range(4)}
+    T_o = {f: T0[f].clone().requires_grad_(True) for f in T0}
+    terms, outs = _oracle_photo_terms(opt, inp, d_o, T_o, noise)
+    d_g = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
+    T_g = {f: dev(T0[f]).requires_grad_(True) for f in T0}
+    photo, si, sel = _hip_photo_terms_ms(FD, opt, inp, d_g, T_g, noise, rows)
+    fids = opt.frame_ids[1:]
+    tot_o, tot_g, flips = 0, 0, 0
+    for s in range(4):
+        diff = cpu(sel[s]).astype(np.int64) != cpu(terms[s][2])
+        flips += int(diff.sum())
+        assert diff.mean() <= 3e-4, "argmin differs on %.4f%% of pixels at scale %d" % (100 * diff.mean(), s)
+        assert_close(cpu(photo[s]), cpu(terms[s][0]), rtol=1e-4, atol=1e-7, what="to_optimise.mean() s%d" % s)
+        assert_close(cpu(si[s]), cpu(terms[s][1]), rtol=1e-4, atol=1e-7, what="si_loss s%d" % s)
+        w = 1.0 + 0.25 * s
+        tot_o = tot_o + w * terms[s][0] + (2.0 - 0.3 * s) * terms[s][1]
+        tot_g = tot_g + w * photo[s] + (2.0 - 0.3 * s) * si[s]
+    want = grads(tot_o, [d_o[s] for s in range(4)] + [T_o[f] for f in fids])
+    got = grads(tot_g, [d_g[s] for s in range(4)] + [T_g[f] for f in fids])
+    for s in range(4):
+        sc = np.abs(want[s]).max()
+        assert_mostly_close(got[s], want[s], rtol=2e-3, atol=2e-4 * sc, what="d loss / d disp s%d" % s)
+    for i, f in enumerate(fids):
+        sc = np.abs(want[4 + i]).max()
+        assert_close(got[4 + i], want[4 + i], rtol=1e-3, atol=(3e-2 if flips else 1e-4) * sc, what="d loss / d T f%d" % f)
+
+
+def test_multiscale_photo_loss_matches_per_scale_kernels(FD):
+    """The two HIP implementations agree with each other (value, selection, gradients) incl. a LiDAR term on scale 0 only."""
+    B, H, W, seed = 2, 64, 96, 404
+    opt = OT.default_opt(height=H, width=W)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp0 = gin.disp_pyramid(rng, B, H, W)
+    poses = {f: gin.small_poses(rng, B) for f in (-1, 1)}
+    T0 = {f: OL.transformation_from_parameters(*poses[f], invert=(f < 0)) for f in (-1, 1)}
+    noise = [torch.from_numpy(np.random.RandomState(1000 + seed + s).randn(B, 2, H, W).astype(np.float32)) for s in range(4)]
+    da = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
+    db = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
+    Ta = {f: dev(T0[f]).requires_grad_(True) for f in T0}
+    Tb = {f: dev(T0[f]).requires_grad_(True) for f in T0}
+    res = _hip_photo_terms(FD, opt, inp, da, Ta, noise, materialize=False)
+    photo, si, sel = _hip_photo_terms_ms(FD, opt, inp, db, Tb, noise, beam_scales=(0,))
+    assert si[1] is None and si[2] is None and si[3] is None
+    tot_a = sum((1 + s) * res[s][0] for s in range(4)) + 0.7 * res[0][1]
+    tot_b = sum((1 + s) * photo[s] for s in range(4)) + 0.7 * si[0]
+    for s in range(4):
+        assert (cpu(res[s][2]) != cpu(sel[s])).mean() <= 3e-4
+        assert_close(cpu(photo[s]), cpu(res[s][0]), rtol=2e-5, atol=1e-7, what="photo s%d" % s)
+    assert_close(cpu(si[0]), cpu(res[0][1]), rtol=2e-5, atol=1e-7, what="si s0")
+    ga = grads(tot_a, [da[s] for s in range(4)] + [Ta[-1], Ta[1]])
+    gb = grads(tot_b, [db[s] for s in range(4)] + [Tb[-1], Tb[1]])
+    for s in range(4):
+        assert_mostly_close(gb[s], ga[s], rtol=2e-3, atol=2e-4 * np.abs(ga[s]).max(), what="d disp s%d" % s)
+    for i in (4, 5):
+        assert_close(gb[i], ga[i], rtol=1e-3, atol=3e-2 * np.abs(ga[i]).max(), what="d T")
+
+
 def test_photo_loss_identity_pose_property(FD):
     """Size-independent property at full size: with T = I the sampling grid is the pixel grid normalised
     by (W-1,H-1) (layers.py:224-226) and the depth cancels out of the projection; because grid_sample
