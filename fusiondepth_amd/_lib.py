@@ -10,7 +10,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdhip.so")
+LIB_PATH = os.environ.get("FD_LIBFDHIP") or os.path.join(_HERE, "libfdhip.so")   # FD_LIBFDHIP: ablation builds (scripts/)
 ABI_VERSION = 1
 PHOTO_OUT_FLOATS = 96        # FD_PHOTO_OUT_FLOATS
 

@@ -31,7 +31,7 @@
 namespace {
 
 #ifndef FD_MS_WAVES
-#define FD_MS_WAVES 3     // waves per SIMD the register allocation is held to
+#define FD_MS_WAVES 2     // waves per SIMD the register allocation is held to
 #endif
 constexpr int OW = 60;             // output columns per strip (lanes 2..61)
 constexpr float K1S = 81.0f * (float)(0.01 * 0.01), K2S = 81.0f * (float)(0.03 * 0.03);
@@ -42,12 +42,37 @@ __device__ __forceinline__ float shr1(float v) {   // lane l <- lane l-1 (0 at t
 __device__ __forceinline__ float shl1(float v) {   // lane l <- lane l+1
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float hsum3(float v) { return (v + shr1(v)) + shl1(v); }
+#ifndef FD_MS_ABLATE
+#define FD_MS_ABLATE 0    // timing experiments only (wrong results): 1 no barrier, 4 no DPP, 8 no LDS lag ring, 16 no LDS exchange
+#endif
+__device__ __forceinline__ float hsum3(float v) {
+    if (FD_MS_ABLATE & 4) return (v + v * 0.99f) + v * 1.01f;
+    return (v + shr1(v)) + shl1(v);
+}
 
 __device__ __forceinline__ int refl_clamp(int i, int n) {
     i = i < 0 ? -i : i;
     i = i >= n ? 2 * n - 2 - i : i;
     return fd_clampi(i, 0, n - 1);
+}
+// gfx950 issues fp32 add / mul / fma / mov on VGPR, inline-constant or literal operands at twice the rate of everything else
+// (scripts/ubench/valu_rate2.hip: 2.6-2.9 vs 4.3-5.0 cycles per wave-instruction); ANY SGPR operand, and min / max / med3 /
+// cmp / floor / cvt / shifts, are on the slow side.  Wave-uniform constants of the hot loop are therefore kept in VGPRs.
+#ifndef FD_MS_VCONST
+#define FD_MS_VCONST 1
+#endif
+#ifndef FD_MS_PREFETCH
+#define FD_MS_PREFETCH 1
+#endif
+__device__ __forceinline__ float vreg(float s) {
+    float v = s;
+    if (FD_MS_VCONST) asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ int vreg(int s) {
+    int v = s;
+    if (FD_MS_VCONST) asm volatile("" : "+v"(v));
+    return v;
 }
 __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -68,12 +93,18 @@ struct MsArgs {
     float* gpart;            // [nblk][2][12]
 };
 
-template <int K>
-struct Slots { static constexpr int cur = K, m1 = (K + 2) % 3, m2 = (K + 1) % 3; };   // rows i, i-1, i-2
-
 // Lagged row data (written when a row is warped, read two rows later by the gradient stage) lives in LDS, 16 floats per
 // lane and row: dX[3], dY[3], KX, KY, u, v, E0, E1, depth, x[3].  float4 groups, lane-contiguous (conflict-free b128 accesses).
 struct Lag { float4 q[4]; };
+
+// Everything of one image row that comes out of memory: issued one row ahead of its use (software prefetch; the gathers of row
+// i+1 are in flight while the ~450 VALU instructions of row i run - a wave has no other independent work, and the register
+// state allows only 2-3 waves per SIMD).
+struct Pre {
+    float nw[3], ne[3], sw[3], se[3], tg[3];
+    float fx, fy, KX, KY, u, v, E0, E1, depth;
+    float idv, nzv, bdv;        // identity candidate / noise / LiDAR value of the row ABOVE (consumed in the same step)
+};
 
 template <bool IDENT, bool GRAD>
 __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
@@ -102,17 +133,25 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
     const unsigned cxc = (unsigned)fd_clampi(cx, 0, W - 1);
     const float* iK = a.inv_K + b * 16;
     const float rayx0 = iK[0] * (float)gx + iK[2], rayx1 = iK[4] * (float)gx + iK[6], rayx2 = iK[8] * (float)gx + iK[10];
-    const float iky0 = iK[1], iky1 = iK[5], iky2 = iK[9];
+    const float iky0 = vreg(iK[1]), iky1 = vreg(iK[5]), iky2 = vreg(iK[9]);
     const float* Pf = a.P + ((long)b * 2 + f) * 12;
     float Pm[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) Pm[k] = Pf[k];
-    const float lo = (float)(1.0 / cfg.max_depth), span = (float)(1.0 / cfg.min_depth - 1.0 / cfg.max_depth);
-    const float sWx = (float)((double)W / (double)(W - 1)), sHy = (float)((double)H / (double)(H - 1));
-    const float xm = (float)(W - 1), ym = (float)(H - 1);
+    for (int k = 0; k < 12; ++k) Pm[k] = vreg(Pf[k]);
+    const float span_s = (float)(1.0 / cfg.min_depth - 1.0 / cfg.max_depth);
+    const float lo = vreg((float)(1.0 / cfg.max_depth)), span = vreg(span_s);
+    const float sWx = vreg((float)((double)W / (double)(W - 1))), sHy = vreg((float)((double)H / (double)(H - 1)));
+    // clamp range of the sampling position: [1e-30, just below W-1].  A position that equals its clamped value is strictly inside
+    // (aten clip_coordinates_set_grad treats the borders as outside); below W-1 the +1 taps always exist, and the sample differs
+    // from the border pixel by < 1e-7 of the local contrast.
+    const float xmm = vreg(__builtin_bit_cast(float, __builtin_bit_cast(int, (float)(W - 1)) - 1));
+    const float ymm = vreg(__builtin_bit_cast(float, __builtin_bit_cast(int, (float)(H - 1)) - 1));
+    const float epsv = vreg(cfg.eps);
+    const float Wf = vreg((float)W);
+    const int W4 = vreg(W * 4);
     const float inv_count = 1.0f / ((float)B * (float)H * (float)W);
     const float wS = (0.85f / 3.0f), wL = (0.15f / 3.0f);
-    const float wSc = wS * inv_count, wLc = wL * inv_count;
+    const float wSc = vreg(wS * inv_count), wLc = vreg(wL * inv_count);
     int x0d, x1d;
     float lxd;
     fd_bilinear_src(gx, (float)Ws / (float)W, Ws, x0d, x1d, lxd);
@@ -127,22 +166,22 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
     const __amdgpu_buffer_rsrc_t r_src = fd_make_rsrc(a.src[f] + (long)b * 3 * P);
     const __amdgpu_buffer_rsrc_t r_tgt = fd_make_rsrc(a.target + (long)b * 3 * P);
     const __amdgpu_buffer_rsrc_t r_disp = fd_make_rsrc(a.disp[s] + (long)b * Hs * Ws);
-    const float* id_b = IDENT ? a.ident + ((long)b * 2 + f) * P : nullptr;
-    const float* nz_b = (IDENT && a.noise[s]) ? a.noise[s] + ((long)b * 2 + f) * P : nullptr;
-    const float* beam_b = has_beam ? a.beam + (long)b * P : nullptr;
-    uint8_t* sel_b = a.sel + ((long)s * B + b) * P;
-    float* d1_b = GRAD ? a.d1 + ((long)s * B + b) * P : nullptr;
+    const bool has_noise = IDENT && a.noise[s];
+    const __amdgpu_buffer_rsrc_t r_id = fd_make_rsrc(IDENT ? a.ident + ((long)b * 2 + f) * P : a.target);
+    const __amdgpu_buffer_rsrc_t r_nz = fd_make_rsrc(has_noise ? a.noise[s] + ((long)b * 2 + f) * P : a.target);
+    const __amdgpu_buffer_rsrc_t r_beam = fd_make_rsrc(has_beam ? a.beam + (long)b * P : a.target);
+    const __amdgpu_buffer_rsrc_t r_sel = fd_make_rsrc(a.sel + ((long)s * B + b) * P);
+    const __amdgpu_buffer_rsrc_t r_d1 = fd_make_rsrc(GRAD ? a.d1 + ((long)s * B + b) * P : a.part);
+    const int cxc4 = (int)cxc * 4;
 
     // ---- streaming state (registers) ----------------------------------------------------------------------------------
-    float yr[3][3];                           // centred target of rows i, i-1, i-2 (slot = row % 3)
+    float y1r[3], y2r[3];                     // centred target of rows i-1, i-2
     float hp[15], hq[15];                     // horizontal 3-sums: previous row, (row before previous + previous row)
     float cp[9], cq[9];                       // same for the masked SSIM derivative coefficients (cq carries the y-fold weight)
     float l1_prev = 0.f, l1_cur = 0.f;        // L1 gradient weight of rows i-2 / i-1
     float lsum_prev = 0.f;                    // sum_c |y - x| of row i-1
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) yr[k][c] = 0.f;
+    for (int c = 0; c < 3; ++c) y1r[c] = y2r[c] = 0.f;
 #pragma unroll
     for (int k = 0; k < 15; ++k) hp[k] = hq[k] = 0.f;
 #pragma unroll
@@ -152,26 +191,58 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
     for (int k = 0; k < 12; ++k) gP[k] = 0.f;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;   // wave 0: sum(min); wave 1: n_valid, sum(d), sum(d^2)
     float pend = 0.f, pend_k = 0.f;                           // wave 0: its own depth gradient of the row in flight
+    Pre pre[2];
+    float dtap[2][5];                                         // disparity taps + row weight, issued two rows ahead
 
-    auto step = [&](auto slots, const int i) __attribute__((always_inline)) {
-        constexpr int KC = decltype(slots)::cur, K1 = decltype(slots)::m1, K2 = decltype(slots)::m2;
-        const int ry = y0s - 2 + i;
-        const int gy = refl_clamp(ry, H);
-        // ---- A: warp row i ---------------------------------------------------------------------------------------------
-        float dup;
+    // Source rows / weight of the bilinear upsampling (aten area_pixel_compute_source_index, align_corners=False).  For the
+    // power-of-two pyramid ratios src = (2 dst + 1 - r) / 2r is exact in fp32, so the integer form on the scalar unit is bit-identical
+    // to the float form (which costs ~12 half-rate VALU instructions per row for one wave-uniform value).
+    const int rup = H / Hs;
+    const bool pow2 = Hs * rup == H && (rup & (rup - 1)) == 0;
+    const int sh2r = 31 - __builtin_clz(2 * rup);
+    const float inv2r = 1.0f / (float)(2 * rup);
+    auto src_rows = [&](const int gy, int& yy0, int& yy1, float& lyd) __attribute__((always_inline)) {
+        if (pow2) {
+            const int tnum = max(2 * gy + 1 - rup, 0);
+            yy0 = min(tnum >> sh2r, Hs - 1);
+            yy1 = yy0 + (yy0 < Hs - 1 ? 1 : 0);
+            lyd = (float)(tnum & (2 * rup - 1)) * inv2r;
+        } else {
+            fd_bilinear_src(gy, shd, Hs, yy0, yy1, lyd);
+            // wave-uniform, but computed with float VALU ops: without the readfirstlane hipcc wraps every load in a waterfall loop
+            yy0 = __builtin_amdgcn_readfirstlane(yy0); yy1 = __builtin_amdgcn_readfirstlane(yy1);
+        }
+    };
+    auto load_disp = [&](float (&da)[5], const int r) __attribute__((always_inline)) {
+        const int gy = refl_clamp(y0s - 2 + r, H);
         if (same) {
-            dup = ld(r_disp, gx * 4, gy * Ws * 4);
+            da[0] = ld(r_disp, gx * 4, gy * Ws * 4);
         } else {
             int yy0, yy1;
-            float lyd;
-            fd_bilinear_src(gy, shd, Hs, yy0, yy1, lyd);
-            const float a00 = ld(r_disp, x0d * 4, yy0 * Ws * 4), a01 = ld(r_disp, x1d * 4, yy0 * Ws * 4);
-            const float a10 = ld(r_disp, x0d * 4, yy1 * Ws * 4), a11 = ld(r_disp, x1d * 4, yy1 * Ws * 4);
-            dup = (1.f - lyd) * (hxd * a00 + lxd * a01) + lyd * (hxd * a10 + lxd * a11);       // trainer.py:434-435
+            src_rows(gy, yy0, yy1, da[4]);
+            da[0] = ld(r_disp, x0d * 4, yy0 * Ws * 4); da[1] = ld(r_disp, x1d * 4, yy0 * Ws * 4);
+            da[2] = ld(r_disp, x0d * 4, yy1 * Ws * 4); da[3] = ld(r_disp, x1d * 4, yy1 * Ws * 4);
         }
-        float tg[3];
+    };
+
+    // ---- A: project row r, issue its gathers -------------------------------------------------------------------------------
+    auto issue = [&](Pre& p, const float (&da)[5], const int r) __attribute__((always_inline)) {
+        const int ry = y0s - 2 + r;
+        const int gy = refl_clamp(ry, H);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tg[c] = ld(r_tgt, gx * 4, (c * P + gy * W) * 4);
+        for (int c = 0; c < 3; ++c) p.tg[c] = ld(r_tgt, gx * 4, (c * P + gy * W) * 4);
+        const int o1 = fd_clampi(ry - 1, 0, H - 1) * W * 4;
+        p.idv = 0.f; p.nzv = 0.f; p.bdv = 0.f;
+        if (IDENT) p.idv = ld(r_id, cxc4, o1);
+        if (has_noise) p.nzv = ld(r_nz, cxc4, o1);
+        if (has_beam && f == 1) p.bdv = ld(r_beam, cxc4, o1);
+        float dup;
+        if (same) {
+            dup = da[0];
+        } else {
+            const float lyd = da[4];
+            dup = (1.f - lyd) * (hxd * da[0] + lxd * da[1]) + lyd * (hxd * da[2] + lxd * da[3]);     // trainer.py:434-435
+        }
         const float sdisp = fmaf(span, dup, lo);                                                  // layers.py:18-19
         const float rc0 = __builtin_amdgcn_rcpf(sdisp);
         const float depth = fmaf(fmaf(-rc0, sdisp, 1.0f), rc0, rc0);
@@ -181,71 +252,69 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
         const float c0 = fmaf(Pm[0], X0, fmaf(Pm[1], X1, fmaf(Pm[2], X2, Pm[3])));               // layers.py:219
         const float c1 = fmaf(Pm[4], X0, fmaf(Pm[5], X1, fmaf(Pm[6], X2, Pm[7])));
         const float c2 = fmaf(Pm[8], X0, fmaf(Pm[9], X1, fmaf(Pm[10], X2, Pm[11])));
-        const float den = c2 + cfg.eps;
+        const float den = c2 + epsv;
         const float rc = __builtin_amdgcn_rcpf(den);
         float u = c0 * rc, v = c1 * rc;                                                           // layers.py:221
         u = fmaf(fmaf(-u, den, c0), rc, u);
         v = fmaf(fmaf(-v, den, c1), rc, v);
         // layers.py:224-226 + aten grid_sampler unnormalize (align_corners=False): ((2(u/(W-1) - .5) + 1) W - 1) / 2
         const float ix = fmaf(u, sWx, -0.5f), iy = fmaf(v, sHy, -0.5f);
-        const float kx = (ix > 0.f && ix < xm) ? sWx : 0.f;      // clip_coordinates_set_grad: borders count as outside
-        const float ky = (iy > 0.f && iy < ym) ? sHy : 0.f;
-        const float ixc = fminf(xm, fmaxf(ix, 0.f)), iyc = fminf(ym, fmaxf(iy, 0.f));
-        const float flx = floorf(ixc), fly = floorf(iyc);
-        const float fx = ixc - flx, fy = iyc - fly;
-        const int x0 = (int)flx, y0 = (int)fly;
-        const int b00 = (y0 * W + x0) * 4;
-        const int dx1 = x0 < W - 1 ? 4 : 0, dy1 = y0 < H - 1 ? W * 4 : 0;
-        const int b01 = b00 + dx1, b10 = b00 + dy1, b11 = b10 + dx1;
-        float nw[3], ne[3], sw[3], se[3];
+        const float ixc = __builtin_amdgcn_fmed3f(ix, 1e-30f, xmm), iyc = __builtin_amdgcn_fmed3f(iy, 1e-30f, ymm);
+        const float kx = ixc == ix ? sWx : 0.f;                  // clip_coordinates_set_grad: borders count as outside
+        const float ky = iyc == iy ? sHy : 0.f;
+        p.fx = __builtin_amdgcn_fractf(ixc); p.fy = __builtin_amdgcn_fractf(iyc);
+        const float flx = ixc - p.fx, fly = iyc - p.fy;
+        const int b00 = (int)(4.0f * fmaf(fly, Wf, flx));        // exact: integers below 2^24
+        const int b01 = b00 + 4, b10 = b00 + W4, b11 = b10 + 4;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            nw[c] = ld(r_src, b00, c * P * 4); ne[c] = ld(r_src, b01, c * P * 4);
-            sw[c] = ld(r_src, b10, c * P * 4); se[c] = ld(r_src, b11, c * P * 4);
+            p.nw[c] = ld(r_src, b00, c * P * 4); p.ne[c] = ld(r_src, b01, c * P * 4);
+            p.sw[c] = ld(r_src, b10, c * P * 4); p.se[c] = ld(r_src, b11, c * P * 4);
         }
-        // identity candidate / LiDAR value of row i-1 (consumed after the SSIM below)
-        const int ry1 = ry - 1;
-        const unsigned o1 = (unsigned)(fd_clampi(ry1, 0, H - 1) * W);
-        float idv = 0.f, nzv = 0.f, bdv = 0.f;
-        if (i >= 2) {
-            if (IDENT) idv = (id_b + o1)[cxc];
-            if (IDENT && nz_b) nzv = (nz_b + o1)[cxc];
-            if (has_beam && f == 1) bdv = (beam_b + o1)[cxc];
+        const float Am0 = (c0 - Pm[3]) * sdisp, Am1 = (c1 - Pm[7]) * sdisp, Am2 = (c2 - Pm[11]) * sdisp;   // P[k,:3] . ray
+        p.KX = kx * rc; p.KY = ky * rc; p.u = u; p.v = v;
+        p.E0 = p.KX * fmaf(-u, Am2, Am0);
+        p.E1 = p.KY * fmaf(-v, Am2, Am1);
+        p.depth = depth;
+    };
+
+    // ---- B..G: everything that consumes row i -----------------------------------------------------------------------------------
+    auto process = [&](const Pre& p, const int i) __attribute__((always_inline)) {
+        const int ry = y0s - 2 + i, ry1 = ry - 1, ry2 = ry - 2;
+        const int KC = i % 3, K1 = (i + 2) % 3, K2 = (i + 1) % 3;          // LDS slots of rows i, i-1, i-2
+        Lag l2;                                                            // row i-2, consumed by the gradient stage at the end
+        if (GRAD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) l2.q[k] = (FD_MS_ABLATE & 8) ? make_float4(p.fx, p.fy, p.u, p.v) : lagr[f][K2][k][lane];
         }
         Lag lg;
-        {
-            const float Am0 = (c0 - Pm[3]) * sdisp, Am1 = (c1 - Pm[7]) * sdisp, Am2 = (c2 - Pm[11]) * sdisp;   // P[k,:3] . ray
-            const float KXv = kx * rc, KYv = ky * rc;
-            lg.q[1].z = KXv; lg.q[1].w = KYv; lg.q[2].x = u; lg.q[2].y = v;
-            lg.q[2].z = KXv * fmaf(-u, Am2, Am0);
-            lg.q[2].w = KYv * fmaf(-v, Am2, Am1);
-            lg.q[3].x = depth;
-        }
-        float hn[15];
+        lg.q[1].z = p.KX; lg.q[1].w = p.KY; lg.q[2].x = p.u; lg.q[2].y = p.v; lg.q[2].z = p.E0; lg.q[2].w = p.E1; lg.q[3].x = p.depth;
+        float hn[15], ycur[3];
         float lsum = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float dt = ne[c] - nw[c], db = se[c] - sw[c];
-            const float top = fmaf(fx, dt, nw[c]), bot = fmaf(fx, db, sw[c]);
+            const float dt = p.ne[c] - p.nw[c], db = p.se[c] - p.sw[c];
+            const float top = fmaf(p.fx, dt, p.nw[c]), bot = fmaf(p.fx, db, p.sw[c]);
             const float dv = bot - top;
-            const float pred = fmaf(fy, dv, top);
-            const float dXv = fmaf(fy, db - dt, dt);
-            const float xc = pred - 0.5f, yc = tg[c] - 0.5f;
+            const float pred = fmaf(p.fy, dv, top);
+            const float dXv = fmaf(p.fy, db - dt, dt);
+            const float xc = pred - 0.5f, yc = p.tg[c] - 0.5f;
             if (c == 0) { lg.q[0].x = dXv; lg.q[0].w = dv; lg.q[3].y = xc; }
             if (c == 1) { lg.q[0].y = dXv; lg.q[1].x = dv; lg.q[3].z = xc; }
             if (c == 2) { lg.q[0].z = dXv; lg.q[1].y = dv; lg.q[3].w = xc; }
-            yr[KC][c] = yc;
+            ycur[c] = yc;
             lsum += fabsf(yc - xc);
-            // ---- B: horizontal window sums of row i ----------------------------------------------------------------
             hn[5 * c + 0] = hsum3(xc);
             hn[5 * c + 1] = hsum3(xc * xc);
             hn[5 * c + 2] = hsum3(xc * yc);
             hn[5 * c + 3] = hsum3(yc);
             hn[5 * c + 4] = hsum3(yc * yc);
         }
-        if (GRAD) {
+        if (GRAD && !(FD_MS_ABLATE & 8)) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) lagr[f][KC][k][lane] = lg.q[k];
+        } else if (GRAD) {
+            acc3 += lg.q[0].x + lg.q[0].y + lg.q[0].z + lg.q[0].w + lg.q[1].x + lg.q[1].y + lg.q[3].y + lg.q[3].z + lg.q[3].w;
         } else if (has_beam) {
             lagr[f][KC][3][lane] = lg.q[3];
         }
@@ -259,7 +328,11 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
         }
         const float lsum1 = lsum_prev;
         lsum_prev = lsum;
-        if (i < 2) return;
+        float yq3[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { yq3[c] = y2r[c]; y2r[c] = y1r[c]; y1r[c] = ycur[c]; }
+        // No early-outs for the first rows of a strip: every stage runs from row 0 on zero-initialised state (finite garbage that
+        // is overwritten before it can reach an owned pixel); only the stores and the accumulators are masked.
 
         // ---- C: SSIM + L1 of row i-1, unmasked derivative coefficients -----------------------------------------------------
         const bool rowvalid1 = ry1 >= 0 && ry1 < H;
@@ -276,28 +349,31 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
             const float rd = __builtin_amdgcn_rcpf(B1 * B2);
             const float q = (A1 * A2) * rd;
             const float val = fmaf(q, -0.5f, 0.5f);
-            ssum += fminf(fmaxf(val, 0.f), 1.f);
+            const float valc = __builtin_amdgcn_fmed3f(val, 0.f, 1.f);
+            ssum += valc;
             if (GRAD) {
-                wr[c] = (val >= 0.f && val <= 1.f) ? rd * wSc : 0.f;
+                wr[c] = valc == val ? rd * wSc : 0.f;             // the clamp passes the gradient on [0, 1] (borders included)
                 ta[c] = fmaf(q, fmaf(-Cx, B1, Sx4 * B2), fmaf(Cy, A1, -(Sy4 * A2)));   // d / d sum(x)           (x wr)
                 tb[c] = 9.0f * (q * B1);                                                 // 2 x d / d sum(x^2)    (x wr)
                 tc[c] = -9.0f * A1;                                                      // d / d sum(xy)         (x wr)
             }
         }
         const float Lown = fmaf(wS, ssum, wL * lsum1);           // trainer.py:476-488
-        const float vown = IDENT ? fmaf(nzv, 0.00001f, idv) : 0.f;   // trainer.py:551-552
+        const float vown = IDENT ? fmaf(p.nzv, 0.00001f, p.idv) : 0.f;   // trainer.py:551-552
         // ---- D: exchange with the other frame's wave, 4-way argmin (trainer.py:549-567) ------------------------------------
         const int par = i & 1;
-        xl[par][f][0][lane] = Lown;
-        if (IDENT) xl[par][f][1][lane] = vown;
-        __syncthreads();
-        const float Loth = xl[par][1 - f][0][lane];
+        if (!(FD_MS_ABLATE & 16)) {
+            xl[par][f][0][lane] = Lown;
+            if (IDENT) xl[par][f][1][lane] = vown;
+        }
+        if (!(FD_MS_ABLATE & 1)) __syncthreads();
+        const float Loth = (FD_MS_ABLATE & 16) ? Lown * 1.01f : xl[par][1 - f][0][lane];
         // order of cat(identity -1, identity +1, reprojection -1, reprojection +1); the first minimum wins
         bool selown = f == 0 ? !(Loth < Lown) : (Lown < Loth);
         float best = fminf(Lown, Loth);
         float vmin = 0.f, voth = 0.f;
         if (IDENT) {
-            voth = xl[par][1 - f][1][lane];
+            voth = (FD_MS_ABLATE & 16) ? vown * 0.99f : xl[par][1 - f][1][lane];
             vmin = fminf(vown, voth);
             selown = selown && (Lown < vmin);
             best = fminf(best, vmin);
@@ -310,16 +386,16 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
                 int bi;
                 if (IDENT) bi = (vmin <= best) ? (voth < vown ? 1 : 0) : (selown ? 2 : 3);
                 else bi = selown ? 0 : 1;
-                sel_b[(unsigned)(ry1 * W + cx)] = (uint8_t)bi;
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bi, r_sel, cx, ry1 * W, 0);
             }
             if (GRAD && i >= 5) {   // D1 of row i-3: this wave's part is in `pend`, frame 1's arrived through xd
                 const float other = xd[(i - 1) & 1][lane];
-                if (colown) d1_b[(unsigned)((ry - 3) * W + cx)] = (pend + other) * pend_k;
+                if (colown) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (pend + other) * pend_k), r_d1, cx * 4, (ry - 3) * W * 4, 0);
             }
         } else if (has_beam) {                                      // trainer.py:577-589 / completor.py:718-723
             const float dep1 = lagr[f][K1][3][lane].x;
             const float d26 = dep1 * cfg.si_depth_scale;
-            const float bd = bdv * cfg.si_beam_scale;
+            const float bd = p.bdv * cfg.si_beam_scale;
             bool m = own1 && bd > cfg.si_lo && d26 < 80.f && d26 > cfg.si_lo;
             if (cfg.si_mode == 0) m = m && fabsf(d26 - bd) < cfg.si_threshold;
             if (__any(m)) {
@@ -353,9 +429,8 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
         }
         // vertical 3-sums of the coefficient rows for image row i-2: c[i-3] + c[i-2] + c[i-1], row 0 counted twice for row 1
         // and row H-1 twice for row H-2 (adjoint of the reflection padding along y)
-        const int ry2 = ry - 2;
-        const float wbot = ry2 == H - 2 ? 2.f : 1.f;             // weight of row i-1 in the sum for row i-2
-        const float wtop = ry1 == 1 ? 2.f : 1.f;                 // weight of row i-2 (== image row 0) in the NEXT row's sum
+        const float wbot = vreg(ry2 == H - 2 ? 2.f : 1.f);       // weight of row i-1 in the sum for row i-2
+        const float wtop = vreg(ry1 == 1 ? 2.f : 1.f);           // weight of row i-2 (== image row 0) in the NEXT row's sum
         float V[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
@@ -363,25 +438,21 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
             cq[j] = fmaf(wtop, cp[j], cn[j]);
             cp[j] = cn[j];
         }
-        if (i < 4) return;
 
         // ---- F/G: gradient of row i-2 ---------------------------------------------------------------------------------
-        Lag l2;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) l2.q[k] = lagr[f][K2][k][lane];
         const float dXq[3] = {l2.q[0].x, l2.q[0].y, l2.q[0].z}, dYq[3] = {l2.q[0].w, l2.q[1].x, l2.q[1].y};
         const float xq3[3] = {l2.q[3].y, l2.q[3].z, l2.q[3].w};
         float gix = 0.f, giy = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float xq = xq3[c], yq = yr[K2][c];
+            const float xq = xq3[c], yq = yq3[c];
             const float dq = xq - yq;
-            const float sg = fminf(fmaxf(dq * 1e30f, -l1_prev), l1_prev);          // l1w * sign(x - y)
+            const float sg = __builtin_amdgcn_fmed3f(dq * 1e30f, -l1_prev, l1_prev);   // l1w * sign(x - y)
             const float g = sg + fmaf(yq, V[3 * c + 2], fmaf(xq, V[3 * c + 1], V[3 * c + 0]));
             gix = fmaf(g, dXq[c], gix);
             giy = fmaf(g, dYq[c], giy);
         }
-        if (!colown) { gix = 0.f; giy = 0.f; }                       // row index i-2 is in [2, rows+2) for every i here
+        if (!(colown && i >= 4 && i < n_iter)) { gix = 0.f; giy = 0.f; }   // row index i-2 must be in [2, rows+2)
         const float dd = fmaf(gix, l2.q[2].z, giy * l2.q[2].w);
         {
             const float ga = gix * l2.q[1].z, gb = giy * l2.q[1].w;
@@ -395,22 +466,50 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
         }
         if (f == 0) {
             pend = dd;
-            pend_k = -l2.q[3].x * l2.q[3].x * span;
+            pend_k = -l2.q[3].x * l2.q[3].x * span_s;
         } else {
             xd[par][lane] = dd;
         }
     };
 
-    for (int i = 0; i < n_iter; i += 3) {
-        step(Slots<0>(), i);
-        if (i + 1 < n_iter) step(Slots<1>(), i + 1);
-        if (i + 2 < n_iter) step(Slots<2>(), i + 2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lagr[f][k][j][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+#if FD_MS_PREFETCH
+    load_disp(dtap[0], 0);
+    load_disp(dtap[1], 1);
+    issue(pre[0], dtap[0], 0);
+#endif
+    // two rows per trip (the prefetch buffers alternate with compile-time indices); an odd row count runs one masked extra row.
+    // Rows past the strip are clamped by refl_clamp / fd_clampi: harmless loads, results unused.
+    const int n_run = (n_iter + 1) & ~1;
+#if FD_MS_PREFETCH
+    // sched_barrier: hipcc otherwise sinks the prefetch loads down to their first use
+    for (int i = 0; i < n_run; i += 2) {
+        load_disp(dtap[0], i + 2);
+        issue(pre[1], dtap[1], i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        process(pre[0], i);
+        __builtin_amdgcn_sched_barrier(0);
+        load_disp(dtap[1], i + 3);
+        issue(pre[0], dtap[0], i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        process(pre[1], i + 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (GRAD) {
+#else
+    for (int i = 0; i < n_run; ++i) {      // no software prefetch: fewer live registers, latency hidden by a third wave per SIMD
+        load_disp(dtap[0], i);
+        issue(pre[0], dtap[0], i);
+        process(pre[0], i);
+    }
+#endif
+    if (GRAD && n_run == n_iter) {
         __syncthreads();
         if (f == 0) {   // last owned row: index n_iter-3
             const float other = xd[(n_iter - 1) & 1][lane];
-            if (colown) d1_b[(unsigned)((y0s + rows - 1) * W + cx)] = (pend + other) * pend_k;
+            if (colown) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (pend + other) * pend_k), r_d1, cx * 4, (y0s + rows - 1) * W * 4, 0);
         }
     }
 
@@ -657,7 +756,7 @@ int check_ms(const fd_photo_ms_cfg* c, const char* who) {
 }
 
 inline int ms_rows(const fd_photo_ms_cfg* c) {
-    int R = c->rows_per_strip > 0 ? c->rows_per_strip : 48;
+    int R = c->rows_per_strip > 0 ? c->rows_per_strip : 32;     // measured at 192x640, batch 12: 24..64 within 2 %, 96 +25 %
     return R > c->base.H ? c->base.H : R;
 }
 inline long ms_blocks_per_image(const fd_photo_ms_cfg* c) {
