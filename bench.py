@@ -10,6 +10,7 @@ decoder, pose decoder, fused photometric/LiDAR loss at 4 scales, full backward, 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -93,23 +94,33 @@ def roofline_probes(args, tr, batch):
     with torch.no_grad():
         ms = graph_time_ms(lambda: FD.conv2d(x, w, None, 1, 1))
     flops = 2.0 * Bc * h8 * w8 * 64 * 64 * 9
-    traffic = None                    # HBM bytes per launch from the committed rocprofv3 --pmc passes of this exact kernel/shape
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_probe_wino.json")))
-        if (Bc, h8, w8) == (12, 48, 160):
-            traffic = pmc["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    # HBM bytes per launch: rocprofv3 --pmc passes cannot run inside this process, so the number comes from the committed passes of
+    # this exact kernel and shape (scripts/pmc_probe.sh) - and only while the kernel source is the one that was profiled.
+    traffic, traffic_src = None, None
+    for name in ("round2_pmc_probe_wino.json", "round1_pmc_probe_wino.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        src = os.path.join(ROOT, "fusiondepth_amd", "csrc", "conv_wino.hip")
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+        if (Bc, h8, w8) != (12, 48, 160):
+            break
+        if pmc.get("source_sha256") not in (None, sha):
+            print("[bench] profiles/%s was measured on a different conv_wino.hip (sha256 %s..., now %s...): roofline.traffic "
+                  "left null - re-run scripts/pmc_probe.sh" % (name, pmc["source_sha256"][:12], sha[:12]), file=sys.stderr, flush=True)
+            break
+        traffic, traffic_src = pmc["traffic_bytes_per_launch"], name
+        break
     out["roofline"] = {"bound": "mfma", "kernel": "k_conv_wino (ResNet layer1 conv 3x3 64->64 @%dx%d, batch %d = the "
                        "stacked micro-batches, alone on the GPU; Winograd F(2,3): algorithmic flops, 2/3 of them executed)" % (h8, w8, Bc),
                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                       "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/round1_pmc_probe_wino.md)",
+                       "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % traffic_src,
                        "us_per_launch": ms * 1e3, "flop_per_launch": flops, "mfma_flop_per_launch": flops * 2.0 / 3.0}
-    # fused loss path: forward + backward kernels of the four scales at the batch the step launches (stacked micro-batches,
-    # SI-log statistics per micro-batch).  Reported against the HBM roofline as the north star asks; the PMC passes in
-    # profiles/round1_pmc_loss.md show the fused kernels are bound by the vector ALU (1 000 / 2 400 lane-instructions per
-    # pixel against 42-44 compulsory bytes), not by HBM.
+    # fused loss path: the multi-scale kernel (forward + gradients of the four scales in one launch) at the batch the step
+    # launches (stacked micro-batches, SI-log statistics per micro-batch).  Reported against the HBM roofline as the north star
+    # asks; the kernel is bound by VALU issue (profiles/round2_pmc_loss.md), not by HBM.
     H, W = args.height, args.width
     po = FD.PhotoOptions()
     B, G = Bc, (tr.accumulate_step if tr.stack_microbatches else 1)
@@ -119,26 +130,27 @@ def roofline_probes(args, tr, batch):
     I = torch.eye(4, device="cuda").repeat(B, 1, 1)
     I[:, 0, 3] = 0.05
     disps = [torch.rand(B, 1, H >> s, W >> s, device="cuda").mul_(0.1).add_(0.02).requires_grad_(True) for s in range(4)]
-    noise = torch.randn(B, 2, H, W, device="cuda")
+    noise = list(torch.randn(4, B, 2, H, W, device="cuda"))          # one draw per scale, as trainer.py:551-552
+    zero = [torch.zeros((), device="cuda") for _ in range(4)]          # the smoothness terms are separate kernels (not timed here)
 
     def loss_fwd_bwd():
-        tot = 0
-        for s in range(4):
-            photo, si = FD.photo_loss(disps[s], [I, I], batch[("K", 0)], batch[("inv_K", 0)], srcs, tgt, ident, noise,
-                                      batch["4beam"], po, False, G)[:2]
-            tot = tot + photo + si
-        tot.backward()
+        # what Trainer.generate_images_pred + compute_losses launch for the four scales: projection matrices, the fused
+        # all-scales kernel (value + unit gradients), its scalar reduction, the loss combination, and on the way back the
+        # gradient scaling + upsample adjoint launch and the projection-matrix adjoints
+        photo, si, _ = FD.photo_loss_ms(disps, [I, I], batch[("K", 0)], batch[("inv_K", 0)], srcs, tgt, ident, noise,
+                                        batch["4beam"], (0, 1, 2, 3), po, G)
+        FD.combine_losses(photo, zero, si, 1e-3)[1].backward()
     ms = graph_time_ms(loss_fwd_bwd, launches=5)
     byts = LOSS_BYTES_PER_PIXEL * H * W * B
-    out["roofline_loss_path"] = {"bound": "hbm", "kernel": "k_photo_fwd + k_photo_bwd x 4 scales (+ finalize / upsample-adjoint "
-                                 "/ projection-matrix launches), batch %d" % B,
+    out["roofline_loss_path"] = {"bound": "hbm", "kernel": "k_photo_ms (4 scales, forward + unit gradients) + k_photo_ms_fin + "
+                                 "k_photo_ms_bwd (+ projection-matrix and loss-combination launches), batch %d" % B,
                                  "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "us_per_launch": ms * 1e3,
                                  "bytes_per_launch": byts}
     return out
 
 
-def cpu_baseline(args, budget_s=45.0):
+def cpu_baseline(args, budget_s=90.0, warm=3, timed_steps=10):
     """Reference-equivalent CPU step (oracle = the restatement proven equal to the imported reference), bounded sample:
     BASELINE.json configs[0]: ResNet-18, 640x192, batch 2, fp32, on the host cores this process may use."""
     import numpy as np
@@ -150,7 +162,7 @@ def cpu_baseline(args, budget_s=45.0):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    cores = max(1, cores)                      # every core this process may run on (stated in the JSON)
     torch.set_num_threads(cores)
     B, H, W = 2, args.height, args.width
     opt = OT.default_opt(height=H, width=W, batch_size=B, num_layers=args.num_layers)
@@ -162,17 +174,55 @@ def cpu_baseline(args, budget_s=45.0):
         inp[("2channel", f, 0)] = torch.from_numpy(two)
     inp["2channel"] = torch.from_numpy(two)
     times, t_start = [], time.time()
-    for i in range(5):          # 1 warm-up + up to 4 timed steps, bounded by the wall-clock budget
+    for i in range(warm + timed_steps):     # 3 warm-up + 10 timed steps (bounded by a wall-clock budget on slow hosts)
         t0 = time.time()
         ot.micro_step({k: v.clone() for k, v in inp.items()})
         times.append(time.time() - t0)
-        if time.time() - t_start > budget_s and len(times) >= 2:
+        if time.time() - t_start > budget_s and len(times) >= warm + 2:
             break
-    timed = times[1:] if len(times) > 1 else times
+    timed = times[warm:]
     step = float(np.median(timed))
     return {"value": B / step, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d timed optimiser step(s) after 1 warm-up of the oracle trainer (ResNet-%d, %dx%d, batch %d, fp32, "
-                      "torch CPU, %d threads); median %.2f s/step" % (len(timed), args.num_layers, W, H, B, cores, step)}
+            "sample": "%d timed optimiser steps after %d warm-up steps of the oracle trainer (ResNet-%d, %dx%d, batch %d, fp32, "
+                      "torch CPU, %d threads); median %.2f s/step, min %.2f, max %.2f"
+                      % (len(timed), warm, args.num_layers, W, H, B, cores, step, min(timed), max(timed))}
+
+
+def dp_probe(tr, step_fn, mbs, t_step, barrier, reps=3):
+    """Multi-rank only, after the timed region: how many ranks answered, what the gradient exchange costs on its own and how
+    much of it the backward pass hides.  exposed = (step with exchange) - (step without); overlap_frac = 1 - exposed / allreduce."""
+    world = dist.get_world_size()
+    n_over = tr.grad_sync.n_overlapped                      # of the last timed step
+    ones = torch.ones(1, device="cuda")
+    dist.all_reduce(ones)
+    g = tr.flat.flat_grad
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    dist.all_reduce(g)                                     # warm
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        dist.all_reduce(g)
+    ev[1].record()
+    torch.cuda.synchronize()
+    ar_ms = ev[0].elapsed_time(ev[1]) / reps
+    tr.flat.zero_grad()
+    tr.grad_sync.skip_comm = True                          # replicas drift apart from here on: this is the last thing the run does
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step_fn(mbs)
+    barrier()
+    t_nocomm = (time.perf_counter() - t0) / reps
+    tr.grad_sync.skip_comm = False
+    tt = torch.tensor([ar_ms, t_nocomm], device="cuda", dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ar_ms, t_nocomm = float(tt[0]), float(tt[1])
+    exposed_ms = max(0.0, 1e3 * (t_step - t_nocomm))
+    return {"ranks_seen": int(ones.item()), "backend": dist.get_backend(), "allreduce_ms": ar_ms,
+            "allreduce_bytes": int(g.numel()) * 4, "allreduce_buckets": len(tr.grad_sync.buckets),
+            "buckets_overlapped": n_over, "ms_per_step_no_exchange": 1e3 * t_nocomm,
+            "exposed_exchange_ms": exposed_ms, "overlap_frac": max(0.0, min(1.0, 1.0 - exposed_ms / ar_ms)) if ar_ms > 0 else None}
 
 
 def main():
@@ -279,6 +329,8 @@ def main():
         tf = CONV_GFLOP_FWD_BWD[key] * 1e9 * (images / world) / dt / 1e12
         result["step_mfma_frac"] = tf / PEAK_FP32_MFMA_TFLOPS
         result["step_conv_tflops_per_gpu"] = tf
+    if world > 1:
+        result.update(dp_probe(tr, step_fn, mbs, dt / args.steps, barrier))
     if rank == 0 and not args.no_roofline:
         result.update(roofline_probes(args, tr, eager_in if tr.stack_microbatches else mbs[0]))
         print("[bench] roofline probes done", file=sys.stderr, flush=True)

@@ -58,6 +58,9 @@ __device__ __forceinline__ int refl_clamp(int i, int n) {
 // gfx950 issues fp32 add / mul / fma / mov on VGPR, inline-constant or literal operands at twice the rate of everything else
 // (scripts/ubench/valu_rate2.hip: 2.6-2.9 vs 4.3-5.0 cycles per wave-instruction); ANY SGPR operand, and min / max / med3 /
 // cmp / floor / cvt / shifts, are on the slow side.  Wave-uniform constants of the hot loop are therefore kept in VGPRs.
+#ifndef FD_MS_EXACT_GRID
+#define FD_MS_EXACT_GRID 0   // 1: normalise / unnormalise the sampling grid with the reference's operation sequence
+#endif
 #ifndef FD_MS_VCONST
 #define FD_MS_VCONST 1
 #endif
@@ -81,6 +84,7 @@ __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, int voff, int soff
 struct MsArgs {
     fd_photo_cfg cfg;        // B, H, W, NF (= 2), depth range, SI parameters, groups (Hs / Ws unused)
     int S, R;                // scales, rows per strip
+    float lo, span;          // 1 / max_depth, 1 / min_depth - 1 / max_depth (host doubles -> float, as the reference's python floats)
     int Hs[4], Ws[4];
     int has_ident, want_grad;
     unsigned beam_mask;      // bit s: scale s carries the LiDAR term
@@ -138,8 +142,8 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
     float Pm[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) Pm[k] = vreg(Pf[k]);
-    const float span_s = (float)(1.0 / cfg.min_depth - 1.0 / cfg.max_depth);
-    const float lo = vreg((float)(1.0 / cfg.max_depth)), span = vreg(span_s);
+    const float span_s = a.span;
+    const float lo = vreg(a.lo), span = vreg(span_s);
     const float sWx = vreg((float)((double)W / (double)(W - 1))), sHy = vreg((float)((double)H / (double)(H - 1)));
     // clamp range of the sampling position: [1e-30, just below W-1].  A position that equals its clamped value is strictly inside
     // (aten clip_coordinates_set_grad treats the borders as outside); below W-1 the +1 taps always exist, and the sample differs
@@ -258,7 +262,12 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
         u = fmaf(fmaf(-u, den, c0), rc, u);
         v = fmaf(fmaf(-v, den, c1), rc, v);
         // layers.py:224-226 + aten grid_sampler unnormalize (align_corners=False): ((2(u/(W-1) - .5) + 1) W - 1) / 2
+#if FD_MS_EXACT_GRID
+        const float gxn = (u / (float)(W - 1) - 0.5f) * 2.0f, gyn = (v / (float)(H - 1) - 0.5f) * 2.0f;
+        const float ix = ((gxn + 1.0f) * (float)W - 1.0f) * 0.5f, iy = ((gyn + 1.0f) * (float)H - 1.0f) * 0.5f;
+#else
         const float ix = fmaf(u, sWx, -0.5f), iy = fmaf(v, sHy, -0.5f);
+#endif
         const float ixc = __builtin_amdgcn_fmed3f(ix, 1e-30f, xmm), iyc = __builtin_amdgcn_fmed3f(iy, 1e-30f, ymm);
         const float kx = ixc == ix ? sWx : 0.f;                  // clip_coordinates_set_grad: borders count as outside
         const float ky = iyc == iy ? sHy : 0.f;
@@ -594,6 +603,7 @@ __global__ void __launch_bounds__(256) k_photo_ms_fin(const float* __restrict__ 
 struct MsBwdArgs {
     fd_photo_cfg cfg;
     int S;
+    float lo, span;
     int Hs[4], Ws[4];
     int first_block[5];                                        // block range of scale s: [first_block[s], first_block[s+1])
     int xchunks[4];                                            // column chunks per low-resolution row
@@ -610,37 +620,71 @@ struct SiTerm {      // per (scale, image): everything the LiDAR gradient of one
     float k_si, k_l1, m1, lo, span;
 };
 
-// d loss / d disp_up at full-resolution pixel (y, x): photometric part (already in D1, unit cotangent) + LiDAR part
+// LiDAR part of d loss / d disp_up at full-resolution pixel (y, x) whose (scaled) LiDAR value bd passed the `bd > si_lo` gate
+__device__ __forceinline__ float si_grad(const MsBwdArgs& a, const SiTerm& st, const float* __restrict__ disp_b, int Hs, int Ws, int y,
+                                         int x, float bd) {
+    const fd_photo_cfg& cfg = a.cfg;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    fd_bilinear_src(y, (float)Hs / (float)cfg.H, Hs, y0, y1, ly);
+    fd_bilinear_src(x, (float)Ws / (float)cfg.W, Ws, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float dup = hy * (hx * disp_b[y0 * Ws + x0] + lx * disp_b[y0 * Ws + x1]) + ly * (hx * disp_b[y1 * Ws + x0] + lx * disp_b[y1 * Ws + x1]);
+    const float sdisp = st.lo + st.span * dup;
+    const float depth = 1.0f / sdisp;
+    const float d26 = depth * cfg.si_depth_scale;
+    float dd = 0.f;
+    if (cfg.si_mode == 1) {
+        if (d26 < 80.f && d26 > cfg.si_lo) dd = d26 > bd ? st.k_l1 : (d26 < bd ? -st.k_l1 : 0.f);
+    } else if (d26 < 80.f && d26 > cfg.si_lo && fabsf(d26 - bd) < cfg.si_threshold) {
+        const float dl = logf(d26) - logf(bd);
+        dd = st.k_si * (dl - cfg.si_var * st.m1) * sdisp;
+    }
+    return -dd * depth * depth * st.span;
+}
+// d loss / d disp_up at pixel (y, x): photometric part (D1 holds it for a unit cotangent) + LiDAR part
 __device__ __forceinline__ float up_grad(const MsBwdArgs& a, const SiTerm& st, const float* __restrict__ d1_b,
                                          const float* __restrict__ beam_b, const float* __restrict__ disp_b, int Hs, int Ws,
                                          float g_photo, int y, int x) {
-    const fd_photo_cfg& cfg = a.cfg;
-    const int W = cfg.W;
-    float v = g_photo * d1_b[y * W + x];
+    float v = g_photo * d1_b[y * a.cfg.W + x];
     if (beam_b) {
-        const float bd = beam_b[y * W + x] * cfg.si_beam_scale;
-        if (bd > cfg.si_lo) {
-            int y0, y1, x0, x1;
-            float ly, lx;
-            fd_bilinear_src(y, (float)Hs / (float)cfg.H, Hs, y0, y1, ly);
-            fd_bilinear_src(x, (float)Ws / (float)W, Ws, x0, x1, lx);
-            const float hy = 1.f - ly, hx = 1.f - lx;
-            const float dup = hy * (hx * disp_b[y0 * Ws + x0] + lx * disp_b[y0 * Ws + x1]) +
-                              ly * (hx * disp_b[y1 * Ws + x0] + lx * disp_b[y1 * Ws + x1]);
-            const float sdisp = st.lo + st.span * dup;
-            const float depth = 1.0f / sdisp;
-            const float d26 = depth * cfg.si_depth_scale;
-            float dd = 0.f;
-            if (cfg.si_mode == 1) {
-                if (d26 < 80.f && d26 > cfg.si_lo) dd = d26 > bd ? st.k_l1 : (d26 < bd ? -st.k_l1 : 0.f);
-            } else if (d26 < 80.f && d26 > cfg.si_lo && fabsf(d26 - bd) < cfg.si_threshold) {
-                const float dl = logf(d26) - logf(bd);
-                dd = st.k_si * (dl - cfg.si_var * st.m1) * sdisp;
-            }
-            v -= dd * depth * depth * st.span;
-        }
+        const float bd = beam_b[y * a.cfg.W + x] * a.cfg.si_beam_scale;
+        if (bd > a.cfg.si_lo) v += si_grad(a, st, disp_b, Hs, Ws, y, x, bd);
     }
     return v;
+}
+
+// Column sums of one low-resolution row iy for an even upsampling factor R_: the 2 R_ full-resolution rows are loaded first
+// (independent loads in flight), then weighted.  Adjoint weights of the align_corners=False upsampling: output row
+// R_ iy - R_/2 + k reads input row iy with weight 1 - |(k + 0.5) / R_ - 1|; rows clamped at the image border carry weight 1
+// (both taps of aten's area_pixel_compute_source_index fall on the border pixel).
+template <int R_>
+__device__ __forceinline__ float column_sum(const MsBwdArgs& a, const SiTerm& st, const float* __restrict__ d1_b,
+                                            const float* __restrict__ beam_b, const float* __restrict__ disp_b, int Hs, int Ws,
+                                            float g_photo, int iy, int x) {
+    const int H = a.cfg.H, W = a.cfg.W;
+    const int oy0 = R_ * iy - R_ / 2;
+    float v[2 * R_], bv[2 * R_];
+#pragma unroll
+    for (int k = 0; k < 2 * R_; ++k) {
+        const int oy = oy0 + k;
+        const bool ok = oy >= 0 && oy < H;
+        v[k] = ok ? d1_b[oy * W + x] : 0.f;
+        bv[k] = (ok && beam_b) ? beam_b[oy * W + x] : 0.f;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * R_; ++k) {
+        const int oy = oy0 + k;
+        const float d = ((float)k + 0.5f) * (1.0f / (float)R_) - 1.0f;
+        float wy = 1.0f - fabsf(d);
+        if ((iy == 0 && d < 0.f) || (iy == Hs - 1 && d > 0.f)) wy = 1.0f;
+        float val = g_photo * v[k];
+        const float bd = bv[k] * a.cfg.si_beam_scale;
+        if (bd > a.cfg.si_lo) val += si_grad(a, st, disp_b, Hs, Ws, oy, x, bd);
+        if (oy >= 0 && oy < H) acc += wy * val;
+    }
+    return acc;
 }
 
 // Block layout per scale s (r = H / Hs = W / Ws, an integer):
@@ -674,7 +718,7 @@ __global__ void __launch_bounds__(256) k_photo_ms_bwd(MsBwdArgs a) {
     const long P = (long)H * W;
     int b, iy = 0, chunk = 0;
     if (r == 1) {
-        const int per_img = a.xchunks[0];
+        const int per_img = a.xchunks[s];
         b = blk / per_img; chunk = blk - b * per_img;
     } else {
         const int per_img = Hs * a.xchunks[s];
@@ -683,7 +727,7 @@ __global__ void __launch_bounds__(256) k_photo_ms_bwd(MsBwdArgs a) {
         iy = rem / a.xchunks[s]; chunk = rem - iy * a.xchunks[s];
     }
     SiTerm st;
-    st.lo = (float)(1.0 / cfg.max_depth); st.span = (float)(1.0 / cfg.min_depth - 1.0 / cfg.max_depth);
+    st.lo = a.lo; st.span = a.span;
     st.k_si = st.k_l1 = st.m1 = 0.f;
     if (has_beam) {
         const int grp = b / (B / cfg.groups);
@@ -697,27 +741,42 @@ __global__ void __launch_bounds__(256) k_photo_ms_bwd(MsBwdArgs a) {
     const float* beam_b = has_beam ? a.beam + (long)b * P : nullptr;
     const float* disp_b = a.disp[s] + (long)b * Hs * Ws;
     float* out_b = a.d_disp[s] + (long)b * Hs * Ws;
-    if (r == 1) {
-        const int per_img = a.xchunks[0];
-        for (long p = (long)chunk * 256 + t; p < P; p += (long)per_img * 256) {
-            const int y = (int)(p / W), x = (int)(p - (long)y * W);
-            out_b[p] = up_grad(a, st, d1_b, beam_b, disp_b, Hs, Ws, g_photo, y, x);
-        }
+    if (r == 1) {                                     // `chunk` strides over the image rows
+        const int per_img = a.xchunks[s];
+        for (int y = chunk; y < H; y += per_img)
+            for (int x = t; x < W; x += 256) out_b[y * W + x] = up_grad(a, st, d1_b, beam_b, disp_b, Hs, Ws, g_photo, y, x);
         return;
     }
     const int TL = 256 / r - 1;
     const int ix0 = chunk * TL;
     const int cx0 = r * ix0 - r / 2;                  // first full-resolution column of this block
     const int x = cx0 + t;
+    // Adjoint weights of the align_corners=False upsampling by an even integer factor r: output row r*iy - r/2 + k (k < 2r) reads
+    // input row iy with weight 1 - |(k + 0.5) / r - 1|; rows / columns clamped at the image border carry weight 1 (both taps
+    // of aten's area_pixel_compute_source_index fall on the border pixel).  Odd factors take the generic weights.
+    const bool even = (r & 1) == 0;
+    const float rinv = 1.0f / (float)r;
     float acc = 0.f;
     if (x >= 0 && x < W) {
-        const int oy_lo = max(0, r * iy - r / 2), oy_hi = min(H - 1, r * iy + r + r / 2 - 1);
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            int y0, y1;
-            float ly;
-            fd_bilinear_src(oy, (float)Hs / (float)H, Hs, y0, y1, ly);
-            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
-            if (wy != 0.f) acc += wy * up_grad(a, st, d1_b, beam_b, disp_b, Hs, Ws, g_photo, oy, x);
+        if (r == 2) acc = column_sum<2>(a, st, d1_b, beam_b, disp_b, Hs, Ws, g_photo, iy, x);
+        else if (r == 4) acc = column_sum<4>(a, st, d1_b, beam_b, disp_b, Hs, Ws, g_photo, iy, x);
+        else if (r == 8) acc = column_sum<8>(a, st, d1_b, beam_b, disp_b, Hs, Ws, g_photo, iy, x);
+        else {
+            const int oy_lo = max(0, r * iy - r / 2), oy_hi = min(H - 1, r * iy + r + r / 2 - 1);
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                float wy;
+                if (even) {
+                    const float d = ((float)(oy - (r * iy - r / 2)) + 0.5f) * rinv - 1.0f;
+                    wy = 1.0f - fabsf(d);
+                    if ((iy == 0 && d < 0.f) || (iy == Hs - 1 && d > 0.f)) wy = 1.0f;
+                } else {
+                    int y0, y1;
+                    float ly;
+                    fd_bilinear_src(oy, (float)Hs / (float)H, Hs, y0, y1, ly);
+                    wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                }
+                if (wy != 0.f) acc += wy * up_grad(a, st, d1_b, beam_b, disp_b, Hs, Ws, g_photo, oy, x);
+            }
         }
     }
     colsum[t] = acc;
@@ -729,10 +788,17 @@ __global__ void __launch_bounds__(256) k_photo_ms_bwd(MsBwdArgs a) {
             const int col = r * t + k;                // relative to cx0
             const int ox = cx0 + col;
             if (ox < 0 || ox >= W) continue;
-            int x0, x1;
-            float lx;
-            fd_bilinear_src(ox, (float)Ws / (float)W, Ws, x0, x1, lx);
-            const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+            float wx;
+            if (even) {
+                const float d = ((float)k + 0.5f) * rinv - 1.0f;
+                wx = 1.0f - fabsf(d);
+                if ((ix == 0 && d < 0.f) || (ix == Ws - 1 && d > 0.f)) wx = 1.0f;
+            } else {
+                int x0, x1;
+                float lx;
+                fd_bilinear_src(ox, (float)Ws / (float)W, Ws, x0, x1, lx);
+                wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+            }
             o += wx * colsum[col];
         }
         out_b[iy * Ws + ix] = o;
@@ -780,6 +846,7 @@ extern "C" int fd_photo_ms_fwd(const fd_photo_ms_cfg* c, const float* const* dis
     MsArgs a;
     a.cfg = c->base;
     a.S = c->n_scales; a.R = ms_rows(c);
+    a.lo = (float)(1.0 / c->base.max_depth); a.span = (float)(1.0 / c->base.min_depth - 1.0 / c->base.max_depth);
     for (int s = 0; s < 4; ++s) {
         const bool on = s < c->n_scales;
         a.Hs[s] = on ? c->Hs[s] : 0; a.Ws[s] = on ? c->Ws[s] : 0;
@@ -819,6 +886,7 @@ extern "C" int fd_photo_ms_bwd(const fd_photo_ms_cfg* c, const float* const* dis
     MsBwdArgs a;
     a.cfg = c->base;
     a.S = c->n_scales;
+    a.lo = (float)(1.0 / c->base.max_depth); a.span = (float)(1.0 / c->base.min_depth - 1.0 / c->base.max_depth);
     const int B = c->base.B, H = c->base.H, W = c->base.W;
     int nb = 0;
     for (int s = 0; s < 4; ++s) {
@@ -836,10 +904,8 @@ extern "C" int fd_photo_ms_bwd(const fd_photo_ms_cfg* c, const float* const* dis
         FD_REQUIRE(r >= 1 && r <= 16 && c->Hs[s] * r == H && c->Ws[s] * r == W,
                    "fd_photo_ms_bwd: scale %d (%dx%d) is not an integer fraction (<= 16) of %dx%d", s, c->Hs[s], c->Ws[s], H, W);
         if (r == 1) {
-            int per_img = fd_cdiv((long)H * W, 256);
-            if (per_img > 256) per_img = 256;
-            a.xchunks[s] = per_img;
-            nb += B * per_img;
+            a.xchunks[s] = H < 96 ? H : 96;          // row-strided blocks per image
+            nb += B * a.xchunks[s];
         } else {
             a.xchunks[s] = fd_cdiv(c->Ws[s], 256 / r - 1);
             nb += B * c->Hs[s] * a.xchunks[s];

@@ -62,29 +62,79 @@ class FlatParameters:
 
 
 class GradientSynchronizer:
-    """Bucketed, backward-overlapped all-reduce(sum) of a FlatParameters' gradient buffer."""
+    """Bucketed, backward-overlapped all-reduce(sum) of a FlatParameters' gradient buffer.
 
-    def __init__(self, flat, world_size, bucket_bytes=25 << 20, group=None):
+    Buckets are contiguous slices of the flat buffer (>= ``bucket_bytes``, never across a ``segments`` boundary: the trainer
+    passes one segment per network because each network's backward runs on its own HIP stream).  A bucket goes out as soon as
+    the kernel that completes its last gradient has been LAUNCHED: the asynchronous collective is ordered behind that kernel
+    through the stream the backward node runs on (RCCL waits on an event of the current stream), so it overlaps with the rest
+    of the backward pass that is still being issued.  Two notification paths: autograd's post-accumulate hooks (gradients that
+    autograd produces) and ``functional.set_grad_ready_callback`` (gradients the HIP kernels accumulate in place).  Few large
+    messages by design: xGMI is point-to-point, a ring all-reduce is bound by one link (~153 GB/s), not by a switch."""
+
+    def __init__(self, flat, world_size, bucket_bytes=25 << 20, group=None, segments=None, overlap=None, never_used=()):
         self.flat, self.world, self.group = flat, world_size, group
         self.armed = False
         self.handles = []
         self.buckets = []           # [start, end, n_params]
         self.param_bucket = []
+        self.overlap = (os.environ.get("FD_DP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        self.skip_comm = False      # bench only: measure a step without the exchange
         per = max(bucket_bytes // 4, 1)
+        ends = set()                # parameter indices after which a bucket must close
+        if segments:
+            acc = 0
+            for n in segments:
+                acc += n
+                ends.add(acc - 1)
+        skip = set(id(p) for p in never_used)   # parameters that never receive a gradient (the ResNet `fc` heads): not waited for
         start, count = 0, 0
         for i, p in enumerate(flat.params):
             self.param_bucket.append(len(self.buckets))
-            count += 1
+            count += 0 if id(p) in skip else 1
             end = flat.offsets[i + 1]
-            if end - start >= per or i == len(flat.params) - 1:
+            if end - start >= per or i == len(flat.params) - 1 or i in ends:
                 self.buckets.append([start, end, count])
                 start, count = end, 0
         self.pending = [b[2] for b in self.buckets]
         self.launched = [False] * len(self.buckets)
+        self.index = {id(p): i for i, p in enumerate(flat.params)}
+        self.n_overlapped = 0       # buckets of the last window that went out before finish()
+        self.done = {}              # parameter index -> in-place gradient kernels launched in this window
+        self.late = []
+        self.seen = set()
         if world_size > 1:
             for i, p in enumerate(flat.params):
                 if p.requires_grad:
                     p.register_post_accumulate_grad_hook(self._make_hook(i))
+            from . import functional as FD
+            FD.set_grad_ready_callback(self._on_direct_grad)
+
+    def _arrived(self, i):
+        # Two notification paths can report the same parameter: the in-place kernels' callback, and autograd's post-accumulate
+        # hook - which this torch also runs for a leaf whose Function returned no gradient (it fires once all uses of the leaf
+        # have run their backward, i.e. never before the callback's last kernel).  Count each parameter once per window.
+        if i in self.seen:
+            return
+        self.seen.add(i)
+        b = self.param_bucket[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0 and self.overlap and not self.skip_comm:
+            self._launch(b)
+            self.n_overlapped += 1
+
+    def _on_direct_grad(self, param):
+        """functional._grad_ready: a kernel that accumulates into ``param.grad`` (a view of the flat buffer) has been launched;
+        the gradient is complete once that has happened as often as the parameter was used in the forward pass."""
+        if self.armed:
+            i = self.index.get(id(param))
+            if i is not None:
+                from . import functional as FD
+                if self.launched[self.param_bucket[i]]:
+                    self.late.append((i, self.done.get(i, 0), FD.param_uses(param)))   # a kernel AFTER its bucket went out
+                self.done[i] = self.done.get(i, 0) + 1
+                if self.done[i] == FD.param_uses(param):
+                    self._arrived(i)
 
     def _make_hook(self, i):
         def hook(param):
@@ -95,10 +145,7 @@ class GradientSynchronizer:
                 # autograd assigned a fresh tensor instead of accumulating into the view: fold it back
                 self.flat.flat_grad[o:o + n].copy_(param.grad.reshape(-1))
                 param.grad = self.flat.flat_grad[o:o + n].view(param.shape)
-            b = self.param_bucket[i]
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                self._launch(b)
+            self._arrived(i)
         return hook
 
     def _launch(self, b):
@@ -106,6 +153,8 @@ class GradientSynchronizer:
             return
         self.launched[b] = True
         s, e, _ = self.buckets[b]
+        if os.environ.get("FD_DP_DEBUG_SYNC") == "1":
+            torch.cuda.synchronize()
         self.handles.append(dist.all_reduce(self.flat.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def arm(self):
@@ -114,14 +163,17 @@ class GradientSynchronizer:
         self.pending = [b[2] for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.handles = []
+        self.n_overlapped = 0
+        self.done = {}
+        self.late = []
+        self.seen = set()
 
     def finish(self):
-        """After backward: reduce buckets whose hooks never fired (unused parameters, e.g. the ResNet ``fc``)
-        and wait for everything.  Returns the factor that turns the summed gradient into the mean."""
-        if self.world > 1 and self.armed:
+        """After backward (and after the module streams were joined): reduce what has not gone out yet - buckets with
+        parameters that received no gradient (the ResNet ``fc`` heads), or everything as ONE message when overlap is off -
+        and make the current stream wait for every collective.  Returns the factor that turns the sum into the mean."""
+        if self.world > 1 and self.armed and not self.skip_comm:
             if not any(self.launched):
-                # no hook fired (the trainer's kernels accumulate gradients in place, autograd never sees them): the whole
-                # flat buffer goes out as ONE all-reduce - the largest message the ring over xGMI can get
                 dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             else:
                 for b in range(len(self.buckets)):
@@ -129,6 +181,10 @@ class GradientSynchronizer:
                 for h in self.handles:
                     h.wait()
         self.armed = False
+        if self.late:
+            raise RuntimeError("GradientSynchronizer: %d gradient kernels were launched after their bucket's all-reduce (first: "
+                               "(parameter, kernels so far, announced uses) %s) - a parameter is used more often in the backward pass "
+                               "than the forward pass announced" % (len(self.late), self.late[:6]))
         return 1.0 / self.world
 
 

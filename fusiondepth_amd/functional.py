@@ -612,6 +612,42 @@ def _wgrad_stream():
     return st
 
 
+# ---- "this parameter's gradient is complete" notifications ------------------------------------------------------------------
+# With in-place accumulation autograd never sees a parameter gradient, so post-accumulate hooks do not fire.  The backward
+# wrappers call this right after LAUNCHING the kernel that finishes a parameter's gradient; dp.GradientSynchronizer uses it to
+# issue a bucket's all-reduce behind that kernel on the same stream while the rest of the backward pass is still being issued.
+_GRAD_READY = [None]
+_PARAM_USES = {}        # id(param) -> number of forward uses since begin_forward_pass() (a network may run twice per pass)
+
+
+def set_grad_ready_callback(fn):
+    _GRAD_READY[0] = fn
+
+
+def begin_forward_pass():
+    """Start counting parameter uses afresh: the backward pass of this forward runs one gradient kernel per use."""
+    _PARAM_USES.clear()
+
+
+def param_uses(p):
+    return _PARAM_USES.get(id(p), 1)
+
+
+def _note_use(*params):
+    if _GRAD_READY[0] is not None:
+        for p in params:
+            if p is not None:
+                _PARAM_USES[id(p)] = _PARAM_USES.get(id(p), 0) + 1
+
+
+def _grad_ready(*params):
+    cb = _GRAD_READY[0]
+    if cb is not None:
+        for p in params:
+            if p is not None:
+                cb(p)
+
+
 def _direct_grad_target(p):
     if p is not None and getattr(p, "_fd_direct_grad", False) and p.grad is not None and p.grad.is_contiguous():
         return p.grad
@@ -682,6 +718,7 @@ class _Conv2d(torch.autograd.Function):
     def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
         cache_id = getattr(w, "_fd_cache_id", None)
         ctx.params = (w, bias)
+        _note_use(w, bias)
         x, w = f32(x), f32(w)
         bias = f32(bias) if bias is not None else None
         _need_cuda(x, w)
@@ -731,6 +768,7 @@ class _Conv2d(torch.autograd.Function):
                 call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
             if direct:
                 gw = gb = None          # already accumulated in place
+                _grad_ready(ctx.params[0], ctx.params[1] if ctx.has_bias else None)
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -740,6 +778,7 @@ class _Conv2dPair(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w0, w1, stride, pad):
         ctx.params = (w0, w1)
+        _note_use(w0, w1)
         ids = (getattr(w0, "_fd_cache_id", None), getattr(w1, "_fd_cache_id", None))
         x, w0, w1 = f32(x), f32(w0), f32(w1)
         _need_cuda(x, w0, w1)
@@ -783,6 +822,7 @@ class _Conv2dPair(torch.autograd.Function):
             call("fd_conv2d_bwd_weight_pair", dp, ptr(x), ptr(gy), ptr(gw0), ptr(gw1), ptr(ws), int(direct), stream())
             if direct:
                 gw0 = gw1 = None
+                _grad_ready(ctx.params[0], ctx.params[1])
         return gx, gw0, gw1, None, None
 
 
@@ -799,6 +839,7 @@ class _BatchNormPair(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wa, ba, wb, bb, residual, rma, rva, rmb, rvb, momentum, eps, relu, groups):
         ctx.params = (wa, ba, wb, bb)
+        _note_use(wa, ba, wb, bb)
         ctx.groups = groups
         x = f32(x)
         _need_cuda(x)
@@ -835,6 +876,8 @@ class _BatchNormPair(torch.autograd.Function):
                  ptr(gx[sl]), ptr(gw), ptr(gb), ptr(gres[sl]) if gres is not None else None, ptr(ws), N, C, H, W, ctx.groups, ctx.relu,
                  int(direct), stream())
             outs += [None, None] if direct else [gw, gb]
+            if direct:
+                _grad_ready(pw, pb)
         return (gx, outs[0], outs[1], outs[2], outs[3], gres) + (None,) * 8
 
 
@@ -885,6 +928,7 @@ class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, groups):
         ctx.params = (weight, bias)
+        _note_use(weight, bias)
         ctx.groups = groups
         x = f32(x)
         _need_cuda(x)
@@ -920,6 +964,7 @@ class _BatchNorm(torch.autograd.Function):
              ptr(gres), ptr(ws), N, C, H, W, ctx.groups, ctx.relu, int(direct), stream())
         if direct:
             gw = gb = None
+            _grad_ready(ctx.params[0], ctx.params[1])
         return gx, gw, gb, gres, None, None, None, None, None, None, None
 
 

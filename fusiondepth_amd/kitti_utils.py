@@ -22,40 +22,48 @@ from . import functional as FD
 
 
 def load_velodyne_points(filename):
-    """kitti_utils.py:8-11."""
-    points = np.fromfile(filename, dtype=np.float32).reshape(-1, 4)
-    points[:, 3] = 1.0  # homogeneous
-    return points
+    """Velodyne scan file (float32 x, y, z, reflectance per point) -> [N,4] float32 with the 4th column set to 1, i.e. points in
+    homogeneous coordinates ready for the 3x4 projection (interface of kitti_utils.py:8-11)."""
+    scan = np.fromfile(filename, dtype=np.float32)
+    if scan.size % 4:
+        raise ValueError("%s: %d floats is not a whole number of (x, y, z, reflectance) records" % (filename, scan.size))
+    scan = scan.reshape(-1, 4)
+    scan[:, 3] = 1.0
+    return scan
 
 
 def read_calib_file(path):
-    """kitti_utils.py:14-30: ``key: value`` lines; values made only of float characters become float64 arrays."""
-    float_chars = set("0123456789.e+- ")
-    data = {}
-    with open(path, "r") as f:
-        for line in f.readlines():
-            key, value = line.split(":", 1)
-            value = value.strip()
-            data[key] = value
-            if float_chars.issuperset(value):
-                try:
-                    data[key] = np.array(list(map(float, value.split(" "))))
-                except ValueError:
-                    pass
-    return data
+    """KITTI ``calib_*.txt`` -> {key: float64 vector | str}.  Every line is ``key: payload``; a payload whose tokens all parse
+    as numbers becomes a float64 vector, anything else (e.g. ``calib_time: 09-Jan-2012 13:57:47``) stays the stripped string
+    (interface of kitti_utils.py:14-30)."""
+    table = {}
+    with open(path, "r") as handle:
+        for raw in handle:
+            key, sep, payload = raw.partition(":")
+            if not sep:
+                continue
+            payload = payload.strip()
+            try:
+                table[key] = np.asarray([float(tok) for tok in payload.split()], dtype=np.float64) if payload else payload
+            except ValueError:
+                table[key] = payload
+    return table
 
 
 def velo_to_image(calib_dir, cam=2):
-    """kitti_utils.py:43-57 -> (P_velo2im [3,4] float64, (im_h, im_w))."""
-    cam2cam = read_calib_file(os.path.join(calib_dir, "calib_cam_to_cam.txt"))
-    velo2cam = read_calib_file(os.path.join(calib_dir, "calib_velo_to_cam.txt"))
-    velo2cam = np.hstack((velo2cam["R"].reshape(3, 3), velo2cam["T"][..., np.newaxis]))
-    velo2cam = np.vstack((velo2cam, np.array([0, 0, 0, 1.0])))
-    im_shape = cam2cam["S_rect_02"][::-1].astype(np.int32)
-    R_cam2rect = np.eye(4)
-    R_cam2rect[:3, :3] = cam2cam["R_rect_00"].reshape(3, 3)
-    P_rect = cam2cam["P_rect_0" + str(cam)].reshape(3, 4)
-    return np.dot(np.dot(P_rect, R_cam2rect), velo2cam), (int(im_shape[0]), int(im_shape[1]))
+    """Velodyne -> rectified image plane of camera ``cam``: (P [3,4] float64, (im_h, im_w)).  P = P_rect_0<cam> . R_rect_00 .
+    Tr_velo_to_cam, multiplied left to right in float64 like kitti_utils.py:43-57 (the products are compared bit for bit with
+    the reference's in tests/test_gpu_rasterize.py)."""
+    intr = read_calib_file(os.path.join(calib_dir, "calib_cam_to_cam.txt"))
+    extr = read_calib_file(os.path.join(calib_dir, "calib_velo_to_cam.txt"))
+    to_cam = np.eye(4)
+    to_cam[:3, :3] = extr["R"].reshape(3, 3)
+    to_cam[:3, 3] = extr["T"]
+    rectify = np.eye(4)
+    rectify[:3, :3] = intr["R_rect_00"].reshape(3, 3)
+    projection = intr["P_rect_0%d" % cam].reshape(3, 4)
+    width, height = (int(v) for v in intr["S_rect_02"][:2])
+    return (projection @ rectify) @ to_cam, (height, width)
 
 
 def _device_scan(velo_filename, device):

@@ -22,7 +22,7 @@ from . import dp
 from . import functional as FD
 from . import networks
 from .layers import disp_to_depth
-from .trainer import Trainer, derived_hparams
+from .trainer import Outputs, Trainer, derived_hparams
 
 REFINER_MODEL_ORDER = ["encoder", "beam_encoder", "beam_encoder_pose", "depth", "pose_encoder", "pose", "refine2d_decoder"]
 
@@ -30,14 +30,18 @@ REFINER_MODEL_ORDER = ["encoder", "beam_encoder", "beam_encoder_pose", "depth", 
 class Refiner(Trainer):
     """Same method names as the reference's ``Refiner``; batches are dicts with the reference's keys (+ ``"inf_gdc"``)."""
 
-    def __init__(self, options, device=None, verbose=True):
+    def __init__(self, options, device=None, rank=0, world_size=1, verbose=True):
         self.opt = options
+        self.verbose = verbose
         if self.opt.no_cuda or not torch.cuda.is_available():
             raise RuntimeError("fusiondepth_amd.Refiner needs an MI355X: there is no CPU path (use oracle/ for CPU checks)")
         self.opt.clone_gdc, self.opt.refine_2d = True, True                                   # refiner.py:29-30
         self.device = torch.device(device if device is not None else "cuda")
-        self.rank, self.world_size = 0, 1
+        if self.device.index is not None:
+            torch.cuda.set_device(self.device)           # every raw-stream launch below targets the current device
+        self.rank, self.world_size = rank, world_size
         self.materialize_outputs = False
+        self.log_path = os.path.join(self.opt.log_dir, self.opt.model_name)
         vram = torch.cuda.get_device_properties(self.device).total_memory / 1024 ** 3
         hp = derived_hparams(self.opt, vram)                                                  # refiner.py:32-45 (same rule)
         self.opt.num_epochs = hp["num_epochs"]
@@ -46,8 +50,13 @@ class Refiner(Trainer):
         self.eval_scales = self.opt.scales
         assert self.opt.height % 32 == 0 and self.opt.width % 32 == 0, "'height' / 'width' must be multiples of 32"
         assert self.opt.frame_ids[0] == 0, "frame_ids must start with 0"
+        if self.opt.train_entire_net:
+            # refiner.py:306-313 computes `features` only under `if not self.opt.train_entire_net`, so the reference itself
+            # stops with an UnboundLocalError at the first batch: there is no behaviour to reproduce
+            raise NotImplementedError("--train_entire_net: the reference's Refiner.process_batch (refiner.py:306-313) never "
+                                      "computes the encoder features on that path (UnboundLocalError at the first batch)")
         if self.opt.use_stereo or self.opt.predictive_mask or self.opt.pose_model_type != "separate_resnet" or \
-                self.opt.v1_multiscale or self.opt.train_entire_net or not self.opt.beam_encoder:
+                self.opt.v1_multiscale or not self.opt.beam_encoder:
             raise NotImplementedError("Refiner: only the default path (frozen nets, separate_resnet pose net, beam encoder, "
                                       "full-resolution sampling) is implemented")
         self.num_scales = len(self.opt.scales)
@@ -67,6 +76,9 @@ class Refiner(Trainer):
         m["refine2d_decoder"] = networks.DepthDecoder(m["encoder"].num_ch_enc, self.opt.scales, road=True,
                                                       catxy=(self.opt.catxy == "true"), deep=(self.opt.refine2d_deep == "true"))
         self.models = {k: m[k].to(self.device) for k in REFINER_MODEL_ORDER}
+        self._load_pretrained()                                                                # refiner.py:56-60, 84-152
+        if world_size > 1:
+            dp.broadcast_module_state(self.models.values())
         self.parameters_to_train = list(self.models["refine2d_decoder"].parameters())          # refiner.py:148-160
         for k, net in self.models.items():
             if k != "refine2d_decoder":
@@ -86,7 +98,7 @@ class Refiner(Trainer):
         self.pair_siblings = self._pair_depth = self._pair_pose = False
         self.stack_microbatches = False
         self._groups = 1
-        self.grad_sync = dp.GradientSynchronizer(self.flat, 1)
+        self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)
         self.photo_options = FD.PhotoOptions(self.opt.min_depth, self.opt.max_depth, self.opt.no_ssim, self.opt.avg_reprojection,
                                              self.opt.gdc_loss_threshold, self.opt.si_var, si_depth_scale=1.0,
                                              si_beam_scale=1.0, si_lo=1e-3)
@@ -99,6 +111,35 @@ class Refiner(Trainer):
         if verbose:
             n = sum(p.numel() for p in self.parameters_to_train)
             print("fusiondepth_amd.Refiner: training refine2d_decoder, %d parameters (%.1f MB fp32), lr %.3g" % (n, n * 4 / 1e6, self.lr))
+
+    def _load_pretrained(self):
+        """refiner.py:56-60 + the ``load_state_dict`` after every constructor (:84-152): the frozen depth / pose networks come
+        from ``--refine_load_weights_folder`` (stage-1 ``Trainer.save_model`` output; the encoder file also carries height /
+        width / use_stereo, filtered by key like the reference does), ``refine2d_decoder.pth`` is optional (resume).
+        Without a folder (synthetic benchmarks / unit tests only) the networks keep their random initialisation."""
+        folder = self.opt.refine_load_weights_folder
+        if folder is None:
+            if self.verbose:
+                print("fusiondepth_amd.Refiner: no --refine_load_weights_folder; frozen networks keep their random initialisation")
+            return
+        folder = os.path.expanduser(folder)
+        assert os.path.isdir(folder), "Cannot find a folder at {}".format(folder)
+        for name, net in self.models.items():
+            path = os.path.join(folder, "{}.pth".format(name))
+            if not os.path.isfile(path):
+                if name == "refine2d_decoder":
+                    continue
+                raise FileNotFoundError("refine_load_weights_folder: %s is missing" % path)
+            own = net.state_dict()
+            loaded = torch.load(path, map_location="cpu")
+            missing = [k for k in own if k not in loaded]
+            if missing and name != "encoder":
+                raise RuntimeError("%s: missing keys %s" % (path, missing[:4]))
+            with torch.no_grad():
+                for k, v in loaded.items():
+                    if k in own:
+                        own[k].copy_(v)
+        FD.bump_weights_epoch()
 
     def set_train(self):
         """refiner.py:80-160: the depth / pose networks stay in eval mode; only the refine decoder trains."""
@@ -143,13 +184,14 @@ class Refiner(Trainer):
         for key, ipt in inputs.items():
             if torch.is_tensor(ipt) and ipt.device != self.device:
                 inputs[key] = ipt.to(self.device)
+        FD.begin_forward_pass()
         with torch.no_grad():
             features = self.models["encoder"](inputs["color_aug", 0, 0])
             beam_features = self.models["beam_encoder"](inputs["2channel"])
             if self.opt.refine_depthnet_with_beam == "true":
-                outputs = dict(self.models["depth"](features, beam_features=beam_features))
+                outputs = Outputs(self.models["depth"](features, beam_features=beam_features))
             else:
-                outputs = dict(self.models["depth"](features))
+                outputs = Outputs(self.models["depth"](features))
             outputs.update(self.refine_inputs(inputs, outputs))
         if self.use_pose_net and not val:
             with torch.no_grad():                     # frozen pose networks (reference: eval mode, not in the optimiser)
@@ -178,6 +220,22 @@ class Refiner(Trainer):
         automask = not self.opt.disable_automasking
         ident = self.identity_losses(inputs, 0) if automask else None
         noise_in = inputs.get("_noise")
+        if self._multiscale_loss_ok(fids):             # all scales in one launch (csrc/photometric_ms.hip)
+            scales = list(self.opt.scales)
+            noise = None
+            if ident is not None:
+                noise = [noise_in[s] for s in scales] if noise_in is not None else \
+                    list(torch.randn((len(scales),) + tuple(ident.shape), device=ident.device))
+            gdc = [i for i, s in enumerate(scales) if (not self.opt.gdc_loss_only_on_scale_0) or s == 0]
+            photo, si, sel = FD.photo_loss_ms(
+                [outputs[("disp", s)] for s in scales], [outputs[("cam_T_cam", 0, f)] for f in fids], inputs[("K", 0)],
+                inputs[("inv_K", 0)], [inputs[("color", f, 0)] for f in fids], inputs[("color", 0, 0)], ident, noise,
+                inputs["inf_gdc"] if gdc else None, gdc, self.photo_options, 1)
+            for i, scale in enumerate(scales):
+                outputs[("photo", scale)] = (photo[i], si[i])
+                if automask:
+                    outputs[("sel", scale)] = (sel[i], ident.shape[1])
+            return
         for scale in self.opt.scales:
             noise = None
             if ident is not None:
@@ -190,7 +248,7 @@ class Refiner(Trainer):
                 inputs["inf_gdc"] if use_gdc else None, self.photo_options, self.materialize_outputs, 1)
             outputs[("photo", scale)] = (photo, si if use_gdc else None)
             if automask:
-                outputs["identity_selection/{}".format(scale)] = (sel > ident.shape[1] - 1).float()
+                outputs[("sel", scale)] = (sel, ident.shape[1])
 
     def compute_losses(self, inputs, outputs, losses, gama=1.0, frame_ids=None):
         """refiner.py:592-693.  The fused kernel's SI term is 0.1 * sqrt(var); the refiner's is 10 * sqrt(var) * weight [* 4]."""
@@ -209,11 +267,33 @@ class Refiner(Trainer):
         losses["loss"] = losses["loss"] + total * gama
         return losses
 
+    def run_epoch(self):
+        """refiner.py:264-297: one optimiser step per batch, the trainer's logging / validation cadence, StepLR at the end."""
+        self.set_train()
+        for batch_idx, inputs in enumerate(self.train_loader):
+            t0 = time.time()
+            step0 = self.step
+            losses = self.train_step(inputs)
+            if self.rank == 0 and self._log_due(batch_idx, step0):
+                self.log_time(batch_idx, time.time() - t0, float(losses["loss"]))
+                if "depth_gt" in inputs:
+                    self.compute_depth_losses(inputs, self._last_outputs, losses)
+                self.log("train", {k: v for k, v in losses.items() if torch.is_tensor(v) or isinstance(v, float)})
+                if getattr(self, "val_loader", None) is not None:
+                    self.log("val", self.val(self.val_loader))
+                    self.set_train()
+        self.lr_scheduler_step()
+
     def train_step(self, inputs):
-        """One optimiser step of refiner.py:262-297 (accumulate_step == 1: batch sizes <= 8)."""
+        """One optimiser step of refiner.py:272-278: zero_grad, backward, step for every batch (the reference's Refiner never
+        accumulates, whatever --batch_size is).  With several ranks the refine decoder's gradient is all-reduced (mean)."""
+        self.grad_sync.arm()
         outputs, losses = self.process_batch(inputs)
         losses["loss"].backward()
-        self.optimizer_step(1.0)
+        scale = self.grad_sync.finish() if self.world_size > 1 else 1.0
+        self.optimizer_step(scale)
         self._ensure_weight_plan()
         self.step += 1
+        self.batch_idx += 1
+        self._last_outputs = outputs
         return losses

@@ -27,6 +27,33 @@ from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transforma
 MODEL_ORDER = ["encoder", "beam_encoder", "beam_encoder_pose", "depth", "pose_encoder", "pose", "predictive_mask"]
 
 
+def _hms(t):
+    """utils.py:37-42."""
+    t = int(t)
+    return "{:02d}h{:02d}m{:02d}s".format(t // 3600, (t % 3600) // 60, t % 60)
+
+
+class Outputs(dict):
+    """The reference's ``outputs`` dict.  ``"identity_selection/<s>"`` (trainer.py:564-565, a monitoring image) is derived
+    from the fused kernel's argmin index on first access instead of costing two element-wise launches per scale and step."""
+
+    def __missing__(self, key):
+        if isinstance(key, str) and key.startswith("identity_selection/"):
+            raw = dict.get(self, ("sel", int(key.split("/")[1])))
+            if raw is not None:
+                sel, n_id = raw
+                val = (sel > n_id - 1).float()
+                self[key] = val
+                return val
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        if dict.__contains__(self, key):
+            return True
+        return isinstance(key, str) and key.startswith("identity_selection/") and \
+            dict.__contains__(self, ("sel", int(key.split("/")[1])))
+
+
 def derived_hparams(opt, vram_gib):
     """trainer.py:28-41: epochs, accumulate_step, lr, StepLR step and micro-batch derived from --batch_size."""
     accumulate = 2 if vram_gib < 15 else 1
@@ -44,6 +71,9 @@ class Trainer:
         if self.opt.no_cuda or not torch.cuda.is_available():
             raise RuntimeError("fusiondepth_amd.Trainer needs an MI355X: there is no CPU path (use oracle/ for CPU checks)")
         self.device = torch.device(device if device is not None else "cuda")
+        if self.device.index is not None:
+            torch.cuda.set_device(self.device)           # libfdhip launches on the CURRENT device's streams (see _lib.stream)
+        self.verbose = verbose
         self.rank, self.world_size = rank, world_size
         self.materialize_outputs = materialize_outputs
 
@@ -116,7 +146,9 @@ class Trainer:
         # (networks.interleaved_forward).  Throughput-neutral on this host (the GPU is saturated either way), so the
         # longer-tested sequential issue order stays the default.
         self.interleave_encoders = os.environ.get("FD_INTERLEAVE", "0") != "0"
-        self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)
+        unused = [p for m in self.models.values() for n, p in m.named_parameters() if n.startswith("encoder.fc.")]
+        self.grad_sync = dp.GradientSynchronizer(self.flat, world_size, never_used=unused,
+                                                 segments=[len(list(m.parameters())) for m in self.models.values()])
         if self.opt.train_load_weights_folder is not None:
             self.load_model()
 
@@ -216,7 +248,8 @@ class Trainer:
         scale = self.grad_sync.finish() if self.world_size > 1 else 1.0
         self.optimizer_step(scale)
         self._ensure_weight_plan()
-        self.step += 1
+        self.step += self.accumulate_step            # the reference counts batches (trainer.py:264), not optimiser steps
+        self._last_io = (stacked if self.stack_microbatches else inputs, outputs)
         return losses
 
     def _ensure_weight_plan(self):
@@ -234,12 +267,95 @@ class Trainer:
                          grad_scale=grad_scale)
         self.flat.zero_grad()
 
-    def end_epoch(self):
-        """StepLR(step_size, 0.1).step()  (trainer.py:266)."""
-        self.epoch += 1
-        if self.scheduler_step_size > 0 and self.epoch % self.scheduler_step_size == 0:
+    def lr_scheduler_step(self):
+        """StepLR(step_size, 0.1).step()  (trainer.py:266): the learning rate drops by 10x every ``scheduler_step_size`` calls."""
+        self.scheduler_epochs = getattr(self, "scheduler_epochs", 0) + 1
+        if self.scheduler_step_size > 0 and self.scheduler_epochs % self.scheduler_step_size == 0:
             self.lr *= 0.1
             self.adam_state[1] = self.lr
+
+    def end_epoch(self):
+        """For callers that drive ``train_step`` themselves: advance the epoch counter and the StepLR schedule."""
+        self.epoch += 1
+        self.lr_scheduler_step()
+
+    # ---- driver loop (trainer.py:219-266, 632-642) -----------------------------------------------------------------------
+    def train(self, train_loader=None, val_loader=None):
+        """trainer.py:219-228 over ANY iterable of batches in the reference's schema (its DataLoader, a list, a generator
+        factory with ``__iter__``): ``num_epochs`` x ``run_epoch``, a checkpoint every ``save_frequency`` epochs."""
+        if train_loader is not None:
+            self.train_loader = train_loader
+        if val_loader is not None:
+            self.val_loader = val_loader
+        if getattr(self, "train_loader", None) is None:
+            raise RuntimeError("Trainer.train: no train_loader (pass one, or set self.train_loader; this package ships no KITTI "
+                               "DataLoader - any iterable of reference-schema batches works)")
+        self.epoch, self.step = 0, 0
+        self.start_time = time.time()
+        try:
+            self.num_total_steps = len(self.train_loader) * self.opt.num_epochs
+        except TypeError:
+            self.num_total_steps = 0
+        if self.rank == 0:
+            self.save_opts()
+        for self.epoch in range(self.opt.num_epochs):
+            self.run_epoch()
+            if (self.epoch + 1) % self.opt.save_frequency == 0 and self.rank == 0:
+                self.save_model()
+
+    def _log_due(self, batch_idx, step):
+        """trainer.py:252-254: every log_frequency batches during the first 2000 steps, then every 2000 steps."""
+        return (batch_idx % self.opt.log_frequency == 0 and step < 2000) or step % 2000 == 0
+
+    def run_epoch(self):
+        """trainer.py:230-266.  The reference runs process_batch + backward per batch and steps the optimiser every
+        ``accumulate_step`` batches; here the window's batches run as one stacked pass (``train_step``), so logging /
+        validation happen once per window, if any batch of the window was due.  A window left unfinished at the end of an epoch is
+        dropped, as the reference's ``zero_grad()`` at the start of the next epoch does."""
+        self.set_train()
+        self.flat.zero_grad()
+        window, t0 = [], time.time()
+        for batch_idx, inputs in enumerate(self.train_loader):
+            if not window:
+                t0 = time.time()
+            window.append(inputs)
+            if len(window) < self.accumulate_step:
+                continue
+            step0, first = self.step, batch_idx - self.accumulate_step + 1
+            losses = self.train_step(window)
+            window = []
+            if self.rank == 0 and any(self._log_due(first + k, step0 + k) for k in range(self.accumulate_step)):
+                loss = float(losses["loss"]) / self.accumulate_step              # the value trainer.py:243 prints (synchronises)
+                self.log_time(batch_idx, (time.time() - t0) / self.accumulate_step, loss)
+                stacked, outputs = self._last_io
+                if "depth_gt" in stacked:
+                    self.compute_depth_losses(stacked, outputs, losses)
+                self.log("train", losses)
+                if getattr(self, "val_loader", None) is not None:
+                    self.log("val", self.val(self.val_loader))
+                    self.set_train()
+        self.lr_scheduler_step()
+
+    def log_time(self, batch_idx, duration, loss):
+        """trainer.py:632-642."""
+        samples_per_sec = self.batch_size / max(duration, 1e-9)
+        time_sofar = time.time() - self.start_time
+        left = (self.num_total_steps / self.step - 1.0) * time_sofar if self.step > 0 and self.num_total_steps else 0
+        if self.verbose:
+            print("epoch {:>3} | batch {:>6} | examples/s: {:5.1f} | loss: {:.5f} | time elapsed: {} | time left: {}".format(
+                self.epoch, batch_idx, samples_per_sec, loss, _hms(time_sofar), _hms(left)))
+        self.last_log_time = dict(epoch=self.epoch, batch=batch_idx, examples_per_s=samples_per_sec, loss=loss)
+
+    def log(self, mode, losses):
+        """trainer.py:644-681 without tensorboard / wandb: one JSON line per event in ``<log_path>/<mode>/scalars.jsonl``
+        (the image summaries are not written; ``outputs`` keeps everything they were made from)."""
+        folder = os.path.join(self.log_path, mode)
+        os.makedirs(folder, exist_ok=True)
+        rec = {"step": self.step, "epoch": self.epoch, "lr": self.lr}
+        for k, v in losses.items():
+            rec[k] = float(v)
+        with open(os.path.join(folder, "scalars.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
 
     # ------------------------------------------------------------------------------------------------
     def train_step_graphed(self, micro_batches):
@@ -265,7 +381,7 @@ class Trainer:
                 if self.world_size > 1:
                     self._sync_and_step()
             torch.cuda.current_stream().wait_stream(self._side)
-            self.step += 1
+            self.step += self.accumulate_step
             self.batch_idx += self.accumulate_step
             return losses
         if micro_batches is not self._last_mbs:
@@ -284,7 +400,7 @@ class Trainer:
         self._graph.replay()
         if self.world_size > 1:
             self._sync_and_step()
-        self.step += 1
+        self.step += self.accumulate_step
         self.batch_idx += self.accumulate_step
         return self._static_losses
 
@@ -371,6 +487,7 @@ class Trainer:
         else:
             enc_in = inputs["color_aug", 0, 0]
         self._groups = groups
+        FD.begin_forward_pass()
         with FD.defer_bn_counters():
             return self._process_batch(inputs, val, groups, par, enc_in)
 
@@ -409,7 +526,7 @@ class Trainer:
             outputs = self.models["depth"](features, beam_features=beam_features)
         else:
             outputs = self.models["depth"](features)
-        outputs = dict(outputs)
+        outputs = Outputs(outputs)
         if self.use_pose_net and not val:
             outputs.update(self.predict_poses(inputs, features, pose_out))
         losses = {}
@@ -561,6 +678,24 @@ class Trainer:
         si_scales = self._lidar_term()[0]
         ident0 = self.identity_losses(inputs, 0) if (automask and not self.opt.v1_multiscale) else None
         noise_in = inputs.get("_noise")               # injected tie-break noise (tests); else drawn like trainer.py:551-552
+        if self._multiscale_loss_ok(fids):
+            # default configuration: ALL scales in one launch that also produces the gradients (csrc/photometric_ms.hip)
+            scales = list(self.opt.scales)
+            B, _, H, W = inputs[("color", 0, 0)].shape
+            noise = None
+            if ident0 is not None:
+                noise = [noise_in[s] for s in scales] if noise_in is not None else \
+                    list(torch.randn((len(scales), B, ident0.shape[1], H, W), device=ident0.device))
+            lidar = [i for i, s in enumerate(scales) if s in si_scales]
+            photo, si, sel = FD.photo_loss_ms(
+                [outputs[("disp", s)] for s in scales], [outputs[("cam_T_cam", 0, f)] for f in fids], inputs[("K", 0)],
+                inputs[("inv_K", 0)], [inputs[("color", f, 0)] for f in fids], inputs[("color", 0, 0)], ident0, noise,
+                inputs["4beam"] if lidar else None, lidar, self.photo_options, getattr(self, "_groups", 1))
+            for i, scale in enumerate(scales):
+                outputs[("photo", scale)] = (photo[i], si[i])
+                if automask:
+                    outputs[("sel", scale)] = (sel[i], ident0.shape[1])
+            return
         for scale in self.opt.scales:
             src_s = scale if self.opt.v1_multiscale else 0
             target = inputs[("color", 0, src_s)]
@@ -589,8 +724,7 @@ class Trainer:
                 beam, self.photo_options, self.materialize_outputs, getattr(self, "_groups", 1))
             outputs[("photo", scale)] = (photo, si if beam is not None else None)
             if automask:
-                n_id = ident.shape[1]
-                outputs["identity_selection/{}".format(scale)] = (sel > n_id - 1).float()
+                outputs[("sel", scale)] = (sel, ident.shape[1])
             if self.materialize_outputs:
                 outputs[("depth", 0, scale)] = depth
                 for i, f in enumerate(fids):
@@ -598,6 +732,16 @@ class Trainer:
                     outputs[("color", f, scale)] = color[i]
                     if automask:
                         outputs[("color_identity", f, scale)] = inputs[("color", f, src_s)]
+
+    def _multiscale_loss_ok(self, fids):
+        """The fused all-scales kernel covers the default loss configuration (two source frames, SSIM, per-frame minimum, one
+        pose per frame shared by the scales, no materialised warps); every flag variant keeps the per-scale kernels."""
+        if os.environ.get("FD_PHOTO_MS", "1") == "0":
+            return False
+        o = self.opt
+        return (FD.photo_ms_supported(self.photo_options, len(fids), self.materialize_outputs) and not o.v1_multiscale
+                and o.pose_model_type != "posecnn" and 1 <= len(o.scales) <= 4
+                and all(o.height % (2 ** s) == 0 and o.width % (2 ** s) == 0 for s in o.scales))
 
     def compute_reprojection_loss(self, pred, target):
         """trainer.py:476-488 (stand-alone, differentiable w.r.t. ``pred`` through the SSIM kernel)."""
@@ -697,18 +841,75 @@ class Trainer:
             if model_name == "encoder":
                 to_save["height"], to_save["width"], to_save["use_stereo"] = self.opt.height, self.opt.width, self.opt.use_stereo
             torch.save(to_save, os.path.join(folder, "{}.pth".format(model_name)))
-        torch.save({"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu(), "step": self.adam_step_count,
-                    "lr": self.lr}, os.path.join(folder, "adam.pth"))
+        torch.save(self.optimizer_state_dict(), os.path.join(folder, "adam.pth"))
         return folder
 
+    def optimizer_state_dict(self):
+        """``torch.optim.Adam.state_dict()`` layout (what trainer.py:714-715 writes), so that ``adam.pth`` interchanges with the
+        reference: per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` in ``parameters_to_train`` order (the reference builds
+        that list in the same network order, trainer.py:66-129), one parameter group carrying the current learning rate."""
+        state = {}
+        step = torch.tensor(float(self.adam_step_count))
+        if self.adam_step_count > 0:
+            avg, sq = self.exp_avg.detach().cpu(), self.exp_avg_sq.detach().cpu()
+            for i, p in enumerate(self.flat.params):
+                o, n = self.flat.offsets[i], p.numel()
+                state[i] = {"step": step.clone(), "exp_avg": avg[o:o + n].view(p.shape).clone(),
+                            "exp_avg_sq": sq[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "initial_lr": self.learning_rate,
+                 "params": list(range(len(self.flat.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, st):
+        """Inverse of ``optimizer_state_dict``; also reads the flat layout round 1 of this package wrote.  Restores the moments,
+        the step count (bias correction) and the learning rate (StepLR decays already taken) on the host AND in the device-side
+        ``adam_state`` the Adam kernel reads."""
+        if "state" in st and "param_groups" in st:
+            n_params = len(self.flat.params)
+            groups = st["param_groups"]
+            listed = sum(len(g["params"]) for g in groups)
+            if listed != n_params:
+                raise RuntimeError("adam.pth holds %d parameters, this trainer has %d (different network set?)" % (listed, n_params))
+            steps = []
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            for i, entry in st["state"].items():
+                i = int(i)
+                p, o = self.flat.params[i], self.flat.offsets[i]
+                if tuple(entry["exp_avg"].shape) != tuple(p.shape):
+                    raise RuntimeError("adam.pth: moment %d has shape %s, parameter has %s" % (i, tuple(entry["exp_avg"].shape), tuple(p.shape)))
+                self.exp_avg[o:o + p.numel()].copy_(entry["exp_avg"].reshape(-1))
+                self.exp_avg_sq[o:o + p.numel()].copy_(entry["exp_avg_sq"].reshape(-1))
+                steps.append(int(float(entry["step"])))
+            if steps and min(steps) != max(steps):
+                raise RuntimeError("adam.pth: per-parameter step counts differ (%d..%d); the flat Adam kernel keeps one" % (min(steps), max(steps)))
+            self.adam_step_count = steps[0] if steps else 0
+            self.lr = float(groups[0]["lr"])
+        elif "exp_avg" in st:
+            if st["exp_avg"].numel() != self.exp_avg.numel():
+                raise RuntimeError("adam.pth: %d moments for %d parameters" % (st["exp_avg"].numel(), self.exp_avg.numel()))
+            self.exp_avg.copy_(st["exp_avg"]); self.exp_avg_sq.copy_(st["exp_avg_sq"])
+            self.adam_step_count = int(st["step"])
+            self.lr = float(st.get("lr", self.lr))
+        else:
+            raise RuntimeError("adam.pth: unknown layout (keys %s)" % sorted(st))
+        self.adam_state[0] = float(self.adam_step_count)
+        self.adam_state[1] = self.lr
+
     def load_model(self):
-        """trainer.py:717-746."""
+        """trainer.py:717-746: weights of ``models_to_load`` (+ the two LiDAR encoders when ``--beam_encoder``, :726-728) copied in
+        place into the flat parameter buffer, then the Adam state if ``adam.pth`` is there."""
         folder = os.path.expanduser(self.opt.train_load_weights_folder)
         assert os.path.isdir(folder), "Cannot find folder {}".format(folder)
-        for n in self.opt.models_to_load:
+        names = list(self.opt.models_to_load)
+        if self.opt.beam_encoder:
+            names += [n for n in ("beam_encoder", "beam_encoder_pose") if n not in names]
+        for n in names:
             if n not in self.models:
-                continue
+                raise KeyError("models_to_load: this trainer has no network %r (has %s)" % (n, sorted(self.models)))
             path = os.path.join(folder, "{}.pth".format(n))
+            if not os.path.isfile(path):
+                raise FileNotFoundError("models_to_load: %s is missing" % path)
             model_dict = self.models[n].state_dict()
             pretrained = torch.load(path, map_location="cpu")
             with torch.no_grad():
@@ -719,10 +920,9 @@ class Trainer:
         FD.refresh_weight_layouts()       # a captured step holds no per-conv re-layout launches: refresh the cached copies now
         adam = os.path.join(folder, "adam.pth")
         if os.path.isfile(adam):
-            st = torch.load(adam, map_location="cpu")
-            if "exp_avg" in st and st["exp_avg"].numel() == self.exp_avg.numel():
-                self.exp_avg.copy_(st["exp_avg"]); self.exp_avg_sq.copy_(st["exp_avg_sq"])
-                self.adam_step_count = int(st["step"])
+            self.load_optimizer_state_dict(torch.load(adam, map_location="cpu"))
+        elif self.verbose:
+            print("Cannot find Adam weights so Adam is randomly initialized")
 
     def save_opts(self):
         """trainer.py:683-692."""

@@ -83,6 +83,8 @@ def assert_mostly_close(actual, expected, rtol, atol, what="", max_bad_frac=1e-2
     bad = err > atol + rtol * np.abs(e)
     frac = bad.mean()
     agg = err.sum() / max(np.abs(e).sum(), 1e-30)
+    if os.environ.get("FD_TEST_VERBOSE"):
+        print("[mostly_close] %s: %.4f%% out of tolerance, aggregate rel-L1 %.3g" % (what, 100 * frac, agg))
     if frac > max_bad_frac or agg > agg_rtol:
         i = np.unravel_index(np.argmax(err), err.shape)
         raise AssertionError("%s: %.4f%% of elements out of tolerance (allowed %.4f%%), aggregate rel-L1 %.3g "

@@ -17,8 +17,9 @@ def main():
     from fusiondepth_amd.options import MonodepthOptions
     from fusiondepth_amd.trainer import Trainer
     out_path, mode = sys.argv[1], sys.argv[2]            # mode: "same" (both ranks see one batch) | "split"
-    rank, world, _ = dp.init_from_env()
-    torch.cuda.set_device(0)
+    rank, world, local_rank = dp.init_from_env()
+    backend = dist.get_backend()
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend == "nccl" else 0)
     H, W, B = 64, 96, 2
 
     def opts():
@@ -43,16 +44,18 @@ def main():
         b["_noise"] = [torch.randn(B, 2, H, W, device="cuda", generator=g) for _ in range(4)]
         return b
 
-    losses = []
+    losses, overlapped = [], 0
     for step in range(2):
         losses.append(float(tr.train_step([batch(step, rank)])["loss"]))
-        log("step %d done, loss %.6f" % (step, losses[-1]))
+        overlapped = tr.grad_sync.n_overlapped
+        log("step %d done, loss %.6f, %d of %d buckets overlapped" % (step, losses[-1], overlapped, len(tr.grad_sync.buckets)))
     p = tr.flat.flat_param.clone()
     s = p.clone()
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     replicas_equal = bool(torch.equal(s, p * world))      # world = 2: x + x == 2x exactly
     res = {"rank": rank, "same_init": same_init, "replicas_equal": replicas_equal, "losses": losses,
-           "finite": bool(torch.isfinite(p).all())}
+           "finite": bool(torch.isfinite(p).all()), "backend": backend, "buckets_overlapped": overlapped, "buckets": len(tr.grad_sync.buckets),
+           "param_checksum": float(p.double().sum()) + float((p.double() * p.double()).sum())}
     log("replica check done")
     if rank == 0:
         # single-process reference from the same initial state

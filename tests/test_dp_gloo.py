@@ -100,3 +100,70 @@ def test_flat_parameters_views_and_buckets():
     sync = dp.GradientSynchronizer(flat, 1)
     sync.arm()
     assert sync.finish() == 1.0
+
+
+class _InPlaceLinear(torch.autograd.Function):
+    """Stand-in for the HIP backward kernels: accumulates the weight gradient straight into ``w.grad`` (a view of the flat
+    buffer), returns no parameter gradient to autograd and reports completion through functional._grad_ready."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        from fusiondepth_amd import functional as FD
+        (x,) = ctx.saved_tensors
+        ctx.w.grad += gy.t() @ x
+        FD._grad_ready(ctx.w)
+        return gy @ ctx.w, None
+
+
+def _worker_direct(rank, world, port, out):
+    from fusiondepth_amd import dp
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dp.init_from_env(backend="gloo")
+    torch.manual_seed(5)
+    ws = [torch.nn.Parameter(torch.randn(16, 8) * 0.3), torch.nn.Parameter(torch.randn(16, 16) * 0.3),
+          torch.nn.Parameter(torch.randn(4, 16) * 0.3), torch.nn.Parameter(torch.randn(7, 3))]       # the last one is never used
+    flat = dp.FlatParameters(ws)
+    sync = dp.GradientSynchronizer(flat, world, bucket_bytes=1 << 30, segments=[1, 2, 1])   # segment boundaries cut the buckets
+    assert [b[2] for b in sync.buckets] == [1, 2, 1]
+    x = torch.randn(world, 5, 8, generator=torch.Generator().manual_seed(9))[rank]
+    sync.arm()
+    h = x
+    for w in ws[:3]:
+        h = torch.tanh(_InPlaceLinear.apply(h, w))
+    h.pow(2).mean().backward()
+    n_over = sync.n_overlapped
+    scale = sync.finish()
+    out[rank] = (flat.flat_grad.clone() * scale, n_over)
+    if rank == 0:                                           # single process over the concatenated shards
+        ref = [w.detach().clone().requires_grad_(True) for w in ws[:3]]
+        xs = torch.randn(world, 5, 8, generator=torch.Generator().manual_seed(9))
+        tot = 0
+        for r in range(world):
+            h = xs[r]
+            for w in ref:
+                h = torch.tanh(h @ w.t())
+            tot = tot + h.pow(2).mean()
+        (tot / world).backward()
+        out["ref"] = torch.cat([w.grad.reshape(-1) for w in ref])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_in_place_gradients_trigger_overlapped_buckets():
+    """The trainer's kernels accumulate parameter gradients in place, so autograd's hooks never fire: the buckets must leave
+    through functional.set_grad_ready_callback instead, one per segment, and the unused parameter's bucket at finish()."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_direct, args=(world, _free_port(), out), nprocs=world, join=True)
+    (g0, n0), (g1, n1) = out[0], out[1]
+    assert n0 == n1 == 2                                     # segments 1 and 2 went out during backward, the unused one at finish
+    assert torch.equal(g0, g1)
+    n = out["ref"].numel()
+    assert torch.allclose(g0[:n], out["ref"], rtol=1e-5, atol=1e-7) and float(g0[n:].abs().max()) == 0.0

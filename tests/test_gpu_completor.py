@@ -58,8 +58,11 @@ def test_completor_loss_path_vs_reference_golden(golden, tag, flags):
         got = grads[s].cpu().numpy()
         ref = g[key] if key in g else g[key + "@s97"]
         cmp_ = got if key in g else got.reshape(-1)[::97]
-        # argmin / clamp ties flip single pixels: per-entry tolerance for all but 1 %, aggregate L1 bound 1e-3
-        assert_mostly_close(cmp_, ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max(), what=key)
+        # argmin / clamp ties flip single pixels: per-entry tolerance for all but 1 % (2.5 % at the coarsest scale,
+        # where one entry collects 16x16 pixels), aggregate L1 bound 1e-3.  The golden is the reference's float32 run, which is
+        # itself 1.2 % / 9e-4 away from a float64 evaluation at this size (scripts/debug_ms64.py); the kernel is held to the
+        # float64 ground truth in test_gpu_losspath.py::test_loss_path_error_against_float64.
+        assert_mostly_close(cmp_, ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max(), what=key, max_bad_frac=2.5e-2 if s == 3 else 1e-2)
         if key + "@l2" in g:
             assert_close(np.sqrt((got.astype(np.float64) ** 2).sum()), g[key + "@l2"], rtol=2e-3, atol=0, what=key + " L2")
 

@@ -1,5 +1,7 @@
 """End-to-end GPU parity: the HIP-backed Trainer (networks + fused loss + flat Adam) against the CPU oracle
 harness on identical weights, inputs and tie-break noise (SURVEY.md §8d 'AbsRel parity' proxy (i))."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,6 +11,10 @@ from conftest import assert_close
 from oracle import trainer as OT
 
 pytestmark = pytest.mark.gpu
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
 
 
 def _opts(**over):
@@ -422,3 +428,69 @@ def test_training_trajectory_is_reproducible_across_runs():
         finals.append(tr.flat.flat_param.clone())
         del tr
     assert torch.equal(finals[0], finals[1]) and torch.equal(finals[0], finals[2])
+
+
+def test_train_loop_schedule(tmp_path):
+    """Trainer(opts).train() over an iterable of reference-schema batches (trainer.py:219-266): optimiser steps per epoch,
+    the batch counter, StepLR, the checkpoint cadence, the logging / validation cadence and resume from the written checkpoint."""
+    from fusiondepth_amd.trainer import Trainer
+    from fusiondepth_amd import synthetic
+    opt = _opts(height=64, width=96, batch_size=2, log_dir=str(tmp_path), num_epochs=2, save_frequency=1, log_frequency=2)
+    tr = Trainer(opt, verbose=False)
+    tr.opt.num_epochs = 2                                   # (derived: (8 * 17) // batch_size = 68 epochs, trainer.py:28)
+    tr.scheduler_step_size = 1                              # StepLR drops after every epoch
+    acc = tr.accumulate_step
+    batches = [synthetic.make_batch(tr.batch_size, 64, 96, seed=20 + i) for i in range(3 * acc)]
+    for b in batches:
+        b["depth_gt"] = (b["4beam"] * 100.0 + 1.0)
+    lr0 = tr.lr
+    calls = {"val": 0}
+    val_orig = tr.val
+
+    def counting_val(loader, save_best=True):
+        calls["val"] += 1
+        return val_orig(loader, save_best)
+    tr.val = counting_val
+    tr.train(batches, [batches[0]])
+    assert tr.adam_step_count == 2 * 3 and tr.step == 2 * 3 * acc
+    assert abs(tr.lr - lr0 * 1e-2) < 1e-12 * lr0 and abs(float(tr.adam_state[1]) - tr.lr) < 1e-9
+    models = tmp_path / "mdp" / "models"
+    assert sorted(p.name for p in models.iterdir() if p.name.startswith("weights_")) >= ["weights_0", "weights_1"]
+    import json
+    recs = [json.loads(l) for l in open(tmp_path / "mdp" / "train" / "scalars.jsonl")]
+    due = [(e, w) for e in range(2) for w in range(3)
+           if any(((w * acc + k) % 2 == 0 and (e * 3 + w) * acc + k < 2000) or ((e * 3 + w) * acc + k) % 2000 == 0 for k in range(acc))]
+    assert len(recs) == len(due) == calls["val"] and all(np.isfinite(r["loss"]) and "de/abs_rel" in r for r in recs)
+    assert os.path.isfile(tmp_path / "mdp" / "val" / "scalars.jsonl") and os.path.isfile(models / "opt.json")
+    # resume: moments, step count and the decayed learning rate come back, and the next step is the one the first run would take
+    opt2 = _opts(height=64, width=96, batch_size=2, log_dir=str(tmp_path / "resume"), train_load_weights_folder=str(models / "weights_1"))
+    tr2 = Trainer(opt2, verbose=False)
+    assert tr2.adam_step_count == tr.adam_step_count and abs(tr2.lr - tr.lr) < 1e-15 and float(tr2.adam_state[0]) == float(tr.adam_step_count)
+    assert torch.equal(tr2.flat.flat_param, tr.flat.flat_param) and torch.equal(tr2.exp_avg, tr.exp_avg)
+    mb = batches[:acc]
+    for b in mb:
+        b["_noise"] = [torch.zeros(tr.batch_size, 2, 64, 96, device="cuda") for _ in range(4)]
+    tr.set_train(); tr2.set_train()
+    la, lb = tr.train_step(mb), tr2.train_step(mb)
+    assert_close(float(lb["loss"]), float(la["loss"]), rtol=1e-6, atol=0, what="loss of the step after resume")
+    assert_close(cpu(tr2.flat.flat_param), cpu(tr.flat.flat_param), rtol=1e-5, atol=1e-8, what="parameters after the resumed step")
+
+
+def test_adam_checkpoint_is_the_reference_optimizer_layout(tmp_path):
+    """adam.pth must load into torch.optim.Adam over the same parameter list (trainer.py:714-715, 740-744) and back."""
+    from fusiondepth_amd.trainer import Trainer
+    from fusiondepth_amd import synthetic
+    tr = Trainer(_opts(height=64, width=96, log_dir=str(tmp_path)), verbose=False)
+    mb = [synthetic.make_batch(tr.batch_size, 64, 96, seed=7 + i) for i in range(tr.accumulate_step)]
+    tr.train_step(mb)
+    st = tr.optimizer_state_dict()
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in tr.parameters_to_train], tr.learning_rate)
+    ref_opt.load_state_dict(st)                                              # what the reference's load_model does
+    back = ref_opt.state_dict()
+    i = max(back["state"])
+    assert float(back["state"][i]["step"]) == 1.0 and back["param_groups"][0]["lr"] == tr.lr
+    tr.exp_avg.zero_(); tr.adam_step_count = 0; tr.adam_state[0] = 0.0
+    tr.load_optimizer_state_dict(back)
+    assert tr.adam_step_count == 1 and float(tr.adam_state[0]) == 1.0
+    o = tr.flat.offsets[i]
+    assert torch.equal(tr.exp_avg[o:o + tr.flat.params[i].numel()].cpu(), back["state"][i]["exp_avg"].reshape(-1).cpu())
