@@ -34,10 +34,21 @@ def _hms(t):
 
 
 class Outputs(dict):
-    """The reference's ``outputs`` dict.  ``"identity_selection/<s>"`` (trainer.py:564-565, a monitoring image) is derived
-    from the fused kernel's argmin index on first access instead of costing two element-wise launches per scale and step."""
+    """The reference's ``outputs`` dict.  Entries the fused loss kernel does not need to materialise are derived on first
+    access instead of costing launches every step: ``"identity_selection/<s>"`` (trainer.py:564-565, a monitoring image) from
+    the kernel's argmin index, ``("depth", 0, s)`` (trainer.py:434-438, read by compute_depth_losses) from ``("disp", s)``."""
+    depth_spec = None          # (height, width, min_depth, max_depth), set by the trainer
 
     def __missing__(self, key):
+        if isinstance(key, tuple) and len(key) == 3 and key[0] == "depth" and key[1] == 0 and self.depth_spec is not None:
+            disp = dict.get(self, ("disp", key[2]))
+            if disp is not None:
+                H, W, lo, hi = self.depth_spec
+                with torch.no_grad():
+                    up = FD.bilinear_upsample(disp.detach(), (H, W)) if tuple(disp.shape[2:]) != (H, W) else disp.detach()
+                    val = disp_to_depth(up, lo, hi)[1]
+                self[key] = val
+                return val
         if isinstance(key, str) and key.startswith("identity_selection/"):
             raw = dict.get(self, ("sel", int(key.split("/")[1])))
             if raw is not None:
@@ -527,6 +538,7 @@ class Trainer:
         else:
             outputs = self.models["depth"](features)
         outputs = Outputs(outputs)
+        outputs.depth_spec = (self.opt.height, self.opt.width, self.opt.min_depth, self.opt.max_depth)
         if self.use_pose_net and not val:
             outputs.update(self.predict_poses(inputs, features, pose_out))
         losses = {}

@@ -239,18 +239,21 @@ def _same_weights(mod_g, mod_o, seed):
                                                  (18, dict(num_input_images=2, beam_encoder=True), 4, 3, 32, 64),
                                                  (18, {}, 3, 2, 128, 192), (50, {}, 3, 2, 128, 192)])
 def test_resnet_encoder_fwd_bwd_vs_oracle(NW, layers, kw, cin, B, H, W):
-    """Train-mode BatchNorm over a handful of samples (layer4 sees B*2*3 values per channel here) amplifies fp32
-    rounding, so the fp32 CPU oracle itself is only accurate to ~1e-3 on the deepest gradients.  Ground truth
-    is therefore the oracle run in float64; the HIP result must be within 1e-4 relative, or within 10x the
-    fp32 oracle's own error (ATen's CPU BatchNorm accumulates in double, ours in fp32), whichever is larger."""
+    """Ground truth is the oracle run in float64.  Train-mode BatchNorm over a handful of samples (layer4 sees B*2*3 values per
+    channel here) amplifies fp32 rounding, so ANY float32 evaluation of the deepest gradients is only accurate to ~1e-3: the
+    yardstick per tensor is the error of two independent float32 evaluations of the same oracle graph - ATen on the CPU (whose
+    BatchNorm accumulates in double) and ATen / MIOpen on the GPU.  Every feature map and every parameter gradient of the HIP
+    encoder must be within 1e-4 (relative L1) of float64, or within 3x the worse of those two float32 errors FOR THAT TENSOR
+    (the two yardsticks themselves differ by up to 2.6x on single tensors of the ResNet-50 case; all errors are printed)."""
     enc_o = ON.ResnetEncoder(layers, False, **kw)
     enc_g = _same_weights(NW.ResnetEncoder(layers, False, **kw), enc_o, 21)
     import copy
     enc_d = copy.deepcopy(enc_o).double()
-    enc_o.train(), enc_g.train(), enc_d.train()
+    enc_a = copy.deepcopy(enc_o).cuda()                      # the oracle's torch graph on the GPU: a second fp32 yardstick
+    enc_o.train(), enc_g.train(), enc_d.train(), enc_a.train()
     rng = np.random.RandomState(17)
     x = torch.from_numpy(rng.rand(B, cin, H, W).astype(np.float32))
-    fo, fd_, fg = enc_o(x), enc_d(x.double()), enc_g(dev(x))
+    fo, fd_, fg, fa = enc_o(x), enc_d(x.double()), enc_g(dev(x)), enc_a(dev(x))
     cots = [torch.from_numpy(rng.randn(*f.shape).astype(np.float32)) for f in fo]
 
     def agg(a, b):
@@ -259,21 +262,21 @@ def test_resnet_encoder_fwd_bwd_vs_oracle(NW, layers, kw, cin, B, H, W):
 
     report, bad = [], []
     for i in range(5):
-        e_hip, e_cpu = agg(cpu(fg[i]), cpu(fd_[i])), agg(cpu(fo[i]), cpu(fd_[i]))
-        report.append(("feature%d" % i, e_hip, e_cpu))
+        report.append(("feature%d" % i, agg(cpu(fg[i]), cpu(fd_[i])), agg(cpu(fo[i]), cpu(fd_[i])), agg(cpu(fa[i]), cpu(fd_[i]))))
     keep = lambda m: [(n, p) for n, p in m.named_parameters() if ".fc." not in n]
     names = [n for n, _ in keep(enc_o)]
     want32 = torch.autograd.grad(sum((f * c).sum() for f, c in zip(fo, cots)), [p for _, p in keep(enc_o)])
     want64 = torch.autograd.grad(sum((f * c.double()).sum() for f, c in zip(fd_, cots)), [p for _, p in keep(enc_d)])
+    wantgpu = torch.autograd.grad(sum((f * dev(c)).sum() for f, c in zip(fa, cots)), [p for _, p in keep(enc_a)])
     got = torch.autograd.grad(sum((f * dev(c)).sum() for f, c in zip(fg, cots)), [p for _, p in keep(enc_g)])
-    for n, a, b32, b64 in zip(names, got, want32, want64):
-        report.append((n, agg(cpu(a), cpu(b64)), agg(cpu(b32), cpu(b64))))
-    cpu_worst = max(r[2] for r in report)      # how badly conditioned this net/batch is for ANY fp32 implementation
-    for n, e_hip, e_cpu in report:
-        if e_hip > max(1e-4, 10 * e_cpu, cpu_worst):
-            bad.append("%s: HIP err %.3g vs fp32-oracle err %.3g" % (n, e_hip, e_cpu))
+    for n, a, b32, bgpu, b64 in zip(names, got, want32, wantgpu, want64):
+        report.append((n, agg(cpu(a), cpu(b64)), agg(cpu(b32), cpu(b64)), agg(cpu(bgpu), cpu(b64))))
+    for n, e_hip, e_cpu, e_gpu in report:
+        if e_hip > max(1e-4, 3 * max(e_cpu, e_gpu)):
+            bad.append("%s: HIP err %.3g vs float32 oracle err %.3g (CPU) / %.3g (GPU)" % (n, e_hip, e_cpu, e_gpu))
     worst = max(report, key=lambda r: r[1])
-    print("worst: %s HIP %.3g (fp32 CPU oracle %.3g)" % worst)
+    print("worst: %s HIP %.3g (float32 oracle: CPU %.3g, GPU %.3g); %d of %d tensors above 1e-4" % (
+        worst + (sum(r[1] > 1e-4 for r in report), len(report))))
     assert not bad, "\n".join(bad[:20])
     sd_o, sd_g = enc_d.state_dict(), enc_g.state_dict()
     for k in sd_o:

@@ -12,18 +12,41 @@ pytestmark = pytest.mark.gpu
 
 
 def _make(B=1, H=192, W=640):
+    """The frozen stage-1 networks reach the Refiner the way the reference feeds them (refiner.py:56-60, 84-152): as a
+    ``Trainer.save_model`` folder (encoder.pth with the height / width / use_stereo extras) given by --refine_load_weights_folder;
+    ``refine2d_decoder.pth`` is there too (the resume case)."""
+    import tempfile
     from fusiondepth_amd.options import MonodepthOptions
     from fusiondepth_amd.refiner import Refiner
+    oopt = OR.default_opt(batch_size=B, height=H, width=W)
+    omodels = gin.refiner_models(OR.build_models(oopt, 0))
+    folder = tempfile.mkdtemp(prefix="fd_stage1_")
+    for k, m in omodels.items():
+        sd = {n: v.detach().clone() for n, v in m.state_dict().items()}
+        if k == "encoder":
+            sd.update(height=H, width=W, use_stereo=False)
+        torch.save(sd, "%s/%s.pth" % (folder, k))
     o = MonodepthOptions().parse(["--num_layers", "18", "--weights_init", "scratch", "--batch_size", str(B),
-                                  "--height", str(H), "--width", str(W)])
+                                  "--height", str(H), "--width", str(W), "--refine_load_weights_folder", folder])
     rf = Refiner(o, verbose=False)
     oopt = OR.default_opt(batch_size=B, height=H, width=W, learning_rate=o.learning_rate)
-    omodels = gin.refiner_models(OR.build_models(oopt, 0))
-    with torch.no_grad():
-        for k, m in omodels.items():
-            for name, t in rf.models[k].state_dict().items():
-                t.copy_(m.state_dict()[name])
+    for k, m in omodels.items():
+        for name, t in rf.models[k].state_dict().items():
+            assert torch.equal(t.cpu(), m.state_dict()[name]), "refine_load_weights_folder: %s.%s was not loaded" % (k, name)
     return rf, oopt, omodels
+
+
+def test_refiner_needs_its_stage1_folder(tmp_path):
+    from fusiondepth_amd.options import MonodepthOptions
+    from fusiondepth_amd.refiner import Refiner
+    o = MonodepthOptions().parse(["--num_layers", "18", "--height", "64", "--width", "96", "--refine_load_weights_folder",
+                                  str(tmp_path / "missing")])
+    with pytest.raises(AssertionError, match="Cannot find a folder"):
+        Refiner(o, verbose=False)
+    (tmp_path / "empty").mkdir()
+    o.refine_load_weights_folder = str(tmp_path / "empty")
+    with pytest.raises(FileNotFoundError):
+        Refiner(o, verbose=False)
 
 
 def test_refiner_step_vs_reference_golden(golden):
