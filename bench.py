@@ -150,7 +150,7 @@ def roofline_probes(args, tr, batch):
     return out
 
 
-def cpu_baseline(args, budget_s=90.0, warm=3, timed_steps=10):
+def cpu_baseline(args, budget_s=60.0, warm=3, timed_steps=10, threads=None):
     """Reference-equivalent CPU step (oracle = the restatement proven equal to the imported reference), bounded sample:
     BASELINE.json configs[0]: ResNet-18, 640x192, batch 2, fp32, on the host cores this process may use."""
     import numpy as np
@@ -159,11 +159,9 @@ def cpu_baseline(args, budget_s=90.0, warm=3, timed_steps=10):
     from oracle import trainer as OT
     from oracle import scatter as OS
     try:
-        cores = len(os.sched_getaffinity(0))
+        host = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, cores)                      # every core this process may run on (stated in the JSON)
-    torch.set_num_threads(cores)
+        host = os.cpu_count() or 1
     B, H, W = 2, args.height, args.width
     opt = OT.default_opt(height=H, width=W, batch_size=B, num_layers=args.num_layers)
     ot = OT.OracleTrainer(opt, seed=0)
@@ -173,19 +171,37 @@ def cpu_baseline(args, budget_s=90.0, warm=3, timed_steps=10):
     for f in (0, -1, 1):
         inp[("2channel", f, 0)] = torch.from_numpy(two)
     inp["2channel"] = torch.from_numpy(two)
-    times, t_start = [], time.time()
-    for i in range(warm + timed_steps):     # 3 warm-up + 10 timed steps (bounded by a wall-clock budget on slow hosts)
-        t0 = time.time()
-        ot.micro_step({k: v.clone() for k, v in inp.items()})
-        times.append(time.time() - t0)
-        if time.time() - t_start > budget_s and len(times) >= warm + 2:
-            break
-    timed = times[warm:]
+    def run(n_threads, n_warm, n_timed, budget):
+        torch.set_num_threads(n_threads)
+        times, t_start = [], time.time()
+        for i in range(n_warm + n_timed):
+            t0 = time.time()
+            ot.micro_step({k: v.clone() for k, v in inp.items()})
+            times.append(time.time() - t0)
+            if time.time() - t_start > budget and len(times) >= n_warm + 1:
+                break
+        return times[n_warm:]
+
+    # torch's CPU kernels do not scale to every logical core of a GPU host (measured on the 2 x 64-core / 256-thread box of this
+    # pool: 0.82 s per step on 32 threads, 2.0 s on 64, 6.3 s on 128, minutes on 256), so the baseline runs at the thread count
+    # that gives the reference path its BEST throughput, found by a short sweep, and reports that count as `cores`.
+    if threads is None:
+        cand = sorted({c for c in (8, 16, 32, 64) if c <= host} or {host})
+        sweep = {}
+        for c in cand:
+            sweep[c] = float(np.median(run(c, 1, 1, 20.0)))
+            if len(sweep) > 1 and sweep[c] > 1.5 * min(sweep.values()):
+                break                          # past the knee: more threads only get slower
+        threads = min(sweep, key=sweep.get)
+    else:
+        sweep = {}
+    timed = run(threads, warm, timed_steps, budget_s)
     step = float(np.median(timed))
-    return {"value": B / step, "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": B / step, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": "%d timed optimiser steps after %d warm-up steps of the oracle trainer (ResNet-%d, %dx%d, batch %d, fp32, "
-                      "torch CPU, %d threads); median %.2f s/step, min %.2f, max %.2f"
-                      % (len(timed), warm, args.num_layers, W, H, B, cores, step, min(timed), max(timed))}
+                      "torch CPU) on %d threads of a %d-thread host - the fastest of the sweep %s (s/step); median %.2f s/step, "
+                      "min %.2f, max %.2f" % (len(timed), warm, args.num_layers, W, H, B, threads, host,
+                                              {k: round(v, 2) for k, v in sweep.items()}, step, min(timed), max(timed))}
 
 
 def dp_probe(tr, step_fn, mbs, t_step, barrier, reps=3):

@@ -87,6 +87,7 @@ struct MsArgs {
     float lo, span;          // 1 / max_depth, 1 / min_depth - 1 / max_depth (host doubles -> float, as the reference's python floats)
     int Hs[4], Ws[4];
     int has_ident, want_grad;
+    int nx, ny;              // strips per image along x / y
     unsigned beam_mask;      // bit s: scale s carries the LiDAR term
     const float* disp[4];
     const float* noise[4];   // [B,2,H,W] each, or NULL
@@ -119,17 +120,25 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
     const int lane = threadIdx.x & 63;
     const int f = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int B = cfg.B, H = cfg.H, W = cfg.W;
-    const int s = blockIdx.z / B, b = blockIdx.z - s * B;
+    // 1-D grid, XCD-aware: workgroup L runs on XCD L % 8 (observed dispatch rule, used for speed only).  The S scales of one strip
+    // read the same target / source / identity rows, so they get consecutive slots of ONE XCD - L = 8 S q + 8 s + r is scale s of
+    // strip 8 q + r - and meet in that XCD's L2 instead of each missing to the fabric (FETCH_SIZE 2.4x -> see profiles/).
+    const int L = blockIdx.x;
+    const int q8 = L / (8 * a.S), r8 = L - q8 * (8 * a.S);
+    const int s = r8 >> 3, strip = q8 * 8 + (r8 & 7);
+    if (strip >= B * a.ny * a.nx) return;                    // padding of the last group of 8 strips (whole workgroup)
+    const int b = strip / (a.ny * a.nx);
+    const int by = (strip - b * a.ny * a.nx) / a.nx, bx = strip - (b * a.ny + by) * a.nx;
     const int P = H * W;
     const int Hs = a.Hs[s], Ws = a.Ws[s];
     const bool same = Hs == H && Ws == W;
-    const int y0s = blockIdx.y * a.R;
+    const int y0s = by * a.R;
     const int rows = min(a.R, H - y0s);
     const int n_iter = rows + 4;
     const bool has_beam = (a.beam_mask >> s) & 1u;
 
     // ---- per-lane invariants ----------------------------------------------------------------------------------------
-    const int xs = blockIdx.x * OW;
+    const int xs = bx * OW;
     const int cx = xs + lane - 2;
     const int gx = refl_clamp(cx, W);
     const bool colvalid = cx >= 0 && cx < W;
@@ -523,7 +532,7 @@ __global__ void __launch_bounds__(128, FD_MS_WAVES) k_photo_ms(MsArgs a) {
     }
 
     // ---- per-workgroup partial sums (fixed shuffle tree; combined in fixed order by k_photo_ms_fin) ----------------------------
-    const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const long blk = (((long)s * B + b) * a.ny + by) * a.nx + bx;
     if (f == 0) {
         const float t = fd_wave_sum(acc0);
         if (lane == 0) a.part[blk * 4 + 0] = t;
@@ -864,7 +873,8 @@ extern "C" int fd_photo_ms_fwd(const fd_photo_ms_cfg* c, const float* const* dis
     a.part = ws; a.gpart = ws + nblk * 4;
     float* gP1 = ws + nblk * 28;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(fd_cdiv(c->base.W, OW), fd_cdiv(c->base.H, a.R), c->base.B * c->n_scales);
+    a.nx = fd_cdiv(c->base.W, OW); a.ny = fd_cdiv(c->base.H, a.R);
+    dim3 grid(fd_cdiv((long)c->base.B * a.ny * a.nx, 8) * 8 * c->n_scales);
     if (ident && d1) hipLaunchKernelGGL((k_photo_ms<true, true>), grid, dim3(128), 0, st, a);
     else if (ident) hipLaunchKernelGGL((k_photo_ms<true, false>), grid, dim3(128), 0, st, a);
     else if (d1) hipLaunchKernelGGL((k_photo_ms<false, true>), grid, dim3(128), 0, st, a);
