@@ -153,8 +153,6 @@ class GradientSynchronizer:
             return
         self.launched[b] = True
         s, e, _ = self.buckets[b]
-        if os.environ.get("FD_DP_DEBUG_SYNC") == "1":
-            torch.cuda.synchronize()
         self.handles.append(dist.all_reduce(self.flat.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def arm(self):
