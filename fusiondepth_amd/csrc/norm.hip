@@ -7,6 +7,7 @@
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -245,6 +246,145 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x
     }
 }
 
+// ---- small planes (ResNet layer3 / layer4: a (group, channel) holds <= 4096 floats): statistics + apply in ONE launch ----------
+// One workgroup per channel; the N * HW / 4 float4 of a (group, channel) live in registers (<= SMALL_K per thread), so x is read
+// once instead of twice and the two launches of the large-plane path (5-8 us each at these sizes, launch-latency bound) become
+// one.  Groups are processed in order by the same workgroup, which makes the in-order running-statistics update and the
+// group-ordered parameter-gradient sums local.  Fixed reduction tree: deterministic.
+#ifndef FD_BN_SMALL_K
+#define FD_BN_SMALL_K 4
+#endif
+constexpr int SMALL_K = FD_BN_SMALL_K;
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {     // result broadcast to every thread
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    a = fd_wave_sum(a); b = fd_wave_sum(b);
+    __syncthreads();                                                               // previous readers of `red` are done
+    if (lane == 0) { red[wv * 2] = a; red[wv * 2 + 1] = b; }
+    __syncthreads();
+    a = (red[0] + red[2]) + (red[4] + red[6]);
+    b = (red[1] + red[3]) + (red[5] + red[7]);
+}
+
+__global__ void __launch_bounds__(NT) k_bn_train_small(const float* __restrict__ x, const float* __restrict__ weight,
+                                                       const float* __restrict__ bias, const float* __restrict__ residual,
+                                                       float* __restrict__ y, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                       float* __restrict__ save_invstd, int N, int C, int q, float eps,
+                                                       float momentum, int relu, int G) {
+    __shared__ float red[8];
+    __shared__ float gstat[16][2];
+    const int c = blockIdx.x, E = N * q;                 // float4 elements of one (group, channel)
+    const float M = (float)N * (float)(4 * q);
+    const float wc = weight ? weight[c] : 1.f, bc = bias ? bias[c] : 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float shift = x[((long)g * N * C + c) * 4 * q];
+        float4 v[SMALL_K];
+        long off[SMALL_K];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SMALL_K; ++k) {
+            const int e = threadIdx.x + k * NT;
+            off[k] = -1;
+            if (e < E) {
+                const int n = e / q, i = e - n * q;
+                off[k] = (((long)g * N + n) * C + c) * 4 * q + 4 * i;
+                v[k] = ld4(x + off[k]);
+                const float d0 = v[k].x - shift, d1 = v[k].y - shift, d2 = v[k].z - shift, d3 = v[k].w - shift;
+                s1 += (d0 + d1) + (d2 + d3);
+                s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+        block_sum2(s1, s2, red);
+        const float m = s1 / M;
+        const float mean = shift + m, var = fmaxf(s2 / M - m * m, 0.f);
+        const float invstd = 1.0f / sqrtf(var + eps);
+        if (threadIdx.x == 0) {
+            save_mean[g * C + c] = mean; save_invstd[g * C + c] = invstd;
+            gstat[g][0] = mean; gstat[g][1] = var;
+        }
+        const float a = invstd * wc, b = bc - mean * a;
+#pragma unroll
+        for (int k = 0; k < SMALL_K; ++k) {
+            if (off[k] < 0) continue;
+            float4 r = v[k];
+            r.x = r.x * a + b; r.y = r.y * a + b; r.z = r.z * a + b; r.w = r.w * a + b;
+            if (residual) { const float4 z = ld4(residual + off[k]); r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w; }
+            if (relu) { r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f; }
+            st4(y + off[k], r);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && running_mean) {              // the G momentum updates in group order, as G consecutive passes would
+        float rm = running_mean[c], rv = running_var[c];
+        for (int g = 0; g < G; ++g) {
+            const float unbiased = M > 1.f ? gstat[g][1] * (M / (M - 1.f)) : gstat[g][1];
+            rm = (1.f - momentum) * rm + momentum * gstat[g][0];
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        running_mean[c] = rm; running_var[c] = rv;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_bn_bwd_small(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ gy, const float* __restrict__ weight,
+                                                     const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                     float* __restrict__ gx, float* __restrict__ gweight, float* __restrict__ gbias,
+                                                     float* __restrict__ g_res, int N, int C, int q, int relu, int accumulate,
+                                                     int G) {
+    __shared__ float red[8];
+    const int c = blockIdx.x, E = N * q;
+    const float M = (float)N * (float)(4 * q);
+    const float wc = weight ? weight[c] : 1.f;
+    float t1 = 0.f, t2 = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const float mean = save_mean[g * C + c], invstd = save_invstd[g * C + c];
+        float4 d[SMALL_K], xh[SMALL_K];
+        long off[SMALL_K];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SMALL_K; ++k) {
+            const int e = threadIdx.x + k * NT;
+            off[k] = -1;
+            if (e < E) {
+                const int n = e / q, i = e - n * q;
+                off[k] = (((long)g * N + n) * C + c) * 4 * q + 4 * i;
+                d[k] = ld4(gy + off[k]);
+                if (relu) {
+                    const float4 yy = ld4(y + off[k]);
+                    d[k].x = yy.x > 0.f ? d[k].x : 0.f; d[k].y = yy.y > 0.f ? d[k].y : 0.f;
+                    d[k].z = yy.z > 0.f ? d[k].z : 0.f; d[k].w = yy.w > 0.f ? d[k].w : 0.f;
+                }
+                const float4 xx = ld4(x + off[k]);
+                xh[k].x = (xx.x - mean) * invstd; xh[k].y = (xx.y - mean) * invstd;
+                xh[k].z = (xx.z - mean) * invstd; xh[k].w = (xx.w - mean) * invstd;
+                s1 += (d[k].x + d[k].y) + (d[k].z + d[k].w);
+                s2 += (d[k].x * xh[k].x + d[k].y * xh[k].y) + (d[k].z * xh[k].z + d[k].w * xh[k].w);
+            }
+        }
+        block_sum2(s1, s2, red);
+        t1 += s1; t2 += s2;
+        const float kk = wc * invstd, m1 = s1 / M, m2 = s2 / M;
+#pragma unroll
+        for (int k = 0; k < SMALL_K; ++k) {
+            if (off[k] < 0) continue;
+            if (g_res) st4(g_res + off[k], d[k]);
+            float4 r;
+            r.x = kk * (d[k].x - m1 - xh[k].x * m2); r.y = kk * (d[k].y - m1 - xh[k].y * m2);
+            r.z = kk * (d[k].z - m1 - xh[k].z * m2); r.w = kk * (d[k].w - m1 - xh[k].w * m2);
+            st4(gx + off[k], r);
+        }
+    }
+    if (threadIdx.x == 0) {                              // parameter gradients: sum over the groups, in group order
+        if (gbias) gbias[c] = (accumulate ? gbias[c] : 0.f) + t1;
+        if (gweight) gweight[c] = (accumulate ? gweight[c] : 0.f) + t2;
+    }
+}
+
+inline bool bn_small(int Ng, long HW, int groups, bool vec) {
+    return vec && groups <= 16 && (long)Ng * (HW >> 2) <= (long)NT * SMALL_K && getenv("FD_BN_SMALL_OFF") == nullptr;
+}
+
 inline int plane_blocks(long HW) {
     long b = (HW + NT * 4 - 1) / (NT * 4);
     return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
@@ -268,6 +408,12 @@ extern "C" int fd_bn_train_fwd(const float* x, const float* weight, const float*
     const int Ng = N / groups;
     const int sp = bn_splits(Ng, C, HW, groups);
     const bool vec = bn_vec_ok(HW, x, y, residual, nullptr, nullptr);
+    if (bn_small(Ng, HW, groups, vec)) {
+        hipLaunchKernelGGL(k_bn_train_small, dim3(C), dim3(NT), 0, st, x, weight, bias, residual, y, running_mean, running_var,
+                           save_mean, save_invstd, Ng, C, (int)(HW >> 2), eps, momentum, relu, groups);
+        FD_LAUNCH_CHECK("fd_bn_train_fwd(small)");
+        return 0;
+    }
     auto stats = vec ? k_bn_stats<true> : k_bn_stats<false>;
     auto apply = vec ? k_bn_apply_train<true> : k_bn_apply_train<false>;
     hipLaunchKernelGGL(stats, dim3(C, sp, groups), dim3(NT), 0, st, x, ws, Ng, C, HW, sp);
@@ -302,6 +448,12 @@ extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, 
     const int Ng = N / groups;
     const int sp = bn_splits(Ng, C, HW, groups);
     const bool vec = bn_vec_ok(HW, x, y, gy, gx, g_residual);
+    if (bn_small(Ng, HW, groups, vec)) {
+        hipLaunchKernelGGL(k_bn_bwd_small, dim3(C), dim3(NT), 0, st, x, y, gy, weight, save_mean, save_invstd, gx, gweight, gbias,
+                           g_residual, Ng, C, (int)(HW >> 2), relu, accumulate, groups);
+        FD_LAUNCH_CHECK("fd_bn_train_bwd(small)");
+        return 0;
+    }
     auto reduce = vec ? k_bn_bwd_reduce<true> : k_bn_bwd_reduce<false>;
     auto apply = vec ? k_bn_bwd_apply<true> : k_bn_bwd_apply<false>;
     hipLaunchKernelGGL(reduce, dim3(C, sp, groups), dim3(NT), 0, st, x, y, gy, save_mean, save_invstd, ws, Ng, C, HW,
