@@ -7,6 +7,7 @@ torch ops on the data path.
 import ctypes
 
 import os
+import weakref
 
 import torch
 
@@ -557,8 +558,33 @@ def _conv_out_hw(d):
 # (``_WEIGHTS_EPOCH``, bumped by adam_step*), i.e. once per optimiser step instead of once per launch (the six ResNet
 # passes of the two micro-batches reuse the same weights).  Tensors that did not opt in are re-laid-out on every call.
 _WEIGHTS_EPOCH = [0]
-_WT_CACHE = {}
+_WT_CACHE = {}            # (cache id, kind) -> [stamp, layout buffer, conv descriptor, weakref(parameter)]
+_WT_RETIRED = []          # replaced layout buffers / job tables: a captured hipGraph may still hold their raw pointers
 _NEXT_CACHE_ID = [1]
+
+
+def _drop_plan():
+    if _WT_PLAN[0] is not None:
+        _WT_RETIRED.append(_WT_PLAN[0][0])
+        _WT_PLAN[0] = None
+
+
+def evict_dead_weight_layouts():
+    """Forget the layouts of parameters that no longer exist (a Trainer that was deleted): their buffers move to the retired
+    list instead of being freed at once, because a hipGraph captured by that Trainer may still reference them; returns the
+    number of entries dropped.  ``release_retired_layouts()`` frees the list once no such graph can be replayed any more."""
+    dead = [k for k, e in _WT_CACHE.items() if e[3]() is None]
+    for k in dead:
+        _WT_RETIRED.append(_WT_CACHE.pop(k)[1])
+    if dead:
+        _drop_plan()
+    return len(dead)
+
+
+def release_retired_layouts():
+    n = len(_WT_RETIRED)
+    _WT_RETIRED.clear()
+    return n
 
 
 def bump_weights_epoch():
@@ -666,10 +692,11 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
             return ent[1], 1
         ent[0] = stamp
         return ent[1], 0
+    if ent is not None:
+        _WT_RETIRED.append(ent[1])      # size changed (another input shape routed this weight to another kernel family)
     buf = torch.empty((nfloats,), device=w.device, dtype=torch.float32)
-    _WT_CACHE[key] = [stamp, buf, desc, w]
-    if _WT_PLAN[0] is not None:
-        _WT_PLAN[0] = None              # a layout the plan does not know: fall back to per-call re-layout until rebuilt
+    _WT_CACHE[key] = [stamp, buf, desc, weakref.ref(w)]
+    _drop_plan()                        # a layout the plan does not know: fall back to per-call re-layout until rebuilt
     return buf, 0
 
 
@@ -681,21 +708,23 @@ _WT_PLAN = [None]
 def build_weight_plan():
     """Collect the re-layout jobs of every cached weight layout into a device table; returns the number of jobs."""
     from ._lib import RelayoutJob
+    evict_dead_weight_layouts()
     ents = [(k, e) for k, e in _WT_CACHE.items() if len(e) >= 4 and e[2] is not None]
     if not ents:
-        _WT_PLAN[0] = None
+        _drop_plan()
         return 0
     jobs = (RelayoutJob * (4 * len(ents)))()
     n = 0
     for (cid, kind), e in ents:
-        n += query("fd_conv2d_relayout_jobs", ctypes.addressof(e[2]), 0 if kind == "f" else 1, ptr(e[3]), ptr(e[1]),
+        n += query("fd_conv2d_relayout_jobs", ctypes.addressof(e[2]), 0 if kind == "f" else 1, ptr(e[3]()), ptr(e[1]),
                    ctypes.addressof(jobs) + n * ctypes.sizeof(RelayoutJob))
     if n == 0:
-        _WT_PLAN[0] = None
+        _drop_plan()
         return 0
     blocks = query("fd_relayout_plan", ctypes.addressof(jobs), n)
     raw = bytes(memoryview(jobs))[: n * ctypes.sizeof(RelayoutJob)]
     dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(ents[0][1][1].device)
+    _drop_plan()
     _WT_PLAN[0] = (dev, n, blocks, [k for k, _ in ents])
     return n
 
@@ -709,7 +738,9 @@ def refresh_weight_layouts():
     call("fd_relayout_batch", ptr(dev), n, blocks, stream())
     for k in keys:
         e = _WT_CACHE[k]
-        e[0] = (e[3]._version, _WEIGHTS_EPOCH[0], e[3].data_ptr())
+        w = e[3]()
+        if w is not None:
+            e[0] = (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
     return True
 
 

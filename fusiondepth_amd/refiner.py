@@ -86,6 +86,7 @@ class Refiner(Trainer):
                     p.requires_grad_(False)          # frozen: no data gradient is propagated into them either
 
         self.flat = dp.FlatParameters(self.parameters_to_train)
+        FD.evict_dead_weight_layouts()
         FD.enable_weight_cache(self.parameters_to_train)
         FD.enable_direct_grad(self.parameters_to_train)
         self.exp_avg = torch.zeros_like(self.flat.flat_param)

@@ -136,6 +136,7 @@ class Trainer:
 
         # ---- optimiser (trainer.py:129-131): Adam + StepLR(gamma 0.1), on one flat buffer ----------------
         self.flat = dp.FlatParameters(self.parameters_to_train)
+        FD.evict_dead_weight_layouts()         # cached layouts / re-layout plan of trainers that no longer exist
         FD.enable_weight_cache(self.parameters_to_train)
         FD.enable_direct_grad(self.parameters_to_train)
         FD.enable_async_wgrad(os.environ.get("FD_ASYNC_WGRAD", "0") == "1")     # opt-in; measured slower

@@ -607,3 +607,27 @@ def test_twenty_step_trajectory_vs_oracle_fixture(golden):
     for k in traj:
         assert_close(np.asarray(traj[k])[:1], g["f32/" + k][:1], rtol=2e-4, atol=1e-6, what="step 0 " + k)
     assert tr.adam_step_count == 20
+
+
+def test_weight_layout_cache_forgets_dead_trainers():
+    """the process-global layout cache must not keep the layouts (and re-layout jobs) of a deleted Trainer alive
+    for ever, and must not free buffers a captured graph may still read: entries of dead parameters move to a retired list."""
+    import gc
+    from fusiondepth_amd import functional as FD, synthetic
+    from fusiondepth_amd.trainer import Trainer
+    FD.evict_dead_weight_layouts(); FD.release_retired_layouts()
+    tr = Trainer(_opts(), verbose=False)
+    mb = [synthetic.make_batch(tr.batch_size, 64, 96, seed=3 + i) for i in range(tr.accumulate_step)]
+    tr.train_step(mb); tr.train_step(mb)
+    ids = {p._fd_cache_id for p in tr.parameters_to_train if hasattr(p, "_fd_cache_id")}
+    mine = [k for k in FD._WT_CACHE if k[0] in ids]
+    assert len(mine) > 50 and FD._WT_PLAN[0] is not None
+    del tr, mb
+    gc.collect()
+    tr2 = Trainer(_opts(), verbose=False)                 # evicts on construction
+    assert not [k for k in FD._WT_CACHE if k[0] in ids], "layouts of the deleted trainer are still cached"
+    assert FD._WT_PLAN[0] is None and len(FD._WT_RETIRED) >= len(mine)
+    mb = [synthetic.make_batch(tr2.batch_size, 64, 96, seed=3 + i) for i in range(tr2.accumulate_step)]
+    losses = tr2.train_step(mb)
+    assert np.isfinite(float(losses["loss"]))
+    assert FD.release_retired_layouts() > 0
