@@ -71,6 +71,8 @@ SIGNATURES = {
     "fd_photo_fwd": ("p" * 16, "i"),
     "fd_photo_bwd_ws_floats": ("iii", "l"),
     "fd_photo_bwd": ("pppppppp" "i" "pppppp", "i"),
+    "fd_photo_fwd_ex": ("p" * 18, "i"),
+    "fd_photo_bwd_ex": ("ppppppppp" "i" "pppppp", "i"),
     "fd_photo_ms_ws_floats": ("p", "l"),
     "fd_photo_ms_fwd": ("p" * 14, "i"),
     "fd_photo_ms_bwd": ("p" * 11, "i"),

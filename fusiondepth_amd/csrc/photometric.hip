@@ -225,10 +225,12 @@ __device__ __forceinline__ void column_losses(const float* __restrict__ sx, cons
 struct PhotoArgs {
     fd_photo_cfg cfg;
     const float* disp; const float* inv_K; const float* P;
-    const float* src[2];
+    const float* src[3];
     const float* target; const float* ident; const float* noise; const float* beam;
+    const float* mask;       // [B,NF,H,W] multiplies the reprojection losses (trainer.py:530-541, --predictive_mask) or NULL
     uint8_t* sel;
     float* depth_out; float* sample_out; float* color_out;
+    float* reproj_out;       // [B,NF,H,W] the UNmasked reprojection losses (what d/d mask needs) or NULL
     float* ws;
 };
 
@@ -253,9 +255,9 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
         s_tgt[i] = t[0]; s_tgt[H1 * W1 + i] = t[P]; s_tgt[2 * H1 * W1 + i] = t[2 * P];
     }
 
-    float Lr[2][PPT];
+    float Lr[3][PPT];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int f = 0; f < 3; ++f) {
         if (f >= NF) {   // NF is workgroup-uniform, so the barriers below stay convergent
 #pragma unroll
             for (int i = 0; i < PPT; ++i) Lr[f][i] = 0.f;
@@ -293,6 +295,16 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
         }
         __syncthreads();
         column_losses<W1, 1, SSIM>(s_pred, s_tgt, H1 * W1, tx, ty, Lr[f]);
+        if (a.mask || a.reproj_out) {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const int y = y0t + ty * PPT + i, xx = x0t + tx;
+                if (y >= H || xx >= W) continue;
+                const long q = ((long)b * NF + f) * P + (long)y * W + xx;
+                if (a.reproj_out) a.reproj_out[q] = Lr[f][i];
+                if (a.mask) Lr[f][i] *= a.mask[q];
+            }
+        }
         __syncthreads();
     }
 
@@ -313,12 +325,12 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(PhotoArgs a) {
             if (a.noise) v += a.noise[((long)b * NI + k) * P + p] * 0.00001f;
             if (first || v < best) { best = v; bi = k; first = false; }
         }
-        if (cfg.avg_reprojection && NF == 2) {
-            const float v = (Lr[0][i] + Lr[1][i]) * 0.5f;
+        if (cfg.avg_reprojection && NF >= 2) {
+            const float v = NF == 2 ? (Lr[0][i] + Lr[1][i]) * 0.5f : div3(Lr[0][i] + Lr[1][i] + Lr[2][i]);
             if (first || v < best) { best = v; bi = NI; first = false; }
         } else {
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
+            for (int f = 0; f < 3; ++f) {
                 if (f >= NF) continue;
                 const float v = Lr[f][i];
                 if (first || v < best) { best = v; bi = NI + f; first = false; }
@@ -383,16 +395,17 @@ __global__ void k_photo_finalize2(float* __restrict__ out, int groups, float cou
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward.  ws layout: [nblk][24] gP partials, then [B,H,W] d(disp upsampled).
+// Backward.  ws layout: [nblk][36] gP partials (3 frames x 12), then [B,H,W] d(disp upsampled).
 struct PhotoBwdArgs {
     fd_photo_cfg cfg;
     const float* disp; const float* inv_K; const float* P;
-    const float* src[2];
+    const float* src[3];
     const float* target; const float* beam;
+    const float* mask;       // as in the forward, or NULL
     const uint8_t* sel;
     const float* stats; const float* g;
     float* d_up;      // [B,H,W]
-    float* part;      // [nblk][24]
+    float* part;      // [nblk][36]
     int has_ident;
 };
 
@@ -432,7 +445,8 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     __shared__ float s_pred[3 * H2 * W2];
     __shared__ float s_coef[3 * H1 * W1];
     __shared__ uint8_t s_sel[H1 * W1];
-    __shared__ float s_red[NWV * 24];
+    __shared__ float s_mask[H1 * W1];
+    __shared__ float s_red[NWV * 36];
     const fd_photo_cfg& cfg = a.cfg;
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
     const int x0t = blockIdx.x * TW, y0t = blockIdx.y * TH, b = blockIdx.z;
@@ -442,8 +456,8 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     const float* disp_b = a.disp + (long)b * cfg.Hs * cfg.Ws;
     const float g_photo = a.g[0] / ((float)cfg.B * (float)H * (float)W);   // d/d(min value) of the mean
     const int NI = a.has_ident ? (cfg.avg_reprojection ? 1 : NF) : 0;
-    const bool avg = cfg.avg_reprojection && NF == 2;
-    const float wfrm = avg ? 0.5f : 1.0f;
+    const bool avg = cfg.avg_reprojection && NF >= 2;
+    const float wfrm = avg ? (NF == 2 ? 0.5f : 1.0f / 3.0f) : 1.0f;
     const int x = x0t + tx;
 
     for (int i = tid; i < H2 * W2; i += NT) {
@@ -461,9 +475,9 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
     float d_depth[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) d_depth[i] = 0.f;
-    float gP0[12], gP1[12];
+    float gP0[12], gP1[12], gP2[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { gP0[i] = 0.f; gP1[i] = 0.f; }
+    for (int i = 0; i < 12; ++i) { gP0[i] = 0.f; gP1[i] = 0.f; gP2[i] = 0.f; }
 
     // d(loss)/d(pred channel c) for the 4 owned pixels; `c` is a compile-time constant so that every
     // register array below is statically indexed.
@@ -484,7 +498,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
                             const float xv = px[(hy + dy) * W2 + hx + dx], yv = py[(hy + dy) * W2 + hx + dx];
                             Sx += xv; Sy += yv; Sxx += xv * xv; Syy += yv * yv; Sxy += xv * yv;
                         }
-                    ssim_coefs(Sx, Sy, Sxx, Syy, Sxy, g_photo * wfrm * (0.85f / 3.0f), ca, cb, cc);
+                    ssim_coefs(Sx, Sy, Sxx, Syy, Sxy, g_photo * wfrm * (0.85f / 3.0f) * s_mask[i], ca, cb, cc);
                 }
                 s_coef[i] = ca; s_coef[H1 * W1 + i] = cb; s_coef[2 * H1 * W1 + i] = cc;
             }
@@ -524,7 +538,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
                 if (s_sel[(ty * PPT + i + 1) * W1 + tx + 1] == my_sel) {
                     const float df = yv - xv;  // |t - p|' w.r.t. p
                     const float sg = df > 0.f ? -1.f : (df < 0.f ? 1.f : 0.f);
-                    g += sg * g_photo * wfrm * ((SSIM ? 0.15f : 1.0f) / 3.0f);
+                    g += sg * g_photo * wfrm * ((SSIM ? 0.15f : 1.0f) / 3.0f) * s_mask[(ty * PPT + i + 1) * W1 + tx + 1];
                 }
             }
             dp[i] = g;
@@ -536,7 +550,12 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
         const float* Pf = a.P + ((long)b * NF + f) * 12;
         const float* src_b = a.src[f] + (long)b * 3 * P;
         const int my_sel = avg ? NI : NI + f;
-        __syncthreads();  // previous readers of s_pred are done; s_tgt / s_sel are complete
+        __syncthreads();  // previous readers of s_pred / s_mask are done; s_tgt / s_sel are complete
+        for (int i = tid; i < H1 * W1; i += NT) {
+            const int hy = i / W1, hx = i - hy * W1;
+            const int py = y0t - 1 + hy, px = x0t - 1 + hx;
+            s_mask[i] = (a.mask && py >= 0 && py < H && px >= 0 && px < W) ? a.mask[((long)b * NF + f) * P + (long)py * W + px] : 1.f;
+        }
 #pragma unroll
         for (int it = 0; it < (H2 * W2 + NT - 1) / NT; ++it) {
             const int i = tid + it * NT;
@@ -590,6 +609,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
 
     frame_pass(0, gP0);
     if (NF > 1) frame_pass(1, gP1);   // NF is workgroup-uniform
+    if (NF > 2) frame_pass(2, gP2);
 
     // SI-log term and conversion depth -> upsampled disparity
     const int grp = b / (cfg.B / cfg.groups);
@@ -616,32 +636,32 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(PhotoBwdArgs a) {
         }
         a.d_up[b * P + p] = -dd * depth * depth * cm.span;
     }
-    float gPa[24];
+    float gPa[36];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { gPa[i] = gP0[i]; gPa[12 + i] = gP1[i]; }
-    const float s = fd_block_sum_n<24, NWV>(gPa, s_red);
-    if (tid < 24) {
+    for (int i = 0; i < 12; ++i) { gPa[i] = gP0[i]; gPa[12 + i] = gP1[i]; gPa[24 + i] = gP2[i]; }
+    const float s = fd_block_sum_n<36, NWV>(gPa, s_red);
+    if (tid < 36) {
         const long blk = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        a.part[blk * 24 + tid] = s;
+        a.part[blk * 36 + tid] = s;
     }
 }
 
-// gP[b][f][12] = sum over the tiles of image b.  One workgroup per image: thread (g, k) sums every 10th tile for entry k,
-// then the 10 group partials are added in a fixed order (deterministic).
+// gP[b][f][12] = sum over the tiles of image b.  One workgroup per image: thread (g, k) sums every 7th tile for entry k,
+// then the 7 group partials are added in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) k_photo_bwd_fin(const float* __restrict__ part, float* __restrict__ gP, int tiles, int NF) {
-    __shared__ float red[10][24];
+    __shared__ float red[7][36];
     const int b = blockIdx.x, t = threadIdx.x;
-    const int k = t % 24, gidx = t / 24;
-    if (gidx < 10) {
+    const int k = t % 36, gidx = t / 36;
+    if (gidx < 7) {
         float s = 0.f;
-        for (int i = gidx; i < tiles; i += 10) s += part[((long)b * tiles + i) * 24 + k];
+        for (int i = gidx; i < tiles; i += 7) s += part[((long)b * tiles + i) * 36 + k];
         red[gidx][k] = s;
     }
     __syncthreads();
     if (t < NF * 12) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) s += red[j][t];
+        for (int j = 0; j < 7; ++j) s += red[j][t];
         gP[(long)b * NF * 12 + t] = s;
     }
 }
@@ -760,7 +780,7 @@ int check_cfg(const fd_photo_cfg* c, const char* who) {
     FD_REQUIRE(c, "%s: cfg is NULL", who);
     FD_REQUIRE(c->B > 0 && c->H >= 4 && c->W >= 4 && c->Hs > 0 && c->Ws > 0 && c->Hs <= c->H && c->Ws <= c->W,
                "%s: bad sizes B=%d H=%d W=%d Hs=%d Ws=%d", who, c->B, c->H, c->W, c->Hs, c->Ws);
-    FD_REQUIRE(c->NF == 1 || c->NF == 2, "%s: NF must be 1 or 2 (got %d)", who, c->NF);
+    FD_REQUIRE(c->NF >= 1 && c->NF <= 3, "%s: NF must be 1, 2 or 3 (got %d)", who, c->NF);
     FD_REQUIRE(c->groups >= 1 && c->groups <= 16 && c->B % c->groups == 0, "%s: batch %d not divisible into %d groups", who, c->B,
                c->groups);
     FD_REQUIRE(c->min_depth > 0 && c->max_depth > c->min_depth, "%s: bad depth range", who);
@@ -771,22 +791,23 @@ int check_cfg(const fd_photo_cfg* c, const char* who) {
 }  // namespace
 
 extern "C" long fd_photo_ws_floats(int B, int H, int W) { return tile_count(B, H, W) * 4; }
-extern "C" long fd_photo_bwd_ws_floats(int B, int H, int W) { return tile_count(B, H, W) * 24 + (long)B * H * W; }
+extern "C" long fd_photo_bwd_ws_floats(int B, int H, int W) { return tile_count(B, H, W) * 36 + (long)B * H * W; }
 
-extern "C" int fd_photo_fwd(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
-                            const float* const* src, const float* target, const float* ident, const float* noise,
-                            const float* beam, uint8_t* sel, float* depth_out, float* sample_out, float* color_out,
-                            float* ws, float* out, void* stream) {
+extern "C" int fd_photo_fwd_ex(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
+                               const float* const* src, const float* target, const float* ident, const float* noise,
+                               const float* beam, const float* mask, uint8_t* sel, float* depth_out, float* sample_out,
+                               float* color_out, float* reproj_out, float* ws, float* out, void* stream) {
     if (int rc = check_cfg(cfg, "fd_photo_fwd")) return rc;
     FD_REQUIRE(disp && inv_K && P && src && target && sel && ws && out, "fd_photo_fwd: NULL argument");
     FD_REQUIRE(!(noise && !ident), "fd_photo_fwd: noise without ident");
     PhotoArgs a;
     a.cfg = *cfg;
     a.disp = disp; a.inv_K = inv_K; a.P = P;
-    a.src[0] = src[0]; a.src[1] = cfg->NF > 1 ? src[1] : src[0];
-    FD_REQUIRE(a.src[0] && a.src[1], "fd_photo_fwd: NULL source image");
-    a.target = target; a.ident = ident; a.noise = noise; a.beam = beam;
-    a.sel = sel; a.depth_out = depth_out; a.sample_out = sample_out; a.color_out = color_out; a.ws = ws;
+    a.src[0] = src[0]; a.src[1] = cfg->NF > 1 ? src[1] : src[0]; a.src[2] = cfg->NF > 2 ? src[2] : src[0];
+    FD_REQUIRE(a.src[0] && a.src[1] && a.src[2], "fd_photo_fwd: NULL source image");
+    FD_REQUIRE(!(mask && ident), "fd_photo_fwd: the predictive mask replaces automasking (trainer.py:117-119); pass one of them");
+    a.target = target; a.ident = ident; a.noise = noise; a.beam = beam; a.mask = mask;
+    a.sel = sel; a.depth_out = depth_out; a.sample_out = sample_out; a.color_out = color_out; a.reproj_out = reproj_out; a.ws = ws;
     dim3 grid = tile_grid(cfg->B, cfg->H, cfg->W);
     hipStream_t st = (hipStream_t)stream;
     if (cfg->use_ssim) hipLaunchKernelGGL(k_photo_fwd<true>, grid, dim3(NT), 0, st, a);
@@ -801,26 +822,34 @@ extern "C" int fd_photo_fwd(const fd_photo_cfg* cfg, const float* disp, const fl
     return 0;
 }
 
+extern "C" int fd_photo_fwd(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
+                            const float* const* src, const float* target, const float* ident, const float* noise,
+                            const float* beam, uint8_t* sel, float* depth_out, float* sample_out, float* color_out,
+                            float* ws, float* out, void* stream) {
+    return fd_photo_fwd_ex(cfg, disp, inv_K, P, src, target, ident, noise, beam, nullptr, sel, depth_out, sample_out, color_out,
+                           nullptr, ws, out, stream);
+}
+
 // defined in geometry.hip
 extern "C" int fd_bilinear_up_bwd(const float*, float*, int, int, int, int, int, void*);
 
-extern "C" int fd_photo_bwd(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
-                            const float* const* src, const float* target, const float* beam, const uint8_t* sel,
-                            int has_ident, const float* stats, const float* g, float* d_disp, float* gP, float* ws,
-                            void* stream) {
+extern "C" int fd_photo_bwd_ex(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
+                               const float* const* src, const float* target, const float* beam, const float* mask,
+                               const uint8_t* sel, int has_ident, const float* stats, const float* g, float* d_disp, float* gP,
+                               float* ws, void* stream) {
     if (int rc = check_cfg(cfg, "fd_photo_bwd")) return rc;
     FD_REQUIRE(disp && inv_K && P && src && target && sel && stats && g && d_disp && gP && ws,
                "fd_photo_bwd: NULL argument");
     PhotoBwdArgs a;
     a.cfg = *cfg;
     a.disp = disp; a.inv_K = inv_K; a.P = P;
-    a.src[0] = src[0]; a.src[1] = cfg->NF > 1 ? src[1] : src[0];
-    FD_REQUIRE(a.src[0] && a.src[1], "fd_photo_bwd: NULL source image");
-    a.target = target; a.beam = beam; a.sel = sel; a.stats = stats; a.g = g;
+    a.src[0] = src[0]; a.src[1] = cfg->NF > 1 ? src[1] : src[0]; a.src[2] = cfg->NF > 2 ? src[2] : src[0];
+    FD_REQUIRE(a.src[0] && a.src[1] && a.src[2], "fd_photo_bwd: NULL source image");
+    a.target = target; a.beam = beam; a.mask = mask; a.sel = sel; a.stats = stats; a.g = g;
     const long ntile = tile_count(cfg->B, cfg->H, cfg->W);
     a.part = ws;
     const bool same = cfg->Hs == cfg->H && cfg->Ws == cfg->W;
-    a.d_up = same ? d_disp : ws + ntile * 24;
+    a.d_up = same ? d_disp : ws + ntile * 36;
     a.has_ident = has_ident;
     dim3 grid = tile_grid(cfg->B, cfg->H, cfg->W);
     hipStream_t st = (hipStream_t)stream;
@@ -831,6 +860,13 @@ extern "C" int fd_photo_bwd(const fd_photo_cfg* cfg, const float* disp, const fl
     FD_LAUNCH_CHECK("fd_photo_bwd_fin");
     if (!same) return fd_bilinear_up_bwd(a.d_up, d_disp, cfg->B, cfg->Hs, cfg->Ws, cfg->H, cfg->W, stream);
     return 0;
+}
+
+extern "C" int fd_photo_bwd(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
+                            const float* const* src, const float* target, const float* beam, const uint8_t* sel,
+                            int has_ident, const float* stats, const float* g, float* d_disp, float* gP, float* ws,
+                            void* stream) {
+    return fd_photo_bwd_ex(cfg, disp, inv_K, P, src, target, beam, nullptr, sel, has_ident, stats, g, d_disp, gP, ws, stream);
 }
 
 extern "C" int fd_reproj_loss_map(const float* pred, const float* target, float* out, long out_batch_stride, int B,

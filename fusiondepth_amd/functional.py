@@ -354,38 +354,42 @@ def _photo_cfg(po, B, H, W, Hs, Ws, NF, groups=1):
 
 
 class _PhotoLoss(torch.autograd.Function):
-    """One pyramid scale of generate_images_pred + the photometric / SI part of compute_losses.
+    """One pyramid scale of generate_images_pred + the photometric / SI part of compute_losses (one to three source frames,
+    optional predictive mask).
 
     Returns (to_optimise.mean(), si_loss, sel, depth, sample, color); the last four are
     non-differentiable by-products (``None`` unless requested)."""
 
     @staticmethod
-    def forward(ctx, disp, T0, T1, K, inv_K, src0, src1, target, ident, noise, beam, po, materialize, groups):
+    def forward(ctx, disp, T0, T1, T2, mask, K, inv_K, src0, src1, src2, target, ident, noise, beam, po, materialize, groups):
         disp, K, inv_K, target = f32(disp), f32(K), f32(inv_K), f32(target)
         _need_cuda(disp, K, inv_K, target, src0)
-        NF = 1 if src1 is None else 2
+        srcs = [f32(t) for t in (src0, src1, src2) if t is not None]
+        Ts = [f32(t) for t in (T0, T1, T2) if t is not None]
+        NF = len(srcs)
+        assert len(Ts) == NF
         B, _, Hs, Ws = disp.shape
         H, W = target.shape[2:]
-        srcs = [f32(src0)] + ([f32(src1)] if NF == 2 else [])
-        Ts = [f32(T0)] + ([f32(T1)] if NF == 2 else [])
         P = _empty((B, NF, 3, 4), disp)
         for f in range(NF):
             call("fd_proj_matrix_fwd", ptr(K), ptr(Ts[f]), P.data_ptr() + f * 48, NF * 12, B, stream())
         ident = f32(ident) if ident is not None else None
         noise = f32(noise) if noise is not None else None
         beam = f32(beam) if beam is not None else None
+        mask = f32(mask) if mask is not None else None
         cfg = _photo_cfg(po, B, H, W, Hs, Ws, NF, groups)
         sel = _empty((B, H, W), disp, torch.uint8)
         depth = _empty((B, 1, H, W), disp) if materialize else None
         sample = _empty((NF, B, H, W, 2), disp) if materialize else None
         color = _empty((NF, B, 3, H, W), disp) if materialize else None
+        reproj = _empty((B, NF, H, W), disp) if mask is not None else None
         ws = _empty((query("fd_photo_ws_floats", B, H, W),), disp)
         out = _empty((96,), disp)
-        src_arr = (ctypes.c_void_p * 2)(ptr(srcs[0]), ptr(srcs[-1]))
-        call("fd_photo_fwd", ctypes.addressof(cfg), ptr(disp), ptr(inv_K), ptr(P), ctypes.addressof(src_arr),
-             ptr(target), ptr(ident), ptr(noise), ptr(beam), ptr(sel), ptr(depth), ptr(sample), ptr(color), ptr(ws),
-             ptr(out), stream())
-        ctx.save_for_backward(disp, K, inv_K, P, target, beam, sel, out, *srcs)
+        src_arr = (ctypes.c_void_p * 3)(*[ptr(srcs[min(f, NF - 1)]) for f in range(3)])
+        call("fd_photo_fwd_ex", ctypes.addressof(cfg), ptr(disp), ptr(inv_K), ptr(P), ctypes.addressof(src_arr),
+             ptr(target), ptr(ident), ptr(noise), ptr(beam), ptr(mask), ptr(sel), ptr(depth), ptr(sample), ptr(color),
+             ptr(reproj), ptr(ws), ptr(out), stream())
+        ctx.save_for_backward(disp, K, inv_K, P, target, beam, sel, out, mask, reproj, *srcs)
         ctx.cfg, ctx.NF, ctx.has_ident = cfg, NF, int(ident is not None)
         ctx.mark_non_differentiable(sel)
         extras = [t for t in (depth, sample, color) if t is not None]
@@ -395,8 +399,8 @@ class _PhotoLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_photo, g_si, *_):
-        disp, K, inv_K, P, target, beam, sel, stats = ctx.saved_tensors[:8]
-        srcs = ctx.saved_tensors[8:]
+        disp, K, inv_K, P, target, beam, sel, stats, mask, reproj = ctx.saved_tensors[:10]
+        srcs = ctx.saved_tensors[10:]
         cfg, NF = ctx.cfg, ctx.NF
         B, H, W = cfg.B, cfg.H, cfg.W
         g = _empty((2,), disp)
@@ -405,30 +409,40 @@ class _PhotoLoss(torch.autograd.Function):
         d_disp = torch.empty_like(disp)
         gP = _empty((B, NF, 3, 4), disp)
         ws = _empty((query("fd_photo_bwd_ws_floats", B, H, W),), disp)
-        src_arr = (ctypes.c_void_p * 2)(ptr(srcs[0]), ptr(srcs[-1]))
-        call("fd_photo_bwd", ctypes.addressof(cfg), ptr(disp), ptr(inv_K), ptr(P), ctypes.addressof(src_arr),
-             ptr(target), ptr(beam), ptr(sel), ctx.has_ident, ptr(stats), ptr(g), ptr(d_disp), ptr(gP), ptr(ws),
+        src_arr = (ctypes.c_void_p * 3)(*[ptr(srcs[min(f, NF - 1)]) for f in range(3)])
+        call("fd_photo_bwd_ex", ctypes.addressof(cfg), ptr(disp), ptr(inv_K), ptr(P), ctypes.addressof(src_arr),
+             ptr(target), ptr(beam), ptr(mask), ptr(sel), ctx.has_ident, ptr(stats), ptr(g), ptr(d_disp), ptr(gP), ptr(ws),
              stream())
         gTs = []
-        for f in range(2):
+        for f in range(3):
             if f < NF and ctx.needs_input_grad[1 + f]:
                 gT = _empty((B, 4, 4), disp)
                 call("fd_proj_matrix_bwd", ptr(K), gP.data_ptr() + f * 48, NF * 12, ptr(gT), B, stream())
                 gTs.append(gT)
             else:
                 gTs.append(None)
-        return (d_disp, gTs[0], gTs[1]) + (None,) * 11
+        g_mask = None
+        if mask is not None and ctx.needs_input_grad[4]:
+            # d mean(min_f mask_f r_f) / d mask_f = r_f / (B H W) where frame f won (everywhere / NF with avg_reprojection)
+            if cfg.avg_reprojection and NF >= 2:
+                g_mask = reproj * (g[0] / float(B * H * W * NF))
+            else:
+                won = sel.unsqueeze(1) == torch.arange(NF, device=sel.device, dtype=sel.dtype).view(1, NF, 1, 1)
+                g_mask = reproj * won * (g[0] / float(B * H * W))
+        return (d_disp, gTs[0], gTs[1], gTs[2], g_mask) + (None,) * 12
 
 
 def photo_loss(disp, T_list, K, inv_K, src_list, target, ident=None, noise=None, beam=None, po=None,
-               materialize=False, groups=1):
-    """Fused per-scale loss.  T_list / src_list: one or two source frames.  ``groups``: the batch is that many stacked
-    micro-batches; the SI-log loss is evaluated per micro-batch and averaged."""
+               materialize=False, groups=1, mask=None):
+    """Fused per-scale loss.  T_list / src_list: one to three source frames.  ``groups``: the batch is that many stacked
+    micro-batches; the SI-log loss is evaluated per micro-batch and averaged.  ``mask`` [B,NF,H,W]: the predictive-mask
+    baseline (trainer.py:530-541; needs ``ident is None``)."""
     po = po or PhotoOptions()
-    T1 = T_list[1] if len(T_list) > 1 else None
-    s1 = src_list[1] if len(src_list) > 1 else None
-    return _PhotoLoss.apply(disp, T_list[0], T1, K, inv_K, src_list[0], s1, target, ident, noise, beam, po, materialize,
-                            int(groups))
+    assert 1 <= len(T_list) == len(src_list) <= 3
+    Ts = list(T_list) + [None] * (3 - len(T_list))
+    ss = list(src_list) + [None] * (3 - len(src_list))
+    return _PhotoLoss.apply(disp, Ts[0], Ts[1], Ts[2], mask, K, inv_K, ss[0], ss[1], ss[2], target, ident, noise, beam, po,
+                            materialize, int(groups))
 
 
 def photo_ms_supported(po, n_src, materialize=False):

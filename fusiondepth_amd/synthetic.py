@@ -61,7 +61,7 @@ def make_batch(batch, height=192, width=640, num_scales=4, frame_ids=(0, -1, 1),
     lo, hi = base.amin(), base.amax()
     base = (base - lo) / (hi - lo)
     for f in frame_ids:
-        off = 4 + 2 * f
+        off = 7 if f == "s" else 4 + 2 * f        # the stereo partner: a 3-pixel horizontal shift
         img = base[..., off:off + width] + 0.01 * torch.randn(batch, 3, height, width, device=device, generator=gen)
         img = img.clamp(0, 1).contiguous()
         for s in range(num_scales):
@@ -77,6 +77,11 @@ def make_batch(batch, height=192, width=640, num_scales=4, frame_ids=(0, -1, 1),
         if f == 0:
             inputs["4beam"] = beam
             inputs["2channel"] = two
+    if "s" in frame_ids:
+        # datasets/mono_dataset.py:216-222: a pure sideways translation of 0.1 (= the 54 cm baseline in the dataset's units)
+        T = torch.eye(4, device=device).repeat(batch, 1, 1)
+        T[:, 0, 3] = -0.1
+        inputs["stereo_T"] = T
     if with_depth_gt:
         inputs["depth_gt"] = torch.empty(batch, 1, 375, 1242, device=device).uniform_(1.0, 80.0, generator=gen)
     return inputs

@@ -100,16 +100,27 @@ class Trainer:
         assert self.opt.height % 32 == 0, "'height' must be a multiple of 32"                 # trainer.py:47-48
         assert self.opt.width % 32 == 0, "'width' must be a multiple of 32"
         assert self.opt.frame_ids[0] == 0, "frame_ids must start with 0"
-        if self.opt.use_stereo or self.opt.predictive_mask or self.opt.pose_model_type == "shared":
-            raise NotImplementedError("stereo / predictive_mask / shared pose encoder are ablations outside the hot path "
-                                      "(SURVEY.md §8); supported: separate_resnet and posecnn pose nets")
-        if self.opt.v1_multiscale and self._lidar_term()[0]:
-            raise NotImplementedError("--v1_multiscale together with the LiDAR SI loss is not supported by the fused kernel "
-                                      "(the SI term is evaluated at the sampling resolution); pass --trainer_siloss false")
         self.num_scales = len(self.opt.scales)
         self.num_input_frames = len(self.opt.frame_ids)
         self.num_pose_frames = 2 if self.opt.pose_model_input == "pairs" else self.num_input_frames
-        self.use_pose_net = True
+        self.use_pose_net = not (self.opt.use_stereo and self.opt.frame_ids == [0])          # trainer.py:61
+        if self.opt.use_stereo:
+            self.opt.frame_ids = list(self.opt.frame_ids) + ["s"]                            # trainer.py:63-64
+        shared = self.opt.pose_model_type == "shared"
+        if shared and self.use_pose_net and self.opt.beam_encoder and self.num_pose_frames == 2:
+            raise NotImplementedError(
+                "--pose_model_type shared with --pose_model_input pairs and the LiDAR encoders: the reference reads "
+                "`beam_pose_feats`, which only its non-shared branch defines (trainer.py:330-346), i.e. it stops with a NameError "
+                "- there is no behaviour to reproduce; pass --beam_encoder false")
+        if shared and self.opt.predictive_mask:
+            raise NotImplementedError("--pose_model_type shared with --predictive_mask: the reference hands the per-frame feature "
+                                      "DICT to the mask decoder (trainer.py:275-283, 305-306) and fails there")
+        if shared and (self.opt.cat_4beam_to_color or self.opt.cat2start):
+            raise NotImplementedError("--pose_model_type shared feeds color_aug alone to the depth encoder (trainer.py:275-283); "
+                                      "it cannot be combined with --cat_4beam_to_color / --cat2start (their stems have 4 / 5 inputs)")
+        if self.opt.predictive_mask:
+            assert self.opt.disable_automasking, \
+                "When using predictive_mask, please disable automasking with --disable_automasking"     # trainer.py:118-119
 
         # ---- networks (trainer.py:66-127) --------------------------------------------------------------
         pre = self.opt.weights_init == "pretrained"
@@ -122,11 +133,16 @@ class Trainer:
             m["beam_encoder_pose"] = networks.ResnetEncoder(pose_layers, pre, num_input_images=self.num_pose_frames,
                                                             beam_encoder=True)
         m["depth"] = networks.DepthDecoder(m["encoder"].num_ch_enc, self.opt.scales, cat2end=self.opt.cat2end)
-        if self.opt.pose_model_type == "separate_resnet":
+        if self.use_pose_net and self.opt.pose_model_type == "separate_resnet":
             m["pose_encoder"] = networks.ResnetEncoder(pose_layers, pre, num_input_images=self.num_pose_frames)
             m["pose"] = networks.PoseDecoder(m["pose_encoder"].num_ch_enc, num_input_features=1, num_frames_to_predict_for=2)
-        elif self.opt.pose_model_type == "posecnn":
+        elif self.use_pose_net and self.opt.pose_model_type == "shared":                      # trainer.py:106-108
+            m["pose"] = networks.PoseDecoder(m["encoder"].num_ch_enc, self.num_pose_frames)
+        elif self.use_pose_net and self.opt.pose_model_type == "posecnn":
             m["pose"] = networks.PoseCNN(self.num_input_frames if self.opt.pose_model_input == "all" else 2)
+        if self.opt.predictive_mask:                                                          # trainer.py:117-127
+            m["predictive_mask"] = networks.DepthDecoder(m["encoder"].num_ch_enc, self.opt.scales,
+                                                         num_output_channels=len(self.opt.frame_ids) - 1)
         self.models = {k: m[k].to(self.device) for k in MODEL_ORDER if k in m}
         if world_size > 1:
             dp.broadcast_module_state(self.models.values())
@@ -153,7 +169,10 @@ class Trainer:
         mode = os.environ.get("FD_PAIR", "0")
         self.pair_siblings = mode != "0"
         self._pair_depth, self._pair_pose = mode in ("1", "depth"), mode in ("1", "pose")
-        self.stack_microbatches = True
+        # the accumulated micro-batches run as one stacked pass where the step has the default shape (see train_step);
+        # the flag variants without a separate pose encoder per frame pair run them one after the other like the reference
+        self.stack_microbatches = (self.use_pose_net and self.opt.pose_model_type == "separate_resnet"
+                                   and self.num_pose_frames == 2)
         # opt-in (FD_INTERLEAVE=1): the four encoders issued block by block in turns instead of one after the other
         # (networks.interleaved_forward).  Throughput-neutral on this host (the GPU is saturated either way), so the
         # longer-tested sequential issue order stays the default.
@@ -491,7 +510,8 @@ class Trainer:
         for key, ipt in inputs.items():
             if key != "date" and key != "path" and torch.is_tensor(ipt) and ipt.device != self.device:
                 inputs[key] = ipt.to(self.device)
-        par = self.parallel_streams and not val and self.opt.pose_model_type == "separate_resnet" and self.num_pose_frames == 2
+        par = (self.parallel_streams and not val and self.use_pose_net and self.opt.pose_model_type == "separate_resnet"
+               and self.num_pose_frames == 2 and len(self._pose_fids()) > 0)
         if self.opt.cat_4beam_to_color:
             enc_in = torch.cat((inputs["color_aug", 0, 0], inputs["4beam"]), 1)
         elif self.opt.cat2start:
@@ -503,10 +523,35 @@ class Trainer:
         with FD.defer_bn_counters():
             return self._process_batch(inputs, val, groups, par, enc_in)
 
+    def _pose_fids(self):
+        """The source frames whose pose comes from the pose network: all but the stereo partner "s" (trainer.py:337, 382)."""
+        return [f for f in self.opt.frame_ids[1:] if f != "s"]
+
+    def _process_batch_shared(self, inputs, val):
+        """trainer.py:275-283: one depth-encoder pass over ALL frames (batch len(frame_ids) * B, one set of BatchNorm
+        statistics), split per frame; the depth decoder sees frame 0, the pose decoder the per-frame features."""
+        fids = self.opt.frame_ids
+        all_features = self.models["encoder"](torch.cat([inputs[("color_aug", i, 0)] for i in fids]))
+        B = inputs[("color_aug", 0, 0)].shape[0]
+        features = {k: [f[i * B:(i + 1) * B] for f in all_features] for i, k in enumerate(fids)}
+        outputs = Outputs(self.models["depth"](features[0]))
+        outputs.depth_spec = (self.opt.height, self.opt.width, self.opt.min_depth, self.opt.max_depth)
+        if self.use_pose_net and not val:
+            outputs.update(self.predict_poses(inputs, features))
+        losses = {}
+        if val:
+            self.generate_images_pred(inputs, outputs, [0])
+        else:
+            self.generate_images_pred(inputs, outputs, self.opt.frame_ids)
+            losses = self.compute_losses(inputs, outputs)
+        return outputs, losses
+
     def _process_batch(self, inputs, val, groups, par, enc_in):
         pose_out = None
         if groups > 1 and not par:
             raise NotImplementedError("stacked micro-batches need the separate_resnet pose path; set stack_microbatches=False")
+        if self.opt.pose_model_type == "shared":
+            return self._process_batch_shared(inputs, val)
         interleave = (par and self.interleave_encoders and self.opt.beam_encoder and not self.opt.cat2end and not self.pair_siblings)
         if par and not interleave:
             pose_out = self._launch_pose_encoders(inputs)          # side streams, joined in predict_poses
@@ -540,6 +585,8 @@ class Trainer:
             outputs = self.models["depth"](features)
         outputs = Outputs(outputs)
         outputs.depth_spec = (self.opt.height, self.opt.width, self.opt.min_depth, self.opt.max_depth)
+        if self.opt.predictive_mask:                                                          # trainer.py:305-306
+            outputs["predictive_mask"] = dict(self.models["predictive_mask"](features))
         if self.use_pose_net and not val:
             outputs.update(self.predict_poses(inputs, features, pose_out))
         losses = {}
@@ -557,7 +604,7 @@ class Trainer:
         axis and run as ONE pass of batch 2B with grouped BatchNorm (``FD.bn_groups(2)``): per-sample arithmetic, the
         per-pass batch statistics and the order of the running-statistics updates are those of the two separate passes,
         but every kernel sees twice the pixels (layer4: 1 440 instead of 720) and half the launches are issued."""
-        fids = self.opt.frame_ids[1:]
+        fids = self._pose_fids()
         G = self._groups
         stack = lambda key: self._stack_pose_inputs(inputs, key)
         res = {}
@@ -583,7 +630,7 @@ class Trainer:
     def _stack_pose_inputs(self, inputs, key):
         """The (source, target) frame pairs of all source frames stacked along the batch axis, in the reference's pass order:
         for each micro-batch g, for each source frame f  (trainer.py:237-248 + 336-351)."""
-        fids = self.opt.frame_ids[1:]
+        fids = self._pose_fids()
         orders = [(f, 0) if f < 0 else (0, f) for f in fids]
         G = self._groups
         Bg = inputs["color_aug", 0, 0].shape[0] // G
@@ -595,7 +642,7 @@ class Trainer:
     def _encoders_interleaved(self, inputs, enc_in, groups):
         """All four encoder modules of the step, each on its own stream, issued block by block in turns
         (networks.interleaved_forward) -> (features, beam_features, pose_out for predict_poses)."""
-        nf = len(self.opt.frame_ids[1:])
+        nf = len(self._pose_fids())
         st_rgb, st_beam, st_lidar = self._fork(1), self._fork(2), self._fork(0)
         with torch.cuda.stream(st_rgb):
             pose_in = self._stack_pose_inputs(inputs, "color_aug")
@@ -610,8 +657,12 @@ class Trainer:
         return features, beam_features, {"stacked": (pf, st_rgb, bf, st_beam)}
 
     def predict_poses(self, inputs, features, precomputed=None):
-        """trainer.py:321-388.  ``precomputed``: encoder features already launched on side streams."""
+        """trainer.py:321-388.  ``precomputed``: encoder features already launched on side streams.  The stereo partner "s"
+        has no predicted pose (trainer.py:337, 382); with ``--pose_model_type shared`` ``features`` maps frame id -> the depth
+        encoder's feature list of that frame (trainer.py:330-331, 376-377)."""
         outputs = {}
+        shared = self.opt.pose_model_type == "shared"
+        fids = self._pose_fids()
         if self.num_pose_frames == 2:
             stacked = None
             if precomputed is not None:
@@ -623,10 +674,10 @@ class Trainer:
                 else:
                     aa_all, tr_all = self.models["pose"]([pf])
                 stacked = (aa_all, tr_all)
-            for k, f_i in enumerate(self.opt.frame_ids[1:]):
+            for k, f_i in enumerate(fids):
                 order = (f_i, 0) if f_i < 0 else (0, f_i)                     # temporal order (trainer.py:338-346)
                 if stacked is not None:
-                    nf, G = len(self.opt.frame_ids[1:]), self._groups
+                    nf, G = len(fids), self._groups
                     Bq = stacked[0].shape[0] // (nf * G)                 # rows are ordered (micro-batch g, frame k, sample)
                     if G == 1:
                         axisangle, translation = stacked[0][k * Bq:(k + 1) * Bq], stacked[1][k * Bq:(k + 1) * Bq]
@@ -634,6 +685,8 @@ class Trainer:
                         sl = [slice((g * nf + k) * Bq, (g * nf + k + 1) * Bq) for g in range(G)]
                         axisangle = torch.cat([stacked[0][q] for q in sl], 0)
                         translation = torch.cat([stacked[1][q] for q in sl], 0)
+                elif shared:
+                    axisangle, translation = self.models["pose"]([features[i] for i in order])
                 else:
                     pose_inputs = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
                     if self.opt.pose_model_type == "separate_resnet":
@@ -649,14 +702,18 @@ class Trainer:
                 outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0],
                                                                                 invert=(f_i < 0))
         else:
-            pose_inputs = torch.cat([inputs[("color_aug", i, 0)] for i in self.opt.frame_ids], 1)
-            if self.opt.pose_model_type == "separate_resnet":
-                pose_inputs = [self.models["pose_encoder"](pose_inputs)]
+            if shared:
+                pose_inputs = [features[i] for i in self.opt.frame_ids if i != "s"]
+            else:
+                pose_inputs = torch.cat([inputs[("color_aug", i, 0)] for i in self.opt.frame_ids if i != "s"], 1)
+                if self.opt.pose_model_type == "separate_resnet":
+                    pose_inputs = [self.models["pose_encoder"](pose_inputs)]
             axisangle, translation = self.models["pose"](pose_inputs)
             for i, f_i in enumerate(self.opt.frame_ids[1:]):
-                outputs[("axisangle", 0, f_i)] = axisangle
-                outputs[("translation", 0, f_i)] = translation
-                outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(axisangle[:, i], translation[:, i])
+                if f_i != "s":
+                    outputs[("axisangle", 0, f_i)] = axisangle
+                    outputs[("translation", 0, f_i)] = translation
+                    outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(axisangle[:, i], translation[:, i])
         return outputs
 
     # ------------------------------------------------------------------------------------------------
@@ -709,6 +766,7 @@ class Trainer:
                 if automask:
                     outputs[("sel", scale)] = (sel[i], ident0.shape[1])
             return
+        pose_of = lambda f: inputs["stereo_T"] if f == "s" else outputs[("cam_T_cam", 0, f)]     # trainer.py:444-447
         for scale in self.opt.scales:
             src_s = scale if self.opt.v1_multiscale else 0
             target = inputs[("color", 0, src_s)]
@@ -726,15 +784,36 @@ class Trainer:
                     disp_up = FD.bilinear_upsample(disp_up, (self.opt.height, self.opt.width))
                 inv_depth = disp_to_depth(disp_up, self.opt.min_depth, self.opt.max_depth)[0]       # 1 / depth
                 mean_inv_depth = FD.spatial_mean(inv_depth, 1.0)                                       # [B,1]
-                Ts = [transformation_from_parameters(outputs[("axisangle", 0, f)][:, 0],
+                Ts = [inputs["stereo_T"] if f == "s" else
+                      transformation_from_parameters(outputs[("axisangle", 0, f)][:, 0],
                                                      outputs[("translation", 0, f)][:, 0] * mean_inv_depth[:, None, :],
                                                      f < 0) for f in fids]
             else:
-                Ts = [outputs[("cam_T_cam", 0, f)] for f in fids]
+                Ts = [pose_of(f) for f in fids]
+            Ts = [T if T.shape[0] == target.shape[0] else T.expand(target.shape[0], 4, 4).contiguous() for T in Ts]
             srcs = [inputs[("color", f, src_s)] for f in fids]
+            mask = weighting = None
+            if self.opt.predictive_mask and not automask:
+                # trainer.py:530-541: the reprojection losses are multiplied by the predicted per-frame mask, and a
+                # 0.2 * BCE(mask, 1) term keeps the mask from collapsing to 0
+                mask = outputs["predictive_mask"][("disp", scale)]
+                if not self.opt.v1_multiscale:
+                    mask = FD.bilinear_upsample(mask, (self.opt.height, self.opt.width))
+                weighting = 0.2 * (-torch.clamp(torch.log(mask), min=-100.0)).mean()      # nn.BCELoss()(mask, ones)
             photo, si, sel, depth, sample, color = FD.photo_loss(
                 outputs[("disp", scale)], Ts, inputs[("K", src_s)], inputs[("inv_K", src_s)], srcs, target, ident, noise,
-                beam, self.photo_options, self.materialize_outputs, getattr(self, "_groups", 1))
+                beam, self.photo_options, self.materialize_outputs, getattr(self, "_groups", 1), mask=mask)
+            if weighting is not None:
+                photo = photo + weighting
+            if scale in si_scales and src_s != 0:
+                # --v1_multiscale: the photometric terms live at the scale's own resolution, the LiDAR term at full resolution
+                # (trainer.py:577-589 upsamples disp before it).  A second pass of the kernel at full resolution supplies it;
+                # only its LiDAR output is used, so its photometric inputs are placeholders.
+                f0 = fids[0]
+                si = FD.photo_loss(outputs[("disp", scale)], [Ts[0]], inputs[("K", 0)], inputs[("inv_K", 0)],
+                                   [inputs[("color", f0, 0)]], inputs[("color", 0, 0)], None, None, inputs["4beam"],
+                                   self.photo_options, False, getattr(self, "_groups", 1))[1]
+                beam = inputs["4beam"]
             outputs[("photo", scale)] = (photo, si if beam is not None else None)
             if automask:
                 outputs[("sel", scale)] = (sel, ident.shape[1])
@@ -753,7 +832,7 @@ class Trainer:
             return False
         o = self.opt
         return (FD.photo_ms_supported(self.photo_options, len(fids), self.materialize_outputs) and not o.v1_multiscale
-                and o.pose_model_type != "posecnn" and 1 <= len(o.scales) <= 4
+                and o.pose_model_type != "posecnn" and not o.predictive_mask and "s" not in fids and 1 <= len(o.scales) <= 4
                 and all(o.height % (2 ** s) == 0 and o.width % (2 ** s) == 0 for s in o.scales))
 
     def compute_reprojection_loss(self, pred, target):

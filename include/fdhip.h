@@ -137,6 +137,21 @@ long fd_photo_bwd_ws_floats(int B, int H, int W);
 int fd_photo_bwd(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
                  const float* const* src, const float* target, const float* beam, const uint8_t* sel, int has_ident,
                  const float* stats, const float* g, float* d_disp, float* gP, float* ws, void* stream);
+/* The same pair with the remaining flag variants of trainer.py:425-567: up to THREE source frames (--use_stereo adds the
+ * stereo partner "s" to frames -1 / +1, trainer.py:436-439) and the predictive-mask baseline (--predictive_mask,
+ * trainer.py:117-127, 530-541).
+ *   mask        [B,NF,H,W] or NULL: the reprojection loss of frame f is multiplied by mask[:, f] before the minimum /
+ *               average (the mask replaces automasking: `ident` must be NULL when it is given)
+ *   reproj_out  [B,NF,H,W] or NULL: the UNmasked reprojection losses; d out[0] / d mask[:, f] = reproj_out[:, f] / (B H W)
+ *               where frame f was selected (`sel`), or / NF everywhere with avg_reprojection - the caller forms it.
+ * fd_photo_fwd / fd_photo_bwd are these with mask = reproj_out = NULL. */
+int fd_photo_fwd_ex(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
+                    const float* const* src, const float* target, const float* ident, const float* noise,
+                    const float* beam, const float* mask, uint8_t* sel, float* depth_out, float* sample_out,
+                    float* color_out, float* reproj_out, float* ws, float* out, void* stream);
+int fd_photo_bwd_ex(const fd_photo_cfg* cfg, const float* disp, const float* inv_K, const float* P,
+                    const float* const* src, const float* target, const float* beam, const float* mask, const uint8_t* sel,
+                    int has_ident, const float* stats, const float* g, float* d_disp, float* gP, float* ws, void* stream);
 
 /* ---- all pyramid scales in one launch, value + unit-cotangent gradient in the same pass ------------------------------
  * Replaces the per-scale loop of trainer.py:425-474 (generate_images_pred) + trainer.py:509-567, 577-589 (compute_losses)

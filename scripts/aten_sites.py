@@ -8,7 +8,7 @@ from fusiondepth_amd import synthetic
 from fusiondepth_amd.options import MonodepthOptions
 from fusiondepth_amd.trainer import Trainer
 
-opt = MonodepthOptions().parse(["--batch_size", "12", "--height", "192", "--width", "640"])
+opt = MonodepthOptions().parse(["--batch_size", "12", "--height", "192", "--width", "640", "--weights_init", "scratch"])
 tr = Trainer(opt, verbose=False)
 mbs = [synthetic.make_batch(tr.batch_size, 192, 640, seed=1234 + i) for i in range(tr.accumulate_step)]
 inp = tr.stack_micro_batches(mbs)

@@ -275,6 +275,74 @@ def test_fused_photo_loss_vs_oracle(FD, seed, B, H, W, over):
         assert_close(got[4 + i], want[4 + i], rtol=1e-3, atol=(3e-2 if flips else 1e-4) * sc, what="d loss / d T f%d" % f)
 
 
+@pytest.mark.parametrize("avg,ssim", [(False, True), (True, True), (False, False)])
+def test_three_source_frames_and_predictive_mask_vs_oracle(FD, avg, ssim):
+    """fd_photo_fwd_ex / fd_photo_bwd_ex: frames -1, +1 and the stereo partner "s" (trainer.py:61-64, 444-447) with the
+    predictive-mask weighting of the reprojection losses (trainer.py:530-541): value, d/d disp, d/d pose of all three frames and
+    d/d mask against the oracle's autograd."""
+    import torch.nn.functional as F
+    B, H, W, seed = 2, 64, 96, 909
+    opt = OT.default_opt(height=H, width=W, disable_automasking=True, avg_reprojection=avg, no_ssim=not ssim, use_stereo=True)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    shifted = torch.roll(inp[("color", 1, 0)], 2, dims=3) * 0.97 + 0.01
+    for s in range(4):
+        inp[("color", "s", s)] = shifted if s == 0 else F.avg_pool2d(shifted, 2 ** s)
+    disp0 = gin.disp_pyramid(rng, B, H, W)
+    fids = [-1, 1, "s"]
+    poses = {f: gin.small_poses(rng, B) for f in fids}
+    T0 = {f: OL.transformation_from_parameters(*poses[f], invert=(f == -1)) for f in fids}
+    masks0 = {s: torch.from_numpy(rng.uniform(0.15, 0.95, size=(B, 3, H >> s, W >> s)).astype(np.float32)) for s in range(4)}
+    # oracle
+    d_o = {s: disp0[("disp", s)].clone().requires_grad_(True) for s in range(4)}
+    T_o = {f: T0[f].clone().requires_grad_(True) for f in fids}
+    m_o = {s: masks0[s].clone().requires_grad_(True) for s in range(4)}
+    oin = dict(inp)
+    oin["stereo_T"] = T_o["s"]
+    outs = {("disp", s): d_o[s] for s in range(4)}
+    for f in (-1, 1):
+        outs[("cam_T_cam", 0, f)] = T_o[f]
+    OT.generate_images_pred(opt, oin, outs)
+    tot_o, vals_o, idx_o = 0, [], []
+    for s in range(4):
+        reproj = torch.cat([OT.reprojection_loss(opt, outs[("color", f, s)], inp[("color", 0, 0)]) for f in fids], 1)
+        reproj = reproj * F.interpolate(m_o[s], [H, W], mode="bilinear", align_corners=False)
+        if avg:
+            v, idx = reproj.mean(1), None
+        else:
+            v, idx = torch.min(reproj, dim=1)
+        vals_o.append(v.mean()); idx_o.append(idx)
+        tot_o = tot_o + (1.0 + 0.25 * s) * vals_o[-1]
+    leaves_o = [d_o[s] for s in range(4)] + [T_o[f] for f in fids] + [m_o[s] for s in range(4)]
+    want = grads(tot_o, leaves_o)
+    # HIP
+    po = FD.PhotoOptions(opt.min_depth, opt.max_depth, opt.no_ssim, opt.avg_reprojection, opt.gdc_loss_threshold, opt.si_var)
+    d_g = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
+    T_g = {f: dev(T0[f]).requires_grad_(True) for f in fids}
+    m_g = {s: dev(masks0[s]).requires_grad_(True) for s in range(4)}
+    target, srcs = dev(inp[("color", 0, 0)]), [dev(inp[("color", f, 0)]) for f in fids]
+    K, inv_K = dev(inp[("K", 0)]), dev(inp[("inv_K", 0)])
+    tot_g, flips = 0, 0
+    for s in range(4):
+        mask_up = FD.bilinear_upsample(m_g[s], (H, W)) if s else m_g[s]
+        photo, si, sel, *_ = FD.photo_loss(d_g[s], [T_g[f] for f in fids], K, inv_K, srcs, target, None, None, None, po, False, 1,
+                                           mask=mask_up)
+        assert_close(cpu(photo), cpu(vals_o[s]), rtol=1e-4, atol=1e-7, what="masked 3-frame loss s%d" % s)
+        if not avg:
+            diff = cpu(sel).astype(np.int64) != cpu(idx_o[s])
+            flips += int(diff.sum())
+            assert diff.mean() <= 3e-4, "argmin differs on %.4f%% of pixels at scale %d" % (100 * diff.mean(), s)
+        tot_g = tot_g + (1.0 + 0.25 * s) * photo
+    got = grads(tot_g, [d_g[s] for s in range(4)] + [T_g[f] for f in fids] + [m_g[s] for s in range(4)])
+    for s in range(4):
+        sc = np.abs(want[s]).max()
+        assert_mostly_close(got[s], want[s], rtol=2e-3, atol=2e-4 * sc, what="d loss / d disp s%d (3 frames, mask)" % s)
+        sc = np.abs(want[7 + s]).max()
+        assert_mostly_close(got[7 + s], want[7 + s], rtol=2e-3, atol=2e-4 * sc, what="d loss / d mask s%d" % s)
+    for i, f in enumerate(fids):
+        sc = np.abs(want[4 + i]).max()
+        assert_close(got[4 + i], want[4 + i], rtol=1e-3, atol=(3e-2 if flips else 1e-4) * sc, what="d loss / d T frame %s" % f)
+
+
 def test_fused_photo_loss_vs_reference_golden(FD, golden):
     """Same inputs as tests/golden/make_golden.py::gold_losses -> compare with what the REFERENCE produced."""
     g = golden("losses_b2_64x96")
