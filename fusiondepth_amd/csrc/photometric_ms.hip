@@ -831,7 +831,7 @@ int check_ms(const fd_photo_ms_cfg* c, const char* who) {
 }
 
 inline int ms_rows(const fd_photo_ms_cfg* c) {
-    int R = c->rows_per_strip > 0 ? c->rows_per_strip : 32;     // measured at 192x640, batch 12: 24..64 within 2 %, 96 +25 %
+    int R = c->rows_per_strip > 0 ? c->rows_per_strip : 40;     // measured at 192x640, batch 12 (scripts/ms_occupancy_sweep.sh): 16: 290 us, 32: 272, 40: 266, 48: 283, 64: 279, 96: 338
     return R > c->base.H ? c->base.H : R;
 }
 inline long ms_blocks_per_image(const fd_photo_ms_cfg* c) {
