@@ -95,7 +95,7 @@ class Refiner(Trainer):
         self.lr = self.learning_rate
         self.adam_state = torch.tensor([0.0, self.lr], device=self.device)
         self._graph, self._streams = None, []
-        self.parallel_streams = False
+        self.parallel_streams = os.environ.get("FD_REFINER_STREAMS", "1") != "0"
         self.pair_siblings = self._pair_depth = self._pair_pose = False
         self.stack_microbatches = False
         self._groups = 1
@@ -158,7 +158,12 @@ class Refiner(Trainer):
         crop = torch.zeros_like(mask)
         crop[:, :, 78:190, 23:617] = 1
         mask = mask * crop
-        beam_med = torch.median(beam[mask] * 100.0)
+        # torch.median(x[mask]) without the host round trip of boolean indexing (its output size has to be read back, which
+        # drains the launch queue once per call, five times a step): masked-out entries become NaN and nanmedian - the same
+        # lower median over the remaining values - skips them
+        nan = torch.full((), float("nan"), device=beam.device)
+        masked_median = lambda x: torch.nanmedian(torch.where(mask, x, nan))
+        beam_med = masked_median(beam * 100.0)
         for scale in opt.scales:
             if opt.refine_a0 != "true":
                 disp = outputs[("disp", scale)]
@@ -167,7 +172,7 @@ class Refiner(Trainer):
                 disp_0 = F.max_pool2d(disp_0, 2, ceil_mode=True)
             disp640 = FD.bilinear_upsample(disp, (opt.height, opt.width)) if disp.shape[2] != opt.height else disp
             depth = disp_to_depth(disp640, opt.min_depth, opt.max_depth)[1]
-            depth = depth * (beam_med / torch.median(depth[mask]))
+            depth = depth * (beam_med / masked_median(depth))
             scaled_disp = (F.interpolate(1 / depth, disp.shape[2:], mode="bilinear", align_corners=False) - 0.01) / 9.9
             if scale != 0:
                 two_cha = F.max_pool2d(two_cha, 2, ceil_mode=True)
@@ -186,9 +191,22 @@ class Refiner(Trainer):
             if torch.is_tensor(ipt) and ipt.device != self.device:
                 inputs[key] = ipt.to(self.device)
         FD.begin_forward_pass()
+        # The four frozen encoders are independent and, at the Refiner's batch of 6, none of them fills 256 CUs: like the
+        # Trainer they run on one HIP stream per module, the two pose passes (frames -1 / +1) stacked into one pass per module.
+        # Eval-mode BatchNorm is per sample, so stacking changes nothing; no autograd graph is recorded for any of them.
+        par = self.parallel_streams and self.use_pose_net and not val and self.num_pose_frames == 2
+        pose_out = None
         with torch.no_grad():
+            if par:
+                pose_out = self._launch_pose_encoders(inputs)
+                st = self._fork(0)
+                with torch.cuda.stream(st):
+                    beam_features = self.models["beam_encoder"](inputs["2channel"])
             features = self.models["encoder"](inputs["color_aug", 0, 0])
-            beam_features = self.models["beam_encoder"](inputs["2channel"])
+            if par:
+                self._join(st, beam_features)
+            else:
+                beam_features = self.models["beam_encoder"](inputs["2channel"])
             if self.opt.refine_depthnet_with_beam == "true":
                 outputs = Outputs(self.models["depth"](features, beam_features=beam_features))
             else:
@@ -196,7 +214,7 @@ class Refiner(Trainer):
             outputs.update(self.refine_inputs(inputs, outputs))
         if self.use_pose_net and not val:
             with torch.no_grad():                     # frozen pose networks (reference: eval mode, not in the optimiser)
-                outputs.update(self.predict_poses(inputs, features))
+                outputs.update(self.predict_poses(inputs, features, pose_out))
         losses = {"loss": 0.0}
         n_iter = self.opt.refine_iter
         for it in range(n_iter):
