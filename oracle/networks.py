@@ -8,7 +8,11 @@ product modules.
 with the stride on the 3x3, downsample = conv1x1(stride)+BN, BN eps 1e-5,
 momentum 0.1).  torchvision is a third-party dependency of the reference
 (networks/resnet_encoder.py:7,62-74) that is neither vendored nor installed
-here => this one piece is "parity unpinned" (structural checks only).
+here; the restatement is pinned against an independent public implementation of the
+same architecture that is installed - ``transformers.ResNetModel`` - with shared weights
+(tests/test_oracle_golden.py::test_resnet_trunk_matches_an_independent_resnet: feature
+maps and input gradients, ResNet-18 / -50, train and eval mode) plus the structural
+checks (torchvision's state-dict keys, shapes and parameter counts).
 """
 from collections import OrderedDict
 

@@ -249,6 +249,54 @@ def test_resnet_trunk_structure():
     assert [tuple(f.shape[1:]) for f in feats] == [(64, 32, 48), (64, 16, 24), (128, 8, 12), (256, 4, 6), (512, 2, 3)]
 
 
+@pytest.mark.parametrize("num_layers", [18, 50])
+def test_resnet_trunk_matches_an_independent_resnet(num_layers):
+    """torchvision (the reference's `models.resnet18/50`, networks/resnet_encoder.py:61-75) is not installed here, so the
+    oracle's ResNetTrunk is pinned against another public implementation of the same architecture that IS: Hugging Face
+    `transformers.ResNetModel` (basic / bottleneck layers, stride on the 3x3 = ResNet v1.5 like torchvision).  Same weights ->
+    the same five feature maps, in training mode (batch statistics) and in eval mode, values and input gradients."""
+    tf = pytest.importorskip("transformers")
+    torch.manual_seed(3)
+    enc = ON.ResnetEncoder(num_layers, False)
+    gin.fill_params(enc, 41)
+    trunk = enc.encoder
+    wide = num_layers > 34
+    cfg = tf.ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048] if wide else [64, 128, 256, 512],
+                          depths={18: [2, 2, 2, 2], 50: [3, 4, 6, 3]}[num_layers], layer_type="bottleneck" if wide else "basic",
+                          hidden_act="relu", downsample_in_first_stage=False, downsample_in_bottleneck=False)
+    hf = tf.ResNetModel(cfg)
+    src, sd = trunk.state_dict(), {}
+
+    def conv_bn(dst, conv, bn):
+        sd[dst + ".convolution.weight"] = src[conv + ".weight"]
+        for k in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
+            sd[dst + ".normalization." + k] = src[bn + "." + k]
+
+    conv_bn("embedder.embedder", "conv1", "bn1")
+    for si in range(4):
+        for bj, block in enumerate(getattr(trunk, "layer%d" % (si + 1))):
+            o, h = "layer%d.%d" % (si + 1, bj), "encoder.stages.%d.layers.%d" % (si, bj)
+            for k in range(3 if wide else 2):
+                conv_bn("%s.layer.%d" % (h, k), "%s.conv%d" % (o, k + 1), "%s.bn%d" % (o, k + 1))
+            if block.downsample is not None:
+                conv_bn(h + ".shortcut", o + ".downsample.0", o + ".downsample.1")
+    hf.load_state_dict(sd, strict=True)           # every tensor of the independent model is covered by the mapping
+    for train in (True, False):
+        enc.train(train); hf.train(train)
+        x = torch.from_numpy(np.random.RandomState(7).rand(2, 3, 64, 96).astype(np.float32)).requires_grad_(True)
+        feats = enc(x)
+        x2 = x.detach().clone().requires_grad_(True)
+        hs = hf((x2 - 0.45) / 0.225, output_hidden_states=True).hidden_states
+        assert len(hs) == 5
+        assert_close(npy(trunk.maxpool(feats[0])), npy(hs[0]), rtol=1e-5, atol=1e-6, what="stem + max-pool (train=%s)" % train)
+        for i in range(1, 5):
+            assert_close(npy(feats[i]), npy(hs[i]), rtol=1e-4, atol=1e-5, what="stage %d (train=%s)" % (i, train))
+        w = torch.from_numpy(np.random.RandomState(8).randn(*feats[4].shape).astype(np.float32))
+        (gx,) = torch.autograd.grad((feats[4] * w).sum() + feats[2].sum(), x)
+        (gx2,) = torch.autograd.grad((hs[4] * w).sum() + hs[2].sum(), x2)
+        assert_close(npy(gx), npy(gx2), rtol=1e-3, atol=1e-5 * float(gx2.abs().max()), what="input gradient (train=%s)" % train)
+
+
 def test_derived_hparams_match_reference_rules():
     hp = OT.derived_hparams(12)
     assert (hp.accumulate_step, hp.micro_batch, hp.scheduler_step_size, hp.num_epochs) == (2, 6, 6, 11)
