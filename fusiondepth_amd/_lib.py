@@ -86,6 +86,7 @@ SIGNATURES = {
     "fd_conv2d_bwd_data_wt_floats": ("p", "l"),
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_data": ("ppppp" "i" "pp", "i"),
+    "fd_conv2d_bwd_data_add": ("pppppp" "i" "pp", "i"),
     "fd_conv3x3_wino_wt_floats": ("p", "l"),
     "fd_conv3x3_wino_ws_floats": ("p", "l"),
     "fd_conv3x3_wino_fwd": ("pppppp" "i" "pp", "i"),

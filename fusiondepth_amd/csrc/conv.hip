@@ -848,11 +848,17 @@ extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
 
 namespace {
 int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const float* w1, float* gx, float* wt_base,
-                  float* wt_base1, int wt_ready, float* ws, void* stream, int siblings);
+                  float* wt_base1, int wt_ready, float* ws, void* stream, int siblings, const float* gx_add = nullptr);
 }
+extern "C" int fd_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream);   // pool.hip
 extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt_base,
                                   int wt_ready, float* ws, void* stream) {
     return bwd_data_impl(d, gy, w, nullptr, gx, wt_base, nullptr, wt_ready, ws, stream, 1);
+}
+extern "C" int fd_conv2d_bwd_data_add(const fd_conv_desc* d, const float* gy, const float* w, const float* gx_add, float* gx,
+                                      float* wt_base, int wt_ready, float* ws, void* stream) {
+    FD_REQUIRE(gx_add != gx, "fd_conv2d_bwd_data_add: gx_add must not alias gx");
+    return bwd_data_impl(d, gy, w, nullptr, gx, wt_base, nullptr, wt_ready, ws, stream, 1, gx_add);
 }
 extern "C" long fd_conv2d_bwd_data_pair_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
@@ -886,8 +892,13 @@ extern "C" int fd_conv2d_bwd_data_pair(const fd_conv_desc* d, const float* gy, c
 }
 namespace {
 int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const float* w1, float* gx, float* wt_base,
-                  float* wt_base1, int wt_ready, float* ws, void* stream, int siblings) {
+                  float* wt_base1, int wt_ready, float* ws, void* stream, int siblings, const float* gx_add) {
     if (int rc = check_desc(d, "fd_conv2d_bwd_data")) return rc;
+    FD_REQUIRE(!(gx_add && siblings != 1), "fd_conv2d_bwd_data: gx_add is not available for sibling pairs");
+    // gx_add joins in the epilogue of the MFMA kernels (and of their split-K reduction); the remaining paths (generic gather
+    // GEMM, reflect padding with its fold pass, parity classes without taps) add it with one element-wise launch afterwards
+    const long gx_n = (long)d->N * d->Cin * d->H * d->W;
+    auto add_after = [&]() -> int { return gx_add ? fd_axpby(gx, gx_add, gx, gx_n, 1.0f, 1.0f, stream) : 0; };
     FD_REQUIRE(gy && w && gx && wt_base, "fd_conv2d_bwd_data: NULL tensor");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_data: empty output");
@@ -901,10 +912,11 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
         if (siblings == 1 && wino_dgrad_desc(d, gd)) {
             if (!wt_ready)
                 if (int rc = wino_weight_launch(w, wt_base, gd.Cout, gd.Cin, 1, st)) return rc;
-            return wino_conv_launch(&gd, gy, wt_base, nullptr, gx, ws, st);
+            return wino_conv_launch(&gd, gy, wt_base, nullptr, gx, ws, st, gx_add);
         }
     }
     const bool fast = fast_dgrad_ok(d);
+    bool add_in_kernel = false;
     const long wt_n = align4((long)d->Cin * d->Cout * KH * KW);
     float* wt = wt_base;                       // per parity class: wt_base + class * wt_n
     float* wt1 = wt_base1;
@@ -935,6 +947,7 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
             f.osy = g.osy; f.ooy = g.ooy; f.osx = g.osx; f.oox = g.oox;
             f.out_total = (long)d->N * g.out_ns; f.slab_stride = f.out_total;
             f.slabs = slabs;       // split-K is only chosen for unit-stride outputs (fast_splitk_slab_floats)
+            f.add = add_in_kernel ? gx_add : nullptr;
             (void)allow_split;
             return fast_gemm_launch(f, st);
         }
@@ -962,11 +975,13 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
             hipLaunchKernelGGL(k_reflect_fold, dim3((unsigned)(fold_bx > 64 ? 64 : fold_bx), (unsigned)(fold_planes > 32768 ? 32768 : fold_planes)),
                                dim3(256), 0, st, gpad, gx, fold_planes, d->H, d->W);
             FD_LAUNCH_CHECK("fd_conv2d_bwd_data(fold)");
-            return 0;
+            return add_after();
         }
         g.NY = d->H; g.NX = d->W; g.oy = -(KH - 1 - d->pad); g.ox = -(KW - 1 - d->pad);
         g.Y = gx; g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin;
-        return run(KH, KW, KH - 1, -1, KW - 1, -1, true);
+        add_in_kernel = fast && gx_add;
+        if (int rc = run(KH, KW, KH - 1, -1, KW - 1, -1, true)) return rc;
+        return add_in_kernel ? 0 : add_after();
     }
     // stride 2: four output-parity classes, each a dense conv over its own tap subset
     g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin; g.Y = gx;
@@ -980,6 +995,7 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
             return -1;
         }
     }
+    add_in_kernel = fast && gx_add && !need_zero;       // every element of gx is written by exactly one parity class
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             const int kh0 = (ph + d->pad) & 1, kw0 = (pw + d->pad) & 1;
@@ -995,7 +1011,7 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
             if (siblings == 2) wt1 = wt_base1 + (long)(ph * 2 + pw) * wt_n;
             if (int rc = run(TA, TB, kh0, 2, kw0, 2, false)) return rc;
         }
-    return 0;
+    return add_in_kernel ? 0 : add_after();
 }
 }  // namespace
 

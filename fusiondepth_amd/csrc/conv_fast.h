@@ -27,6 +27,8 @@ struct FastGemmArgs {
     const float* A1;     // sibling 1: re-laid-out weights
     const float* bias1;
     float* slabs1_unused;
+    const float* add;    // optional, laid out like Y: Y = act(conv + bias) + add  (a second gradient arriving at the same tensor:
+                         // the residual branch of a ResNet block joins the data gradient in the epilogue); siblings == 1 only
 };
 
 struct FastWgradArgs {
@@ -49,14 +51,15 @@ int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumul
 
 // Y[i] = act(sum_z slabs[z][i] + bias[channel(i)]) - the deterministic split-K epilogue (also used by conv_wino.hip)
 int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, long total, long slab_stride, int splits, long out_cs,
-                              int M, int act, hipStream_t st);
+                              int M, int act, hipStream_t st, const float* add = nullptr);
 
 // conv_wino.hip: 3x3 stride-1 convolutions through the 1-D Winograd F(2,3) transform
 bool wino_fwd_ok(const fd_conv_desc* d);
 long wino_wt_floats(int M, int C);
 long wino_ws_floats(const fd_conv_desc* d);
 int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStream_t st);
-int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st);
+int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st,
+                     const float* add = nullptr);
 bool wino_wgrad_ok(const fd_conv_desc* d);
 long wino_wgrad_ws_floats(const fd_conv_desc* d);
 int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st);

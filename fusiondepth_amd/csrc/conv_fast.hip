@@ -206,7 +206,9 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
         const int n = (int)(p / plane);
         const int rem = (int)(p - (long)n * plane);
         const int y = rem / g.NX, x = rem - y * g.NX;
-        float* yo = Y + (long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox);
+        const long po = (long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox);
+        float* yo = Y + po;
+        const float* ao = (final_pass && g.add) ? g.add + po : nullptr;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -217,6 +219,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
                     if (final_pass) {
                         if (bias) v += bias[m];
                         v = act_apply(v, g.act);
+                        if (ao) v += ao[(long)m * g.out_cs];
                     }
                     yo[(long)m * g.out_cs] = v;
                 }
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
 // Y[i] = act(sum_z slabs[z][i] + bias[channel(i)])   (fixed z order => deterministic)
 __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ slabs, float* __restrict__ Y,
                                                        const float* __restrict__ bias, long total, long slab_stride,
-                                                       int splits, long out_cs, int M, int act) {
+                                                       int splits, long out_cs, int M, int act, const float* __restrict__ add) {
     const unsigned cs = (unsigned)out_cs, uM = (unsigned)M;              // total < 2^31 (fast-path size guard)
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {
         float s = 0.f;
@@ -239,7 +242,9 @@ __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__
         }
         for (; z < splits; ++z) s += slabs[(size_t)z * slab_stride + i];
         if (bias) s += bias[(i / cs) % uM];
-        Y[i] = act_apply(s, act);
+        s = act_apply(s, act);
+        if (add) s += add[i];
+        Y[i] = s;
     }
 }
 
@@ -607,7 +612,7 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
         for (int sib = 0; sib < (a.siblings > 1 ? a.siblings : 1); ++sib) {
             hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(a.out_total)), dim3(256), 0, st,
                                a.slabs + (size_t)sib * splits * a.slab_stride, a.Y + (size_t)sib * a.Nb * a.out_ns,
-                               sib ? a.bias1 : a.bias, a.out_total, a.slab_stride, splits, a.out_cs, a.M, a.act);
+                               sib ? a.bias1 : a.bias, a.out_total, a.slab_stride, splits, a.out_cs, a.M, a.act, a.add);
             e = hipGetLastError();
             if (e != hipSuccess) { fd_set_error("k_splitk_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
         }
@@ -629,9 +634,9 @@ int fast_wgrad_finish_launch(const float* slabs, float* gw, int M, int C, int T,
 }
 
 int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, long total, long slab_stride, int splits, long out_cs,
-                              int M, int act, hipStream_t st) {
+                              int M, int act, hipStream_t st, const float* add) {
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(total)), dim3(256), 0, st, slabs, Y, bias, total, slab_stride, splits, out_cs, M,
-                       act);
+                       act, add);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_splitk_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
     return 0;

@@ -66,6 +66,7 @@ __global__ void k_wino_weight(const float* __restrict__ w, float* __restrict__ U
 
 struct WinoArgs {
     const float* U; const float* X; float* Y; const float* bias; float* slabs;
+    const float* add;    // optional, laid out like Y: Y = act(conv + bias) + add
     long slab_stride;
     int M, C, Nb, H, W;
     int pad_mode, act;
@@ -220,7 +221,9 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     float* Y = final_pass ? g.Y : g.slabs + (size_t)zs * g.slab_stride;
     {
         const int n = (int)(pg / plane2);
-        float* yo = Y + ((long)n * g.M) * hw + (long)y0 * g.W + 2 * j0;
+        const long po = ((long)n * g.M) * hw + (long)y0 * g.W + 2 * j0;
+        float* yo = Y + po;
+        const float* ao = (final_pass && g.add) ? g.add + po : nullptr;
 #pragma unroll 4
         for (int t = 0; t < 16; ++t) {
             const int ml = kr + 4 * t, m = m0 + ml;
@@ -233,6 +236,10 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
             if (final_pass) {
                 const float b = g.bias ? g.bias[m] : 0.f;
                 o.x = wino_act(o.x + b, g.act); o.y = wino_act(o.y + b, g.act);
+                if (ao) {
+                    const f32x2 a2 = *reinterpret_cast<const f32x2*>(ao + (long)m * hw);
+                    o.x += a2.x; o.y += a2.y;
+                }
             }
             *reinterpret_cast<f32x2*>(yo + (long)m * hw) = o;
         }
@@ -438,9 +445,10 @@ int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStre
     return 0;
 }
 // y = act(conv3x3(x; U) + bias); d describes the convolution being computed (for a data gradient: Cin / Cout already swapped).
-int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st) {
+int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st,
+                     const float* add) {
     WinoArgs g = {};
-    g.U = U; g.X = x; g.Y = y; g.bias = bias; g.slabs = ws;
+    g.U = U; g.X = x; g.Y = y; g.bias = bias; g.slabs = ws; g.add = add;
     g.M = d->Cout; g.C = d->Cin; g.Nb = d->N; g.H = d->H; g.W = d->W;
     g.pad_mode = d->pad_mode; g.act = d->act;
     const long out_total = (long)d->N * d->Cout * d->H * d->W;
@@ -456,7 +464,7 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
     g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
     hipLaunchKernelGGL(k_conv_wino, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
     FD_LAUNCH_CHECK("k_conv_wino");
-    if (sp > 1) return fast_splitk_finish_launch(ws, y, bias, out_total, out_total, sp, (long)d->H * d->W, d->Cout, d->act, st);
+    if (sp > 1) return fast_splitk_finish_launch(ws, y, bias, out_total, out_total, sp, (long)d->H * d->W, d->Cout, d->act, st, add);
     return 0;
 }
 

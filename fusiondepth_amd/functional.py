@@ -758,63 +758,103 @@ def refresh_weight_layouts():
     return True
 
 
-class _Conv2d(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
-        cache_id = getattr(w, "_fd_cache_id", None)
-        ctx.params = (w, bias)
-        _note_use(w, bias)
-        x, w = f32(x), f32(w)
-        bias = f32(bias) if bias is not None else None
-        _need_cuda(x, w)
-        d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
-        Ho, Wo = _conv_out_hw(d)
-        y = _empty((d.N, d.Cout, Ho, Wo), x)
-        nws = query("fd_conv2d_fwd_ws_floats", ctypes.addressof(d))
-        nwt = query("fd_conv2d_fwd_wt_floats", ctypes.addressof(d))
-        ws = _empty((nws,), x) if nws > 0 else None
-        wt, ready = _weight_layout(w, cache_id, "f", nwt, d) if nwt > 0 else (None, 0)
-        call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), stream())
-        ctx.save_for_backward(x, w, y if act != 0 else None)
-        ctx.desc, ctx.has_bias, ctx.cache_id = d, bias is not None, cache_id
-        return y
+def _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+    cache_id = getattr(w, "_fd_cache_id", None)
+    ctx.params = (w, bias)
+    _note_use(w, bias)
+    x, w = f32(x), f32(w)
+    bias = f32(bias) if bias is not None else None
+    _need_cuda(x, w)
+    d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
+    Ho, Wo = _conv_out_hw(d)
+    y = _empty((d.N, d.Cout, Ho, Wo), x)
+    nws = query("fd_conv2d_fwd_ws_floats", ctypes.addressof(d))
+    nwt = query("fd_conv2d_fwd_wt_floats", ctypes.addressof(d))
+    ws = _empty((nws,), x) if nws > 0 else None
+    wt, ready = _weight_layout(w, cache_id, "f", nwt, d) if nwt > 0 else (None, 0)
+    call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), stream())
+    ctx.save_for_backward(x, w, y if act != 0 else None)
+    ctx.desc, ctx.has_bias, ctx.cache_id = d, bias is not None, cache_id
+    return x, y
 
-    @staticmethod
-    def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
-        d = ctx.desc
-        gy = f32(gy)
-        if d.act != 0:
-            gpre = torch.empty_like(gy)
-            call("fd_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), d.act, stream())
-            gy = gpre
-        dp = ctypes.addressof(d)
-        gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            ws = _empty((max(query("fd_conv2d_bwd_data_ws_floats", dp), 1),), x)
-            wt, ready = _weight_layout(w, ctx.cache_id, "d", query("fd_conv2d_bwd_data_wt_floats", dp), d)
+
+def _conv_backward(ctx, gy, gx_add=None):
+    """-> (gx, gw, gb).  ``gx_add``: a second gradient arriving at the conv's input (see ``conv2d_tap``); it joins the data
+    gradient in the kernel's epilogue (fd_conv2d_bwd_data_add)."""
+    x, w, y = ctx.saved_tensors
+    d = ctx.desc
+    gx = gw = gb = None
+    if gy is None:                   # only the tap was used downstream
+        return (f32(gx_add) if gx_add is not None else None), None, None
+    gy = f32(gy)
+    if d.act != 0:
+        gpre = torch.empty_like(gy)
+        call("fd_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), d.act, stream())
+        gy = gpre
+    dp = ctypes.addressof(d)
+    if ctx.needs_input_grad[0]:
+        gx = torch.empty_like(x)
+        ws = _empty((max(query("fd_conv2d_bwd_data_ws_floats", dp), 1),), x)
+        wt, ready = _weight_layout(w, ctx.cache_id, "d", query("fd_conv2d_bwd_data_wt_floats", dp), d)
+        if gx_add is not None and not d.in_norm:
+            call("fd_conv2d_bwd_data_add", dp, ptr(gy), ptr(w), ptr(f32(gx_add)), ptr(gx), ptr(wt), ready, ptr(ws), stream())
+        else:
             call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(w), ptr(gx), ptr(wt), ready, ptr(ws), stream())
             if d.in_norm:   # d/dx of (x - 0.45) / 0.225
                 call("fd_axpby", ptr(gx), ptr(gx), ptr(gx), gx.numel(), 1.0 / 0.225, 0.0, stream())
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            tw = _direct_grad_target(ctx.params[0])
-            tb = _direct_grad_target(ctx.params[1]) if ctx.has_bias else None
-            direct = tw is not None and (not ctx.has_bias or tb is not None)
-            gw = tw if direct else torch.empty_like(w)
-            gb = (tb if direct else _empty((d.Cout,), x)) if ctx.has_bias else None
-            ws = _empty((max(query("fd_conv2d_bwd_weight_ws_floats", dp), 1),), x)
-            if direct and _WGRAD_ASYNC[0]:
-                side = _wgrad_stream()                     # ordered after everything queued so far (gy is complete)
-                with torch.cuda.stream(side):
-                    call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), 1, stream())
-                _WGRAD_KEEPALIVE.append((x, gy, ws))
-            else:
-                call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
-            if direct:
-                gw = gb = None          # already accumulated in place
-                _grad_ready(ctx.params[0], ctx.params[1] if ctx.has_bias else None)
-        return gx, gw, gb, None, None, None, None, None
+            if gx_add is not None:
+                call("fd_axpby", ptr(gx), ptr(f32(gx_add)), ptr(gx), gx.numel(), 1.0, 1.0, stream())
+    if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        tw = _direct_grad_target(ctx.params[0])
+        tb = _direct_grad_target(ctx.params[1]) if ctx.has_bias else None
+        direct = tw is not None and (not ctx.has_bias or tb is not None)
+        gw = tw if direct else torch.empty_like(w)
+        gb = (tb if direct else _empty((d.Cout,), x)) if ctx.has_bias else None
+        ws = _empty((max(query("fd_conv2d_bwd_weight_ws_floats", dp), 1),), x)
+        if direct and _WGRAD_ASYNC[0]:
+            side = _wgrad_stream()                     # ordered after everything queued so far (gy is complete)
+            with torch.cuda.stream(side):
+                call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), 1, stream())
+            _WGRAD_KEEPALIVE.append((x, gy, ws))
+        else:
+            call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
+        if direct:
+            gw = gb = None          # already accumulated in place
+            _grad_ready(ctx.params[0], ctx.params[1] if ctx.has_bias else None)
+    return gx, gw, gb
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+        return _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm)[1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _conv_backward(ctx, gy) + (None, None, None, None, None)
+
+
+class _Conv2dTap(torch.autograd.Function):
+    """conv2d that also hands its input on: (y, x_tap) with x_tap == x.  A tensor that feeds a convolution and something else (the
+    input of a ResNet block is also its residual branch) normally receives two gradients that autograd sums with an element-wise
+    kernel; routing the second consumer through ``x_tap`` brings that gradient to THIS node instead, where it is added in the
+    epilogue of the data-gradient kernel.  Same values, one pass over the tensor less, one launch less."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+        xf, y = _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm)
+        return y, xf.view_as(xf)
+
+    @staticmethod
+    def backward(ctx, gy, g_tap):
+        return _conv_backward(ctx, gy, g_tap) + (None, None, None, None, None)
+
+
+def conv2d_tap(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", in_norm=False):
+    """-> (conv2d(x, ...), x): use the second value wherever ``x`` itself is needed again (see ``_Conv2dTap``)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return conv2d(x, weight, bias, stride, pad, pad_mode, act, in_norm), x
+    return _Conv2dTap.apply(x, weight, bias, int(stride), int(pad), PAD_MODE[pad_mode], ACT[act], bool(in_norm))
 
 
 class _Conv2dPair(torch.autograd.Function):

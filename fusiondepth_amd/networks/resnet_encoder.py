@@ -7,6 +7,8 @@ module tree (so ``state_dict()`` keys/shapes are identical: ``encoder.conv1.weig
 ``nn.BatchNorm2d`` used purely as parameter/buffer holders.  Every forward op is a libfdhip kernel:
 MFMA implicit-GEMM convs, BatchNorm fused with the residual add + ReLU, 3x3/s2 max-pool.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -19,6 +21,15 @@ _SPEC = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottlen
 
 def _conv(x, conv, in_norm=False):
     return FD.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0], in_norm=in_norm)
+
+
+def _conv_tap(x, conv):
+    """(conv(x), x): the block input is needed twice - by the first convolution and by the residual branch.  Taking the second
+    use from the tap makes the residual gradient join the first convolution's data gradient inside that kernel
+    (functional._Conv2dTap) instead of being summed by a separate element-wise launch."""
+    if os.environ.get("FD_CONV_TAP", "1") == "0":
+        return _conv(x, conv), x
+    return FD.conv2d_tap(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0])
 
 
 class BasicBlock(nn.Module):
@@ -35,10 +46,11 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
 
     def forward(self, x):
+        out, x = _conv_tap(x, self.conv1)
         identity = x
         if self.downsample is not None:
             identity = FD.batch_norm(_conv(x, self.downsample[0]), self.downsample[1])
-        out = FD.batch_norm(_conv(x, self.conv1), self.bn1, relu=True)
+        out = FD.batch_norm(out, self.bn1, relu=True)
         return FD.batch_norm(_conv(out, self.conv2), self.bn2, residual=identity, relu=True)
 
 
@@ -59,10 +71,11 @@ class Bottleneck(nn.Module):
                                             nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):
+        out, x = _conv_tap(x, self.conv1)
         identity = x
         if self.downsample is not None:
             identity = FD.batch_norm(_conv(x, self.downsample[0]), self.downsample[1])
-        out = FD.batch_norm(_conv(x, self.conv1), self.bn1, relu=True)
+        out = FD.batch_norm(out, self.bn1, relu=True)
         out = FD.batch_norm(_conv(out, self.conv2), self.bn2, relu=True)
         return FD.batch_norm(_conv(out, self.conv3), self.bn3, residual=identity, relu=True)
 

@@ -259,6 +259,12 @@ long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d);
 long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d);
 int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt, int wt_ready, float* ws,
                        void* stream);
+/* gx = (data gradient as above) + gx_add, gx_add [N,Cin,H,W] (must not alias gx): where a tensor feeds a convolution AND a second
+ * consumer - the input of a ResNet block also is its residual branch (torchvision BasicBlock / Bottleneck `out += identity`, used
+ * by networks/resnet_encoder.py:61-75) - autograd has to sum two gradients; here the second one joins in the epilogue of the
+ * data-gradient kernel instead of costing an element-wise pass over both tensors.  Bitwise the sum torch would form. */
+int fd_conv2d_bwd_data_add(const fd_conv_desc* d, const float* gy, const float* w, const float* gx_add, float* gx, float* wt,
+                           int wt_ready, float* ws, void* stream);
 /* gw [Cout,Cin,KH,KW], gbias [Cout] (NULL to skip).  accumulate != 0: gw += / gbias += (gradient accumulation straight
  * into the caller's buffers).  ws: fd_conv2d_bwd_weight_ws_floats(d) floats. */
 long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d);

@@ -107,6 +107,43 @@ def test_conv2d_fwd_bwd(FD, case):
         relclose(cpu(got[2]), cpu(want[2]), "conv bias grad")
 
 
+@pytest.mark.parametrize("case", [
+    (2, 64, 16, 24, 64, 3, 1, 1, "zero"),        # Winograd data gradient, split-K finish
+    (12, 64, 48, 160, 64, 3, 1, 1, "zero"),      # Winograd data gradient, direct epilogue (layer1 at the bench batch)
+    (2, 64, 16, 24, 128, 3, 2, 1, "zero"),       # stride 2: four parity classes, each adds its own elements
+    (2, 64, 15, 23, 128, 3, 2, 1, "zero"),       # odd sizes
+    (2, 64, 16, 24, 128, 1, 2, 0, "zero"),       # 1x1 stride 2: classes without taps -> element-wise fallback
+    (2, 64, 8, 12, 256, 1, 1, 0, "zero"),        # bottleneck conv1 (1x1): MFMA GEMM epilogue
+    (2, 48, 16, 24, 32, 3, 1, 1, "zero"),        # < 64 output channels: direct kernel
+    (2, 96, 16, 24, 32, 3, 1, 1, "reflect"),     # reflect padding: fold pass, then element-wise fallback
+    (2, 5, 16, 24, 7, 3, 1, 1, "zero"),          # generic gather GEMM: fallback
+])
+def test_conv_tap_adds_the_second_gradient_in_the_epilogue(FD, case):
+    """FD.conv2d_tap (fd_conv2d_bwd_data_add): d/dx of  sum(conv(x) * a) + sum(x_tap * b)  must be the BITWISE sum torch forms from
+    the plain data gradient and b, on every kernel family the data gradient can take."""
+    N, Cin, H, W, Cout, K, stride, pad, mode = case
+    import zlib
+    rng = np.random.RandomState(zlib.crc32(repr(case).encode()) % (2 ** 31))
+    x = dev(torch.from_numpy(rng.randn(N, Cin, H, W).astype(np.float32)))
+    w = dev(torch.from_numpy((rng.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32)))
+    x1, w1 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y1 = FD.conv2d(x1, w1, None, stride, pad, mode)
+    a = dev(torch.from_numpy(rng.randn(*y1.shape).astype(np.float32)))
+    b = dev(torch.from_numpy(rng.randn(N, Cin, H, W).astype(np.float32)))
+    gx_plain, gw_plain = torch.autograd.grad((y1 * a).sum(), [x1, w1])
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y2, tap = FD.conv2d_tap(x2, w2, None, stride, pad, mode)
+    assert torch.equal(y2, y1) and torch.equal(tap, x2) and tap.data_ptr() == x2.data_ptr()
+    gx, gw = torch.autograd.grad((y2 * a).sum() + (tap * b).sum(), [x2, w2])
+    assert torch.equal(gx, gx_plain + b), "max |diff| %g" % float((gx - (gx_plain + b)).abs().max())
+    assert torch.equal(gw, gw_plain)
+    # the tap alone, and the conv alone, still give the right thing
+    (g_only_tap,) = torch.autograd.grad((FD.conv2d_tap(x2, w2, None, stride, pad, mode)[1] * b).sum(), [x2])
+    assert torch.equal(g_only_tap, b)
+    (g_only_conv,) = torch.autograd.grad((FD.conv2d_tap(x2, w2, None, stride, pad, mode)[0] * a).sum(), [x2])
+    assert torch.equal(g_only_conv, gx_plain)
+
+
 def test_conv_transpose_detecting(FD):
     """A = I-style check with asymmetric data: a conv whose weight is a one-hot tap must shift/copy channels
     exactly (catches row/col swaps in the MFMA fragment maps bit-exactly)."""
