@@ -142,11 +142,23 @@ def roofline_probes(args, tr, batch):
         FD.combine_losses(photo, zero, si, 1e-3)[1].backward()
     ms = graph_time_ms(loss_fwd_bwd, launches=5)
     byts = LOSS_BYTES_PER_PIXEL * H * W * B
+    loss_traffic, loss_traffic_src = None, None
+    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_loss.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        sha = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fusiondepth_amd", "csrc",
+                                               "photometric_ms.hip"), "rb").read()).hexdigest()
+        if pmc.get("source_sha256") == sha and pmc.get("batch") == B and (H, W) == (192, 640):
+            loss_traffic, loss_traffic_src = pmc["traffic_bytes_per_launch"], "round2_pmc_loss.json"
+        else:
+            print("[bench] profiles/round2_pmc_loss.json was measured on a different photometric_ms.hip / batch / size: "
+                  "roofline_loss_path.traffic left null - re-run scripts/pmc_loss_ms.sh", file=sys.stderr, flush=True)
     out["roofline_loss_path"] = {"bound": "hbm", "kernel": "k_photo_ms (4 scales, forward + unit gradients) + k_photo_ms_fin + "
                                  "k_photo_ms_bwd (+ projection-matrix and loss-combination launches), batch %d" % B,
                                  "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None, "us_per_launch": ms * 1e3,
-                                 "bytes_per_launch": byts}
+                                 "frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": loss_traffic,
+                                 "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE of the three kernels, profiles/%s)"
+                                                 % loss_traffic_src, "us_per_launch": ms * 1e3, "bytes_per_launch": byts}
     return out
 
 

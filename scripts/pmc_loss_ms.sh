@@ -25,3 +25,23 @@ for k, d in acc.items():
 PY
 done
 cat $OUT
+# machine-readable traffic record for bench.py (carries the sha256 of the kernel source it was measured on)
+python - <<PY
+import csv, glob, json, hashlib, collections
+tot = collections.defaultdict(lambda: collections.defaultdict(list))
+for i, name in ((3, "FETCH_SIZE"), (4, "WRITE_SIZE")):
+    for f in glob.glob("/tmp/pmc_%d/**/*counter_collection.csv" % i, recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "k_photo_ms" in k and r["Counter_Name"] == name:
+                kk = "k_photo_ms_bwd" if "k_photo_ms_bwd" in k else ("k_photo_ms_fin" if "k_photo_ms_fin" in k else "k_photo_ms")
+                tot[kk][name].append(float(r["Counter_Value"]))
+mean = lambda v: sum(v) / max(len(v), 1)
+per = {k: {"FETCH_SIZE_KB": mean(d["FETCH_SIZE"]), "WRITE_SIZE_KB": mean(d["WRITE_SIZE"])} for k, d in tot.items()}
+traffic = sum(int(p["FETCH_SIZE_KB"] * 1024 * 2 + p["WRITE_SIZE_KB"] * 1024) for p in per.values())
+out = {"kernels": per, "fetch_correction": 2.0, "batch": $B, "traffic_bytes_per_launch": traffic,
+       "collected": "rocprofv3 --pmc <one group per pass> --kernel-trace (scripts/pmc_loss_ms.sh), means over the probe's launches",
+       "source_sha256": hashlib.sha256(open("$R/fusiondepth_amd/csrc/photometric_ms.hip", "rb").read()).hexdigest()}
+json.dump(out, open("$R/gpurun_out/pmc_loss.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
