@@ -195,26 +195,14 @@ class Refiner(Trainer):
         # Trainer they run on one HIP stream per module, the two pose passes (frames -1 / +1) stacked into one pass per module.
         # Eval-mode BatchNorm is per sample, so stacking changes nothing; no autograd graph is recorded for any of them.
         par = self.parallel_streams and self.use_pose_net and not val and self.num_pose_frames == 2
-        pose_out = None
+        want_poses = self.use_pose_net and not val
         with torch.no_grad():
-            if par:
-                pose_out = self._launch_pose_encoders(inputs)
-                st = self._fork(0)
-                with torch.cuda.stream(st):
-                    beam_features = self.models["beam_encoder"](inputs["2channel"])
-            features = self.models["encoder"](inputs["color_aug", 0, 0])
-            if par:
-                self._join(st, beam_features)
-            else:
-                beam_features = self.models["beam_encoder"](inputs["2channel"])
-            if self.opt.refine_depthnet_with_beam == "true":
-                outputs = Outputs(self.models["depth"](features, beam_features=beam_features))
-            else:
-                outputs = Outputs(self.models["depth"](features))
+            # (Replaying this frozen section from a hipGraph was tried: 348 vs 356 images/s - hipGraphLaunch on this ROCm costs the host
+            # as much per kernel node as the eager launches it replaces)
+            features, beam_features, depth, poses = self._frozen_forward(inputs, par, want_poses)
+            outputs = Outputs(depth)
             outputs.update(self.refine_inputs(inputs, outputs))
-        if self.use_pose_net and not val:
-            with torch.no_grad():                     # frozen pose networks (reference: eval mode, not in the optimiser)
-                outputs.update(self.predict_poses(inputs, features, pose_out))
+            outputs.update(poses)
         losses = {"loss": 0.0}
         n_iter = self.opt.refine_iter
         for it in range(n_iter):
@@ -227,6 +215,27 @@ class Refiner(Trainer):
                 gama = (1.0 if n_iter == 1 else self.opt.refine_iter_gama) ** (n_iter - it)
                 losses = self.compute_losses(inputs, outputs, losses, gama=gama)
         return outputs, losses
+
+    def _frozen_forward(self, inputs, par, want_poses):
+        """The part of refiner.py:299-330 that involves only frozen networks: depth / beam encoders, depth decoder and (training)
+        the pose networks -> (features, beam_features, {("disp", s)}, {cam_T_cam / axisangle / translation}).  Call under no_grad."""
+        pose_out = None
+        if par:
+            pose_out = self._launch_pose_encoders(inputs)
+            st = self._fork(0)
+            with torch.cuda.stream(st):
+                beam_features = self.models["beam_encoder"](inputs["2channel"])
+        features = self.models["encoder"](inputs["color_aug", 0, 0])
+        if par:
+            self._join(st, beam_features)
+        else:
+            beam_features = self.models["beam_encoder"](inputs["2channel"])
+        if self.opt.refine_depthnet_with_beam == "true":
+            depth = dict(self.models["depth"](features, beam_features=beam_features))
+        else:
+            depth = dict(self.models["depth"](features))
+        poses = self.predict_poses(inputs, features, pose_out) if want_poses else {}
+        return features, beam_features, depth, poses
 
     def generate_images_pred(self, inputs, outputs, frame_ids):
         """refiner.py:487-541 fused with the per-pixel part of compute_losses; the SI term is the GDC loss (compute_losses)."""
