@@ -758,6 +758,45 @@ def refresh_weight_layouts():
     return True
 
 
+# Shape-keyed plans: the descriptor of a convolution and the workspace / layout sizes the library reports for it depend only on
+# the shapes and flags, so they are asked for once per distinct layer shape instead of on every launch (a step launches ~220
+# convolutions forward and as many backward; the size queries alone were ~1 300 library calls per step).
+_CONV_PLANS = {}
+
+
+class _ConvPlan:
+    __slots__ = ("d", "dp", "Ho", "Wo", "fwd_ws", "fwd_wt", "bwd_data_ws", "bwd_data_wt", "bwd_weight_ws")
+
+    def __init__(self, x, w, stride, pad, pad_mode, act, in_norm):
+        self.d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
+        self.dp = ctypes.addressof(self.d)
+        self.Ho, self.Wo = _conv_out_hw(self.d)
+        self.fwd_ws = query("fd_conv2d_fwd_ws_floats", self.dp)
+        self.fwd_wt = query("fd_conv2d_fwd_wt_floats", self.dp)
+        self.bwd_data_ws = self.bwd_data_wt = self.bwd_weight_ws = None
+
+    def data_sizes(self):
+        if self.bwd_data_ws is None:
+            self.bwd_data_ws = max(query("fd_conv2d_bwd_data_ws_floats", self.dp), 1)
+            self.bwd_data_wt = query("fd_conv2d_bwd_data_wt_floats", self.dp)
+        return self.bwd_data_ws, self.bwd_data_wt
+
+    def weight_ws(self):
+        if self.bwd_weight_ws is None:
+            self.bwd_weight_ws = max(query("fd_conv2d_bwd_weight_ws_floats", self.dp), 1)
+        return self.bwd_weight_ws
+
+
+def _conv_plan(x, w, stride, pad, pad_mode, act, in_norm):
+    # FD_CONV_FORCE is the one tuning variable the library re-reads on every call (scripts/conv_cfg_sweep.py flips it within a
+    # process) and it changes the split-K workspace size: part of the key
+    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, os.environ.get("FD_CONV_FORCE"))
+    plan = _CONV_PLANS.get(key)
+    if plan is None:
+        plan = _CONV_PLANS[key] = _ConvPlan(x, w, stride, pad, pad_mode, act, in_norm)
+    return plan
+
+
 def _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
     cache_id = getattr(w, "_fd_cache_id", None)
     ctx.params = (w, bias)
@@ -765,16 +804,14 @@ def _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
     x, w = f32(x), f32(w)
     bias = f32(bias) if bias is not None else None
     _need_cuda(x, w)
-    d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
-    Ho, Wo = _conv_out_hw(d)
+    plan = _conv_plan(x, w, stride, pad, pad_mode, act, bool(in_norm))
+    d, Ho, Wo, nws, nwt = plan.d, plan.Ho, plan.Wo, plan.fwd_ws, plan.fwd_wt
     y = _empty((d.N, d.Cout, Ho, Wo), x)
-    nws = query("fd_conv2d_fwd_ws_floats", ctypes.addressof(d))
-    nwt = query("fd_conv2d_fwd_wt_floats", ctypes.addressof(d))
     ws = _empty((nws,), x) if nws > 0 else None
     wt, ready = _weight_layout(w, cache_id, "f", nwt, d) if nwt > 0 else (None, 0)
-    call("fd_conv2d_fwd", ctypes.addressof(d), ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), stream())
+    call("fd_conv2d_fwd", plan.dp, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), stream())
     ctx.save_for_backward(x, w, y if act != 0 else None)
-    ctx.desc, ctx.has_bias, ctx.cache_id = d, bias is not None, cache_id
+    ctx.desc, ctx.has_bias, ctx.cache_id, ctx.plan = d, bias is not None, cache_id, plan
     return x, y
 
 
@@ -791,11 +828,13 @@ def _conv_backward(ctx, gy, gx_add=None):
         gpre = torch.empty_like(gy)
         call("fd_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), d.act, stream())
         gy = gpre
-    dp = ctypes.addressof(d)
+    plan = ctx.plan
+    dp = plan.dp
     if ctx.needs_input_grad[0]:
         gx = torch.empty_like(x)
-        ws = _empty((max(query("fd_conv2d_bwd_data_ws_floats", dp), 1),), x)
-        wt, ready = _weight_layout(w, ctx.cache_id, "d", query("fd_conv2d_bwd_data_wt_floats", dp), d)
+        n_ws, n_wt = plan.data_sizes()
+        ws = _empty((n_ws,), x)
+        wt, ready = _weight_layout(w, ctx.cache_id, "d", n_wt, d)
         if gx_add is not None and not d.in_norm:
             call("fd_conv2d_bwd_data_add", dp, ptr(gy), ptr(w), ptr(f32(gx_add)), ptr(gx), ptr(wt), ready, ptr(ws), stream())
         else:
@@ -810,7 +849,7 @@ def _conv_backward(ctx, gy, gx_add=None):
         direct = tw is not None and (not ctx.has_bias or tb is not None)
         gw = tw if direct else torch.empty_like(w)
         gb = (tb if direct else _empty((d.Cout,), x)) if ctx.has_bias else None
-        ws = _empty((max(query("fd_conv2d_bwd_weight_ws_floats", dp), 1),), x)
+        ws = _empty((plan.weight_ws(),), x)
         if direct and _WGRAD_ASYNC[0]:
             side = _wgrad_stream()                     # ordered after everything queued so far (gy is complete)
             with torch.cuda.stream(side):
