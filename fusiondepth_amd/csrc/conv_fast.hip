@@ -227,6 +227,202 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     }
 }
 
+// ------------------------------------------------------------------------------------------------ split-precision variant
+// Exploration behind FD_CONV_LIMB=1 (off by default; DESIGN.md "known gaps" 5, profiles/round2_limb_gemm.md): the same implicit GEMM
+// with every fp32 operand split into three bf16 limbs x = h + m + l (8 + 8 + 8 mantissa bits, exact) as it is written to LDS, and
+// the product formed from the six limb products of weight >= 2^-16 (lh, hl, mm, mh, hm, hh) on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: fp32 accuracy (the dropped terms are <= 2^-24 relative) at 16/6 of the f32 MFMA rate.  Chunk = 32 channels of one
+// tap; LDS holds K-contiguous bf16 rows ([limb][row][32 + 8]) so that a lane's 8-element MFMA fragment is one 16-byte read; single
+// LDS buffer, the next chunk's global loads are in flight during the MFMA phase.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r = x - (float)h;      // exact
+    m = (__bf16)r;
+    l = (__bf16)(r - (float)m);        // r - m is exact as well
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_limb(FastGemmArgs g) {
+    constexpr int BKC = 32;
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
+    constexpr int LDK = BKC + 8;                // bf16 per LDS row (80 bytes: fragments stay 16-byte aligned, rows spread over the banks)
+    constexpr int RP = NT / BN;                 // threads per pixel column
+    constexpr int NB_LOAD = BKC / RP;           // CONSECUTIVE channels per thread (one or more 8-element fragments)
+    constexpr int A_V4_PER_ROW = BKC / 4;
+    constexpr int A_ROWS_PER_PASS = NT / A_V4_PER_ROW;
+    constexpr int NA_LOAD = (BM + A_ROWS_PER_PASS - 1) / A_ROWS_PER_PASS;
+    constexpr bool A_PARTIAL = (BM % A_ROWS_PER_PASS) != 0;
+    static_assert(NT % BN == 0 && NB_LOAD % 8 == 0, "tile/loader mismatch");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* sA = reinterpret_cast<__bf16*>(smem);           // [3][BM][LDK]
+    __bf16* sB = sA + 3 * BM * LDK;                         // [3][BN][LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    int bx = blockIdx.x;
+    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    const int m0 = blockIdx.y * BM;
+    const long p0 = (long)bx * BN;
+    const int plane = g.NY * g.NX;
+    const long Np = (long)g.Nb * plane;
+    const unsigned chw = (unsigned)(g.Hi * g.Wi);
+    const int cpt = g.C / BKC;
+    const int nchunk_all = g.T * cpt;
+    const int nsplit = (int)gridDim.z, zs = (int)blockIdx.z;
+    const int per_split = (nchunk_all + nsplit - 1) / nsplit;
+    const int ch_lo = zs * per_split;
+    const int ch_hi = ch_lo + per_split < nchunk_all ? ch_lo + per_split : nchunk_all;
+
+    const int jn = tid % BN;
+    const int kr = __builtin_amdgcn_readfirstlane(tid / BN);
+    const long pg = p0 + jn;
+    const bool pvalid = pg < Np;
+    int ry0, cx0;
+    unsigned nbase;
+    {
+        const long pp = pvalid ? pg : 0;
+        const int n = (int)(pp / plane);
+        const int rem = (int)(pp - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        ry0 = y * g.sy + g.oy; cx0 = x * g.sx + g.ox;
+        nbase = (unsigned)n * (unsigned)g.C * chw;
+    }
+    const int a4 = tid % A_V4_PER_ROW, ar = tid / A_V4_PER_ROW;
+    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(g.A), rsX = fd_make_rsrc(g.X);
+    float4 ra[NA_LOAD];
+    float rb[NB_LOAD];
+    unsigned a_off[NA_LOAD], b_off = FD_OOB;
+    const unsigned b_step = 4u * chw;
+    int pc_ta, pc_tb, pc_c0;
+    { const int t = ch_lo / cpt; pc_c0 = (ch_lo - t * cpt) * BKC; pc_ta = t / g.TB; pc_tb = t - pc_ta * g.TB; }
+    const bool refl = g.pad_mode == 1;
+    auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
+        const unsigned k0 = (unsigned)(pc_ta * g.TB + pc_tb) * (unsigned)g.C + (unsigned)pc_c0;
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) {
+            int m = m0 + ar + A_ROWS_PER_PASS * i;
+            m = m < g.M ? m : g.M - 1;
+            a_off[i] = live ? 4u * ((unsigned)m * (unsigned)g.K + k0 + 4u * a4) : FD_OOB;
+        }
+        int r = ry0 + pc_ta * g.da, cc = cx0 + pc_tb * g.db;
+        const bool inb = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
+        const int rr = refl_idx(r, g.Hi), rc = refl_idx(cc, g.Wi);
+        r = refl ? rr : r; cc = refl ? rc : cc;
+        const bool ok = pvalid & live & (refl | inb);
+        b_off = ok ? 4u * (nbase + (unsigned)(pc_c0 + kr * NB_LOAD) * chw + (unsigned)(r * g.Wi + cc)) : FD_OOB;
+        pc_c0 += BKC;
+        if (pc_c0 >= g.C) { pc_c0 = 0; ++pc_tb; if (pc_tb >= g.TB) { pc_tb = 0; ++pc_ta; } }
+    };
+    auto load_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i)
+            if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM) ra[i] = fd_ldg128(rsA, a_off[i]);
+#pragma unroll
+        for (int i = 0; i < NB_LOAD; ++i) rb[i] = fd_ldg32(rsX, b_off + (unsigned)i * b_step);
+    };
+    auto store_all = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA_LOAD; ++i) {
+            if (A_PARTIAL && ar + A_ROWS_PER_PASS * i >= BM) continue;
+            const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            bf16x4 q[3];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { __bf16 h, m, l; split3(v[e], h, m, l); q[0][e] = h; q[1][e] = m; q[2][e] = l; }
+            const int row = ar + A_ROWS_PER_PASS * i;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4*>(sA + ((size_t)t * BM + row) * LDK + 4 * a4) = q[t];
+        }
+#pragma unroll
+        for (int f = 0; f < NB_LOAD / 8; ++f) {
+            bf16x8 q[3];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { __bf16 h, m, l; split3(rb[8 * f + e], h, m, l); q[0][e] = h; q[1][e] = m; q[2][e] = l; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x8*>(sB + ((size_t)t * BN + jn) * LDK + kr * NB_LOAD + 8 * f) = q[t];
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int arow = lane >> 5, acol = lane & 31;
+    if (ch_lo < ch_hi) {
+        prep_chunk(true);
+        load_all();
+        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+            store_all();
+            __syncthreads();
+            prep_chunk(ch + 1 < ch_hi);
+            load_all();                                   // in flight during the MFMA phase below
+#pragma unroll
+            for (int kb = 0; kb < BKC / 16; ++kb) {
+                bf16x8 a[3][WM], b[3][WN];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+                        a[t][i] = *reinterpret_cast<const bf16x8*>(sA + ((size_t)t * BM + wave_m * 32 * WM + i * 32 + acol) * LDK + kb * 16 + arow * 8);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        b[t][j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)t * BN + wave_n * 32 * WN + j * 32 + acol) * LDK + kb * 16 + arow * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        f32x16 c = acc[i][j];                                    // smallest terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+            }
+            __syncthreads();
+        }
+    }
+
+    const bool final_pass = nsplit == 1;
+    float* Y = final_pass ? g.Y : g.slabs + (size_t)blockIdx.z * g.slab_stride;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const long p = p0 + wave_n * 32 * WN + j * 32 + acol;
+        if (p >= Np) continue;
+        const int n = (int)(p / plane);
+        const int rem = (int)(p - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        const long po = (long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox);
+        float* yo = Y + po;
+        const float* ao = (final_pass && g.add) ? g.add + po : nullptr;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                if (m < g.M) {
+                    float v = acc[i][j][r];
+                    if (final_pass) {
+                        if (g.bias) v += g.bias[m];
+                        v = act_apply(v, g.act);
+                        if (ao) v += ao[(long)m * g.out_cs];
+                    }
+                    yo[(long)m * g.out_cs] = v;
+                }
+            }
+    }
+}
+
 // Y[i] = act(sum_z slabs[z][i] + bias[channel(i)])   (fixed z order => deterministic)
 __global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ slabs, float* __restrict__ Y,
                                                        const float* __restrict__ bias, long total, long slab_stride,
@@ -492,6 +688,24 @@ void launch_cfg(const FastGemmArgs& a, int splits, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(gx, gy, splits * g.siblings), dim3(64 * WAVES_M * WAVES_N), lds, st, g);
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+void launch_cfg_limb(const FastGemmArgs& a, int splits, hipStream_t st) {
+    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
+    const long Np = (long)a.Nb * a.NY * a.NX;
+    const int gx = fd_cdiv(Np, BN), gy = fd_cdiv(a.M, BM);
+    FastGemmArgs g = a;
+    g.siblings = 1;
+    g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
+    const size_t lds = 2 * 3 * (size_t)(BM + BN) * (32 + 8);
+    auto kern = k_conv_limb<WAVES_M, WAVES_N, WM, WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(64 * WAVES_M * WAVES_N), lds, st, g);
+}
+
 }  // namespace
 
 namespace {
@@ -599,7 +813,13 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
     const int splits = ch.splits;
     if (splits > 1 && !a.slabs) { fd_set_error("conv: split-K workspace missing"); return -1; }
     const bool b32 = a.C % 32 == 0;
-    if (ch.cfg == 0) {
+    const char* limb_env = getenv("FD_CONV_LIMB");       // exploration switch (see k_conv_limb), read per call like FD_CONV_FORCE
+    const int limb = limb_env ? atoi(limb_env) : 0;
+    if (limb && b32 && a.siblings <= 1) {
+        if (ch.cfg == 0) launch_cfg_limb<2, 2, 2, 2>(a, splits, st);
+        else if (ch.cfg == 1) launch_cfg_limb<2, 2, 1, 2>(a, splits, st);
+        else launch_cfg_limb<1, 4, 1, 2>(a, splits, st);
+    } else if (ch.cfg == 0) {
         if (b32) launch_cfg<2, 2, 2, 2, 32>(a, splits, st); else launch_cfg<2, 2, 2, 2, 16>(a, splits, st);
     } else if (ch.cfg == 1) {
         if (b32) launch_cfg<2, 2, 1, 2, 32>(a, splits, st); else launch_cfg<2, 2, 1, 2, 16>(a, splits, st);

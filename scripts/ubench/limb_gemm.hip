@@ -36,9 +36,10 @@ __global__ void k_split(const float* __restrict__ x, __bf16* __restrict__ h, __b
 
 // PRE_A: the A operand (the weights of a convolution: re-laid-out once per optimiser step anyway) arrives already split, as three
 // bf16 matrices; only the activation operand is split in the loader.
-template <int NPROD, bool PRE_A = false>   // 6: fp32-accurate; 3: hh + hm + mh (~2^-16); 1: plain bf16
+template <int NPROD, bool PRE_A = false, bool PRE_B = false>   // 6: fp32-accurate; 3: hh + hm + mh (~2^-16); 1: plain bf16
 __global__ void __launch_bounds__(NT) k_gemm_limb(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C,
-                                                  int M, int N, int K, const __bf16* __restrict__ A3 = nullptr) {
+                                                  int M, int N, int K, const __bf16* __restrict__ A3 = nullptr,
+                                                  const __bf16* __restrict__ B3 = nullptr) {
     __shared__ __attribute__((aligned(16))) __bf16 sA[3][BM][LDK];
     __shared__ __attribute__((aligned(16))) __bf16 sB[3][BN][LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,12 +50,22 @@ __global__ void __launch_bounds__(NT) k_gemm_limb(const float* __restrict__ A, c
     constexpr int NLA = NPROD > 3 ? 3 : (NPROD > 1 ? 2 : 1);
     float4 ra[4], rb[4];
     bf16x8 pa[NLA][2];                 // PRE_A: 128 rows x 32 k of bf16 per limb = 512 fragments of 8 = 2 per thread
+    bf16x8 pb[NLA][2];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int idx = tid + p * NT, row = idx >> 3, kq = (idx & 7) * 4;
             if (!PRE_A) ra[p] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * K + k0 + kq);
-            rb[p] = *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + row) * K + k0 + kq);
+            if (!PRE_B) rb[p] = *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + row) * K + k0 + kq);
+        }
+        if (PRE_B) {
+#pragma unroll
+            for (int t = 0; t < NLA; ++t)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int idx = tid + p * NT, row = idx >> 2, kq = (idx & 3) * 8;
+                    pb[t][p] = *reinterpret_cast<const bf16x8*>(B3 + (size_t)t * N * K + (size_t)(n0 + row) * K + k0 + kq);
+                }
         }
         if (PRE_A) {
 #pragma unroll
@@ -67,6 +78,15 @@ __global__ void __launch_bounds__(NT) k_gemm_limb(const float* __restrict__ A, c
         }
     };
     auto lstore = [&]() {
+        if (PRE_B) {
+#pragma unroll
+            for (int t = 0; t < NLA; ++t)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int idx = tid + p * NT, row = idx >> 2, kq = (idx & 3) * 8;
+                    *reinterpret_cast<bf16x8*>(&sB[t][row][kq]) = pb[t][p];
+                }
+        }
         if (PRE_A) {
 #pragma unroll
             for (int t = 0; t < NLA; ++t)
@@ -78,6 +98,7 @@ __global__ void __launch_bounds__(NT) k_gemm_limb(const float* __restrict__ A, c
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
+            if (PRE_A && PRE_B) break;
             const int idx = tid + p * NT, row = idx >> 3, kq = (idx & 7) * 4;
             const float va[4] = {ra[p].x, ra[p].y, ra[p].z, ra[p].w}, vb[4] = {rb[p].x, rb[p].y, rb[p].z, rb[p].w};
             bf16x4 ah, am, al, bh, bm, bl;
@@ -85,17 +106,17 @@ __global__ void __launch_bounds__(NT) k_gemm_limb(const float* __restrict__ A, c
             for (int e = 0; e < 4; ++e) {
                 __bf16 h, m, l;
                 if (!PRE_A) { split3(va[e], h, m, l); ah[e] = h; am[e] = m; al[e] = l; }
-                split3(vb[e], h, m, l); bh[e] = h; bm[e] = m; bl[e] = l;
+                if (!PRE_B) { split3(vb[e], h, m, l); bh[e] = h; bm[e] = m; bl[e] = l; }
             }
             if (!PRE_A) *reinterpret_cast<bf16x4*>(&sA[0][row][kq]) = ah;
-            *reinterpret_cast<bf16x4*>(&sB[0][row][kq]) = bh;
+            if (!PRE_B) *reinterpret_cast<bf16x4*>(&sB[0][row][kq]) = bh;
             if (NPROD > 1) {
                 if (!PRE_A) *reinterpret_cast<bf16x4*>(&sA[1][row][kq]) = am;
-                *reinterpret_cast<bf16x4*>(&sB[1][row][kq]) = bm;
+                if (!PRE_B) *reinterpret_cast<bf16x4*>(&sB[1][row][kq]) = bm;
             }
             if (NPROD > 3) {
                 if (!PRE_A) *reinterpret_cast<bf16x4*>(&sA[2][row][kq]) = al;
-                *reinterpret_cast<bf16x4*>(&sB[2][row][kq]) = bl;
+                if (!PRE_B) *reinterpret_cast<bf16x4*>(&sB[2][row][kq]) = bl;
             }
         }
     };
@@ -124,23 +145,16 @@ __global__ void __launch_bounds__(NT) k_gemm_limb(const float* __restrict__ A, c
                     a[t][i] = *reinterpret_cast<const bf16x8*>(&sA[t][wm * 64 + i * 32 + r][kb * 16 + kh * 8]);
                     b[t][i] = *reinterpret_cast<const bf16x8*>(&sB[t][wn * 64 + i * 32 + r][kb * 16 + kh * 8]);
                 }
+            // product-major order: consecutive MFMAs go to different accumulators (a chain of six on one accumulator would wait
+            // for each result), smallest terms first
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int q = (NPROD > 3 ? 0 : (NPROD > 1 ? 3 : 5)); q < 6; ++q)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16 c = acc[i][j];
-                    if (NPROD > 3) {            // smallest terms first
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NL - 1][i], b[0][j], c, 0, 0, 0);      // l h
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[NL - 1][j], c, 0, 0, 0);      // h l
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);           // m m
-                    }
-                    if (NPROD > 1) {
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);           // m h
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);           // h m
-                    }
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);               // h h
-                    acc[i][j] = c;
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q] < NL ? PA[q] : 0][i], b[PB[q] < NL ? PB[q] : 0][j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -272,19 +286,26 @@ static void run(int M, int N, int K) {
     printf("M %d  N %d  K %d\n", M, N, K);
     double us = time_us([&]() { hipLaunchKernelGGL(k_gemm_f32, grid, blk, 0, 0, dA, dB, dC, M, N, K); }, 10);
     check("f32 MFMA 32x32x2", us);
-    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<6, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, nullptr); }, 10);
+    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<6, false, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, nullptr, nullptr); }, 10);
     check("3 bf16 limbs, 6 products", us);
     __bf16* dA3;
     CK(hipMalloc(&dA3, (size_t)3 * M * K * 2));
     hipLaunchKernelGGL(k_split, dim3(2048), dim3(256), 0, 0, dA, dA3, dA3 + (size_t)M * K, dA3 + (size_t)2 * M * K, (long)M * K);
-    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<6, true>), grid, blk, 0, 0, dA, dB, dC, M, N, K, dA3); }, 10);
+    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<6, true, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, dA3, nullptr); }, 10);
     check("3 limbs, 6 products, A pre-split", us);
-    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<3, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, nullptr); }, 10);
+    __bf16* dB3;
+    CK(hipMalloc(&dB3, (size_t)3 * N * K * 2));
+    hipLaunchKernelGGL(k_split, dim3(2048), dim3(256), 0, 0, dB, dB3, dB3 + (size_t)N * K, dB3 + (size_t)2 * N * K, (long)N * K);
+    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<6, true, true>), grid, blk, 0, 0, dA, dB, dC, M, N, K, dA3, dB3); }, 10);
+    check("3 limbs, 6 products, A and B pre-split", us);
+    us = time_us([&]() { hipLaunchKernelGGL(k_split, dim3(2048), dim3(256), 0, 0, dB, dB3, dB3 + (size_t)N * K, dB3 + (size_t)2 * N * K, (long)N * K); }, 10);
+    printf("  %-34s %8.1f us  (the pass that splits B once: %.1f MB read, %.1f MB written)\n", "k_split(B)", us, N * (double)K * 4e-6, N * (double)K * 6e-6);
+    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<3, false, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, nullptr, nullptr); }, 10);
     check("2 bf16 limbs, 3 products", us);
-    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<3, true>), grid, blk, 0, 0, dA, dB, dC, M, N, K, dA3); }, 10);
+    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<3, true, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, dA3, nullptr); }, 10);
     check("2 limbs, 3 products, A pre-split", us);
-    CK(hipFree(dA3));
-    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<1, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, nullptr); }, 10);
+    CK(hipFree(dA3)); CK(hipFree(dB3));
+    us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<1, false, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, nullptr, nullptr); }, 10);
     check("bf16 (1 product)", us);
     CK(hipFree(dA)); CK(hipFree(dB)); CK(hipFree(dC));
 }

@@ -144,6 +144,42 @@ def test_conv_tap_adds_the_second_gradient_in_the_epilogue(FD, case):
     assert torch.equal(g_only_conv, gx_plain)
 
 
+@pytest.mark.parametrize("case", [
+    (2, 64, 16, 24, 128, 3, 2, 1, "zero"),       # stride 2 (parity classes in the data gradient)
+    (2, 64, 8, 12, 256, 1, 1, 0, "zero"),        # 1x1
+    (2, 96, 16, 24, 32, 3, 1, 1, "reflect"),     # decoder layer, reflect padding, 32x256 tile
+    (2, 64, 16, 24, 48, 3, 1, 1, "zero"),        # 64x128 tile with a ragged channel tile
+    (1, 256, 6, 20, 512, 3, 2, 1, "zero"),       # split-K
+])
+def test_split_precision_conv_keeps_fp32_accuracy(FD, case, monkeypatch):
+    """FD_CONV_LIMB=1 (exploration, off by default): the direct convolution kernel with every fp32 operand split into three bf16
+    limbs and six limb products on the bf16 MFMA.  Forward and data gradient against float64: the error must stay within twice the
+    f32-MFMA kernel's own error (or 2e-7 of the accumulated magnitude) - i.e. the split form is fp32-accurate, not bf16-accurate."""
+    N, Cin, H, W, Cout, K, stride, pad, mode = case
+    import zlib
+    rng = np.random.RandomState(zlib.crc32(repr(case).encode()) % (2 ** 31))
+    x = torch.from_numpy(rng.randn(N, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rng.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32))
+    x64, w64 = x.double().requires_grad_(True), w.double()
+    xin = F.pad(x64, (pad,) * 4, mode="reflect") if mode == "reflect" else x64
+    y64 = F.conv2d(xin, w64, None, stride, 0 if mode == "reflect" else pad)
+    cot = torch.from_numpy(rng.randn(*y64.shape).astype(np.float32))
+    (gx64,) = torch.autograd.grad((y64 * cot.double()).sum(), [x64])
+    mag_y = float(F.conv2d(F.pad(x.abs().double(), (pad,) * 4, mode="reflect") if mode == "reflect" else x.abs().double(),
+                           w.abs().double(), None, stride, 0 if mode == "reflect" else pad).max())
+    errs = {}
+    for limb in ("0", "1"):
+        monkeypatch.setenv("FD_CONV_LIMB", limb)
+        xg = dev(x).requires_grad_(True)
+        yg = FD.conv2d(xg, dev(w), None, stride, pad, mode)
+        (gxg,) = torch.autograd.grad((yg * dev(cot)).sum(), [xg])
+        errs[limb] = (float((yg.detach().cpu().double() - y64.detach()).abs().max()) / mag_y,
+                      float((gxg.cpu().double() - gx64).abs().max()) / float(gx64.abs().max()))
+    print("conv %s: |err| / sum|x w|  f32 MFMA %.2e, bf16 limbs %.2e;  dgrad rel. err  f32 %.2e, limbs %.2e"
+          % (case, errs["0"][0], errs["1"][0], errs["0"][1], errs["1"][1]))
+    assert errs["1"][0] <= max(2 * errs["0"][0], 2e-7) and errs["1"][1] <= max(2 * errs["0"][1], 2e-6)
+
+
 def test_conv_transpose_detecting(FD):
     """A = I-style check with asymmetric data: a conv whose weight is a one-hot tap must shift/copy channels
     exactly (catches row/col swaps in the MFMA fragment maps bit-exactly)."""
