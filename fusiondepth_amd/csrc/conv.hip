@@ -702,10 +702,17 @@ inline bool wino_use_wgrad(const fd_conv_desc* d) {
     if (min_cc < 0) { const char* e = getenv("FD_WINO_WGRAD_MIN"); min_cc = e ? atol(e) : 0; }
     return on != 0 && wino_enabled() && wino_wgrad_ok(d) && (long)d->Cin * d->Cout >= min_cc;
 }
-inline bool wino_use_fwd(const fd_conv_desc* d) { return wino_enabled() && wino_fwd_ok(d) && d->Cout >= 64; }
+// FD_WINO_FWD=0: forward and data gradient stay on the direct kernels, the weight gradient keeps its Winograd kernel (A/B runs of
+// the split-precision direct kernel, FD_CONV_LIMB=1, against the f32 Winograd kernel)
+bool wino_fwd_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FD_WINO_FWD"); on = e ? atoi(e) : 1; }
+    return on != 0 && wino_enabled();
+}
+inline bool wino_use_fwd(const fd_conv_desc* d) { return wino_fwd_enabled() && wino_fwd_ok(d) && d->Cout >= 64; }
 // the data gradient of a zero-padded 3x3 stride-1 conv is the same kind of conv over dY (channels swapped, kernel flipped)
 inline bool wino_dgrad_desc(const fd_conv_desc* d, fd_conv_desc& g) {
-    if (!(wino_enabled() && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0)) return false;
+    if (!(wino_fwd_enabled() && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0)) return false;
     g = *d;
     g.Cin = d->Cout; g.Cout = d->Cin; g.act = 0; g.in_norm = 0;
     return wino_fwd_ok(&g) && g.Cout >= 64;
