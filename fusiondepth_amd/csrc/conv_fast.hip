@@ -375,19 +375,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_limb(FastGemmAr
                     for (int j = 0; j < WN; ++j)
                         b[t][j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)t * BN + wave_n * 32 * WN + j * 32 + acol) * LDK + kb * 16 + arow * 8);
                 }
+                // product-major order (consecutive MFMAs go to different accumulators), smallest terms first
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                for (int q = 0; q < 6; ++q)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) {
-                        f32x16 c = acc[i][j];                                    // smallest terms first
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2][i], b[0][j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[2][j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[1][j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], c, 0, 0, 0);
-                        acc[i][j] = c;
-                    }
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
             }
             __syncthreads();
         }
