@@ -170,6 +170,207 @@ __global__ void __launch_bounds__(NT) k_gemm_limb(const float* __restrict__ A, c
             }
 }
 
+// Software-pipelined variant of the six-product kernel: K chunks of 16 (one MFMA K), LDS double-buffered (one barrier per chunk),
+// and the loader woven between the MFMA groups of the wave itself: while the 24 MFMAs of chunk c run from buffer c % 2, the
+// registers holding chunk c+1 are split and stored into the other buffer (after the first two product groups) and the global loads
+// of chunk c+2 are issued (after the fourth).  Products hh first, so the first MFMAs need only two of the six fragment pairs.
+constexpr int BK2 = 16, LDK2 = BK2 + 8;            // 48-byte rows: 16 lanes x 16-byte fragments cover the 64 banks exactly once
+__global__ void __launch_bounds__(NT) k_gemm_limb_pipe(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C,
+                                                       int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][3][BM][LDK2];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][3][BN][LDK2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int r = lane & 31, kh = lane >> 5;
+    // 128 rows x 16 k = 512 float4 per operand: two per thread
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int idx = tid + p * NT, row = idx >> 2, kq = (idx & 3) * 4;
+            ra[p] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * K + k0 + kq);
+            rb[p] = *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + row) * K + k0 + kq);
+        }
+    };
+    auto lstore = [&](int buf, int p) __attribute__((always_inline)) {
+        const int idx = tid + p * NT, row = idx >> 2, kq = (idx & 3) * 4;
+        const float va[4] = {ra[p].x, ra[p].y, ra[p].z, ra[p].w}, vb[4] = {rb[p].x, rb[p].y, rb[p].z, rb[p].w};
+        bf16x4 qa[3], qb[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h, m, l;
+            split3(va[e], h, m, l); qa[0][e] = h; qa[1][e] = m; qa[2][e] = l;
+            split3(vb[e], h, m, l); qb[0][e] = h; qb[1][e] = m; qb[2][e] = l;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            *reinterpret_cast<bf16x4*>(&sA[buf][t][row][kq]) = qa[t];
+            *reinterpret_cast<bf16x4*>(&sB[buf][t][row][kq]) = qb[t];
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int nchunk = K / BK2;
+    gload(0);
+    lstore(0, 0); lstore(0, 1);
+    if (nchunk > 1) gload(BK2);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        bf16x8 a[3][2], b[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[t][i] = *reinterpret_cast<const bf16x8*>(&sA[cur][t][wm * 64 + i * 32 + r][kh * 8]);
+                b[t][i] = *reinterpret_cast<const bf16x8*>(&sB[cur][t][wn * 64 + i * 32 + r][kh * 8]);
+            }
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};       // hh hm mh mm hl lh
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 < nchunk) {
+                if (q == 1) lstore(cur ^ 1, 0);
+                if (q == 2) lstore(cur ^ 1, 1);
+                if (q == 4 && c + 2 < nchunk) gload((c + 2) * BK2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                const int n = n0 + wn * 64 + j * 32 + r;
+                C[(size_t)m * N + n] = acc[i][j][q];
+            }
+}
+
+// Second pipelined variant: the fragments of chunk c+1 are read from LDS into a second register set DURING the last three product
+// groups of chunk c (their latency hides behind 12 MFMAs), so the only exposed step per chunk is one barrier in its middle:
+//   first half : 3 product groups on F(c)  +  split / store of chunk c+1 into the other buffer
+//   barrier
+//   second half: 3 product groups on F(c)  +  fragment reads F(c+1)  +  global loads of chunk c+2
+__global__ void __launch_bounds__(NT) k_gemm_limb_pipe2(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C,
+                                                        int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) __bf16 sA[2][3][BM][LDK2];
+    __shared__ __attribute__((aligned(16))) __bf16 sB[2][3][BN][LDK2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int r = lane & 31, kh = lane >> 5;
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int idx = tid + p * NT, row = idx >> 2, kq = (idx & 3) * 4;
+            ra[p] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * K + k0 + kq);
+            rb[p] = *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + row) * K + k0 + kq);
+        }
+    };
+    auto lstore = [&](int buf, int p) __attribute__((always_inline)) {
+        const int idx = tid + p * NT, row = idx >> 2, kq = (idx & 3) * 4;
+        const float va[4] = {ra[p].x, ra[p].y, ra[p].z, ra[p].w}, vb[4] = {rb[p].x, rb[p].y, rb[p].z, rb[p].w};
+        bf16x4 qa[3], qb[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h, m, l;
+            split3(va[e], h, m, l); qa[0][e] = h; qa[1][e] = m; qa[2][e] = l;
+            split3(vb[e], h, m, l); qb[0][e] = h; qb[1][e] = m; qb[2][e] = l;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            *reinterpret_cast<bf16x4*>(&sA[buf][t][row][kq]) = qa[t];
+            *reinterpret_cast<bf16x4*>(&sB[buf][t][row][kq]) = qb[t];
+        }
+    };
+    bf16x8 fa[2][3][2], fb[2][3][2];
+    auto fread = [&](int set, int buf, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa[set][t][i] = *reinterpret_cast<const bf16x8*>(&sA[buf][t][wm * 64 + i * 32 + r][kh * 8]);
+            fb[set][t][i] = *reinterpret_cast<const bf16x8*>(&sB[buf][t][wn * 64 + i * 32 + r][kh * 8]);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};       // hh hm mh mm hl lh
+    auto group = [&](int set, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][PA[q]][i], fb[set][PB[q]][j], acc[i][j], 0, 0, 0);
+    };
+    const int nchunk = K / BK2;
+    gload(0);
+    lstore(0, 0); lstore(0, 1);
+    if (nchunk > 1) gload(BK2);
+    __syncthreads();
+    fread(0, 0, 0); fread(0, 0, 1); fread(0, 0, 2);
+    auto chunk = [&](int c, const int set) __attribute__((always_inline)) {      // `set` = c & 1, compile-time after unrolling by two
+        const bool more = c + 1 < nchunk;
+        group(set, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) lstore(set ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        group(set, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) lstore(set ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(set, 2);
+        __syncthreads();
+        if (more) fread(set ^ 1, set ^ 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        group(set, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) fread(set ^ 1, set ^ 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        group(set, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) fread(set ^ 1, set ^ 1, 2);
+        if (c + 2 < nchunk) gload((c + 2) * BK2);
+        __builtin_amdgcn_sched_barrier(0);
+        group(set, 5);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk(c, 0);
+        if (c + 1 < nchunk) chunk(c + 1, 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                const int n = n0 + wn * 64 + j * 32 + r;
+                C[(size_t)m * N + n] = acc[i][j][q];
+            }
+}
+
 // the same tiling on the f32 MFMA (operands transposed into LDS as [k][row], one float per lane and k-step)
 __global__ void __launch_bounds__(NT) k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C,
                                                  int M, int N, int K) {
@@ -288,6 +489,10 @@ static void run(int M, int N, int K) {
     check("f32 MFMA 32x32x2", us);
     us = time_us([&]() { hipLaunchKernelGGL((k_gemm_limb<6, false, false>), grid, blk, 0, 0, dA, dB, dC, M, N, K, nullptr, nullptr); }, 10);
     check("3 bf16 limbs, 6 products", us);
+    us = time_us([&]() { hipLaunchKernelGGL(k_gemm_limb_pipe, grid, blk, 0, 0, dA, dB, dC, M, N, K); }, 10);
+    check("3 limbs, 6 products, pipelined", us);
+    us = time_us([&]() { hipLaunchKernelGGL(k_gemm_limb_pipe2, grid, blk, 0, 0, dA, dB, dC, M, N, K); }, 10);
+    check("3 limbs, 6 products, pipelined 2", us);
     __bf16* dA3;
     CK(hipMalloc(&dA3, (size_t)3 * M * K * 2));
     hipLaunchKernelGGL(k_split, dim3(2048), dim3(256), 0, 0, dA, dA3, dA3 + (size_t)M * K, dA3 + (size_t)2 * M * K, (long)M * K);
