@@ -371,6 +371,105 @@ __global__ void __launch_bounds__(NT) k_gemm_limb_pipe2(const float* __restrict_
             }
 }
 
+// Large-tile variant, shaped by the LDS wall measured in mfma_bf16_lds.hip: 128 x 128 per WAVE (4 x 4 blocks, 256 accumulator
+// registers, one wave per SIMD), workgroup = 2 x 2 waves = 256 x 256, K chunks of 16, LDS double-buffered (147 KB).  24 fragment reads
+// feed 96 MFMAs (half the LDS bytes per MFMA of the 64 x 64 tile); fragments are requested in the order the product groups need them
+// (hh -> a0 b0, hm -> b1, mh -> a1, mm, hl -> b2, lh -> a2) and the next chunk's split / store / global loads ride between the groups.
+constexpr int BM3 = 256, BN3 = 256;
+__global__ void __launch_bounds__(NT, 1) k_gemm_limb_big(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C,
+                                                         int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 smem3[];
+    // [buf][operand][limb][256 rows][LDK2]
+    auto S = [&](int buf, int op, int t, int row, int k) -> __bf16* { return smem3 + ((((size_t)buf * 2 + op) * 3 + t) * 256 + row) * LDK2 + k; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM3, n0 = blockIdx.x * BN3;
+    const int r = lane & 31, kh = lane >> 5;
+    // 256 rows x 16 k = 1024 float4 per operand: four per thread
+    float4 ra[4], rb[4];
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = tid + p * NT, row = idx >> 2, kq = (idx & 3) * 4;
+            ra[p] = *reinterpret_cast<const float4*>(A + (size_t)(m0 + row) * K + k0 + kq);
+            rb[p] = *reinterpret_cast<const float4*>(Bt + (size_t)(n0 + row) * K + k0 + kq);
+        }
+    };
+    auto lstore = [&](int buf, int p) __attribute__((always_inline)) {
+        const int idx = tid + p * NT, row = idx >> 2, kq = (idx & 3) * 4;
+        const float va[4] = {ra[p].x, ra[p].y, ra[p].z, ra[p].w}, vb[4] = {rb[p].x, rb[p].y, rb[p].z, rb[p].w};
+        bf16x4 qa[3], qb[3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 h, m, l;
+            split3(va[e], h, m, l); qa[0][e] = h; qa[1][e] = m; qa[2][e] = l;
+            split3(vb[e], h, m, l); qb[0][e] = h; qb[1][e] = m; qb[2][e] = l;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            *reinterpret_cast<bf16x4*>(S(buf, 0, t, row, kq)) = qa[t];
+            *reinterpret_cast<bf16x4*>(S(buf, 1, t, row, kq)) = qb[t];
+        }
+    };
+    bf16x8 fa[3][4], fb[3][4];
+    auto fread = [&](int buf, int op, int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (op == 0) fa[t][i] = *reinterpret_cast<const bf16x8*>(S(buf, 0, t, wm * 128 + i * 32 + r, kh * 8));
+            else fb[t][i] = *reinterpret_cast<const bf16x8*>(S(buf, 1, t, wn * 128 + i * 32 + r, kh * 8));
+        }
+    };
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    auto group = [&](int ta, int tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ta][i], fb[tb][j], acc[i][j], 0, 0, 0);
+    };
+    const int nchunk = K / BK2;
+    gload(0);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) lstore(0, p);
+    if (nchunk > 1) gload(BK2);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < nchunk;
+        fread(cur, 0, 0); fread(cur, 1, 0); fread(cur, 1, 1); fread(cur, 0, 1); fread(cur, 1, 2); fread(cur, 0, 2);
+        // 6 product groups x 4 row blocks = 24 slots of 4 MFMAs; the loader's work is cut into slices that ride behind the slots
+        constexpr int GA[6] = {0, 0, 1, 1, 0, 2}, GB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+        for (int slot = 0; slot < 24; ++slot) {
+            const int q = slot >> 2, i = slot & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[GA[q]][i], fb[GB[q]][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && slot >= 2 && slot < 18 && ((slot - 2) & 3) == 0) lstore(cur ^ 1, (slot - 2) >> 2);     // slots 2, 6, 10, 14
+            if (c + 2 < nchunk && slot == 19) gload((c + 2) * BK2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + wm * 128 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                const int n = n0 + wn * 128 + j * 32 + r;
+                C[(size_t)m * N + n] = acc[i][j][q];
+            }
+}
+
 // the same tiling on the f32 MFMA (operands transposed into LDS as [k][row], one float per lane and k-step)
 __global__ void __launch_bounds__(NT) k_gemm_f32(const float* __restrict__ A, const float* __restrict__ Bt, float* __restrict__ C,
                                                  int M, int N, int K) {
@@ -493,6 +592,12 @@ static void run(int M, int N, int K) {
     check("3 limbs, 6 products, pipelined", us);
     us = time_us([&]() { hipLaunchKernelGGL(k_gemm_limb_pipe2, grid, blk, 0, 0, dA, dB, dC, M, N, K); }, 10);
     check("3 limbs, 6 products, pipelined 2", us);
+    if (M % BM3 == 0 && N % BN3 == 0) {
+        const size_t lds3 = (size_t)2 * 2 * 3 * 256 * LDK2 * 2;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_limb_big), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        us = time_us([&]() { hipLaunchKernelGGL(k_gemm_limb_big, dim3(N / BN3, M / BM3), blk, lds3, 0, dA, dB, dC, M, N, K); }, 10);
+        check("3 limbs, 6 products, 128x128 per wave", us);
+    }
     __bf16* dA3;
     CK(hipMalloc(&dA3, (size_t)3 * M * K * 2));
     hipLaunchKernelGGL(k_split, dim3(2048), dim3(256), 0, 0, dA, dA3, dA3 + (size_t)M * K, dA3 + (size_t)2 * M * K, (long)M * K);
