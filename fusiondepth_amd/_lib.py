@@ -92,12 +92,6 @@ SIGNATURES = {
     "fd_conv3x3_wino_fwd": ("pppppp" "i" "pp", "i"),
     "fd_velo_rasterize_ws_bytes": ("iii", "l"),
     "fd_velo_rasterize": ("pipiiiiipppp", "i"),
-    "fd_conv2d_fwd_pair_ws_floats": ("p", "l"),
-    "fd_conv2d_fwd_pair": ("ppppppp" "i" "pp", "i"),
-    "fd_conv2d_bwd_data_pair_ws_floats": ("p", "l"),
-    "fd_conv2d_bwd_data_pair": ("ppppppp" "i" "pp", "i"),
-    "fd_conv2d_bwd_weight_pair_ws_floats": ("p", "l"),
-    "fd_conv2d_bwd_weight_pair": ("pppppp" "i" "p", "i"),
     "fd_conv2d_relayout_jobs": ("pippp", "i"),
     "fd_relayout_plan": ("pi", "l"),
     "fd_relayout_batch": ("pilp", "i"),

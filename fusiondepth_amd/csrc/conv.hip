@@ -702,8 +702,7 @@ inline bool wino_use_wgrad(const fd_conv_desc* d) {
     if (min_cc < 0) { const char* e = getenv("FD_WINO_WGRAD_MIN"); min_cc = e ? atol(e) : 0; }
     return on != 0 && wino_enabled() && wino_wgrad_ok(d) && (long)d->Cin * d->Cout >= min_cc;
 }
-// FD_WINO_FWD=0: forward and data gradient stay on the direct kernels, the weight gradient keeps its Winograd kernel (A/B runs of
-// the split-precision direct kernel, FD_CONV_LIMB=1, against the f32 Winograd kernel)
+// FD_WINO_FWD=0: forward and data gradient stay on the direct kernels, the weight gradient keeps its Winograd kernel (A/B runs)
 bool wino_fwd_enabled() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("FD_WINO_FWD"); on = e ? atoi(e) : 1; }
@@ -788,42 +787,6 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
     return 0;
 }
 
-// ---- sibling pair: two networks of identical architecture in one launch (see FastGemmArgs::siblings).  `d->N` is the batch
-// of ONE sibling; x / y hold 2 * N images, sibling-major.  Convolutions without bias only (the ResNet trunks).
-extern "C" long fd_conv2d_fwd_pair_ws_floats(const fd_conv_desc* d) {
-    if (!d) return 0;
-    ConvShape s;
-    if (!conv_out_shape(d, s) || !fast_fwd_ok(d) || wino_use_fwd(d)) return fd_conv2d_fwd_ws_floats(d);
-    FastGemmArgs f;
-    fill_fwd_args(d, s, f);
-    f.siblings = 2;
-    return fast_splitk_slab_floats(f, nullptr);
-}
-
-extern "C" int fd_conv2d_fwd_pair(const fd_conv_desc* d, const float* x, const float* w0, const float* w1, float* y, float* wt0,
-                                  float* wt1, int wt_ready, float* ws, void* stream) {
-    if (int rc = check_desc(d, "fd_conv2d_fwd_pair")) return rc;
-    FD_REQUIRE(x && w0 && w1 && y, "fd_conv2d_fwd_pair: NULL tensor");
-    ConvShape s;
-    FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_fwd_pair: empty output");
-    const size_t xin = (size_t)d->N * d->Cin * d->H * d->W, yout = (size_t)d->N * d->Cout * s.Ho * s.Wo;
-    if (!fast_fwd_ok(d) || wino_use_fwd(d)) {                // no paired kernel for this shape: two launches
-        if (int rc = fd_conv2d_fwd(d, x, w0, nullptr, y, wt0, wt_ready, ws, stream)) return rc;
-        return fd_conv2d_fwd(d, x + xin, w1, nullptr, y + yout, wt1, wt_ready, ws, stream);
-    }
-    FD_REQUIRE(wt0 && wt1, "fd_conv2d_fwd_pair: weight-layout buffers required");
-    FD_REQUIRE(xin < (1UL << 29) && yout < (1UL << 29), "fd_conv2d_fwd_pair: tensor too large for 32-bit byte offsets");
-    hipStream_t st = (hipStream_t)stream;
-    if (!wt_ready) {
-        if (int rc = fast_weight_relayout(w0, wt0, d->Cout, d->Cin, d->KH, d->KW, d->KH, d->KW, 0, 1, 0, 1, 0, st)) return rc;
-        if (int rc = fast_weight_relayout(w1, wt1, d->Cout, d->Cin, d->KH, d->KW, d->KH, d->KW, 0, 1, 0, 1, 0, st)) return rc;
-    }
-    FastGemmArgs f;
-    fill_fwd_args(d, s, f);
-    f.siblings = 2; f.A = wt0; f.A1 = wt1; f.X = x; f.Y = y; f.bias = nullptr; f.bias1 = nullptr; f.slabs = ws;
-    return fast_gemm_launch(f, st);
-}
-
 extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     fd_conv_desc g;
@@ -854,54 +817,23 @@ extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
 }
 
 namespace {
-int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const float* w1, float* gx, float* wt_base,
-                  float* wt_base1, int wt_ready, float* ws, void* stream, int siblings, const float* gx_add = nullptr);
+int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt_base, int wt_ready, float* ws,
+                  void* stream, const float* gx_add = nullptr);
 }
 extern "C" int fd_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream);   // pool.hip
 extern "C" int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt_base,
                                   int wt_ready, float* ws, void* stream) {
-    return bwd_data_impl(d, gy, w, nullptr, gx, wt_base, nullptr, wt_ready, ws, stream, 1);
+    return bwd_data_impl(d, gy, w, gx, wt_base, wt_ready, ws, stream);
 }
 extern "C" int fd_conv2d_bwd_data_add(const fd_conv_desc* d, const float* gy, const float* w, const float* gx_add, float* gx,
                                       float* wt_base, int wt_ready, float* ws, void* stream) {
     FD_REQUIRE(gx_add != gx, "fd_conv2d_bwd_data_add: gx_add must not alias gx");
-    return bwd_data_impl(d, gy, w, nullptr, gx, wt_base, nullptr, wt_ready, ws, stream, 1, gx_add);
-}
-extern "C" long fd_conv2d_bwd_data_pair_ws_floats(const fd_conv_desc* d) {
-    if (!d) return 0;
-    ConvShape s;
-    if (!conv_out_shape(d, s)) return 0;
-    fd_conv_desc gw;
-    if (!(fast_dgrad_ok(d) && d->pad_mode == 0) || wino_dgrad_desc(d, gw)) return fd_conv2d_bwd_data_ws_floats(d);
-    long slabs = 0;
-    if (d->stride == 1) {
-        FastGemmArgs f = {};
-        f.M = d->Cin; f.C = d->Cout; f.T = d->KH * d->KW; f.Nb = d->N; f.NY = d->H; f.NX = d->W; f.osy = 1; f.osx = 1;
-        f.out_total = (long)d->N * d->Cin * f.NY * f.NX;
-        f.siblings = 2;
-        slabs = fast_splitk_slab_floats(f, nullptr);
-    }
-    return slabs;
-}
-extern "C" int fd_conv2d_bwd_data_pair(const fd_conv_desc* d, const float* gy, const float* w0, const float* w1, float* gx,
-                                       float* wt0, float* wt1, int wt_ready, float* ws, void* stream) {
-    if (int rc = check_desc(d, "fd_conv2d_bwd_data_pair")) return rc;
-    FD_REQUIRE(gy && w0 && w1 && gx && wt0 && wt1, "fd_conv2d_bwd_data_pair: NULL tensor");
-    ConvShape s;
-    FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_data_pair: empty output");
-    fd_conv_desc gw;
-    if (!(fast_dgrad_ok(d) && d->pad_mode == 0) || wino_dgrad_desc(d, gw)) {   // no paired kernel for this shape: two launches
-        const size_t xin = (size_t)d->N * d->Cin * d->H * d->W, yout = (size_t)d->N * d->Cout * s.Ho * s.Wo;
-        if (int rc = fd_conv2d_bwd_data(d, gy, w0, gx, wt0, wt_ready, ws, stream)) return rc;
-        return fd_conv2d_bwd_data(d, gy + yout, w1, gx + xin, wt1, wt_ready, ws, stream);
-    }
-    return bwd_data_impl(d, gy, w0, w1, gx, wt0, wt1, wt_ready, ws, stream, 2);
+    return bwd_data_impl(d, gy, w, gx, wt_base, wt_ready, ws, stream, gx_add);
 }
 namespace {
-int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const float* w1, float* gx, float* wt_base,
-                  float* wt_base1, int wt_ready, float* ws, void* stream, int siblings, const float* gx_add) {
+int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt_base, int wt_ready, float* ws,
+                  void* stream, const float* gx_add) {
     if (int rc = check_desc(d, "fd_conv2d_bwd_data")) return rc;
-    FD_REQUIRE(!(gx_add && siblings != 1), "fd_conv2d_bwd_data: gx_add is not available for sibling pairs");
     // gx_add joins in the epilogue of the MFMA kernels (and of their split-K reduction); the remaining paths (generic gather
     // GEMM, reflect padding with its fold pass, parity classes without taps) add it with one element-wise launch afterwards
     const long gx_n = (long)d->N * d->Cin * d->H * d->W;
@@ -915,8 +847,8 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
     const int KH = d->KH, KW = d->KW;
     {
         fd_conv_desc gd;
-        conv_log("dgrad", (siblings == 1 && wino_dgrad_desc(d, gd)) ? "wino" : "direct", d);
-        if (siblings == 1 && wino_dgrad_desc(d, gd)) {
+        conv_log("dgrad", wino_dgrad_desc(d, gd) ? "wino" : "direct", d);
+        if (wino_dgrad_desc(d, gd)) {
             if (!wt_ready)
                 if (int rc = wino_weight_launch(w, wt_base, gd.Cout, gd.Cin, 1, st)) return rc;
             return wino_conv_launch(&gd, gy, wt_base, nullptr, gx, ws, st, gx_add);
@@ -926,7 +858,6 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
     bool add_in_kernel = false;
     const long wt_n = align4((long)d->Cin * d->Cout * KH * KW);
     float* wt = wt_base;                       // per parity class: wt_base + class * wt_n
-    float* wt1 = wt_base1;
     float* gpad = ws;
     const long pad_n = d->pad_mode == 1 ? align4((long)d->N * d->Cin * (d->H + 2) * (d->W + 2)) : 0;
     float* slabs = ws ? ws + pad_n : nullptr;
@@ -938,13 +869,9 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
     g.M = d->Cin; g.Nb = d->N; g.C = d->Cout; g.Hi = s.Ho; g.Wi = s.Wo;
     auto run = [&](int TA, int TB, int kh0, int dkh, int kw0, int dkw, bool allow_split) -> int {
         if (fast) {
-            if (!wt_ready) {
+            if (!wt_ready)
                 if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, KH, KW, TA, TB, kh0, dkh, kw0, dkw, 1, st)) return rc;
-                if (siblings == 2)
-                    if (int rc = fast_weight_relayout(w1, wt1, d->Cout, d->Cin, KH, KW, TA, TB, kh0, dkh, kw0, dkw, 1, st)) return rc;
-            }
             FastGemmArgs f = {};
-            f.siblings = siblings; f.A1 = wt1;
             f.A = wt; f.X = gy; f.Y = g.Y; f.bias = nullptr;
             f.M = d->Cin; f.C = d->Cout; f.T = TA * TB; f.TB = TB; f.K = f.T * f.C;
             f.Nb = d->N; f.Hi = s.Ho; f.Wi = s.Wo; f.NY = g.NY; f.NX = g.NX;
@@ -997,7 +924,7 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
         for (int pw = 0; pw < 2; ++pw)
             if (((ph + d->pad) & 1) >= KH || ((pw + d->pad) & 1) >= KW) need_zero = true;
     if (need_zero) {
-        if (hipMemsetAsync(gx, 0, sizeof(float) * (size_t)siblings * d->N * d->Cin * d->H * d->W, st) != hipSuccess) {
+        if (hipMemsetAsync(gx, 0, sizeof(float) * (size_t)d->N * d->Cin * d->H * d->W, st) != hipSuccess) {
             fd_set_error("fd_conv2d_bwd_data: memset failed");
             return -1;
         }
@@ -1015,7 +942,6 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, const 
             g.sx = 1; g.ox = (pw + d->pad - kw0) / 2; g.db = -1;
             g.osy = 2; g.ooy = ph; g.osx = 2; g.oox = pw;
             wt = wt_base + (long)(ph * 2 + pw) * wt_n;
-            if (siblings == 2) wt1 = wt_base1 + (long)(ph * 2 + pw) * wt_n;
             if (int rc = run(TA, TB, kh0, 2, kw0, 2, false)) return rc;
         }
     return add_in_kernel ? 0 : add_after();
@@ -1099,40 +1025,6 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     const long bias_part = (long)d->Cout * CS_SPLITS;
     if (slabs < wsz) slabs = wsz;                            // accumulate mode stages a single slab
     return slabs > bias_part ? slabs : bias_part;          // the two uses are sequential on the stream
-}
-
-extern "C" long fd_conv2d_bwd_weight_pair_ws_floats(const fd_conv_desc* d) {
-    if (!d) return 0;
-    ConvShape s;
-    if (!conv_out_shape(d, s)) return 0;
-    if (!fast_wgrad_ok(d) || narrow_wgrad_ok(d) || stem_wgrad_ok(d) || wino_use_wgrad(d)) return fd_conv2d_bwd_weight_ws_floats(d);
-    const long wsz = (long)d->Cout * d->Cin * d->KH * d->KW;
-    return 2L * fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo, 2) * wsz;
-}
-extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* gbias,
-                                    float* ws, int accumulate, void* stream);
-extern "C" int fd_conv2d_bwd_weight_pair(const fd_conv_desc* d, const float* x, const float* gy, float* gw0, float* gw1, float* ws,
-                                         int accumulate, void* stream) {
-    if (int rc = check_desc(d, "fd_conv2d_bwd_weight_pair")) return rc;
-    FD_REQUIRE(x && gy && gw0 && gw1 && ws, "fd_conv2d_bwd_weight_pair: NULL tensor / workspace");
-    ConvShape s;
-    FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_weight_pair: empty output");
-    const size_t xin = (size_t)d->N * d->Cin * d->H * d->W, yout = (size_t)d->N * d->Cout * s.Ho * s.Wo;
-    if (!fast_wgrad_ok(d) || narrow_wgrad_ok(d) || stem_wgrad_ok(d) || wino_use_wgrad(d)) {      // no paired kernel: two launches
-        if (int rc = fd_conv2d_bwd_weight(d, x, gy, gw0, nullptr, ws, accumulate, stream)) return rc;
-        return fd_conv2d_bwd_weight(d, x + xin, gy + yout, gw1, nullptr, ws, accumulate, stream);
-    }
-    FD_REQUIRE(xin < (1UL << 29) && yout < (1UL << 29), "fd_conv2d_bwd_weight_pair: tensor too large for 32-bit byte offsets");
-    FastWgradArgs f = {};
-    f.siblings = 2;
-    f.dY = gy; f.X = x; f.slabs = ws;
-    f.M = d->Cout; f.C = d->Cin; f.T = d->KH * d->KW; f.TB = d->KW;
-    f.Nb = d->N; f.Hi = d->H; f.Wi = d->W; f.NY = s.Ho; f.NX = s.Wo;
-    f.sy = d->stride; f.oy = -d->pad; f.da = 1; f.sx = d->stride; f.ox = -d->pad; f.db = 1;
-    f.pad_mode = d->pad_mode;
-    f.dy_cs = (long)s.Ho * s.Wo; f.dy_ns = f.dy_cs * d->Cout;
-    const long Np = (long)d->N * s.Ho * s.Wo;
-    return fast_wgrad_launch(f, gw0, fast_wgrad_splits(f.M, f.C, f.T, Np, 2), accumulate, (hipStream_t)stream, gw1);
 }
 
 extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* gbias,

@@ -20,15 +20,8 @@ struct FastGemmArgs {
     int out_w, osy, ooy, osx, oox;
     int act;
     int xcd_swizzle;
-    // Sibling batching: two networks of identical architecture (e.g. the RGB and the LiDAR pose encoders) run as ONE launch.
-    // Their activations share a tensor ([2 * Nb] images, sibling-major); each sibling has its own weights / bias.  gridDim.z =
-    // siblings * splits.  Nb stays the per-sibling batch.
-    int siblings;        // 1 or 2
-    const float* A1;     // sibling 1: re-laid-out weights
-    const float* bias1;
-    float* slabs1_unused;
     const float* add;    // optional, laid out like Y: Y = act(conv + bias) + add  (a second gradient arriving at the same tensor:
-                         // the residual branch of a ResNet block joins the data gradient in the epilogue); siblings == 1 only
+                         // the residual branch of a ResNet block joins the data gradient in the epilogue)
 };
 
 struct FastWgradArgs {
@@ -39,15 +32,14 @@ struct FastWgradArgs {
     int pad_mode;
     long dy_ns, dy_cs;
     long pix_per_split;
-    int siblings;        // 1 or 2: gridDim.z = siblings * splits; slabs [sibling][split][M][T][C]
 };
 
 long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out);
 int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st);
 int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh, int kw0,
                          int dkw, int mode, hipStream_t st);
-int fast_wgrad_splits(int M, int C, int T, long Np, int siblings = 1);
-int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st, float* gw1 = nullptr);
+int fast_wgrad_splits(int M, int C, int T, long Np);
+int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st);
 
 // Y[i] = act(sum_z slabs[z][i] + bias[channel(i)]) - the deterministic split-K epilogue (also used by conv_wino.hip)
 int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, long total, long slab_stride, int splits, long out_cs,

@@ -63,8 +63,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     const int cpt = g.C / BKC;                  // chunks per tap
     const int nchunk_all = g.T * cpt;
     // split-K: this workgroup handles chunks [ch_lo, ch_hi)
-    const int nsplit = (int)gridDim.z / g.siblings;          // gridDim.z = siblings * splits
-    const int sib = (int)blockIdx.z / nsplit, zs = (int)blockIdx.z - sib * nsplit;
+    const int nsplit = (int)gridDim.z, zs = (int)blockIdx.z;
     const int per_split = (nchunk_all + nsplit - 1) / nsplit;
     const int ch_lo = zs * per_split;
     const int ch_hi = ch_lo + per_split < nchunk_all ? ch_lo + per_split : nchunk_all;
@@ -87,8 +86,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
     // ---- weight loader: float4 column a4 of row ar + A_ROWS_PER_PASS*i
     const int a4 = tid % A_V4_PER_ROW, ar = tid / A_V4_PER_ROW;
 
-    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(sib ? g.A1 : g.A),
-                                 rsX = fd_make_rsrc(g.X + (size_t)sib * g.Nb * g.C * chw);
+    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(g.A), rsX = fd_make_rsrc(g.X);
     float4 ra[NA_LOAD];
     float rb[NB_LOAD];
     // state of the chunk being fetched (set by prep_chunk, consumed by the load/store slices); byte offsets
@@ -197,8 +195,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
     const bool final_pass = nsplit == 1;
-    float* Y = final_pass ? g.Y + (size_t)sib * g.Nb * g.out_ns : g.slabs + (size_t)blockIdx.z * g.slab_stride;
-    const float* bias = sib ? g.bias1 : g.bias;
+    float* Y = final_pass ? g.Y : g.slabs + (size_t)blockIdx.z * g.slab_stride;
+    const float* bias = g.bias;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const long p = p0 + wave_n * 32 * WN + j * 32 + acol;
@@ -218,198 +216,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
                     float v = acc[i][j][r];
                     if (final_pass) {
                         if (bias) v += bias[m];
-                        v = act_apply(v, g.act);
-                        if (ao) v += ao[(long)m * g.out_cs];
-                    }
-                    yo[(long)m * g.out_cs] = v;
-                }
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ split-precision variant
-// Exploration behind FD_CONV_LIMB=1 (off by default; DESIGN.md "known gaps" 5, profiles/round2_limb_gemm.md): the same implicit GEMM
-// with every fp32 operand split into three bf16 limbs x = h + m + l (8 + 8 + 8 mantissa bits, exact) as it is written to LDS, and
-// the product formed from the six limb products of weight >= 2^-16 (lh, hl, mm, mh, hm, hh) on v_mfma_f32_32x32x16_bf16 with fp32
-// accumulation: fp32 accuracy (the dropped terms are <= 2^-24 relative) at 16/6 of the f32 MFMA rate.  Chunk = 32 channels of one
-// tap; LDS holds K-contiguous bf16 rows ([limb][row][32 + 8]) so that a lane's 8-element MFMA fragment is one 16-byte read; single
-// LDS buffer, the next chunk's global loads are in flight during the MFMA phase.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r = x - (float)h;      // exact
-    m = (__bf16)r;
-    l = (__bf16)(r - (float)m);        // r - m is exact as well
-}
-
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_limb(FastGemmArgs g) {
-    constexpr int BKC = 32;
-    constexpr int NT = 64 * WAVES_M * WAVES_N;
-    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
-    constexpr int LDK = BKC + 8;                // bf16 per LDS row (80 bytes: fragments stay 16-byte aligned, rows spread over the banks)
-    constexpr int RP = NT / BN;                 // threads per pixel column
-    constexpr int NB_LOAD = BKC / RP;           // CONSECUTIVE channels per thread (one or more 8-element fragments)
-    constexpr int A_V4_PER_ROW = BKC / 4;
-    constexpr int A_ROWS_PER_PASS = NT / A_V4_PER_ROW;
-    constexpr int NA_LOAD = (BM + A_ROWS_PER_PASS - 1) / A_ROWS_PER_PASS;
-    constexpr bool A_PARTIAL = (BM % A_ROWS_PER_PASS) != 0;
-    static_assert(NT % BN == 0 && NB_LOAD % 8 == 0, "tile/loader mismatch");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* sA = reinterpret_cast<__bf16*>(smem);           // [3][BM][LDK]
-    __bf16* sB = sA + 3 * BM * LDK;                         // [3][BN][LDK]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    int bx = blockIdx.x;
-    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
-    const int m0 = blockIdx.y * BM;
-    const long p0 = (long)bx * BN;
-    const int plane = g.NY * g.NX;
-    const long Np = (long)g.Nb * plane;
-    const unsigned chw = (unsigned)(g.Hi * g.Wi);
-    const int cpt = g.C / BKC;
-    const int nchunk_all = g.T * cpt;
-    const int nsplit = (int)gridDim.z, zs = (int)blockIdx.z;
-    const int per_split = (nchunk_all + nsplit - 1) / nsplit;
-    const int ch_lo = zs * per_split;
-    const int ch_hi = ch_lo + per_split < nchunk_all ? ch_lo + per_split : nchunk_all;
-
-    const int jn = tid % BN;
-    const int kr = __builtin_amdgcn_readfirstlane(tid / BN);
-    const long pg = p0 + jn;
-    const bool pvalid = pg < Np;
-    int ry0, cx0;
-    unsigned nbase;
-    {
-        const long pp = pvalid ? pg : 0;
-        const int n = (int)(pp / plane);
-        const int rem = (int)(pp - (long)n * plane);
-        const int y = rem / g.NX, x = rem - y * g.NX;
-        ry0 = y * g.sy + g.oy; cx0 = x * g.sx + g.ox;
-        nbase = (unsigned)n * (unsigned)g.C * chw;
-    }
-    const int a4 = tid % A_V4_PER_ROW, ar = tid / A_V4_PER_ROW;
-    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(g.A), rsX = fd_make_rsrc(g.X);
-    float4 ra[NA_LOAD];
-    float rb[NB_LOAD];
-    unsigned a_off[NA_LOAD], b_off = FD_OOB;
-    const unsigned b_step = 4u * chw;
-    int pc_ta, pc_tb, pc_c0;
-    { const int t = ch_lo / cpt; pc_c0 = (ch_lo - t * cpt) * BKC; pc_ta = t / g.TB; pc_tb = t - pc_ta * g.TB; }
-    const bool refl = g.pad_mode == 1;
-    auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
-        const unsigned k0 = (unsigned)(pc_ta * g.TB + pc_tb) * (unsigned)g.C + (unsigned)pc_c0;
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) {
-            int m = m0 + ar + A_ROWS_PER_PASS * i;
-            m = m < g.M ? m : g.M - 1;
-            a_off[i] = live ? 4u * ((unsigned)m * (unsigned)g.K + k0 + 4u * a4) : FD_OOB;
-        }
-        int r = ry0 + pc_ta * g.da, cc = cx0 + pc_tb * g.db;
-        const bool inb = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
-        const int rr = refl_idx(r, g.Hi), rc = refl_idx(cc, g.Wi);
-        r = refl ? rr : r; cc = refl ? rc : cc;
-        const bool ok = pvalid & live & (refl | inb);
-        b_off = ok ? 4u * (nbase + (unsigned)(pc_c0 + kr * NB_LOAD) * chw + (unsigned)(r * g.Wi + cc)) : FD_OOB;
-        pc_c0 += BKC;
-        if (pc_c0 >= g.C) { pc_c0 = 0; ++pc_tb; if (pc_tb >= g.TB) { pc_tb = 0; ++pc_ta; } }
-    };
-    auto load_all = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i)
-            if (!A_PARTIAL || ar + A_ROWS_PER_PASS * i < BM) ra[i] = fd_ldg128(rsA, a_off[i]);
-#pragma unroll
-        for (int i = 0; i < NB_LOAD; ++i) rb[i] = fd_ldg32(rsX, b_off + (unsigned)i * b_step);
-    };
-    auto store_all = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < NA_LOAD; ++i) {
-            if (A_PARTIAL && ar + A_ROWS_PER_PASS * i >= BM) continue;
-            const float v[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-            bf16x4 q[3];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { __bf16 h, m, l; split3(v[e], h, m, l); q[0][e] = h; q[1][e] = m; q[2][e] = l; }
-            const int row = ar + A_ROWS_PER_PASS * i;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x4*>(sA + ((size_t)t * BM + row) * LDK + 4 * a4) = q[t];
-        }
-#pragma unroll
-        for (int f = 0; f < NB_LOAD / 8; ++f) {
-            bf16x8 q[3];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { __bf16 h, m, l; split3(rb[8 * f + e], h, m, l); q[0][e] = h; q[1][e] = m; q[2][e] = l; }
-#pragma unroll
-            for (int t = 0; t < 3; ++t) *reinterpret_cast<bf16x8*>(sB + ((size_t)t * BN + jn) * LDK + kr * NB_LOAD + 8 * f) = q[t];
-        }
-    };
-
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int arow = lane >> 5, acol = lane & 31;
-    if (ch_lo < ch_hi) {
-        prep_chunk(true);
-        load_all();
-        for (int ch = ch_lo; ch < ch_hi; ++ch) {
-            store_all();
-            __syncthreads();
-            prep_chunk(ch + 1 < ch_hi);
-            load_all();                                   // in flight during the MFMA phase below
-#pragma unroll
-            for (int kb = 0; kb < BKC / 16; ++kb) {
-                bf16x8 a[3][WM], b[3][WN];
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-#pragma unroll
-                    for (int i = 0; i < WM; ++i)
-                        a[t][i] = *reinterpret_cast<const bf16x8*>(sA + ((size_t)t * BM + wave_m * 32 * WM + i * 32 + acol) * LDK + kb * 16 + arow * 8);
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        b[t][j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)t * BN + wave_n * 32 * WN + j * 32 + acol) * LDK + kb * 16 + arow * 8);
-                }
-                // product-major order (consecutive MFMAs go to different accumulators), smallest terms first
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-#pragma unroll
-                    for (int i = 0; i < WM; ++i)
-#pragma unroll
-                        for (int j = 0; j < WN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
-            }
-            __syncthreads();
-        }
-    }
-
-    const bool final_pass = nsplit == 1;
-    float* Y = final_pass ? g.Y : g.slabs + (size_t)blockIdx.z * g.slab_stride;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const long p = p0 + wave_n * 32 * WN + j * 32 + acol;
-        if (p >= Np) continue;
-        const int n = (int)(p / plane);
-        const int rem = (int)(p - (long)n * plane);
-        const int y = rem / g.NX, x = rem - y * g.NX;
-        const long po = (long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox);
-        float* yo = Y + po;
-        const float* ao = (final_pass && g.add) ? g.add + po : nullptr;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
-                if (m < g.M) {
-                    float v = acc[i][j][r];
-                    if (final_pass) {
-                        if (g.bias) v += g.bias[m];
                         v = act_apply(v, g.act);
                         if (ao) v += ao[(long)m * g.out_cs];
                     }
@@ -464,9 +270,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
     const int plane = g.NY * g.NX;
     const long Np = (long)g.Nb * plane;
     const unsigned chw = (unsigned)(g.Hi * g.Wi);
-    const int nsplit = (int)gridDim.z / g.siblings;
-    const int sib = (int)blockIdx.z / nsplit, zs = (int)blockIdx.z - sib * nsplit;
-    const long pbeg = (long)zs * g.pix_per_split;
+    const long pbeg = (long)blockIdx.z * g.pix_per_split;
     long pend = pbeg + g.pix_per_split;
     if (pend > Np) pend = Np;
 
@@ -474,8 +278,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_fast(FastWgrad
     const int ncol = g.C - c0 < BN ? g.C - c0 : BN;          // valid channel columns of this tile
     const int nrow = g.M - m0 < BM ? g.M - m0 : BM;
 
-    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY + (size_t)sib * g.Nb * g.dy_ns),
-                                 rsX = fd_make_rsrc(g.X + (size_t)sib * g.Nb * g.C * chw);
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY), rsX = fd_make_rsrc(g.X);
     float ra[NA_LOAD], rb[NB_LOAD];
     // Byte offsets of this thread's dY rows / X channels.  Rows past the tile's valid range are clamped to the last valid
     // one: their products land in accumulator rows / columns the epilogue never stores.
@@ -672,30 +475,11 @@ void launch_cfg(const FastGemmArgs& a, int splits, hipStream_t st) {
     const long Np = (long)a.Nb * a.NY * a.NX;
     const int gx = fd_cdiv(Np, BN), gy = fd_cdiv(a.M, BM);
     FastGemmArgs g = a;
-    if (g.siblings < 1) g.siblings = 1;
     g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
     const size_t lds = sizeof(float) * 2 * BKC * ((BM + 1) + BN);
     auto kern = k_conv_fast<WAVES_M, WAVES_N, WM, WN, BKC>;
     static bool attr_set = false;
     if (!attr_set) {   // allow > 64 KiB of dynamic LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(gx, gy, splits * g.siblings), dim3(64 * WAVES_M * WAVES_N), lds, st, g);
-}
-
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-void launch_cfg_limb(const FastGemmArgs& a, int splits, hipStream_t st) {
-    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
-    const long Np = (long)a.Nb * a.NY * a.NX;
-    const int gx = fd_cdiv(Np, BN), gy = fd_cdiv(a.M, BM);
-    FastGemmArgs g = a;
-    g.siblings = 1;
-    g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
-    const size_t lds = 2 * 3 * (size_t)(BM + BN) * (32 + 8);
-    auto kern = k_conv_limb<WAVES_M, WAVES_N, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
@@ -708,12 +492,7 @@ namespace {
 // Tile / split-K choice.  Workgroups resident on one CU share its four matrix pipes, so a launch takes
 // ~ceil(blocks / 256) block-times: pick the configuration whose block count fills the 256 CUs most evenly
 // (measured: 360 blocks of 128x128 leave 30 % of the chip idle, 720 blocks of 64x128 do not).
-struct FastChoice { int cfg; int splits; };   // cfg 0: 128x128, 1: 64x128, 2: 32x256
-int g_policy = -1;   // 0: fill rule (default); 1: largest tile, split only tiny grids; 2: the earlier cost model
-int policy() {
-    if (g_policy < 0) { const char* e = getenv("FD_CONV_POLICY"); g_policy = e ? atoi(e) : 0; }
-    return g_policy;
-}
+struct FastChoice { int cfg; int splits; };   // cfg 0: 128x128 (FD_CONV_FORCE only), 1: 64x128, 2: 32x256
 FastChoice choose_config(const FastGemmArgs& a) {
     if (const char* f = getenv("FD_CONV_FORCE")) {        // tuning aid (scripts/conv_cfg_sweep.py): "cfg,splits", read per call
         int c = -1, sp = 1;
@@ -723,73 +502,26 @@ FastChoice choose_config(const FastGemmArgs& a) {
             if (ok_c) return {c, can ? sp : 1};
         }
     }
-    if (policy() == 1) {
-        // Largest tile that M allows (best MFMA : LDS ratio); split K only when even the concurrent streams of the training
-        // step cannot fill the chip (< 64 tiles), and keep >= 8 chunks per split.
-        const long Np1 = (long)a.Nb * a.NY * a.NX;
-        const int c = a.M > 64 ? 0 : (a.M > 32 ? 1 : 2);
-        const int bm1[3] = {128, 64, 32}, bn1[3] = {128, 128, 256};
-        const long tiles = (long)fd_cdiv(Np1, bn1[c]) * fd_cdiv(a.M, bm1[c]);
-        const int bkc1 = (a.C % 32 == 0) ? 32 : 16;
-        const int nchunk1 = a.T * (a.C / bkc1);
-        int sp = 1;
-        if (a.osy == 1 && a.osx == 1 && a.slab_stride > 0 && tiles < 64) {
-            sp = (int)((128 + tiles - 1) / tiles);
-            const int cap = nchunk1 / 8 > 0 ? nchunk1 / 8 : 1;
-            if (sp > cap) sp = cap;
-            if (sp > 8) sp = 8;
-        }
-        return {c, sp};
-    }
     const long Np = (long)a.Nb * a.NY * a.NX;
     const int bkc = (a.C % 32 == 0) ? 32 : 16;
     const int nchunk = a.T * (a.C / bkc);
     const bool can_split = a.osy == 1 && a.osx == 1 && a.slab_stride > 0;
     const int bm[3] = {128, 64, 32}, bn[3] = {128, 128, 256};
-    if (policy() == 0) {
-        // Measured rule (scripts/conv_cfg_sweep.py, every ResNet / decoder shape at batch 12 and 24): the 64x128 tile (32x256 for
-        // <= 32 output channels) with split-K chosen so that tiles x splits comes closest to, without exceeding, the 768
-        // workgroups the chip holds (3 per CU) wins or ties everywhere: 720 = 720x1 = 360x2 = 180x4, 768 = 96x8 = 48x16.
-        const int c = a.M > 32 ? 1 : 2;
-        const long tiles = (long)fd_cdiv(Np, bn[c]) * fd_cdiv(a.M, bm[c]) * (a.siblings > 1 ? a.siblings : 1);
-        static long fill = 0;
-        if (!fill) { const char* e = getenv("FD_CONV_TARGET"); fill = e ? atol(e) : 768; }
-        int sp = 1;
-        if (can_split && tiles < fill) {
-            sp = (int)(fill / tiles);
-            const int cap = nchunk / 4 > 0 ? (nchunk / 4 < 16 ? nchunk / 4 : 16) : 1;
-            if (sp > cap) sp = cap;
-            if (sp < 1) sp = 1;
-        }
-        return {c, sp};
+    // Measured rule (scripts/conv_cfg_sweep.py, every ResNet / decoder shape at batch 12 and 24): the 64x128 tile (32x256 for
+    // <= 32 output channels) with split-K chosen so that tiles x splits comes closest to, without exceeding, the 768
+    // workgroups the chip holds (3 per CU) wins or ties everywhere: 720 = 720x1 = 360x2 = 180x4, 768 = 96x8 = 48x16.
+    const int c = a.M > 32 ? 1 : 2;
+    const long tiles = (long)fd_cdiv(Np, bn[c]) * fd_cdiv(a.M, bm[c]);
+    static long fill = 0;
+    if (!fill) { const char* e = getenv("FD_CONV_TARGET"); fill = e ? atol(e) : 768; }
+    int sp = 1;
+    if (can_split && tiles < fill) {
+        sp = (int)(fill / tiles);
+        const int cap = nchunk / 4 > 0 ? (nchunk / 4 < 16 ? nchunk / 4 : 16) : 1;
+        if (sp > cap) sp = cap;
+        if (sp < 1) sp = 1;
     }
-    // policy 2: the earlier measured cost model (kept for A/B runs): a launch takes ceil(blocks/256) "block times"; a block time
-    // is chunks * t_chunk + t_fixed (prologue, first-chunk latency, epilogue); split-K adds a slab write + finish pass.
-    static double t_chunk[3] = {2.4, 1.2, 1.3}, t_fixed = 5.0;                 // microseconds
-    static bool tuned = false;
-    if (!tuned) {                                                                // FD_CONV_MODEL="t128,t64,t32,tfixed" (tuning aid)
-        if (const char* e = getenv("FD_CONV_MODEL")) sscanf(e, "%lf,%lf,%lf,%lf", &t_chunk[0], &t_chunk[1], &t_chunk[2], &t_fixed);
-        tuned = true;
-    }
-    const double scale = bkc == 32 ? 1.0 : 0.55;
-    FastChoice best = {a.M > 64 ? 0 : (a.M > 32 ? 1 : 2), 1};
-    double best_t = 1e30;
-    for (int c = 0; c < 3; ++c) {
-        if (c == 0 && a.M <= 64) continue;
-        if (c == 2 && a.M > 32) continue;
-        if (c == 1 && a.M <= 32) continue;
-        const long tiles = (long)fd_cdiv(Np, bn[c]) * fd_cdiv(a.M, bm[c]);
-        const int max_split = can_split ? (nchunk / 4 > 0 ? (nchunk / 4 < 16 ? nchunk / 4 : 16) : 1) : 1;
-        for (int sp = 1; sp <= max_split; ++sp) {
-            const long blocks = tiles * sp * (a.siblings > 1 ? a.siblings : 1);
-            const double rounds = (double)((blocks + 255) / 256);
-            const double per_block = ((double)nchunk / sp) * t_chunk[c] * scale + t_fixed;
-            double t = rounds * per_block;
-            if (sp > 1) t += 3.0 + (double)(sp + 1) * (double)a.out_total * 4.0 / 4.0e6;
-            if (t < best_t) { best_t = t; best = {c, sp}; }
-        }
-    }
-    return best;
+    return {c, sp};
 }
 }  // namespace
 
@@ -798,7 +530,7 @@ long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out) {
     if (probe.slab_stride <= 0) probe.slab_stride = probe.out_total > 0 ? probe.out_total : 1;   // sizing query
     const FastChoice ch = choose_config(probe);
     if (splits_out) *splits_out = ch.splits;
-    return ch.splits > 1 ? (long)ch.splits * a.out_total * (a.siblings > 1 ? a.siblings : 1) : 0;
+    return ch.splits > 1 ? (long)ch.splits * a.out_total : 0;
 }
 
 int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
@@ -809,13 +541,7 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
     const int splits = ch.splits;
     if (splits > 1 && !a.slabs) { fd_set_error("conv: split-K workspace missing"); return -1; }
     const bool b32 = a.C % 32 == 0;
-    const char* limb_env = getenv("FD_CONV_LIMB");       // exploration switch (see k_conv_limb), read per call like FD_CONV_FORCE
-    const int limb = limb_env ? atoi(limb_env) : 0;
-    if (limb && b32 && a.siblings <= 1) {
-        if (ch.cfg == 0) launch_cfg_limb<2, 2, 2, 2>(a, splits, st);
-        else if (ch.cfg == 1) launch_cfg_limb<2, 2, 1, 2>(a, splits, st);
-        else launch_cfg_limb<1, 4, 1, 2>(a, splits, st);
-    } else if (ch.cfg == 0) {
+    if (ch.cfg == 0) {
         if (b32) launch_cfg<2, 2, 2, 2, 32>(a, splits, st); else launch_cfg<2, 2, 2, 2, 16>(a, splits, st);
     } else if (ch.cfg == 1) {
         if (b32) launch_cfg<2, 2, 1, 2, 32>(a, splits, st); else launch_cfg<2, 2, 1, 2, 16>(a, splits, st);
@@ -824,15 +550,8 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_conv_fast launch failed: %s", hipGetErrorString(e)); return (int)e; }
-    if (splits > 1) {
-        for (int sib = 0; sib < (a.siblings > 1 ? a.siblings : 1); ++sib) {
-            hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(a.out_total)), dim3(256), 0, st,
-                               a.slabs + (size_t)sib * splits * a.slab_stride, a.Y + (size_t)sib * a.Nb * a.out_ns,
-                               sib ? a.bias1 : a.bias, a.out_total, a.slab_stride, splits, a.out_cs, a.M, a.act, a.add);
-            e = hipGetLastError();
-            if (e != hipSuccess) { fd_set_error("k_splitk_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }
-        }
-    }
+    if (splits > 1)
+        return fast_splitk_finish_launch(a.slabs, a.Y, a.bias, a.out_total, a.slab_stride, splits, a.out_cs, a.M, a.act, st, a.add);
     return 0;
 }
 
@@ -868,7 +587,7 @@ int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int 
     return 0;
 }
 
-int fast_wgrad_splits(int M, int C, int T, long Np, int siblings) {
+int fast_wgrad_splits(int M, int C, int T, long Np) {
     // Workgroups co-resident on a CU share its matrix pipes, so a launch finishes when the fullest CU does: 513 workgroups
     // on 256 CUs (one CU with 3) take 1.5x the time of 512.  Aim at 3 per CU (what the 50 KB LDS tiles allow) and never
     // exceed it; measured in the training step against 256 / 512 / 1024 and against a rounds-based cost model.
@@ -876,7 +595,7 @@ int fast_wgrad_splits(int M, int C, int T, long Np, int siblings) {
     if (!target) { const char* e = getenv("FD_WGRAD_TARGET"); target = e ? atol(e) : 768; }
     const int bn = C >= 128 ? 128 : 64;
     const long tiles = (long)T * fd_cdiv(C, bn) * fd_cdiv(M, M > 32 ? 64 : 32);
-    long sp = target / (tiles * (siblings > 1 ? siblings : 1));
+    long sp = target / tiles;
     const long maxs = (Np + 511) / 512;
     if (sp > maxs) sp = maxs;
     if (sp < 1) sp = 1;
@@ -884,10 +603,8 @@ int fast_wgrad_splits(int M, int C, int T, long Np, int siblings) {
     return (int)sp;
 }
 
-int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st, float* gw1) {
+int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumulate, hipStream_t st) {
     FastWgradArgs g = a;
-    if (g.siblings < 1) g.siblings = 1;
-    const int nsib = g.siblings;
     const long Np = (long)a.Nb * a.NY * a.NX;
     if ((double)a.Nb * a.C * a.Hi * a.Wi * 4.0 >= 2147483648.0 || (double)a.Nb * (double)a.dy_ns * 4.0 >= 2147483648.0) {
         fd_set_error("conv wgrad: tensor exceeds the 2 GiB addressing range of the fast path"); return -1;
@@ -897,7 +614,7 @@ int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumul
     g.pix_per_split = pps;
     auto go = [&](auto kern, int BM, int BN) {
         const size_t lds = sizeof(float) * 2 * 32 * ((BM + 1) + (BN + 1));
-        dim3 grid(a.T * fd_cdiv(a.C, BN), fd_cdiv(a.M, BM), splits * nsib);
+        dim3 grid(a.T * fd_cdiv(a.C, BN), fd_cdiv(a.M, BM), splits);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g);
     };
     if (a.M <= 32) go(k_wgrad_fast<1, 4, 1, 1>, 32, 128);
@@ -905,9 +622,5 @@ int fast_wgrad_launch(const FastWgradArgs& a, float* gw, int splits, int accumul
     else go(k_wgrad_fast<2, 2, 1, 1>, 64, 64);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_wgrad_fast launch failed: %s", hipGetErrorString(e)); return (int)e; }
-    const long n = (long)a.M * a.C * a.T;
-    for (int sib = 0; sib < nsib; ++sib)
-        if (int rc = fast_wgrad_finish_launch(a.slabs + (size_t)sib * splits * n, sib ? gw1 : gw, a.M, a.C, a.T, splits, accumulate, st))
-            return rc;
-    return 0;
+    return fast_wgrad_finish_launch(a.slabs, gw, a.M, a.C, a.T, splits, accumulate, st);
 }

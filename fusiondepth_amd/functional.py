@@ -620,38 +620,6 @@ def enable_direct_grad(params):
         p._fd_direct_grad = True
 
 
-# ---- weight gradients on side streams -------------------------------------------------------------------------------
-# In a conv's backward the data gradient feeds the previous layer (critical path) while the weight gradient is a leaf:
-# with this switch on (and in-place gradient accumulation, so autograd never needs the result) the wgrad kernels of a
-# module stream run on a paired side stream, concurrently with the rest of that module's backward chain.  The tensors a
-# side-stream kernel reads are kept alive until ``join_wgrad_streams`` (the caching allocator would otherwise hand their
-# memory to later kernels of the main stream).
-_WGRAD_ASYNC = [False]
-_WGRAD_STREAMS = {}
-_WGRAD_KEEPALIVE = []
-
-
-def enable_async_wgrad(on=True):
-    _WGRAD_ASYNC[0] = bool(on)
-
-
-def join_wgrad_streams():
-    """Order every side-stream weight gradient before what follows on the current stream (optimiser / all-reduce)."""
-    cur = torch.cuda.current_stream()
-    for st in _WGRAD_STREAMS.values():
-        cur.wait_stream(st)
-    _WGRAD_KEEPALIVE.clear()
-
-
-def _wgrad_stream():
-    cur = torch.cuda.current_stream()
-    st = _WGRAD_STREAMS.get(cur.cuda_stream)
-    if st is None:
-        st = _WGRAD_STREAMS[cur.cuda_stream] = torch.cuda.Stream()
-    st.wait_stream(cur)
-    return st
-
-
 # ---- "this parameter's gradient is complete" notifications ------------------------------------------------------------------
 # With in-place accumulation autograd never sees a parameter gradient, so post-accumulate hooks do not fire.  The backward
 # wrappers call this right after LAUNCHING the kernel that finishes a parameter's gradient; dp.GradientSynchronizer uses it to
@@ -850,13 +818,7 @@ def _conv_backward(ctx, gy, gx_add=None):
         gw = tw if direct else torch.empty_like(w)
         gb = (tb if direct else _empty((d.Cout,), x)) if ctx.has_bias else None
         ws = _empty((plan.weight_ws(),), x)
-        if direct and _WGRAD_ASYNC[0]:
-            side = _wgrad_stream()                     # ordered after everything queued so far (gy is complete)
-            with torch.cuda.stream(side):
-                call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), 1, stream())
-            _WGRAD_KEEPALIVE.append((x, gy, ws))
-        else:
-            call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
+        call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
         if direct:
             gw = gb = None          # already accumulated in place
             _grad_ready(ctx.params[0], ctx.params[1] if ctx.has_bias else None)
@@ -894,128 +856,6 @@ def conv2d_tap(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none
     if not (torch.is_grad_enabled() and x.requires_grad):
         return conv2d(x, weight, bias, stride, pad, pad_mode, act, in_norm), x
     return _Conv2dTap.apply(x, weight, bias, int(stride), int(pad), PAD_MODE[pad_mode], ACT[act], bool(in_norm))
-
-
-class _Conv2dPair(torch.autograd.Function):
-    """Bias-free convolution of two sibling networks in one launch: x = [2N, Cin, H, W] (sibling-major), weights w0 / w1."""
-
-    @staticmethod
-    def forward(ctx, x, w0, w1, stride, pad):
-        ctx.params = (w0, w1)
-        _note_use(w0, w1)
-        ids = (getattr(w0, "_fd_cache_id", None), getattr(w1, "_fd_cache_id", None))
-        x, w0, w1 = f32(x), f32(w0), f32(w1)
-        _need_cuda(x, w0, w1)
-        N2 = x.shape[0]
-        if N2 % 2 or w0.shape != w1.shape:
-            raise RuntimeError("conv2d_pair: needs an even stacked batch and identically shaped weights")
-        d = _conv_desc(x[:N2 // 2], w0, stride, pad, 0, 0, False)          # per-sibling descriptor
-        Ho, Wo = _conv_out_hw(d)
-        y = _empty((N2, d.Cout, Ho, Wo), x)
-        dp = ctypes.addressof(d)
-        nws = query("fd_conv2d_fwd_pair_ws_floats", dp)
-        nwt = query("fd_conv2d_fwd_wt_floats", dp)
-        ws = _empty((nws,), x) if nws > 0 else None
-        wt0, r0 = _weight_layout(w0, ids[0], "f", nwt, d) if nwt > 0 else (None, 1)
-        wt1, r1 = _weight_layout(w1, ids[1], "f", nwt, d) if nwt > 0 else (None, 1)
-        call("fd_conv2d_fwd_pair", dp, ptr(x), ptr(w0), ptr(w1), ptr(y), ptr(wt0), ptr(wt1), int(r0 and r1), ptr(ws), stream())
-        ctx.save_for_backward(x, w0, w1)
-        ctx.desc, ctx.ids = d, ids
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, w0, w1 = ctx.saved_tensors
-        d = ctx.desc
-        dp = ctypes.addressof(d)
-        gy = f32(gy)
-        gx = gw0 = gw1 = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty_like(x)
-            ws = _empty((max(query("fd_conv2d_bwd_data_pair_ws_floats", dp), 1),), x)
-            nwt = query("fd_conv2d_bwd_data_wt_floats", dp)
-            wt0, r0 = _weight_layout(w0, ctx.ids[0], "d", nwt, d)
-            wt1, r1 = _weight_layout(w1, ctx.ids[1], "d", nwt, d)
-            call("fd_conv2d_bwd_data_pair", dp, ptr(gy), ptr(w0), ptr(w1), ptr(gx), ptr(wt0), ptr(wt1), int(r0 and r1), ptr(ws),
-                 stream())
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            t0, t1 = _direct_grad_target(ctx.params[0]), _direct_grad_target(ctx.params[1])
-            direct = t0 is not None and t1 is not None
-            gw0, gw1 = (t0, t1) if direct else (torch.empty_like(w0), torch.empty_like(w1))
-            ws = _empty((max(query("fd_conv2d_bwd_weight_pair_ws_floats", dp), 1),), x)
-            call("fd_conv2d_bwd_weight_pair", dp, ptr(x), ptr(gy), ptr(gw0), ptr(gw1), ptr(ws), int(direct), stream())
-            if direct:
-                gw0 = gw1 = None
-                _grad_ready(ctx.params[0], ctx.params[1])
-        return gx, gw0, gw1, None, None
-
-
-def conv2d_pair(x, w0, w1, stride=1, pad=0):
-    """Two sibling networks' bias-free convolutions as one launch (``fd_conv2d_fwd_pair``): ``x`` stacks the two siblings'
-    batches, sibling-major; returns the stacked outputs."""
-    return _Conv2dPair.apply(x, w0, w1, int(stride), int(pad))
-
-
-class _BatchNormPair(torch.autograd.Function):
-    """Training-mode BatchNorm (+ residual + ReLU) of two siblings stacked in one tensor: the two halves are normalised with
-    their own modules' parameters / running statistics (two launches each way on contiguous halves, one autograd node)."""
-
-    @staticmethod
-    def forward(ctx, x, wa, ba, wb, bb, residual, rma, rva, rmb, rvb, momentum, eps, relu, groups):
-        ctx.params = (wa, ba, wb, bb)
-        _note_use(wa, ba, wb, bb)
-        ctx.groups = groups
-        x = f32(x)
-        _need_cuda(x)
-        N2, C, H, W = x.shape
-        N = N2 // 2
-        y = torch.empty_like(x)
-        res = f32(residual) if residual is not None else None
-        mean, invstd = _empty((2, groups * C), x), _empty((2, groups * C), x)
-        ws = _empty((query("fd_bn_ws_floats", N, C, H, W, groups),), x)
-        for i, (w_, b_, rm, rv) in enumerate(((wa, ba, rma, rva), (wb, bb, rmb, rvb))):
-            call("fd_bn_train_fwd", ptr(x[i * N:(i + 1) * N]), ptr(w_), ptr(b_), ptr(res[i * N:(i + 1) * N]) if res is not None else None,
-                 ptr(y[i * N:(i + 1) * N]), ptr(rm), ptr(rv), ptr(mean[i]), ptr(invstd[i]), ptr(ws), N, C, H, W, groups, float(eps),
-                 float(momentum), int(relu), stream())
-        ctx.save_for_backward(x, y if relu else None, wa, wb, mean, invstd)
-        ctx.relu, ctx.has_res = int(relu), residual is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, y, wa, wb, mean, invstd = ctx.saved_tensors
-        N2, C, H, W = x.shape
-        N = N2 // 2
-        gy = f32(gy)
-        gx = torch.empty_like(x)
-        gres = torch.empty_like(x) if ctx.has_res and ctx.needs_input_grad[5] else None
-        ws = _empty((query("fd_bn_ws_floats", N, C, H, W, ctx.groups),), x)
-        outs = []
-        for i, (w_, pw, pb) in enumerate(((wa, ctx.params[0], ctx.params[1]), (wb, ctx.params[2], ctx.params[3]))):
-            tw, tb = _direct_grad_target(pw), _direct_grad_target(pb)
-            direct = tw is not None and tb is not None
-            gw, gb = (tw, tb) if direct else (_empty((C,), x), _empty((C,), x))
-            sl = slice(i * N, (i + 1) * N)
-            call("fd_bn_train_bwd", ptr(x[sl]), ptr(y[sl]) if y is not None else None, ptr(gy[sl]), ptr(w_), ptr(mean[i]), ptr(invstd[i]),
-                 ptr(gx[sl]), ptr(gw), ptr(gb), ptr(gres[sl]) if gres is not None else None, ptr(ws), N, C, H, W, ctx.groups, ctx.relu,
-                 int(direct), stream())
-            outs += [None, None] if direct else [gw, gb]
-            if direct:
-                _grad_ready(pw, pb)
-        return (gx, outs[0], outs[1], outs[2], outs[3], gres) + (None,) * 8
-
-
-def batch_norm_pair(x, bn_a, bn_b, residual=None, relu=False):
-    """``batch_norm`` for two stacked siblings (training mode): halves of ``x`` use ``bn_a`` / ``bn_b``."""
-    groups = _BN_GROUPS[0]
-    for bn in (bn_a, bn_b):
-        if bn.num_batches_tracked is not None:
-            if _BN_COUNTERS[0] is not None:
-                _BN_COUNTERS[0].append((bn.num_batches_tracked, groups))
-            else:
-                bn.num_batches_tracked.add_(groups)
-    return _BatchNormPair.apply(x, bn_a.weight, bn_a.bias, bn_b.weight, bn_b.bias, residual, bn_a.running_mean, bn_a.running_var,
-                                bn_b.running_mean, bn_b.running_var, bn_a.momentum, bn_a.eps, relu, groups)
 
 
 class _InputNormalize(torch.autograd.Function):

@@ -16,38 +16,48 @@ class _ConvChain(nn.Sequential):
     """``deep`` refiner variant: Sequential(ConvBlock, ConvBlock) (depth_decoder.py:29-32,45-48)."""
 
 
+DEC_WIDTHS = (16, 32, 64, 128, 256)      # output channels of decoder level 0..4 (depth_decoder.py:19)
+
+
+def decoder_layer_table(enc_widths, scales, out_channels, use_skips, cat2end, road, catxy):
+    """The decoder as a table of (key, Cin, Cout) rows in state-dict order - ``decoder.<row index>`` is the checkpoint key
+    the reference produces (depth_decoder.py:23-59): per level 4..0 the pair (upconv, i, 0), (upconv, i, 1), then one
+    (dispconv, s) per scale; ``cat2end`` widens the full-resolution head by the two LiDAR channels."""
+    rows = []
+    for level in (4, 3, 2, 1, 0):
+        below = enc_widths[-1] if level == 4 else DEC_WIDTHS[level + 1]
+        rows.append((("upconv", level, 0), int(below), DEC_WIDTHS[level]))
+        merged = DEC_WIDTHS[level]
+        if use_skips and level > 0:
+            merged += int(enc_widths[level - 1])
+            if road and level in scales:
+                merged += 6 if catxy else 3
+        elif use_skips and road and level in scales:
+            merged += 6 if catxy else 3
+        rows.append((("upconv", level, 1), merged, DEC_WIDTHS[level]))
+    heads = {s: DEC_WIDTHS[s] for s in scales}
+    if cat2end:
+        heads[0] = DEC_WIDTHS[0] + 2
+    rows += [(("dispconv", s), cin, out_channels) for s, cin in heads.items()]
+    return rows
+
+
 class DepthDecoder(nn.Module):
     def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True, cat2end=False, road=False,
                  catxy=False, deep=False):
         super().__init__()
-        self.num_output_channels = num_output_channels
-        self.use_skips = use_skips
-        self.upsample_mode = "nearest"
-        self.scales = scales
-        self.num_ch_enc = num_ch_enc
-        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
-        self.cat2end = cat2end
-
-        def block(cin, cout):
-            if not deep:
-                return ConvBlock(cin, cout)
-            return _ConvChain(ConvBlock(cin, cin), ConvBlock(cin, cout))
-
+        self.num_ch_enc, self.num_ch_dec = num_ch_enc, np.array(DEC_WIDTHS)
+        self.scales, self.num_output_channels = scales, num_output_channels
+        self.use_skips, self.cat2end, self.upsample_mode = use_skips, cat2end, "nearest"
         self.convs = OrderedDict()
-        for i in range(4, -1, -1):
-            cin = self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
-            self.convs[("upconv", i, 0)] = block(cin, self.num_ch_dec[i])
-            cin = self.num_ch_dec[i]
-            if self.use_skips and i > 0:
-                cin += self.num_ch_enc[i - 1]
-            if road and i in self.scales and self.use_skips:
-                cin += 6 if catxy else 3
-            self.convs[("upconv", i, 1)] = block(cin, self.num_ch_dec[i])
-        for s in self.scales:
-            self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], self.num_output_channels)
-        if self.cat2end:
-            self.convs[("dispconv", 0)] = Conv3x3(self.num_ch_dec[0] + 2, self.num_output_channels)
-        self.decoder = nn.ModuleList(list(self.convs.values()))
+        for key, cin, cout in decoder_layer_table(num_ch_enc, scales, num_output_channels, use_skips, cat2end, road, catxy):
+            if key[0] == "dispconv":
+                self.convs[key] = Conv3x3(cin, cout)
+            elif deep:
+                self.convs[key] = _ConvChain(ConvBlock(cin, cin), ConvBlock(cin, cout))
+            else:
+                self.convs[key] = ConvBlock(cin, cout)
+        self.decoder = nn.ModuleList(self.convs.values())
         self.sigmoid = nn.Sigmoid()
 
     @staticmethod

@@ -8,35 +8,38 @@ import torch.nn as nn
 from .. import functional as FD
 
 
+def pose_layer_table(enc_width, num_input_features, num_frames, stride):
+    """(key, Cin, Cout, kernel, stride, pad) in state-dict order ``net.0 .. net.3`` (pose_decoder.py:19-27)."""
+    return [("squeeze", int(enc_width), 256, 1, 1, 0),
+            (("pose", 0), num_input_features * 256, 256, 3, stride, 1),
+            (("pose", 1), 256, 256, 3, stride, 1),
+            (("pose", 2), 256, 6 * num_frames, 1, 1, 0)]
+
+
 class PoseDecoder(nn.Module):
     def __init__(self, num_ch_enc, num_input_features, num_frames_to_predict_for=None, stride=1):
         super().__init__()
-        self.num_ch_enc = num_ch_enc
-        self.num_input_features = num_input_features
-        if num_frames_to_predict_for is None:
-            num_frames_to_predict_for = num_input_features - 1
-        self.num_frames_to_predict_for = num_frames_to_predict_for
-        self.convs = OrderedDict()
-        self.convs[("squeeze")] = nn.Conv2d(self.num_ch_enc[-1], 256, 1)
-        self.convs[("pose", 0)] = nn.Conv2d(num_input_features * 256, 256, 3, stride, 1)
-        self.convs[("pose", 1)] = nn.Conv2d(256, 256, 3, stride, 1)
-        self.convs[("pose", 2)] = nn.Conv2d(256, 6 * num_frames_to_predict_for, 1)
+        self.num_ch_enc, self.num_input_features = num_ch_enc, num_input_features
+        self.num_frames_to_predict_for = (num_input_features - 1 if num_frames_to_predict_for is None
+                                          else num_frames_to_predict_for)
+        self.convs = OrderedDict((key, nn.Conv2d(cin, cout, k, st, pad)) for key, cin, cout, k, st, pad in
+                                 pose_layer_table(num_ch_enc[-1], num_input_features, self.num_frames_to_predict_for, stride))
         self.relu = nn.ReLU()
-        self.net = nn.ModuleList(list(self.convs.values()))
+        self.net = nn.ModuleList(self.convs.values())
 
     @staticmethod
     def _conv(x, conv, act):
         return FD.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0], act=act)
 
     def forward(self, input_features, beam_inputs=None):
-        if beam_inputs is not None:
-            last_features = [FD.add(input_features[0][-1], beam_inputs[0][-1])]
+        if beam_inputs is not None:                          # RGB + LiDAR bottleneck features, one input (pose_decoder.py:30-31)
+            deepest = [FD.add(input_features[0][-1], beam_inputs[0][-1])]
         else:
-            last_features = [f[-1] for f in input_features]
-        cat_features = [self._conv(f, self.convs["squeeze"], "relu") for f in last_features]
-        out = cat_features[0] if len(cat_features) == 1 else torch.cat(cat_features, 1)
-        for i in range(3):
-            out = self._conv(out, self.convs[("pose", i)], "relu" if i != 2 else "none")
+            deepest = [feats[-1] for feats in input_features]
+        squeezed = [self._conv(f, self.convs["squeeze"], "relu") for f in deepest]
+        out = squeezed[0] if len(squeezed) == 1 else torch.cat(squeezed, 1)
+        for i, act in enumerate(("relu", "relu", "none")):
+            out = self._conv(out, self.convs[("pose", i)], act)
         out = FD.spatial_mean(out, 0.01)                     # 0.01 * out.mean(3).mean(2)
         out = out.view(-1, self.num_frames_to_predict_for, 1, 6)
         return out[..., :3], out[..., 3:]

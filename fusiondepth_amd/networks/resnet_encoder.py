@@ -186,48 +186,3 @@ def interleaved_forward(jobs):
                 except StopIteration:
                     alive.remove(i)
     return [enc.features for enc, _, _, _ in jobs]
-
-
-# ------------------------------------------------------------------------------------------------------------------------
-# Sibling pairing.  The training step runs four ResNet encoders, two by two of identical architecture and batch (RGB / LiDAR
-# depth encoders; RGB / LiDAR pose encoders).  A layer of one encoder at 640x192 is only 180-720 output tiles on 256 CUs, so a
-# pair advances layer by layer through ONE launch per convolution (FD.conv2d_pair: twice the tiles, half the launches).  Each
-# sibling keeps its own module (parameters, BatchNorm statistics, checkpoint keys); per sibling the arithmetic is unchanged.
-def _pair_conv(x, ca, cb):
-    return FD.conv2d_pair(x, ca.weight, cb.weight, stride=ca.stride[0], pad=ca.padding[0])
-
-
-def _pair_block(x, ba, bb):
-    identity = x
-    if ba.downsample is not None:
-        identity = FD.batch_norm_pair(_pair_conv(x, ba.downsample[0], bb.downsample[0]), ba.downsample[1], bb.downsample[1])
-    if isinstance(ba, BasicBlock):
-        out = FD.batch_norm_pair(_pair_conv(x, ba.conv1, bb.conv1), ba.bn1, bb.bn1, relu=True)
-        return FD.batch_norm_pair(_pair_conv(out, ba.conv2, bb.conv2), ba.bn2, bb.bn2, residual=identity, relu=True)
-    out = FD.batch_norm_pair(_pair_conv(x, ba.conv1, bb.conv1), ba.bn1, bb.bn1, relu=True)
-    out = FD.batch_norm_pair(_pair_conv(out, ba.conv2, bb.conv2), ba.bn2, bb.bn2, relu=True)
-    return FD.batch_norm_pair(_pair_conv(out, ba.conv3, bb.conv3), ba.bn3, bb.bn3, residual=identity, relu=True)
-
-
-def paired_forward(enc_a, enc_b, image_a, image_b):
-    """``(enc_a(image_a), enc_b(image_b))`` with the two trunks advanced together.  Both encoders must be in training mode,
-    have the same depth and see the same batch / resolution; the stems differ in input channels and stay separate."""
-    ea, eb = enc_a.encoder, enc_b.encoder
-    if image_a.shape[0] != image_b.shape[0] or image_a.shape[2:] != image_b.shape[2:]:
-        raise RuntimeError("paired_forward: the siblings need the same batch and resolution")
-    if not (enc_a.training and enc_b.training):
-        raise RuntimeError("paired_forward: training mode only")
-    N = image_a.shape[0]
-    xa = FD.conv2d(FD.input_normalize(image_a), ea.conv1.weight, None, stride=2, pad=3)
-    xb = FD.conv2d(FD.input_normalize(image_b), eb.conv1.weight, None, stride=2, pad=3)
-    f0 = FD.batch_norm_pair(torch.cat((xa, xb), 0), ea.bn1, eb.bn1, relu=True)
-    feats = [f0]
-    x = FD.max_pool3x3s2(f0)
-    for li in range(1, 5):
-        for ba, bb in zip(getattr(ea, "layer%d" % li), getattr(eb, "layer%d" % li)):
-            x = _pair_block(x, ba, bb)
-        feats.append(x)
-    fa, fb = [f[:N] for f in feats], [f[N:] for f in feats]
-    enc_a.features, enc_b.features = fa, fb
-    return fa, fb
-

@@ -96,7 +96,6 @@ class Refiner(Trainer):
         self.adam_state = torch.tensor([0.0, self.lr], device=self.device)
         self._graph, self._streams = None, []
         self.parallel_streams = os.environ.get("FD_REFINER_STREAMS", "1") != "0"
-        self.pair_siblings = self._pair_depth = self._pair_pose = False
         self.stack_microbatches = False
         self._groups = 1
         self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)

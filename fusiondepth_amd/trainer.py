@@ -155,7 +155,6 @@ class Trainer:
         FD.evict_dead_weight_layouts()         # cached layouts / re-layout plan of trainers that no longer exist
         FD.enable_weight_cache(self.parameters_to_train)
         FD.enable_direct_grad(self.parameters_to_train)
-        FD.enable_async_wgrad(os.environ.get("FD_ASYNC_WGRAD", "0") == "1")     # opt-in; measured slower
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.adam_step_count = 0
@@ -164,11 +163,6 @@ class Trainer:
         self._graph = None
         self._streams = []
         self.parallel_streams = True
-        # sibling encoders through shared launches (networks.paired_forward): measured 30.6-31.9 ms/step against 30.4 with
-        # one stream per encoder at this workload, so opt-in ("1", "pose", "depth")
-        mode = os.environ.get("FD_PAIR", "0")
-        self.pair_siblings = mode != "0"
-        self._pair_depth, self._pair_pose = mode in ("1", "depth"), mode in ("1", "pose")
         # the accumulated micro-batches run as one stacked pass where the step has the default shape (see train_step);
         # the flag variants without a separate pose encoder per frame pair run them one after the other like the reference
         self.stack_microbatches = (self.use_pose_net and self.opt.pose_model_type == "separate_resnet"
@@ -481,7 +475,6 @@ class Trainer:
         cur = torch.cuda.current_stream()
         for st in self._streams:
             cur.wait_stream(st)
-        FD.join_wgrad_streams()          # side-stream weight gradients (ordered after their module streams were joined)
 
     def _fork(self, idx):
         """Side stream #idx, ordered after everything already queued on the current stream."""
@@ -552,19 +545,12 @@ class Trainer:
             raise NotImplementedError("stacked micro-batches need the separate_resnet pose path; set stack_microbatches=False")
         if self.opt.pose_model_type == "shared":
             return self._process_batch_shared(inputs, val)
-        interleave = (par and self.interleave_encoders and self.opt.beam_encoder and not self.opt.cat2end and not self.pair_siblings)
+        interleave = par and self.interleave_encoders and self.opt.beam_encoder and not self.opt.cat2end
         if par and not interleave:
             pose_out = self._launch_pose_encoders(inputs)          # side streams, joined in predict_poses
         beam_features = None
-        pair = (par and self._pair_depth and self.opt.beam_encoder and not self.opt.cat2end
-                and enc_in.shape[0] == inputs["2channel"].shape[0] and self.models["encoder"].training)
         if interleave:
             features, beam_features, pose_out = self._encoders_interleaved(inputs, enc_in, groups)
-        elif pair:
-            # RGB and LiDAR depth encoders: same architecture and batch -> one launch per convolution for both
-            with FD.bn_groups(groups):
-                features, beam_features = networks.paired_forward(self.models["encoder"], self.models["beam_encoder"], enc_in,
-                                                                  inputs["2channel"])
         else:
             if self.opt.beam_encoder and not self.opt.cat2end:
                 if par:
@@ -609,12 +595,6 @@ class Trainer:
         stack = lambda key: self._stack_pose_inputs(inputs, key)
         res = {}
         st_rgb = self._fork(1)
-        if self._pair_pose and self.opt.beam_encoder and self.models["pose_encoder"].training:
-            with torch.cuda.stream(st_rgb), FD.bn_groups(G * len(fids)):
-                pf, bf = networks.paired_forward(self.models["pose_encoder"], self.models["beam_encoder_pose"], stack("color_aug"),
-                                                 stack("2channel"))
-            res["stacked"] = (pf, st_rgb, bf, st_rgb)
-            return res
         with torch.cuda.stream(st_rgb):
             with FD.bn_groups(G * len(fids)):
                 pf = self.models["pose_encoder"](stack("color_aug"))

@@ -216,21 +216,6 @@ long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d);
 long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d);
 int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
                   int wt_ready, float* ws, void* stream);
-/* Sibling pair: two networks of identical architecture (the RGB and LiDAR pose encoders; the RGB and LiDAR depth encoders)
- * advance layer by layer as ONE launch per convolution - twice the tiles per launch on 256 CUs, half the launches.
- * d->N is the batch of ONE sibling; x / y / gy / gx hold 2 * N images, sibling-major; each sibling has its own weights
- * (w0, w1), re-laid-out copies (wt0, wt1) and weight gradients (gw0, gw1).  Bias-free convolutions only (ResNet trunks).
- * Shapes without a paired kernel run as two ordinary launches.  Workspaces: the *_pair_ws_floats queries. */
-long fd_conv2d_fwd_pair_ws_floats(const fd_conv_desc* d);
-int fd_conv2d_fwd_pair(const fd_conv_desc* d, const float* x, const float* w0, const float* w1, float* y, float* wt0, float* wt1,
-                       int wt_ready, float* ws, void* stream);
-long fd_conv2d_bwd_data_pair_ws_floats(const fd_conv_desc* d);
-int fd_conv2d_bwd_data_pair(const fd_conv_desc* d, const float* gy, const float* w0, const float* w1, float* gx, float* wt0,
-                            float* wt1, int wt_ready, float* ws, void* stream);
-long fd_conv2d_bwd_weight_pair_ws_floats(const fd_conv_desc* d);
-int fd_conv2d_bwd_weight_pair(const fd_conv_desc* d, const float* x, const float* gy, float* gw0, float* gw1, float* ws,
-                              int accumulate, void* stream);
-
 /* Batched weight re-layout.  A training step re-derives the kernel-side copy of every conv weight once per optimiser
  * step; instead of one small launch per convolution inside fd_conv2d_fwd / fd_conv2d_bwd_data (wt_ready = 0) the caller can
  * collect the work of all its convolutions once and run it as ONE launch after each optimiser update, then call the

@@ -144,42 +144,6 @@ def test_conv_tap_adds_the_second_gradient_in_the_epilogue(FD, case):
     assert torch.equal(g_only_conv, gx_plain)
 
 
-@pytest.mark.parametrize("case", [
-    (2, 64, 16, 24, 128, 3, 2, 1, "zero"),       # stride 2 (parity classes in the data gradient)
-    (2, 64, 8, 12, 256, 1, 1, 0, "zero"),        # 1x1
-    (2, 96, 16, 24, 32, 3, 1, 1, "reflect"),     # decoder layer, reflect padding, 32x256 tile
-    (2, 64, 16, 24, 48, 3, 1, 1, "zero"),        # 64x128 tile with a ragged channel tile
-    (1, 256, 6, 20, 512, 3, 2, 1, "zero"),       # split-K
-])
-def test_split_precision_conv_keeps_fp32_accuracy(FD, case, monkeypatch):
-    """FD_CONV_LIMB=1 (exploration, off by default): the direct convolution kernel with every fp32 operand split into three bf16
-    limbs and six limb products on the bf16 MFMA.  Forward and data gradient against float64: the error must stay within twice the
-    f32-MFMA kernel's own error (or 2e-7 of the accumulated magnitude) - i.e. the split form is fp32-accurate, not bf16-accurate."""
-    N, Cin, H, W, Cout, K, stride, pad, mode = case
-    import zlib
-    rng = np.random.RandomState(zlib.crc32(repr(case).encode()) % (2 ** 31))
-    x = torch.from_numpy(rng.randn(N, Cin, H, W).astype(np.float32))
-    w = torch.from_numpy((rng.randn(Cout, Cin, K, K) * np.sqrt(2.0 / (Cin * K * K))).astype(np.float32))
-    x64, w64 = x.double().requires_grad_(True), w.double()
-    xin = F.pad(x64, (pad,) * 4, mode="reflect") if mode == "reflect" else x64
-    y64 = F.conv2d(xin, w64, None, stride, 0 if mode == "reflect" else pad)
-    cot = torch.from_numpy(rng.randn(*y64.shape).astype(np.float32))
-    (gx64,) = torch.autograd.grad((y64 * cot.double()).sum(), [x64])
-    mag_y = float(F.conv2d(F.pad(x.abs().double(), (pad,) * 4, mode="reflect") if mode == "reflect" else x.abs().double(),
-                           w.abs().double(), None, stride, 0 if mode == "reflect" else pad).max())
-    errs = {}
-    for limb in ("0", "1"):
-        monkeypatch.setenv("FD_CONV_LIMB", limb)
-        xg = dev(x).requires_grad_(True)
-        yg = FD.conv2d(xg, dev(w), None, stride, pad, mode)
-        (gxg,) = torch.autograd.grad((yg * dev(cot)).sum(), [xg])
-        errs[limb] = (float((yg.detach().cpu().double() - y64.detach()).abs().max()) / mag_y,
-                      float((gxg.cpu().double() - gx64).abs().max()) / float(gx64.abs().max()))
-    print("conv %s: |err| / sum|x w|  f32 MFMA %.2e, bf16 limbs %.2e;  dgrad rel. err  f32 %.2e, limbs %.2e"
-          % (case, errs["0"][0], errs["1"][0], errs["0"][1], errs["1"][1]))
-    assert errs["1"][0] <= max(2 * errs["0"][0], 2e-7) and errs["1"][1] <= max(2 * errs["0"][1], 2e-6)
-
-
 def test_conv_transpose_detecting(FD):
     """A = I-style check with asymmetric data: a conv whose weight is a one-hot tap must shift/copy channels
     exactly (catches row/col swaps in the MFMA fragment maps bit-exactly)."""
@@ -504,40 +468,6 @@ def test_grouped_batchnorm_equals_separate_passes(FD, N, C, H, W, G, res):
     relclose(cpu(bn_g.running_mean), cpu(bn_o.running_mean), "running_mean after %d in-order updates" % G)
     relclose(cpu(bn_g.running_var), cpu(bn_o.running_var), "running_var after %d in-order updates" % G)
     assert int(bn_g.num_batches_tracked) == int(bn_o.num_batches_tracked) == G
-
-
-def test_paired_encoders_equal_separate_passes(NW):
-    """networks.paired_forward (one launch per conv for two sibling encoders) == the two encoders run on their own: features,
-    parameter gradients and BatchNorm running statistics, per sibling, to rounding of the split-K / slab summation order."""
-    import copy
-    torch.manual_seed(11)
-    B, H, W = 4, 64, 96
-    enc_a = NW.ResnetEncoder(18, False).cuda()
-    enc_b = NW.ResnetEncoder(18, False, beam_encoder=True).cuda()
-    ref_a, ref_b = copy.deepcopy(enc_a), copy.deepcopy(enc_b)
-    xa, xb = torch.rand(B, 3, H, W, device="cuda"), torch.rand(B, 2, H, W, device="cuda")
-    cots = [torch.randn(B, c, H >> (i + 1), W >> (i + 1), device="cuda") for i, c in enumerate((64, 64, 128, 256, 512))]
-
-    def run(fn, ea, eb):
-        fa, fb = fn(ea, eb)
-        loss = sum((f * c).sum() for f, c in zip(fa, cots)) + sum((f * c).sum() * 0.5 for f, c in zip(fb, cots))
-        loss.backward()
-        return fa, fb
-
-    fa, fb = run(lambda ea, eb: NW.paired_forward(ea, eb, xa, xb), enc_a, enc_b)
-    ga, gb = run(lambda ea, eb: (ea(xa), eb(xb)), ref_a, ref_b)
-    for got, want, nm in ((fa, ga, "a"), (fb, gb, "b")):
-        for i, (g, w) in enumerate(zip(got, want)):
-            assert_close(g.detach().cpu().numpy(), w.detach().cpu().numpy(), rtol=1e-5, atol=1e-5, what="feature %s%d" % (nm, i))
-    for e, r, nm in ((enc_a, ref_a, "a"), (enc_b, ref_b, "b")):
-        for (n, p), (_, q) in zip(e.named_parameters(), r.named_parameters()):
-            if q.grad is None:
-                assert p.grad is None
-                continue
-            scale = float(q.grad.abs().max()) + 1e-12
-            assert_close(p.grad.cpu().numpy(), q.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale, what="grad %s %s" % (nm, n))
-        for (n, p), (_, q) in zip(e.named_buffers(), r.named_buffers()):
-            assert_close(p.float().cpu().numpy(), q.float().cpu().numpy(), rtol=1e-5, atol=1e-6, what="buffer %s %s" % (nm, n))
 
 
 # ------------------------------------------------------------------------------------------------ Winograd F(2,3) path
