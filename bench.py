@@ -1,18 +1,27 @@
 #!/usr/bin/env python
 """Benchmark of the FusionDepth training hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-    python bench.py --gpus N --steps K --warmup W          # N>1: launched by torch.distributed.run, one rank per GPU
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 works both ways: under ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` (one rank per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), and as a plain ``python bench.py --gpus N``, which re-launches itself
+through torch.distributed.run on 127.0.0.1 with N ranks.  It refuses to run when fewer than N devices are visible and checks
+``ranks_seen == N`` and the RCCL backend before printing.
 
 One "step" = one optimiser step of the reference trainer at --batch_size 12 (ResNet-18, 640x192, 4-beam):
-trainer.py:28-41 turns that into 2 accumulated micro-batches of 6 images per process, then Adam.  Inputs are synthetic
-KITTI-shaped tensors already resident in HBM; everything inside the timed region is the real work: 6 ResNet passes,
-decoder, pose decoder, fused photometric/LiDAR loss at 4 scales, full backward, gradient all-reduce (N>1), Adam.
+trainer.py:28-41 turns that into 2 accumulated micro-batches of 6 images per process, then Adam.  Inputs: a pool of distinct
+synthetic scene batches (fusiondepth_amd.synthetic.make_scene_batch: a ground-truth depth field, frames -1 / +1 rendered
+through it, LiDAR returns sampled from it), a fresh one per step, all resident in HBM before the timed region starts;
+everything inside the timed region is the real work: 6 ResNet passes, decoder, pose decoder, fused photometric/LiDAR loss at 4
+scales, full backward, gradient all-reduce (N>1), Adam.  The run fails (exit code 3) if the final loss is not finite.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -45,6 +54,10 @@ def parse():
     ap.add_argument("--no_stack", action="store_true", help="run the accumulated micro-batches sequentially (reference order) "
                     "instead of as one stacked pass with grouped BatchNorm")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--share_device", action="store_true", help="testing aid: with --gpus N on a box with fewer devices, let the N "
+                    "ranks share them over gloo (FD_DIST_BACKEND=gloo) instead of refusing; such a line is not a scaling measurement")
+    ap.add_argument("--pool", type=int, default=0, help="distinct pre-generated step batches (default: one per step incl. warm-up, "
+                    "at most 48)")
     ap.add_argument("--probe_only", action="store_true", help="run only the roofline probes (no training steps) and print their "
                     "JSON: the command profiled for profiles/*probe_kernel_stats*.md, so that rocprofv3's per-kernel average "
                     "covers the probe launches alone")
@@ -216,7 +229,7 @@ def cpu_baseline(args, budget_s=60.0, warm=3, timed_steps=10, threads=None):
                                               {k: round(v, 2) for k, v in sweep.items()}, step, min(timed), max(timed))}
 
 
-def dp_probe(tr, step_fn, mbs, t_step, barrier, reps=3):
+def dp_probe(tr, step_fn, t_step, barrier, reps=3):
     """Multi-rank only, after the timed region: how many ranks answered, what the gradient exchange costs on its own and how
     much of it the backward pass hides.  exposed = (step with exchange) - (step without); overlap_frac = 1 - exposed / allreduce."""
     world = dist.get_world_size()
@@ -239,7 +252,7 @@ def dp_probe(tr, step_fn, mbs, t_step, barrier, reps=3):
     barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
-        step_fn(mbs)
+        step_fn()
     barrier()
     t_nocomm = (time.perf_counter() - t0) / reps
     tr.grad_sync.skip_comm = False
@@ -253,24 +266,64 @@ def dp_probe(tr, step_fn, mbs, t_step, barrier, reps=3):
             "exposed_exchange_ms": exposed_ms, "overlap_frac": max(0.0, min(1.0, 1.0 - exposed_ms / ar_ms)) if ar_ms > 0 else None}
 
 
+def self_launch(args):
+    """Plain ``python bench.py --gpus N`` (no torchrun environment): start N ranks of this script through torch.distributed.run."""
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if n_dev < args.gpus:
+        if not args.share_device:
+            sys.exit("bench.py --gpus %d: only %d device(s) visible (torch.cuda.device_count()); refusing to oversubscribe "
+                     "(--share_device runs the ranks over gloo on the visible devices: a functional check, not a measurement)"
+                     % (args.gpus, n_dev))
+        env["FD_DIST_BACKEND"] = "gloo"
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without a torchrun environment: launching %s" % (args.gpus, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     from fusiondepth_amd import dp, synthetic
     from fusiondepth_amd.options import MonodepthOptions
     from fusiondepth_amd.trainer import Trainer
     rank, world, local_rank = dp.init_from_env()
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    if world != args.gpus:
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with --nproc-per-node %d (or plainly, it launches "
+                 "itself)" % (args.gpus, world, args.gpus))
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not args.share_device:
+        sys.exit("bench.py: %d ranks but only %d device(s) visible" % (world, n_dev))
+    torch.cuda.set_device(local_rank % n_dev)
     opt = MonodepthOptions().parse(["--num_layers", str(args.num_layers), "--weights_init", "scratch", "--batch_size",
                                     str(args.batch_size), "--height", str(args.height), "--width", str(args.width)])
     tr = Trainer(opt, rank=rank, world_size=world, verbose=(rank == 0))
     tr.stack_microbatches = not args.no_stack
-    mbs = [synthetic.make_batch(tr.batch_size, args.height, args.width, seed=1234 + 17 * rank + i)
-           for i in range(tr.accumulate_step)]
+    # A pool of distinct step batches, resident in HBM.  The reference's loader yields the step's 12 images as 2 micro-batches of 6;
+    # the stacked step consumes them as one batch: concatenate once, outside the timed region.
+    n_pool = args.pool if args.pool > 0 else min(48, args.steps + max(args.warmup, 2) + 4)
+    pool = []
+    for i in range(n_pool):
+        mbs_i = [synthetic.make_scene_batch(tr.batch_size, args.height, args.width, seed=1234 + 1009 * rank + 17 * i + j)
+                 for j in range(tr.accumulate_step)]
+        for mb in mbs_i:
+            mb.pop("depth_gt", None)                 # training batches: the validation batch below keeps its ground truth
+            for f in (-1, 1):
+                mb.pop(("T_gt", f), None)
+        pool.append((mbs_i, tr.stack_micro_batches(mbs_i) if tr.stack_microbatches else mbs_i))
+    val_batch = synthetic.make_scene_batch(tr.batch_size, args.height, args.width, seed=99991 + rank)
+    mbs, eager_in = pool[0]
+    cursor = [0]
 
-    # The reference's loader yields the step's 12 images as 2 micro-batches of 6; the stacked step consumes them as one
-    # batch.  Concatenate once, outside the timed region (inputs are resident in HBM when timing starts).
-    eager_in = tr.stack_micro_batches(mbs) if tr.stack_microbatches else mbs
+    def next_batch():
+        cursor[0] += 1
+        return pool[cursor[0] % n_pool]
 
     def barrier():
         if world > 1:
@@ -282,15 +335,22 @@ def main():
             print(json.dumps(roofline_probes(args, tr, eager_in if tr.stack_microbatches else mbs[0])))
         return
 
+    def eager_step():
+        return tr.train_step(next_batch()[1])
+
+    def graph_step():
+        return tr.train_step_graphed(next_batch()[0])
+
     def timed(fn, n):
         barrier()
         t = time.perf_counter()
         for _ in range(n):
-            fn(mbs)
+            fn()
         barrier()
         return (time.perf_counter() - t) / n
 
     barrier(); barrier()          # the first collective builds the communicator (seconds): keep it out of every measurement
+    abs_rel_before = float(tr.val_metrics([val_batch])["de/abs_rel"])
     launch = "eager" if args.eager else ("graph" if args.graph else "auto")
     if launch == "auto" and world > 1:
         # Multi-process runs keep to the eager path: it measured faster than hipGraph replay on one GPU (profiles/README.md),
@@ -299,30 +359,26 @@ def main():
     if launch == "auto":
         # Both launch paths run the same kernels on the same streams; which one keeps the GPU busier depends on the host
         # (Python issue rate vs hipGraphLaunch cost per node).  Decide inside the untimed warm-up, identically on all ranks.
-        tr.train_step(eager_in)                              # allocator / autotune warm-up
-        t_eager = timed(lambda _: tr.train_step(eager_in), 2)
-        tr.train_step_graphed(mbs); tr.train_step_graphed(mbs)   # eager warm-up on the capture stream + capture
-        t_graph = timed(tr.train_step_graphed, 2)
-        if world > 1:
-            tt = torch.tensor([t_eager, t_graph], device="cuda", dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_eager, t_graph = float(tt[0]), float(tt[1])
+        eager_step()                                         # allocator / autotune warm-up
+        t_eager = timed(eager_step, 2)
+        graph_step(); graph_step()                           # eager warm-up on the capture stream + capture
+        t_graph = timed(graph_step, 2)
         launch = "eager" if t_eager <= t_graph else "graph"
         if rank == 0:
             print("[bench] warm-up: eager %.2f ms/step, hipGraph replay %.2f ms/step -> %s" % (1e3 * t_eager, 1e3 * t_graph, launch),
                   file=sys.stderr, flush=True)
-    step_fn = (lambda _: tr.train_step(eager_in)) if launch == "eager" else tr.train_step_graphed
+    step_fn = eager_step if launch == "eager" else graph_step
     # two extra untimed steps of the chosen path, so that the caching allocator, the weight-layout caches and the batched
     # re-layout plan (built after the first step; re-derived when the trial above switched between the two launch paths) are
     # in their steady state before the W warm-up steps even when W is 0 or 1
     for _ in range(2):
-        step_fn(mbs)
+        step_fn()
     for _ in range(max(args.warmup, 0 if launch == "eager" else 2)):     # graph mode: 1 eager warm-up + 1 capture/replay
-        step_fn(mbs)
+        step_fn()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = step_fn(mbs)
+        losses = step_fn()
     t_host = time.perf_counter() - t0            # host time to ISSUE the steps (no sync): == dt when launch-bound
     barrier()
     dt = time.perf_counter() - t0
@@ -333,11 +389,12 @@ def main():
     images = args.steps * opt.batch_size * world
     loss_val = float(losses["loss"].detach())
     # The SI-log term of a scale is NaN by definition when no LiDAR return passes its validity mask (mean / variance of an
-    # empty set - trainer.py:577-589 behaves the same); it then contributes no gradient and the parameters stay finite.
-    # Training from scratch on synthetic frames can drive the 1/8-scale disparity out of the mask, so also report the
-    # photometric + smoothness part, which is always defined.
+    # empty set - trainer.py:577-589 behaves the same, tests/test_gpu_losspath.py::test_empty_lidar_mask_*).  The scene feed keeps
+    # the returns consistent with the scene the networks learn, so the mask stays populated; a NaN here fails the run.
     photo_val = float(sum(losses["loss/%d" % s_].detach() for s_ in range(4) if ("loss/%d" % s_) in losses) / 4.0)
     params_finite = bool(torch.isfinite(tr.flat.flat_param).all())
+    n_steps_run = tr.adam_step_count
+    abs_rel_after = float(tr.val_metrics([val_batch])["de/abs_rel"])
     if rank == 0:
         print("[bench] timed %d steps in %.3f s (host issue time %.3f s)" % (args.steps, dt, t_host), file=sys.stderr, flush=True)
     result = {
@@ -350,7 +407,8 @@ def main():
                    "global_batch": opt.batch_size * world, "parallelism": "dp%d" % world, "launch": "eager (4 HIP streams)" if launch == "eager" else "hipGraph replay",
                    "micro_batches": "stacked (grouped BatchNorm)" if tr.stack_microbatches else "sequential"},
         "final_loss": loss_val if loss_val == loss_val else None, "final_loss_photometric": photo_val,
-        "params_finite": params_finite,
+        "params_finite": params_finite, "optimizer_steps_run": n_steps_run, "distinct_step_batches": n_pool,
+        "abs_rel_heldout_scene": {"before": abs_rel_before, "after": abs_rel_after},
     }
     key = (args.num_layers, args.height, args.width)
     if key in CONV_GFLOP_FWD_BWD:
@@ -358,17 +416,21 @@ def main():
         result["step_mfma_frac"] = tf / PEAK_FP32_MFMA_TFLOPS
         result["step_conv_tflops_per_gpu"] = tf
     if world > 1:
-        result.update(dp_probe(tr, step_fn, mbs, dt / args.steps, barrier))
+        result.update(dp_probe(tr, step_fn, dt / args.steps, barrier))
+        if result["ranks_seen"] != args.gpus or (result["backend"] != "nccl" and not args.share_device):
+            sys.exit("bench.py: %d ranks answered over %r, expected %d over nccl (= RCCL)" % (result["ranks_seen"], result["backend"], args.gpus))
     if rank == 0 and not args.no_roofline:
         result.update(roofline_probes(args, tr, eager_in if tr.stack_microbatches else mbs[0]))
         print("[bench] roofline probes done", file=sys.stderr, flush=True)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not (loss_val == loss_val and params_finite):
+        sys.exit(3)            # a degenerate run is not a measurement
 
 
 if __name__ == "__main__":

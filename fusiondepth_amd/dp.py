@@ -69,7 +69,7 @@ class GradientSynchronizer:
     the kernel that completes its last gradient has been LAUNCHED: the asynchronous collective is ordered behind that kernel
     through the stream the backward node runs on (RCCL waits on an event of the current stream), so it overlaps with the rest
     of the backward pass that is still being issued.  Two notification paths: autograd's post-accumulate hooks (gradients that
-    autograd produces) and ``functional.set_grad_ready_callback`` (gradients the HIP kernels accumulate in place).  Few large
+    autograd produces) and ``functional.add_grad_ready_callback`` (gradients the HIP kernels accumulate in place).  Few large
     messages by design: xGMI is point-to-point, a ring all-reduce is bound by one link (~153 GB/s), not by a switch."""
 
     def __init__(self, flat, world_size, bucket_bytes=25 << 20, group=None, segments=None, overlap=None, never_used=()):
@@ -108,7 +108,7 @@ class GradientSynchronizer:
                 if p.requires_grad:
                     p.register_post_accumulate_grad_hook(self._make_hook(i))
             from . import functional as FD
-            FD.set_grad_ready_callback(self._on_direct_grad)
+            FD.add_grad_ready_callback(self._on_direct_grad)
 
     def _arrived(self, i):
         # Two notification paths can report the same parameter: the in-place kernels' callback, and autograd's post-accumulate

@@ -624,12 +624,22 @@ def enable_direct_grad(params):
 # With in-place accumulation autograd never sees a parameter gradient, so post-accumulate hooks do not fire.  The backward
 # wrappers call this right after LAUNCHING the kernel that finishes a parameter's gradient; dp.GradientSynchronizer uses it to
 # issue a bucket's all-reduce behind that kernel on the same stream while the rest of the backward pass is still being issued.
-_GRAD_READY = [None]
+_GRAD_READY = []        # weak references to the bound callbacks of live subscribers (one per GradientSynchronizer with world > 1)
 _PARAM_USES = {}        # id(param) -> number of forward uses since begin_forward_pass() (a network may run twice per pass)
 
 
-def set_grad_ready_callback(fn):
-    _GRAD_READY[0] = fn
+def add_grad_ready_callback(bound_method):
+    """Subscribe ``bound_method(param)``.  Held weakly: a deleted trainer's synchroniser (and its flat buffers) is not kept
+    alive by this module, and several trainers in one process (a Trainer and a Refiner, two Trainers) each keep their overlap -
+    every subscriber is told about every parameter and ignores the ones it does not own."""
+    _GRAD_READY.append(weakref.WeakMethod(bound_method))
+
+
+def _live_grad_ready():
+    live = [(r, r()) for r in _GRAD_READY]
+    if any(cb is None for _, cb in live):
+        _GRAD_READY[:] = [r for r, cb in live if cb is not None]
+    return [cb for _, cb in live if cb is not None]
 
 
 def begin_forward_pass():
@@ -642,18 +652,18 @@ def param_uses(p):
 
 
 def _note_use(*params):
-    if _GRAD_READY[0] is not None:
+    if _GRAD_READY:
         for p in params:
             if p is not None:
                 _PARAM_USES[id(p)] = _PARAM_USES.get(id(p), 0) + 1
 
 
 def _grad_ready(*params):
-    cb = _GRAD_READY[0]
-    if cb is not None:
-        for p in params:
-            if p is not None:
-                cb(p)
+    if _GRAD_READY:
+        for cb in _live_grad_ready():
+            for p in params:
+                if p is not None:
+                    cb(p)
 
 
 def _direct_grad_target(p):

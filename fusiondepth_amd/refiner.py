@@ -199,7 +199,7 @@ class Refiner(Trainer):
             # (Replaying this frozen section from a hipGraph was tried: 348 vs 356 images/s - hipGraphLaunch on this ROCm costs the host
             # as much per kernel node as the eager launches it replaces)
             features, beam_features, depth, poses = self._frozen_forward(inputs, par, want_poses)
-            outputs = Outputs(depth)
+            outputs = Outputs.for_options(self.opt, depth)
             outputs.update(self.refine_inputs(inputs, outputs))
             outputs.update(poses)
         losses = {"loss": 0.0}

@@ -36,21 +36,40 @@ def _hms(t):
 class Outputs(dict):
     """The reference's ``outputs`` dict.  Entries the fused loss kernel does not need to materialise are derived on first
     access instead of costing launches every step: ``"identity_selection/<s>"`` (trainer.py:564-565, a monitoring image) from
-    the kernel's argmin index, ``("depth", 0, s)`` (trainer.py:434-438, read by compute_depth_losses) from ``("disp", s)``."""
-    depth_spec = None          # (height, width, min_depth, max_depth), set by the trainer
+    the kernel's argmin index, ``("depth", 0, s)`` (trainer.py:430-438, read by compute_depth_losses) from ``("disp", s)``."""
+
+    def __init__(self, *args, depth_spec=None, **kw):
+        super().__init__(*args, **kw)
+        self.depth_spec = depth_spec       # (height, width, min_depth, max_depth, v1_multiscale)
+
+    @classmethod
+    def for_options(cls, opt, *args):
+        return cls(*args, depth_spec=(opt.height, opt.width, opt.min_depth, opt.max_depth, bool(getattr(opt, "v1_multiscale", False))))
+
+    @staticmethod
+    def _selection_scale(key):
+        """"identity_selection/<s>" -> s, or None for any other key."""
+        if isinstance(key, str) and key.startswith("identity_selection/"):
+            tail = key.split("/", 1)[1]
+            if tail.isdigit():
+                return int(tail)
+        return None
 
     def __missing__(self, key):
         if isinstance(key, tuple) and len(key) == 3 and key[0] == "depth" and key[1] == 0 and self.depth_spec is not None:
             disp = dict.get(self, ("disp", key[2]))
             if disp is not None:
-                H, W, lo, hi = self.depth_spec
+                H, W, lo, hi, v1 = self.depth_spec
                 with torch.no_grad():
-                    up = FD.bilinear_upsample(disp.detach(), (H, W)) if tuple(disp.shape[2:]) != (H, W) else disp.detach()
+                    up = disp.detach()
+                    if not v1 and tuple(up.shape[2:]) != (H, W):       # --v1_multiscale keeps the scale's own resolution
+                        up = FD.bilinear_upsample(up, (H, W))
                     val = disp_to_depth(up, lo, hi)[1]
                 self[key] = val
                 return val
-        if isinstance(key, str) and key.startswith("identity_selection/"):
-            raw = dict.get(self, ("sel", int(key.split("/")[1])))
+        s = self._selection_scale(key)
+        if s is not None:
+            raw = dict.get(self, ("sel", s))
             if raw is not None:
                 sel, n_id = raw
                 val = (sel > n_id - 1).float()
@@ -61,8 +80,8 @@ class Outputs(dict):
     def __contains__(self, key):
         if dict.__contains__(self, key):
             return True
-        return isinstance(key, str) and key.startswith("identity_selection/") and \
-            dict.__contains__(self, ("sel", int(key.split("/")[1])))
+        s = self._selection_scale(key)
+        return s is not None and dict.__contains__(self, ("sel", s))
 
 
 def derived_hparams(opt, vram_gib):
@@ -316,6 +335,7 @@ class Trainer:
             raise RuntimeError("Trainer.train: no train_loader (pass one, or set self.train_loader; this package ships no KITTI "
                                "DataLoader - any iterable of reference-schema batches works)")
         self.epoch, self.step = 0, 0
+        self.scheduler_epochs = 0              # a second train() on the same object starts its StepLR count afresh
         self.start_time = time.time()
         try:
             self.num_total_steps = len(self.train_loader) * self.opt.num_epochs
@@ -354,7 +374,11 @@ class Trainer:
                 self.log_time(batch_idx, (time.time() - t0) / self.accumulate_step, loss)
                 stacked, outputs = self._last_io
                 if "depth_gt" in stacked:
-                    self.compute_depth_losses(stacked, outputs, losses)
+                    # the reference logs the metrics of the batch that was due - the window's last one, not the stacked window
+                    n = stacked["depth_gt"].shape[0] // self.accumulate_step if self.stack_microbatches else stacked["depth_gt"].shape[0]
+                    last_in = {"depth_gt": stacked["depth_gt"][-n:]}
+                    last_out = Outputs.for_options(self.opt, {("disp", 0): outputs[("disp", 0)][-n:]})
+                    self.compute_depth_losses(last_in, last_out, losses)
                 self.log("train", losses)
                 if getattr(self, "val_loader", None) is not None:
                     self.log("val", self.val(self.val_loader))
@@ -527,8 +551,7 @@ class Trainer:
         all_features = self.models["encoder"](torch.cat([inputs[("color_aug", i, 0)] for i in fids]))
         B = inputs[("color_aug", 0, 0)].shape[0]
         features = {k: [f[i * B:(i + 1) * B] for f in all_features] for i, k in enumerate(fids)}
-        outputs = Outputs(self.models["depth"](features[0]))
-        outputs.depth_spec = (self.opt.height, self.opt.width, self.opt.min_depth, self.opt.max_depth)
+        outputs = Outputs.for_options(self.opt, self.models["depth"](features[0]))
         if self.use_pose_net and not val:
             outputs.update(self.predict_poses(inputs, features))
         losses = {}
@@ -569,8 +592,7 @@ class Trainer:
             outputs = self.models["depth"](features, beam_features=beam_features)
         else:
             outputs = self.models["depth"](features)
-        outputs = Outputs(outputs)
-        outputs.depth_spec = (self.opt.height, self.opt.width, self.opt.min_depth, self.opt.max_depth)
+        outputs = Outputs.for_options(self.opt, outputs)
         if self.opt.predictive_mask:                                                          # trainer.py:305-306
             outputs["predictive_mask"] = dict(self.models["predictive_mask"](features))
         if self.use_pose_net and not val:

@@ -30,6 +30,23 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+# Measured errors that tests want in the driver's log even when they pass (pytest -q prints no captured stdout for passing
+# tests): tests call ``conftest.report(...)``, the terminal summary prints the table.
+_MEASURED = []
+
+
+def report(what, measured, bound, note=""):
+    _MEASURED.append((what, float(measured), float(bound), note))
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _MEASURED:
+        return
+    terminalreporter.section("measured errors (HIP path vs ground truth) | bound")
+    for what, m, b, note in _MEASURED:
+        terminalreporter.write_line("%-78s %.3e | %.3e %s" % (what, m, b, note))
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

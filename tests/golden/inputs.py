@@ -75,6 +75,20 @@ def disp_pyramid(rng, B, H, W, num_scales=4):
     return out
 
 
+def make_si_mask_empty(inputs, disp, mode):
+    """In place: empty the LiDAR validity mask (trainer.py:580-584) - ``"all"``: no LiDAR returns; ``"scale2"``: the 1/4-scale
+    disparity is 0.9 everywhere (26 / (0.01 + 9.99 * 0.9) = 2.9 m, further than 2 m from every 5 .. 65 m return); ``"sample0"``:
+    the first sample of the batch has no returns (an empty micro-batch inside a stacked pass); ``None``: nothing."""
+    if mode == "all":
+        inputs["4beam"].zero_()
+    elif mode == "scale2":
+        disp[("disp", 2)].fill_(0.9)
+    elif mode == "sample0":
+        inputs["4beam"][0].zero_()
+    elif mode is not None:
+        raise ValueError(mode)
+
+
 def small_poses(rng, B):
     """(axisangle[B,1,3], translation[B,1,3]) of KITTI-like magnitude."""
     aa = (0.02 * rng.randn(B, 1, 3)).astype(np.float32)

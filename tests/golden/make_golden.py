@@ -235,10 +235,14 @@ def _trainer_self(RL, RT, opt_over, B, H, W):
     return ns
 
 
-def gold_losses(RL, RT, name, seed, B, H, W, full_arrays, opt_over=None):
+def gold_losses(RL, RT, name, seed, B, H, W, full_arrays, opt_over=None, empty_si=None):
+    """``empty_si``: make the LiDAR validity mask of trainer.py:580-584 empty - "all": no LiDAR returns at all; "scale2": the
+    1/4-scale disparity predicts 2.9 m everywhere (no return within 2 m of it).  The reference then takes the mean of an empty
+    selection: that scale's si_loss and the total are NaN, the gradients stay finite (trainer.py:585-589)."""
     ns = _trainer_self(RL, RT, opt_over or {}, B, H, W)
     inp, rng = gin.batch_inputs(seed, B, H, W)
     disp = gin.disp_pyramid(rng, B, H, W)
+    gin.make_si_mask_empty(inp, disp, empty_si)
     outputs, leaves = {}, []
     for s in range(4):
         outputs[("disp", s)] = disp[("disp", s)].clone().requires_grad_(True)
@@ -483,6 +487,8 @@ def main():
     gold_losses(RL, RT, "losses_b1_192x640", 505, 1, 192, 640, full_arrays=False)
     gold_losses(RL, RT, "losses_nossim_noautomask_b2_64x96", 606, 2, 64, 96, full_arrays=False,
                 opt_over=dict(no_ssim=True, disable_automasking=True))
+    gold_losses(RL, RT, "losses_emptysi_all_b2_64x96", 404, 2, 64, 96, full_arrays=False, empty_si="all")
+    gold_losses(RL, RT, "losses_emptysi_scale2_b2_64x96", 404, 2, 64, 96, full_arrays=False, empty_si="scale2")
     gold_scatter(get2ch)
     gold_depth_losses(RL, RT)
     gold_refiner(RL, DD, PD)

@@ -157,7 +157,7 @@ def _worker_direct(rank, world, port, out):
 
 def test_in_place_gradients_trigger_overlapped_buckets():
     """The trainer's kernels accumulate parameter gradients in place, so autograd's hooks never fire: the buckets must leave
-    through functional.set_grad_ready_callback instead, one per segment, and the unused parameter's bucket at finish()."""
+    through functional.add_grad_ready_callback instead, one per segment, and the unused parameter's bucket at finish()."""
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()

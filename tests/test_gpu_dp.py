@@ -80,6 +80,8 @@ def test_bench_two_ranks_reports_the_exchange(tmp_path, backend):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--height", "64", "--width", "96", "--batch_size", "2", "--no_roofline", "--no_cpu_baseline"]
+    if backend == "gloo":
+        cmd.append("--share_device")         # two ranks on the one GPU of the test box: allowed only when asked for
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -88,3 +90,35 @@ def test_bench_two_ranks_reports_the_exchange(tmp_path, backend):
     assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["backend"] == backend and res["config"]["parallelism"] == "dp2"
     assert res["allreduce_ms"] > 0 and 0.0 <= res["overlap_frac"] <= 1.0 and res["buckets_overlapped"] == res["allreduce_buckets"]
     assert res["value"] > 0 and res["params_finite"]
+
+
+def _bench_plain(extra, timeout=500):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("FD_DIST_BACKEND", None)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "64",
+           "--width", "96", "--batch_size", "2", "--no_roofline", "--no_cpu_baseline"] + extra
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_plain_bench_gpus2_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` WITHOUT torch.distributed.run - the way the driver's single-GPU harness invokes bench.py -
+    must start two ranks itself.  With two or more devices: one rank per device over RCCL, no flag.
+    On the one-GPU test box the same command must REFUSE (it cannot measure two GPUs there) and name the reason; with
+    --share_device the two ranks share the device over gloo, which exercises the self-launch path end to end."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        r = _bench_plain([])
+        want_backend = "nccl"
+    else:
+        refused = _bench_plain([], timeout=120)
+        assert refused.returncode != 0 and "only 1 device" in refused.stderr and not [l for l in refused.stdout.splitlines() if l.startswith("{")]
+        r = _bench_plain(["--share_device"])
+        want_backend = "gloo"
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["backend"] == want_backend and res["config"]["parallelism"] == "dp2"
+    assert res["final_loss"] is not None and res["params_finite"] and res["value"] > 0

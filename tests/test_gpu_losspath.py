@@ -202,7 +202,7 @@ def _oracle_photo_terms(opt, inp, disp, Ts, noise):
     return terms, outputs
 
 
-def _hip_photo_terms(FD, opt, inp, disp, Ts, noise, materialize=True):
+def _hip_photo_terms(FD, opt, inp, disp, Ts, noise, materialize=True, groups=1):
     po = FD.PhotoOptions(opt.min_depth, opt.max_depth, opt.no_ssim, opt.avg_reprojection, opt.gdc_loss_threshold, opt.si_var)
     fids = opt.frame_ids[1:]
     target = dev(inp[("color", 0, 0)])
@@ -216,7 +216,7 @@ def _hip_photo_terms(FD, opt, inp, disp, Ts, noise, materialize=True):
     res = []
     for s in opt.scales:
         nz = dev(noise[s]) if ident is not None else None
-        res.append(FD.photo_loss(disp[s], [Ts[f] for f in fids], K, inv_K, srcs, target, ident, nz, beam, po, materialize))
+        res.append(FD.photo_loss(disp[s], [Ts[f] for f in fids], K, inv_K, srcs, target, ident, nz, beam, po, materialize, groups))
     return res
 
 
@@ -343,41 +343,7 @@ def test_three_source_frames_and_predictive_mask_vs_oracle(FD, avg, ssim):
         assert_close(got[4 + i], want[4 + i], rtol=1e-3, atol=(3e-2 if flips else 1e-4) * sc, what="d loss / d T frame %s" % f)
 
 
-def test_fused_photo_loss_vs_reference_golden(FD, golden):
-    """Same inputs as tests/golden/make_golden.py::gold_losses -> compare with what the REFERENCE produced."""
-    g = golden("losses_b2_64x96")
-    B, H, W, seed = 2, 64, 96, 404
-    opt = OT.default_opt(height=H, width=W)
-    inp, rng = gin.batch_inputs(seed, B, H, W)
-    disp0 = gin.disp_pyramid(rng, B, H, W)
-    d_g = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
-    T_g = {f: torch.from_numpy(g["T%d" % f]).cuda().requires_grad_(True) for f in (-1, 1)}
-    noise = [torch.from_numpy(g["noise%d" % s]) for s in range(4)]
-    res = _hip_photo_terms(FD, opt, inp, d_g, T_g, noise)
-    total = 0
-    for s in range(4):
-        photo, si, sel, depth, sample, color = res[s]
-        assert_close(cpu(depth), g["depth%d" % s], rtol=1e-5, atol=1e-6, what="depth")
-        for i, f in enumerate((-1, 1)):
-            assert_close(cpu(color[i]), g["color%d_%d" % (f, s)], rtol=1e-4, atol=2e-5, what="color")
-        assert ((cpu(sel) > 1).astype(np.uint8) != g["idsel%d" % s]).mean() <= 2e-4
-        smooth = FD.normalized_smooth_loss(d_g[s], dev(inp[("color", 0, s)]))
-        loss_s = photo + opt.disparity_smoothness * smooth / (2 ** s)
-        assert_close(cpu(loss_s), g["L/loss_%d" % s], rtol=1e-4, atol=1e-7, what="loss/%d" % s)
-        assert_close(cpu(si), g["L/loss_si_loss%d" % s], rtol=1e-4, atol=1e-7, what="si_loss%d" % s)
-        total = total + loss_s + si
-    total = total / 4
-    assert_close(cpu(total), g["L/loss"], rtol=1e-4, atol=1e-7, what="total loss")
-    got = grads(total, [d_g[s] for s in range(4)] + [T_g[-1], T_g[1]])
-    for s in range(4):
-        sc = np.abs(g["g_disp%d" % s]).max()
-        assert_mostly_close(got[s], g["g_disp%d" % s], rtol=2e-3, atol=2e-4 * sc, what="g disp%d vs reference" % s)
-    # pose gradients are sums over every pixel: a handful of argmin/clamp branch flips moves them by ~1e-4 of max
-    assert_close(got[4], g["g_T-1"], rtol=1e-3, atol=5e-4 * np.abs(g["g_T-1"]).max(), what="g T-1 vs reference")
-    assert_close(got[5], g["g_T1"], rtol=1e-3, atol=5e-4 * np.abs(g["g_T1"]).max(), what="g T+1 vs reference")
-
-
-def _hip_photo_terms_ms(FD, opt, inp, disp, Ts, noise, rows=0, beam_scales=(0, 1, 2, 3)):
+def _hip_photo_terms_ms(FD, opt, inp, disp, Ts, noise, rows=0, beam_scales=(0, 1, 2, 3), groups=1):
     po = FD.PhotoOptions(opt.min_depth, opt.max_depth, opt.no_ssim, opt.avg_reprojection, opt.gdc_loss_threshold, opt.si_var)
     fids = opt.frame_ids[1:]
     target = dev(inp[("color", 0, 0)])
@@ -388,7 +354,7 @@ def _hip_photo_terms_ms(FD, opt, inp, disp, Ts, noise, rows=0, beam_scales=(0, 1
     K, inv_K, beam = dev(inp[("K", 0)]), dev(inp[("inv_K", 0)]), dev(inp["4beam"])
     nz = [dev(noise[s]) for s in opt.scales] if ident is not None else None
     return FD.photo_loss_ms([disp[s] for s in opt.scales], [Ts[f] for f in fids], K, inv_K, srcs, target, ident, nz, beam,
-                            beam_scales, po, 1, rows)
+                            beam_scales, po, groups, rows)
 
 
 @pytest.mark.parametrize("seed,B,H,W,rows,over", [
@@ -488,6 +454,126 @@ def test_loss_path_error_against_float64(FD, seed, B, H, W):
                   "(float32 reference %.2e)" % (name, s, 100 * bad, 100 * bad_ref, l1, l1_ref))
             assert bad <= 1.5 * bad_ref + 2e-3, "%s s%d: %.3f%% vs %.3f%% for the float32 reference" % (name, s, 100 * bad, 100 * bad_ref)
             assert l1 <= 1.5 * l1_ref + 3e-4, "%s s%d: rel-L1 %.3g vs %.3g for the float32 reference" % (name, s, l1, l1_ref)
+
+def _golden_loss_case(FD, g, seed, B, H, W, kernel, empty_si=None):
+    """Inputs of tests/golden/make_golden.py::gold_losses -> (per-scale loss terms, total, leaves) from one of the two HIP
+    implementations ("ms": fd_photo_ms_* = what the trainer and the bench run; "per_scale": fd_photo_fwd_ex / bwd_ex)."""
+    opt = OT.default_opt(height=H, width=W)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp0 = gin.disp_pyramid(rng, B, H, W)
+    gin.make_si_mask_empty(inp, disp0, empty_si)
+    d_g = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
+    T_g = {f: torch.from_numpy(g["T%d" % f]).cuda().requires_grad_(True) for f in (-1, 1)}
+    torch.manual_seed(int(g["noise_seed"]))
+    noise = [torch.randn(B, 2, H, W) for _ in range(4)]
+    np.testing.assert_array_equal(noise[0].numpy().reshape(-1)[:16], g["noise_head"])
+    if kernel == "ms":
+        photo, si, sel = _hip_photo_terms_ms(FD, opt, inp, d_g, T_g, noise)
+    else:
+        res = _hip_photo_terms(FD, opt, inp, d_g, T_g, noise, materialize=True)
+        photo, si, sel = [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]
+        for s in range(4):           # the materialised by-products against the reference's ("depth", 0, s) / ("color", f, s)
+            depth, color = res[s][3], res[s][5]
+            if "depth%d" % s in g:
+                assert_close(cpu(depth), g["depth%d" % s], rtol=1e-5, atol=1e-6, what="depth s%d" % s)
+                for i, f in enumerate((-1, 1)):
+                    assert_close(cpu(color[i]), g["color%d_%d" % (f, s)], rtol=1e-4, atol=2e-5, what="color f%d s%d" % (f, s))
+            elif "depth%d_sub" % s in g:
+                assert_close(cpu(depth)[:, :, ::16, ::16], g["depth%d_sub" % s], rtol=1e-5, atol=1e-6, what="depth s%d" % s)
+                for i, f in enumerate((-1, 1)):
+                    assert_close(cpu(color[i])[:, :, ::16, ::16], g["color%d_%d_sub" % (f, s)], rtol=1e-4, atol=2e-5,
+                                 what="color f%d s%d" % (f, s))
+    loss_s = [photo[s] + opt.disparity_smoothness * FD.normalized_smooth_loss(d_g[s], dev(inp[("color", 0, s)])) / (2 ** s)
+              for s in range(4)]
+    total = sum(loss_s[s] + si[s] for s in range(4)) / 4
+    return loss_s, si, sel, total, [d_g[s] for s in range(4)] + [T_g[-1], T_g[1]]
+
+
+@pytest.mark.parametrize("name,seed,B,H,W", [("losses_b2_64x96", 404, 2, 64, 96), ("losses_b1_192x640", 505, 1, 192, 640)])
+@pytest.mark.parametrize("kernel", ["ms", "per_scale"])
+def test_default_loss_kernels_vs_reference_golden(FD, golden, name, seed, B, H, W, kernel):
+    """BOTH HIP implementations of generate_images_pred + compute_losses (trainer.py:425-596) - the all-scales kernel the trainer
+    and bench.py run by default, and the per-scale kernels of the flag variants - directly against what the REFERENCE produced on
+    these inputs (tests/golden/make_golden.py::gold_losses), at 64x96 and at the full 192x640."""
+    g = golden(name)
+    loss_s, si, sel, total, leaves = _golden_loss_case(FD, g, seed, B, H, W, kernel)
+    for s in range(4):
+        assert_close(cpu(loss_s[s]), g["L/loss_%d" % s], rtol=1e-4, atol=1e-7, what="loss/%d" % s)
+        assert_close(cpu(si[s]), g["L/loss_si_loss%d" % s], rtol=1e-4, atol=1e-7, what="si_loss%d" % s)
+        assert ((cpu(sel[s]) > 1).astype(np.uint8) != g["idsel%d" % s]).mean() <= 3e-4
+    assert_close(cpu(total), g["L/loss"], rtol=1e-4, atol=1e-7, what="total loss")
+    got = grads(total, leaves)
+    for s in range(4):
+        sc = np.abs(g["g_disp%d" % s]).max()
+        assert_mostly_close(got[s], g["g_disp%d" % s], rtol=2e-3, atol=2e-4 * sc, what="g disp%d vs reference (%s)" % (s, kernel))
+    assert_close(got[4], g["g_T-1"], rtol=1e-3, atol=5e-4 * np.abs(g["g_T-1"]).max(), what="g T-1 vs reference")
+    assert_close(got[5], g["g_T1"], rtol=1e-3, atol=5e-4 * np.abs(g["g_T1"]).max(), what="g T+1 vs reference")
+
+
+@pytest.mark.parametrize("mode", ["all", "scale2"])
+@pytest.mark.parametrize("kernel", ["ms", "per_scale"])
+def test_empty_lidar_mask_vs_reference_golden(FD, golden, mode, kernel):
+    """trainer.py:577-589 with no LiDAR return inside the validity mask (no returns at all / none at the 1/4 scale): the reference
+    takes the mean of an empty selection - si_loss of that scale and the total are NaN, all gradients stay finite (golden:
+    make_golden.py gold_losses(empty_si=...)).  Same NaN pattern, same values elsewhere, same gradients, for both kernels - this is
+    the state a from-scratch run on synthetic frames drifts into (bench.py)."""
+    g = golden("losses_emptysi_%s_b2_64x96" % mode)
+    loss_s, si, sel, total, leaves = _golden_loss_case(FD, g, 404, 2, 64, 96, kernel, empty_si=mode)
+    want_nan = [0, 1, 2, 3] if mode == "all" else [2]
+    for s in range(4):
+        assert bool(torch.isnan(si[s])) == (s in want_nan), "si_loss%d: %r" % (s, float(si[s]))
+        assert_close(cpu(si[s]), g["L/loss_si_loss%d" % s], rtol=1e-4, atol=1e-7, what="si_loss%d" % s)     # NaN == NaN here
+        assert_close(cpu(loss_s[s]), g["L/loss_%d" % s], rtol=1e-4, atol=1e-7, what="loss/%d" % s)
+    assert bool(torch.isnan(total)) and np.isnan(g["L/loss"])
+    got = grads(total, leaves)
+    for s in range(4):
+        assert np.isfinite(got[s]).all(), "d loss / d disp%d has non-finite entries" % s
+        sc = np.abs(g["g_disp%d" % s]).max()
+        assert_mostly_close(got[s], g["g_disp%d" % s], rtol=2e-3, atol=2e-4 * sc, what="g disp%d vs reference (%s, %s)" % (s, kernel, mode))
+    for i, f in ((4, -1), (5, 1)):
+        assert np.isfinite(got[i]).all()
+        assert_close(got[i], g["g_T%d" % f], rtol=1e-3, atol=5e-4 * np.abs(g["g_T%d" % f]).max(), what="g T%d vs reference" % f)
+
+
+@pytest.mark.parametrize("kernel", ["ms", "per_scale"])
+def test_empty_lidar_mask_in_one_stacked_micro_batch(FD, kernel):
+    """Two micro-batches stacked into one pass (groups = 2, Trainer.train_step), the first without any LiDAR return: the reference
+    runs them one after the other (trainer.py:237-248) - micro-batch 0 gives a NaN si_loss and finite gradients, micro-batch 1 is
+    unaffected - so the stacked value (mean over the micro-batches) is NaN at every scale while micro-batch 1's disparities still
+    receive exactly half of their stand-alone SI gradient.  Oracle: the two micro-batches evaluated separately."""
+    B, H, W, seed = 2, 64, 96, 404
+    opt = OT.default_opt(height=H, width=W)
+    inp, rng = gin.batch_inputs(seed, B, H, W)
+    disp0 = gin.disp_pyramid(rng, B, H, W)
+    gin.make_si_mask_empty(inp, disp0, "sample0")
+    poses = {f: gin.small_poses(rng, B) for f in (-1, 1)}
+    T0 = {f: OL.transformation_from_parameters(*poses[f], invert=(f < 0)) for f in (-1, 1)}
+    noise = [torch.from_numpy(np.random.RandomState(1000 + seed + s).randn(B, 2, H, W).astype(np.float32)) for s in range(4)]
+    # oracle: micro-batch b on its own, total = sum_b (sum_s photo + si) / 2
+    want_g, want_si = [], []
+    for b in range(B):
+        sl = slice(b, b + 1)
+        i_b = {k: (v[sl] if torch.is_tensor(v) else v) for k, v in inp.items()}
+        d_b = {s: disp0[("disp", s)][sl].clone().requires_grad_(True) for s in range(4)}
+        T_b = {f: T0[f][sl].clone().requires_grad_(True) for f in T0}
+        terms, _ = _oracle_photo_terms(opt, i_b, d_b, T_b, [n[sl] for n in noise])
+        tot = sum(terms[s][0] + terms[s][1] for s in range(4)) / B
+        want_g.append(grads(tot, [d_b[s] for s in range(4)]))
+        want_si.append([float(terms[s][1]) for s in range(4)])
+    assert all(np.isnan(v) for v in want_si[0]) and all(np.isfinite(v) for v in want_si[1])
+    d_g = {s: dev(disp0[("disp", s)]).requires_grad_(True) for s in range(4)}
+    T_g = {f: dev(T0[f]).requires_grad_(True) for f in T0}
+    if kernel == "ms":
+        photo, si, _ = _hip_photo_terms_ms(FD, opt, inp, d_g, T_g, noise, groups=2)
+    else:
+        res = _hip_photo_terms(FD, opt, inp, d_g, T_g, noise, materialize=False, groups=2)
+        photo, si = [r[0] for r in res], [r[1] for r in res]
+    assert all(bool(torch.isnan(v)) for v in si), [float(v) for v in si]
+    got = grads(sum(photo[s] + si[s] for s in range(4)), [d_g[s] for s in range(4)])
+    for s in range(4):
+        assert np.isfinite(got[s]).all()
+        want = np.concatenate([want_g[0][s], want_g[1][s]], 0)
+        assert_mostly_close(got[s], want, rtol=2e-3, atol=2e-4 * np.abs(want).max(), what="d loss / d disp s%d (%s)" % (s, kernel))
 
 
 def test_multiscale_photo_loss_matches_per_scale_kernels(FD):

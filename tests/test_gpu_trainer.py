@@ -26,18 +26,24 @@ def _opts(**over):
     return o
 
 
-def _make_pair(opt, seed=3):
-    from fusiondepth_amd.trainer import Trainer
-    tr = Trainer(opt, verbose=False, materialize_outputs=True)
+def _make_oracle(opt, seed=3):
+    """The oracle trainer in the deterministic initial state every test pair starts from."""
     oopt = OT.default_opt(height=opt.height, width=opt.width, batch_size=opt.batch_size, num_layers=opt.num_layers,
                           learning_rate=opt.learning_rate)
     omodels = OT.build_models(oopt, seed)
     for k, m in omodels.items():
         gin.fill_params(m, 100 + len(k))
-        with torch.no_grad():
+    return OT.OracleTrainer(oopt, models=omodels)
+
+
+def _make_pair(opt, seed=3):
+    from fusiondepth_amd.trainer import Trainer
+    tr = Trainer(opt, verbose=False, materialize_outputs=True)
+    ot = _make_oracle(opt, seed)
+    with torch.no_grad():
+        for k, m in ot.models.items():
             for name, t in tr.models[k].state_dict().items():
                 t.copy_(m.state_dict()[name])
-    ot = OT.OracleTrainer(oopt, models=omodels)
     return tr, ot
 
 
@@ -60,6 +66,46 @@ def _batch(B, H, W, seed):
     return inp, noise
 
 
+def _rel_err(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float((np.abs(a - ref) / np.maximum(np.abs(ref), 1e-30)).max())
+
+
+def _float64_models(models):
+    import copy
+    out = {k: copy.deepcopy(m).double() for k, m in models.items()}
+    for m in out.values():
+        m.train()
+    return out
+
+
+def _to64(inp):
+    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
+
+
+def _check_forward_against_float64(tag, outs_g, losses_g, ot, inp, noise, keys):
+    """One training forward of the HIP trainer against GROUND TRUTH = the oracle's graph in float64, tensor by tensor (worst
+    element-wise relative error) and loss by loss.  Bound: the north-star 1e-4, or twice the error the reference's own float32
+    arithmetic (the float32 oracle, same weights) shows on that tensor - whichever is larger.  A 10x regression cannot pass: the
+    measured errors sit at 0.3 - 1x the float32 oracle's.  Every measured error goes to the terminal summary (conftest.report)."""
+    import conftest
+    with torch.no_grad():
+        o32, l32 = OT.process_batch(ot.opt, ot.models, {k: v.clone() for k, v in inp.items()}, noise)
+        o64, l64 = OT.process_batch(ot.opt, _float64_models(ot.models), _to64(inp), [n.double() for n in noise])
+    for key in keys:
+        r64 = o64[key].numpy()
+        e_hip, e_ref = _rel_err(outs_g[key].detach().cpu().numpy(), r64), _rel_err(o32[key].numpy(), r64)
+        bound = max(1e-4, 2 * e_ref)
+        conftest.report("%s %s" % (tag, key), e_hip, bound, "(float32 oracle %.2e)" % e_ref)
+        assert e_hip <= bound, "%s %s: HIP %.3g vs float64, float32 oracle %.3g" % (tag, key, e_hip, e_ref)
+    for k in l64:
+        r64 = float(l64[k])
+        e_hip, e_ref = abs(float(losses_g[k]) - r64) / abs(r64), abs(float(l32[k]) - r64) / abs(r64)
+        bound = max(1e-4, 2 * e_ref)
+        conftest.report("%s %s" % (tag, k), e_hip, bound, "(float32 oracle %.2e)" % e_ref)
+        assert e_hip <= bound, "%s %s: HIP %.3g vs float64, float32 oracle %.3g" % (tag, k, e_hip, e_ref)
+
+
 def test_trainer_matches_oracle_over_optimizer_steps():
     opt = _opts(height=128, width=192)     # layer4 BatchNorm then sees 2*4*6 = 48 samples per channel (64x96 gives 12)
     tr, ot = _make_pair(opt)
@@ -75,16 +121,14 @@ def test_trainer_matches_oracle_over_optimizer_steps():
         if step == 0:   # gradient parity before the first update (BN buffers are restored after this extra forward)
             saved = {k: {n: b.clone() for n, b in m.named_buffers()} for k, m in tr.models.items()}
             outs_g, losses_g = tr.process_batch(ginp)
-            for k in losses_o:
-                assert_close(float(losses_g[k]), float(losses_o[k]), rtol=2e-4, atol=1e-6, what="step0 " + k)
-            for s in range(4):
-                a, b = outs_g[("disp", s)].detach().cpu().numpy(), outs_o[("disp", s)].detach().numpy()
-                assert_close(a, b, rtol=1e-3, atol=1e-4, what="disp%d" % s)
-                assert_close(outs_g[("depth", 0, s)].cpu().numpy(), outs_o[("depth", 0, s)].detach().numpy(), rtol=2e-3,
-                             atol=1e-3, what="depth%d" % s)
-            for f in (-1, 1):
+            # the state BEFORE the oracle's micro_step above is gone (it stepped): rebuild the pair's float32 / float64 yardsticks
+            # from the HIP trainer's (still untouched) weights
+            ot0 = _make_oracle(opt)
+            _check_forward_against_float64("R18 128x192 b2 step0", outs_g, losses_g, ot0, inp, noise,
+                                           [("disp", s) for s in range(4)] + [("depth", 0, s) for s in range(4)])
+            for f in (-1, 1):      # 4x4 matrices with exact 0 / 1 entries: absolute bound on top of the relative one
                 assert_close(outs_g[("cam_T_cam", 0, f)].detach().cpu().numpy(), outs_o[("cam_T_cam", 0, f)].detach().numpy(),
-                             rtol=1e-3, atol=1e-5, what="cam_T_cam %d" % f)
+                             rtol=1e-4, atol=2e-6, what="cam_T_cam %d" % f)
             tr.flat.zero_grad()
             with torch.no_grad():
                 for k, m in tr.models.items():
@@ -161,11 +205,9 @@ def test_other_baseline_configs_match_oracle(layers, H, W, B):
         if step == 0:
             saved = {k: {n: b.clone() for n, b in m.named_buffers()} for k, m in tr.models.items()}
             outs_g, losses_g = tr.process_batch(ginp)
-            for k in losses_o:
-                assert_close(float(losses_g[k]), float(losses_o[k]), rtol=5e-4, atol=1e-6, what="step0 " + k)
-            for s in range(4):
-                assert_close(outs_g[("disp", s)].detach().cpu().numpy(), outs_o[("disp", s)].detach().numpy(), rtol=2e-3,
-                             atol=2e-4, what="disp%d" % s)
+            ot0 = _make_oracle(opt)          # same initial weights as the pair above (the oracle has already stepped)
+            _check_forward_against_float64("R%d %dx%d b%d step0" % (layers, W, H, B), outs_g, losses_g, ot0, inp, noise,
+                                           [("disp", s) for s in range(4)])
             tr.flat.zero_grad()
             with torch.no_grad():
                 for k, m in tr.models.items():
@@ -511,23 +553,6 @@ def test_adam_checkpoint_is_the_reference_optimizer_layout(tmp_path):
     assert torch.equal(tr.exp_avg[o:o + tr.flat.params[i].numel()].cpu(), back["state"][i]["exp_avg"].reshape(-1).cpu())
 
 
-def _rel_err(a, ref):
-    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
-    return float((np.abs(a - ref) / np.maximum(np.abs(ref), 1e-30)).max())
-
-
-def _float64_models(models):
-    import copy
-    out = {k: copy.deepcopy(m).double() for k, m in models.items()}
-    for m in out.values():
-        m.train()
-    return out
-
-
-def _to64(inp):
-    return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
-
-
 @pytest.mark.parametrize("H,W,B,groups", [(128, 192, 2, 1), (192, 640, 6, 2)])
 def test_full_step_outputs_against_float64(H, W, B, groups):
     """North-star tolerance at trainer level: ("disp", s), ("depth", 0, s) and every loss of one full training forward, compared
@@ -536,6 +561,7 @@ def test_full_step_outputs_against_float64(H, W, B, groups):
     samples amplifies rounding), whichever is larger; the measured errors are printed.
     Second case = BASELINE.json config 2 exactly: ResNet-18, 640x192, --batch_size 12 = 2 micro-batches of 6, run as ONE stacked
     pass (grouped BatchNorm, per-group SI-log loss) and checked per micro-batch against separate float64 passes."""
+    import conftest
     opt = _opts(height=H, width=W, batch_size=B * groups)
     tr, ot = _make_pair(opt)
     assert tr.batch_size == B and tr.accumulate_step == groups
@@ -565,6 +591,8 @@ def test_full_step_outputs_against_float64(H, W, B, groups):
                 e_hip, e_ref = _rel_err(cpu(outs_g[key][sl]), r64), _rel_err(r32, r64)
                 worst = max(worst, e_hip)
                 print("[vs float64] group %d %-16s HIP %.2e | float32 oracle %.2e" % (g, key, e_hip, e_ref))
+                conftest.report("R18 %dx%d b%dx%d micro-batch %d %s" % (W, H, B, groups, g, key), e_hip, max(1e-4, 2 * e_ref),
+                                "(float32 oracle %.2e)" % e_ref)
                 assert e_hip <= max(1e-4, 2 * e_ref), "%s (micro-batch %d): HIP %.3g vs float32 oracle %.3g" % (key, g, e_hip, e_ref)
     # losses: the stacked pass reports sum_g loss_g / groups (trainer.py:237-248 accumulates loss / accumulate_step)
     for k in ref64[0][1]:
@@ -572,6 +600,7 @@ def test_full_step_outputs_against_float64(H, W, B, groups):
         r32 = sum(float(r[1][k]) for r in ref32) / groups
         e_hip, e_ref = abs(float(losses_g[k]) - r64) / abs(r64), abs(r32 - r64) / abs(r64)
         print("[vs float64] %-16s HIP %.2e | float32 oracle %.2e" % (k, e_hip, e_ref))
+        conftest.report("R18 %dx%d b%dx%d %s" % (W, H, B, groups, k), e_hip, max(1e-4, 2 * e_ref), "(float32 oracle %.2e)" % e_ref)
         assert e_hip <= max(1e-4, 2 * e_ref), "%s: HIP %.3g vs float32 oracle %.3g" % (k, e_hip, e_ref)
     print("worst element-wise relative error of disp / depth vs float64: %.2e" % worst)
 

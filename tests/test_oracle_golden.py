@@ -144,10 +144,11 @@ def test_refine_decoder_variant_against_reference(golden):
         assert_close(npy(o[("disp", s)]), g["disp%d" % s], rtol=1e-5, atol=1e-6, what="refine disp%d" % s)
 
 
-def _loss_case(g, seed, B, H, W, **opt_over):
+def _loss_case(g, seed, B, H, W, empty_si=None, **opt_over):
     opt = OT.default_opt(height=H, width=W, **opt_over)
     inp, rng = gin.batch_inputs(seed, B, H, W)
     disp = gin.disp_pyramid(rng, B, H, W)
+    gin.make_si_mask_empty(inp, disp, empty_si)
     outputs, leaves = {}, []
     for s in range(4):
         outputs[("disp", s)] = disp[("disp", s)].clone().requires_grad_(True)
@@ -194,6 +195,24 @@ def test_loss_path_flags_no_ssim_no_automask(golden):
         assert_close(float(v), g["L/" + k.replace("/", "_")], rtol=1e-6, atol=1e-8, what=k)
     for s in range(4):
         assert_close(npy(grads[s]), g["g_disp%d" % s], rtol=1e-5, atol=1e-9, what="g disp%d" % s)
+
+
+@pytest.mark.parametrize("mode", ["all", "scale2"])
+def test_loss_path_with_empty_lidar_mask(golden, mode):
+    """trainer.py:577-589 when no LiDAR return passes the validity mask (everywhere / at one scale): the reference's si_loss of
+    that scale and the total are NaN, every gradient stays finite (an empty selection passes nothing back).  The oracle must show
+    the same NaN pattern and the same gradients."""
+    g = golden("losses_emptysi_%s_b2_64x96" % mode)
+    opt, outputs, losses, grads = _loss_case(g, 404, 2, 64, 96, empty_si=mode)
+    nan_keys = [k for k in losses if np.isnan(float(losses[k]))]
+    assert nan_keys == (["loss/si_loss%d" % s for s in range(4)] + ["loss"] if mode == "all" else ["loss/si_loss2", "loss"])
+    for k, v in losses.items():
+        assert_close(float(v), g["L/" + k.replace("/", "_")], rtol=1e-6, atol=1e-8, what=k)       # checks the NaN pattern too
+    for s in range(4):
+        assert np.isfinite(npy(grads[s])).all()
+        assert_close(npy(grads[s]), g["g_disp%d" % s], rtol=1e-5, atol=1e-9, what="g disp%d" % s)
+    assert_close(npy(grads[4]), g["g_T-1"], rtol=1e-4, atol=1e-6, what="g T-1")
+    assert_close(npy(grads[5]), g["g_T1"], rtol=1e-4, atol=1e-6, what="g T+1")
 
 
 def test_scatter_c_oracle_bit_exact_vs_reference(golden):
