@@ -310,7 +310,7 @@ def main():
     n_pool = args.pool if args.pool > 0 else min(48, args.steps + max(args.warmup, 2) + 4)
     pool = []
     for i in range(n_pool):
-        mbs_i = [synthetic.make_scene_batch(tr.batch_size, args.height, args.width, seed=1234 + 1009 * rank + 17 * i + j)
+        mbs_i = [synthetic.make_scene_batch(tr.batch_size, args.height, args.width, seed=1234 + 1009 * rank + 17 * i + j, clutter=0.5)
                  for j in range(tr.accumulate_step)]
         for mb in mbs_i:
             mb.pop("depth_gt", None)                 # training batches: the validation batch below keeps its ground truth

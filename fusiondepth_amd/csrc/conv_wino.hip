@@ -21,25 +21,39 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((__vector_size__(2 * sizeof(unsigned int))));
 
 __device__ __forceinline__ f32x2 fd_ldg64(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0));
 }
-__device__ __forceinline__ float wino_act(float v, int act) {
-    if (act == 1) return v > 0.f ? v : 0.f;
+// ELU / sigmoid / tanh (decoder layers): one out-of-line copy, so that the fully unrolled epilogue (32 values per lane) does not
+// carry 32 inlined copies of three libm routines
+__device__ __attribute__((noinline)) float wino_act_slow(float v, int act) {
     if (act == 2) return v > 0.f ? v : expm1f(v);
     if (act == 3) return 1.0f / (1.0f + expf(-v));
-    if (act == 4) return tanhf(v);
-    return v;
+    return tanhf(v);
+}
+__device__ __forceinline__ float wino_act(float v, int act) {
+    if (act >= 2) return wino_act_slow(v, act);
+    return act == 1 ? fmaxf(v, 0.f) : v;
 }
 
+#ifndef FD_WINO_ABLATE
+#define FD_WINO_ABLATE 0     // timing experiments only (wrong results): 1 no main loop, 2 no output stores, 4 no epilogue at all, 8 no prologue loads,
+                             // 16 loop loads out of range (no traffic), 32 no operand LDS stores in the loop, 64 loop loads from a 16 KB window
+#endif
 constexpr int WBM = 64, WBN = 64, WBKC = 16, WNT = 256;
 constexpr int LDU = WBM + 1, LDV = WBN, LDM = WBN + 1;
-constexpr int W_BUF_FLOATS = 4 * WBKC * (LDU + LDV);          // one operand buffer (all four components)
+// k_conv_wino keeps the activations RAW in LDS - one row of the tile's 128 pixels per channel: [0] a cell that stays 0.0,
+// [3] the pixel left of the tile, [4 .. 131] the tile, [132] the pixel right of it - and applies the input transform when the
+// B operands are read: 8.7 KB per chunk instead of the 16.4 KB of four transformed components (the VGPR -> LDS store path is what
+// bounds the main loop, scripts/wino_ksweep.py), and 50.7 KB per workgroup = three workgroups per CU.
+constexpr int LDR = 2 * WBN + 8;
+constexpr int W_BUF_FLOATS = 4 * WBKC * LDU + WBKC * LDR;     // one operand buffer: U (four components) + raw activations
 // double-buffered operands: 66 KB -> 2 workgroups per CU.  (A single-buffered variant - 33 KB, 4 per CU, two barriers per chunk - and a
 // one-chunk-deep register pipeline both measured the same; an 8-channel-chunk variant - 33 KB, 3 per CU - was 2-5 % faster alone
 // and 2 % slower inside the training step, where its extra resident waves take CUs from the other streams' kernels.)
-constexpr int W_LDS_FLOATS = (2 * W_BUF_FLOATS > 4 * WBM * LDM) ? 2 * W_BUF_FLOATS : 4 * WBM * LDM;
+constexpr int W_LDS_FLOATS = 2 * W_BUF_FLOATS;       // k_conv_wino: the double-buffered operands (its output transform stays in registers)
 
 // U[t][m][ky][c] from W[m][c][ky][kx] (forward) or, for the data gradient (flip = 1: a conv over dY with the spatially flipped,
 // channel-transposed kernel), from W[c][m][2-ky][2-kx].
@@ -75,14 +89,16 @@ struct WinoArgs {
 
 __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, comp = tid >> 6;       // wave index = Winograd component
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W2 = g.W >> 1;
-    const long plane2 = (long)g.H * W2, Np = (long)g.Nb * plane2;
+    const int plane2 = g.H * W2;                                         // pairs per image; Nb * plane2 < 2^29 (size guard)
+    const int Np = g.Nb * plane2;
     const unsigned hw = (unsigned)(g.H * g.W);
     const int m0 = blockIdx.y * WBM;
     int bx = blockIdx.x;
     if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
-    const long p0 = (long)bx * WBN;
+    const int p0 = bx * WBN;
     const int cpt = g.C / WBKC, nchunk_all = 3 * cpt;
     const int nsplit = (int)gridDim.z, zs = (int)blockIdx.z;
     const int per_split = (nchunk_all + nsplit - 1) / nsplit;
@@ -90,21 +106,24 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     const int ch_hi = ch_lo + per_split < nchunk_all ? ch_lo + per_split : nchunk_all;
 
     // ---- activation loader: this thread always fetches pair jn of the tile, channel rows kr + 4 i
-    const int jn = tid & 63;
-    const int kr = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long pg = p0 + jn;
+    const int jn = lane;
+    const int kr = wave;
+    const int pg = p0 + jn;
     const bool pvalid = pg < Np;
     int y0, j0;
     unsigned nbase;
     {
-        const long pp = pvalid ? pg : 0;
-        const int n = (int)(pp / plane2);
-        const int rem = (int)(pp - (long)n * plane2);
+        const int pp = pvalid ? pg : 0;
+        const int n = pp / plane2;
+        const int rem = pp - n * plane2;
         y0 = rem / W2; j0 = rem - y0 * W2;
         nbase = (unsigned)n * (unsigned)g.C * hw;
     }
     const bool refl = g.pad_mode == 1;
     const bool left_edge = j0 == 0, right_edge = 2 * j0 + 2 >= g.W;
+    // the tile's two halo pixels per channel row are fetched by lane 0 (left of its pair) and lane 63 (right of its pair); a pair
+    // at an image border has no such pixel (its reader substitutes the padding value), every other lane stays out of range
+    const bool halo_l = jn == 0 && !left_edge, halo_r = jn == WBN - 1 && !right_edge;
     // ---- weight loader: float4 a4 (of the chunk's 16 channels) of row ar, for each component
     const int a4 = tid & 3, ar = tid >> 2;
     int mrow = m0 + ar;
@@ -114,135 +133,193 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
 
     float4 ru[4];
     f32x2 rmid[4];
-    float rl[4], rr[4];
-    unsigned u_off = FD_OOB, mid_off = FD_OOB, l_off = FD_OOB, r_off = FD_OOB;
+    float rh[4];
+    unsigned u_off = FD_OOB, mid_off = FD_OOB, h_off = FD_OOB;
     const unsigned c_step = 4u * 4u * hw;                                // 4 channel rows further
     int pc_ky, pc_c0;
     { pc_ky = ch_lo / cpt; pc_c0 = (ch_lo - pc_ky * cpt) * WBKC; }
-    auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
+    // Offsets of the next chunk to fetch, in two branch-free halves (each small enough to hide behind one MFMA, see the k-loop)
+    unsigned prep_base = 0u;
+    bool prep_ok = false;
+    const int H2m2 = 2 * g.H - 2;
+    auto prep_a = [&](bool live) __attribute__((always_inline)) {
         u_off = live ? 4u * (((unsigned)mrow * 3u + (unsigned)pc_ky) * (unsigned)g.C + (unsigned)pc_c0 + 4u * a4) : FD_OOB;
-        int r = y0 + pc_ky - 1;
+        const int r = y0 + pc_ky - 1;
         const bool inb = (unsigned)r < (unsigned)g.H;
-        if (refl) r = r < 0 ? -r : (r >= g.H ? 2 * g.H - 2 - r : r);
-        const bool ok = pvalid & live & (refl | inb);
-        const unsigned base = 4u * (nbase + (unsigned)(pc_c0 + kr) * hw + (unsigned)(r * g.W + 2 * j0));
-        mid_off = ok ? base : FD_OOB;
-        l_off = (ok & !left_edge) ? base - 4u : FD_OOB;
-        r_off = (ok & !right_edge) ? base + 8u : FD_OOB;
+        int rr_ = r < 0 ? -r : r;
+        rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
+        const int ruse = refl ? rr_ : r;
+        prep_ok = pvalid & live & (refl | inb);
+        prep_base = 4u * (nbase + (unsigned)(pc_c0 + kr) * hw + (unsigned)(ruse * g.W + 2 * j0));
+    };
+    auto prep_b = [&]() __attribute__((always_inline)) {
+        mid_off = prep_ok ? prep_base : FD_OOB;
+        h_off = (prep_ok & halo_l) ? prep_base - 4u : ((prep_ok & halo_r) ? prep_base + 8u : FD_OOB);
+        if (FD_WINO_ABLATE & 16) { u_off = mid_off = h_off = FD_OOB; }                             // loads issue, no memory traffic
         pc_c0 += WBKC;
-        if (pc_c0 >= g.C) { pc_c0 = 0; ++pc_ky; }
+        const bool wrap = pc_c0 >= g.C;
+        pc_c0 = wrap ? 0 : pc_c0;
+        pc_ky += wrap ? 1 : 0;
     };
     auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off + (unsigned)t * u_comp); };   // FD_OOB + (< 2^31) stays out of range
-    auto load_v = [&](int i) __attribute__((always_inline)) {
-        const unsigned s = (unsigned)i * c_step;
-        rmid[i] = fd_ldg64(rsX, mid_off + s);                             // an FD_OOB base + (offset < 2^31) is still >= 2^31: reads 0
-        rl[i] = fd_ldg32(rsX, l_off + s);
-        rr[i] = fd_ldg32(rsX, r_off + s);
-    };
+    // an FD_OOB base + (offset < 2^31) is still >= 2^31: reads 0 - vertical zero padding and pairs past the end need no select
+    auto load_mid = [&](int i) __attribute__((always_inline)) { rmid[i] = fd_ldg64(rsX, mid_off + (unsigned)i * c_step); };
+    auto load_h = [&](int i) __attribute__((always_inline)) { rh[i] = fd_ldg32(rsX, h_off + (unsigned)i * c_step); };
     auto store_u = [&](int buf, int t) __attribute__((always_inline)) {
         float* q = smem + buf * W_BUF_FLOATS + t * WBKC * LDU + (4 * a4) * LDU + ar;
         q[0] = ru[t].x; q[LDU] = ru[t].y; q[2 * LDU] = ru[t].z; q[3 * LDU] = ru[t].w;
     };
+    const int v_row = 4 * WBKC * LDU + kr * LDR;                         // this thread's first channel row of the raw buffer
+    const int h_col = jn == 0 ? 3 : 2 * WBN + 4;                         // where a halo lane puts its pixel
     auto store_v = [&](int buf, int i) __attribute__((always_inline)) {
-        const float d1 = rmid[i].x, d2 = rmid[i].y;
-        const float d0 = (refl & left_edge) ? d2 : rl[i];               // reflect: column -1 is column 1, column W is column W-2
-        const float d3 = (refl & right_edge) ? d1 : rr[i];
-        float* q = smem + buf * W_BUF_FLOATS + 4 * WBKC * LDU + (kr + 4 * i) * LDV + jn;
-        q[0] = d0 - d2;
-        q[WBKC * LDV] = d1 + d2;
-        q[2 * WBKC * LDV] = d2 - d1;
-        q[3 * WBKC * LDV] = d1 - d3;
+        float* q = smem + buf * W_BUF_FLOATS + v_row + 4 * i * LDR;
+        *reinterpret_cast<f32x2*>(q + 4 + 2 * jn) = rmid[i];
+        if (jn == 0 || jn == WBN - 1) q[h_col] = rh[i];
     };
+    if (tid < 2 * WBKC) smem[(tid >> 4) * W_BUF_FLOATS + 4 * WBKC * LDU + (tid & 15) * LDR] = 0.f;     // the zero cells
 
-    f32x16 acc[2][2];
+    // Wave w owns the 32 (channels) x 32 (pairs) block (w >> 1, w & 1) of the tile with ALL FOUR Winograd components: one
+    // accumulator per component.  The four component products of an output therefore sit in the same lane and register, and the
+    // output transform (M0 + M1 + M2, M1 - M2 - M3) is plain register arithmetic in the epilogue.  (Round 1 / 2 gave each wave ONE
+    // component of the whole 64 x 64 tile - half the LDS operand reads per MFMA - and met the other components in LDS: a
+    // 64 KB round trip + barrier that took ~6 us per workgroup, a fifth of a 12-chunk tile; scripts/wino_ksweep.py.)
+    const int wm = wave >> 1, wn = wave & 1;
+    // Columns of the raw row this lane's B operands come from: d1, d2 = the pair itself, d0 / d3 = its left / right neighbour
+    // pixel - the halo cells for the tile's first / last pair - or, where the pair touches an image border, the padding value:
+    // the zero cell, or for reflection padding the mirror pixel (column -1 is column 1, column W is column W - 2).
+    int o12, o0, o3;
+    {
+        const int jp = 32 * wn + (lane & 31);
+        const int pp = p0 + jp < Np ? p0 + jp : 0;
+        const int rem = pp % plane2;
+        const int jj = rem % W2;
+        const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
+        o12 = 4 + 2 * jp;
+        o0 = le ? (refl ? o12 + 1 : 0) : o12 - 1;
+        o3 = re ? (refl ? o12 : 0) : o12 + 2;
+    }
+    f32x16 acc[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    // Main loop.  One v_mfma_f32_32x32x2_f32 occupies the SIMD's matrix pipe for 64 cycles, during which the issuing wave is free
+    // to issue a handful of other instructions.  Everything that is not an MFMA is therefore cut into pieces of <= 4-5
+    // instructions and placed BETWEEN the four MFMAs of a k-step (sched_barrier pins the order): the operand reads of the next
+    // k-step, the staging of the following chunks and their address arithmetic.  With the same instructions in one block ahead
+    // of the four MFMAs (round 2) the matrix pipe idled while that block issued: scripts/ubench/mfma_ablate2.hip measures
+    // 112 -> 128 TFLOP/s for this instruction mix at two workgroups per CU on random operands (124 -> 142 on constants).
+    //
+    // Staging pipeline, one register set, three chunks deep: in slot i (= k-step i of the first half) of chunk ch the registers
+    // of slot i - loaded one whole chunk earlier - are written to the LDS buffer of chunk ch + 1 and immediately re-loaded with
+    // chunk ch + 2.  Every global load thus has a full chunk (8 k-steps, >= 2 000 cycles) to return before its s_waitcnt; with
+    // load and store of the same chunk four k-steps apart (round 2) the wait stalled the wave - and the MFMAs behind it - whenever
+    // the fabric was slower than that (scripts/wino_ksweep.py + FD_WINO_ABLATE: 14 % of the loop time).
     constexpr int NK = WBKC / 2;       // 8 MFMA k-steps per chunk
-    constexpr int LS = NK / 2;         // loads in the first 4 k-steps, LDS stores in the last 4
+    constexpr int LS = NK / 2;         // staging slots: k-steps 0-3
     const int arow = lane >> 5, acol = lane & 31;
     if (ch_lo < ch_hi) {
-        prep_chunk(true);
+        prep_a(true); prep_b();
+        if (FD_WINO_ABLATE & 8) { u_off = mid_off = h_off = FD_OOB; }
 #pragma unroll
         for (int t = 0; t < 4; ++t) load_u(t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_v(i);
+        for (int i = 0; i < 4; ++i) { load_mid(i); load_h(i); }
 #pragma unroll
         for (int t = 0; t < 4; ++t) store_u(0, t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) store_v(0, i);
+        prep_a(ch_lo + 1 < ch_hi); prep_b();                     // chunk ch_lo + 1: loaded now, written to LDS during chunk ch_lo
+#pragma unroll
+        for (int t = 0; t < 4; ++t) load_u(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load_mid(i); load_h(i); }
+        prep_a(ch_lo + 2 < ch_hi); prep_b();                     // offsets of chunk ch_lo + 2, re-loaded during chunk ch_lo
         __syncthreads();
-        for (int ch = ch_lo; ch < ch_hi; ++ch) {
+        for (int ch = ch_lo; ch < ((FD_WINO_ABLATE & 1) ? ch_lo : ch_hi); ++ch) {
             const int cur = (ch - ch_lo) & 1;
-            prep_chunk(ch + 1 < ch_hi);
-            const float* pa = smem + cur * W_BUF_FLOATS + comp * WBKC * LDU + arow * LDU + acol;
-            const float* pb = smem + cur * W_BUF_FLOATS + 4 * WBKC * LDU + comp * WBKC * LDV + arow * LDV + acol;
-            float av[2][2], bv[2][2];
-            av[0][0] = pa[0]; av[0][1] = pa[32]; bv[0][0] = pb[0]; bv[0][1] = pb[32];
+            // operands of component t: A = U_t[k][32 wm + acol], B = input transform of the raw row k at this lane's pair;
+            // k = 2 kk + arow
+            const float* pa = smem + cur * W_BUF_FLOATS + arow * LDU + 32 * wm + acol;
+            const float* pr = smem + cur * W_BUF_FLOATS + 4 * WBKC * LDU + arow * LDR;
+            float av[2][4], bv[2][4];
+            auto read_a = [&](int nb, int k2, int t) __attribute__((always_inline)) { av[nb][t] = pa[t * WBKC * LDU + k2 * LDU]; };
+            f32x2 d12;
+            float d0, d3;
+            auto read_b = [&](int k2) __attribute__((always_inline)) {
+                d12 = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o12);
+                d0 = pr[k2 * LDR + o0]; d3 = pr[k2 * LDR + o3];
+            };
+            auto xform_b = [&](int nb) __attribute__((always_inline)) {   // (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
+                bv[nb][0] = d0 - d12.y; bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = d12.x - d3;
+            };
+#pragma unroll
+            for (int t = 0; t < 4; ++t) read_a(0, 0, t);
+            read_b(0); xform_b(0);
 #pragma unroll
             for (int kk = 0; kk < NK; ++kk) {
                 const int cb = kk & 1, nb = cb ^ 1;
-                if (kk + 1 < NK) {
-                    av[nb][0] = pa[(kk + 1) * 2 * LDU]; av[nb][1] = pa[(kk + 1) * 2 * LDU + 32];
-                    bv[nb][0] = pb[(kk + 1) * 2 * LDV]; bv[nb][1] = pb[(kk + 1) * 2 * LDV + 32];
-                }
-                if (kk < LS) { load_u(kk); load_v(kk); }
-                else { store_u(cur ^ 1, kk - LS); store_v(cur ^ 1, kk - LS); }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) { read_b(2 * (kk + 1)); read_a(nb, 2 * (kk + 1), 0); read_a(nb, 2 * (kk + 1), 1); }
+                if (kk < LS && !(FD_WINO_ABLATE & (32 | 128))) store_u(cur ^ 1, kk);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) { read_a(nb, 2 * (kk + 1), 2); read_a(nb, 2 * (kk + 1), 3); }
+                if (kk < LS) load_u(kk);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < LS && !(FD_WINO_ABLATE & (32 | 256))) store_v(cur ^ 1, kk);
+                if (kk + 1 < NK) xform_b(nb);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < LS) { load_mid(kk); load_h(kk); }
+                if (kk == NK - 2) prep_a(ch + 3 < ch_hi);        // every load of chunk ch + 2 has been issued by now
+                if (kk == NK - 1) prep_b();
             }
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
     }
 
-    // ---- output transform through LDS: sM[t][m][pair]
-    float* sM = smem;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
-                sM[(comp * WBM + m) * LDM + j * 32 + acol] = acc[i][j][r];
-            }
-    __syncthreads();
-    if (!pvalid) return;
+    // ---- epilogue: output transform in registers.  C/D layout of the 32x32 MFMA: column (pair) = lane & 31,
+    //      row (channel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (FD_WINO_ABLATE & 4) { if (acc[0][0] == 123.456f) g.Y[tid] = acc[1][3] + acc[2][2] + acc[3][1]; return; }
+    const int po = p0 + 32 * wn + acol;                                   // this lane's output pair
     const bool final_pass = nsplit == 1;
-    float* Y = final_pass ? g.Y : g.slabs + (size_t)zs * g.slab_stride;
-    {
-        const int n = (int)(pg / plane2);
-        const long po = ((long)n * g.M) * hw + (long)y0 * g.W + 2 * j0;
-        float* yo = Y + po;
-        const float* ao = (final_pass && g.add) ? g.add + po : nullptr;
-#pragma unroll 4
-        for (int t = 0; t < 16; ++t) {
-            const int ml = kr + 4 * t, m = m0 + ml;
-            if (m >= g.M) break;
-            const float M0 = sM[(0 * WBM + ml) * LDM + jn], M1 = sM[(1 * WBM + ml) * LDM + jn];
-            const float M2 = sM[(2 * WBM + ml) * LDM + jn], M3 = sM[(3 * WBM + ml) * LDM + jn];
-            f32x2 o;
-            o.x = (M0 + M1) + M2;
-            o.y = (M1 - M2) - M3;
-            if (final_pass) {
-                const float b = g.bias ? g.bias[m] : 0.f;
-                o.x = wino_act(o.x + b, g.act); o.y = wino_act(o.y + b, g.act);
-                if (ao) {
-                    const f32x2 a2 = *reinterpret_cast<const f32x2*>(ao + (long)m * hw);
-                    o.x += a2.x; o.y += a2.y;
-                }
+    unsigned out_base = FD_OOB;
+    if (po < Np) {
+        const int n = po / plane2;
+        const int rem = po - n * plane2;
+        const int yy = rem / W2, jj = rem - yy * W2;
+        out_base = 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(yy * g.W + 2 * jj));
+    }
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(final_pass ? g.Y : g.slabs + (size_t)zs * g.slab_stride);
+    const __amdgpu_buffer_rsrc_t rsAdd = fd_make_rsrc(g.add ? g.add : g.Y);
+    const bool has_add = final_pass && g.add;
+    const int mbase = m0 + 32 * wm + 4 * arow;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hw : FD_OOB;       // out of range: the store is dropped
+        f32x2 o;
+        o.x = (acc[0][r] + acc[1][r]) + acc[2][r];
+        o.y = (acc[1][r] - acc[2][r]) - acc[3][r];
+        if (final_pass) {
+            const float b = (g.bias && m < g.M) ? g.bias[m] : 0.f;
+            o.x = wino_act(o.x + b, g.act); o.y = wino_act(o.y + b, g.act);
+            if (has_add) {
+                const f32x2 a2 = fd_ldg64(rsAdd, off);
+                o.x += a2.x; o.y += a2.y;
             }
-            *reinterpret_cast<f32x2*>(yo + (long)m * hw) = o;
         }
+        if (!(FD_WINO_ABLATE & 2) || o.x == 123.456f)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsY, (int)off, 0, 0);
     }
 }
 

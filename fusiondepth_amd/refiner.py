@@ -15,6 +15,7 @@ three small maps, the masked medians, the bilinear down-sampling of 1/depth) use
 import os
 import time
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -305,7 +306,7 @@ class Refiner(Trainer):
                 self.log_time(batch_idx, time.time() - t0, float(losses["loss"]))
                 if "depth_gt" in inputs:
                     self.compute_depth_losses(inputs, self._last_outputs, losses)
-                self.log("train", {k: v for k, v in losses.items() if torch.is_tensor(v) or isinstance(v, float)})
+                self.log("train", {k: v for k, v in losses.items() if torch.is_tensor(v) or np.ndim(v) == 0})
                 if getattr(self, "val_loader", None) is not None:
                     self.log("val", self.val(self.val_loader))
                     self.set_train()

@@ -147,12 +147,15 @@ def render_frame(image0, depth_units, K, inv_K, T_0_to_f, iterations=5):
 
 
 def make_scene_batch(batch, height=192, width=640, num_scales=4, frame_ids=(0, -1, 1), seed=1234, device="cuda", scatter=None,
-                     gt_size=(375, 1242)):
+                     gt_size=(375, 1242), clutter=0.0):
     """One minibatch of the consistent scene (see the module docstring), reference schema, float32 on ``device``.
     ``device="cpu"`` (tests / fixtures: the same tensors can be fed to the CPU oracle and uploaded for the HIP path) needs
     ``scatter``: a callable beam[B,1,H,W] -> [B,2,H,W] (the oracle's gen2channel restatement); on the GPU the scatter kernel
-    is used.  Also returns nothing else: the ground truth rides in the batch as ``depth_gt`` (metres, KITTI's 375x1242) and
-    ``("T_gt", f)``."""
+    is used.  The ground truth rides in the batch as ``depth_gt`` (metres, KITTI's 375x1242) and ``("T_gt", f)``.
+    ``clutter``: fraction of the LiDAR returns replaced by clutter spread evenly over 2 .. 78 m (real scans carry outliers too).
+    bench.py uses 0.5: whatever a from-scratch network predicts while it is still wandering, some returns then lie within the
+    2 m validity window of trainer.py:580-584, so the LiDAR term stays defined (with no valid return it is NaN by construction,
+    in the reference as well - tests/test_gpu_losspath.py::test_empty_lidar_mask_*)."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     inputs = {}
@@ -183,7 +186,13 @@ def make_scene_batch(batch, height=192, width=640, num_scales=4, frame_ids=(0, -
         for r in rows:
             cols = torch.arange(2 + (r + i) % 3, width - 2, 3, device=device)
             rng = 1.0 + 0.01 * torch.randn(batch, cols.numel(), device=device, generator=gen)       # 1 % range noise
-            beam[:, 0, r, cols] = depth_m[:, 0, r][:, cols] * rng / 100.0                            # metres / 100
+            ranges = depth_m[:, 0, r][:, cols] * rng
+            if clutter > 0:
+                n_cl = int(cols.numel() * clutter)
+                pick = torch.randperm(cols.numel(), device=device, generator=gen)[:n_cl]
+                ladder = 2.0 + 76.0 * (torch.arange(n_cl, device=device, dtype=torch.float32) + 0.5) / max(n_cl, 1)
+                ranges[:, pick] = ladder.unsqueeze(0).expand(batch, n_cl)
+            beam[:, 0, r, cols] = ranges / 100.0                                                     # metres / 100
         two = FD.scatter_2channel(beam, roi) if scatter is None else scatter(beam)
         inputs[("2channel", f, 0)] = two
         if f == 0:

@@ -8,7 +8,7 @@ from fusiondepth_amd.options import MonodepthOptions
 from fusiondepth_amd.trainer import Trainer
 opt = MonodepthOptions().parse(["--num_layers", "18", "--weights_init", "scratch", "--batch_size", "12", "--height", "192", "--width", "640"])
 tr = Trainer(opt, rank=0, world_size=1, verbose=False)
-mbs = [synthetic.make_batch(tr.batch_size, 192, 640, seed=1234 + i) for i in range(tr.accumulate_step)]
+mbs = [synthetic.make_scene_batch(tr.batch_size, 192, 640, seed=1234 + i, clutter=0.5) for i in range(tr.accumulate_step)]
 batch = tr.stack_micro_batches(mbs)
 marks = []
 def mark(name):

@@ -13,6 +13,13 @@ for p in (ROOT, GOLD):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle runs next to the HIP path in most tests.  torch's CPU kernels get SLOWER beyond ~16 threads on the GPU boxes'
+    # 256-thread hosts (bench.py's cpu_baseline sweep: 16 threads 0.4 s / step, 128 threads 6 s), so cap them for the whole session.
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):

@@ -116,3 +116,26 @@ def test_refiner_steps_are_reproducible_under_gpu_contention():
         finals.append(torch.cat([p.detach().reshape(-1) for p in rf.models["refine2d_decoder"].parameters()]).clone())
         del rf
     assert torch.equal(finals[0], finals[1]) and torch.equal(finals[0], finals[2])
+
+
+def test_refiner_train_loop_logs_depth_metrics(tmp_path):
+    """Refiner.train() / run_epoch (refiner.py:264-297) over batches that carry ``depth_gt``: the logged batches go through
+    compute_depth_losses, which reads ("depth", 0, 0) - derived lazily from the refined disparity (the Refiner's
+    ``Outputs`` had no depth_spec and the first logged batch raised KeyError)."""
+    import json
+    B, H, W = 1, 192, 640
+    rf, _, _ = _make(B, H, W)
+    rf.opt.log_dir, rf.log_path = str(tmp_path), str(tmp_path / "rf")
+    rf.opt.num_epochs, rf.opt.log_frequency, rf.opt.save_frequency = 1, 1, 1
+    batches = []
+    for i in range(2):
+        inp, noise = gin.refiner_inputs(860 + i, B, H, W)
+        g = {k: v.cuda() for k, v in inp.items()}
+        g["_noise"] = [n.cuda() for n in noise]
+        gt = torch.rand(B, 1, 375, 1242, generator=torch.Generator().manual_seed(60 + i)) * 50.0 + 3.0
+        g["depth_gt"] = gt.cuda()
+        batches.append(g)
+    rf.train(batches)
+    recs = [json.loads(l) for l in open(tmp_path / "rf" / "train" / "scalars.jsonl")]
+    assert len(recs) == 2 and all(np.isfinite(r["loss"]) and np.isfinite(r["de/abs_rel"]) and r["de/abs_rel"] > 0 for r in recs)
+    assert rf.adam_step_count == 2
