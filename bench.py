@@ -294,6 +294,7 @@ def main():
     from fusiondepth_amd.options import MonodepthOptions
     from fusiondepth_amd.trainer import Trainer
     rank, world, local_rank = dp.init_from_env()
+    torch.manual_seed(20260928 + rank)          # weights (CPU generator) and the loss path's tie-break noise (device generator): a run is reproducible
     if world != args.gpus:
         sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with --nproc-per-node %d (or plainly, it launches "
                  "itself)" % (args.gpus, world, args.gpus))
@@ -394,6 +395,8 @@ def main():
     photo_val = float(sum(losses["loss/%d" % s_].detach() for s_ in range(4) if ("loss/%d" % s_) in losses) / 4.0)
     params_finite = bool(torch.isfinite(tr.flat.flat_param).all())
     n_steps_run = tr.adam_step_count
+    flat64 = tr.flat.flat_param.double()
+    param_checksum = [float(flat64.sum()), float(flat64.abs().sum())]        # equal between two runs of one build: the step is deterministic
     abs_rel_after = float(tr.val_metrics([val_batch])["de/abs_rel"])
     if rank == 0:
         print("[bench] timed %d steps in %.3f s (host issue time %.3f s)" % (args.steps, dt, t_host), file=sys.stderr, flush=True)
@@ -407,7 +410,7 @@ def main():
                    "global_batch": opt.batch_size * world, "parallelism": "dp%d" % world, "launch": "eager (4 HIP streams)" if launch == "eager" else "hipGraph replay",
                    "micro_batches": "stacked (grouped BatchNorm)" if tr.stack_microbatches else "sequential"},
         "final_loss": loss_val if loss_val == loss_val else None, "final_loss_photometric": photo_val,
-        "params_finite": params_finite, "optimizer_steps_run": n_steps_run, "distinct_step_batches": n_pool,
+        "params_finite": params_finite, "optimizer_steps_run": n_steps_run, "distinct_step_batches": n_pool, "param_checksum": param_checksum,
         "abs_rel_heldout_scene": {"before": abs_rel_before, "after": abs_rel_after},
     }
     key = (args.num_layers, args.height, args.width)

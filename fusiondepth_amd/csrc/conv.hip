@@ -746,8 +746,27 @@ extern "C" long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d) {
     return fast_splitk_slab_floats(f, nullptr);
 }
 
+namespace {
+int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt, int wt_ready,
+                    float* ws, float* stat_part, void* stream);
+}
 extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
                              int wt_ready, float* ws, void* stream) {
+    return conv2d_fwd_impl(d, x, w, bias, y, wt, wt_ready, ws, nullptr, stream);
+}
+extern "C" long fd_conv2d_fwd_stat_slots(const fd_conv_desc* d) {
+    if (!d || check_desc(d, "fd_conv2d_fwd_stat_slots")) return 0;
+    return (fast_fwd_ok(d) && wino_use_fwd(d)) ? wino_stat_slots(d) : 0;
+}
+extern "C" int fd_conv2d_fwd_stats(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
+                                   int wt_ready, float* ws, float* stat_part, void* stream) {
+    FD_REQUIRE(stat_part, "fd_conv2d_fwd_stats: stat_part is NULL");
+    FD_REQUIRE(fd_conv2d_fwd_stat_slots(d) > 0, "fd_conv2d_fwd_stats: this convolution has no statistics epilogue (fd_conv2d_fwd_stat_slots == 0)");
+    return conv2d_fwd_impl(d, x, w, bias, y, wt, wt_ready, ws, stat_part, stream);
+}
+namespace {
+int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt, int wt_ready,
+                    float* ws, float* stat_part, void* stream) {
     if (int rc = check_desc(d, "fd_conv2d_fwd")) return rc;
     FD_REQUIRE(x && w && y, "fd_conv2d_fwd: NULL tensor");
     ConvShape s;
@@ -761,7 +780,7 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
             conv_log("fwd", "wino", d);
             if (!wt_ready)
                 if (int rc = wino_weight_launch(w, wt, d->Cout, d->Cin, 0, st)) return rc;
-            return wino_conv_launch(d, x, wt, bias, y, ws, st);
+            return wino_conv_launch(d, x, wt, bias, y, ws, st, nullptr, stat_part);
         }
         conv_log("fwd", "direct", d);
         FastGemmArgs f;
@@ -786,6 +805,7 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
     FD_LAUNCH_CHECK("fd_conv2d_fwd");
     return 0;
 }
+}  // namespace
 
 extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
     if (!d) return 0;

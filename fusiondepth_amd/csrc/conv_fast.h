@@ -51,7 +51,8 @@ long wino_wt_floats(int M, int C);
 long wino_ws_floats(const fd_conv_desc* d);
 int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStream_t st);
 int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st,
-                     const float* add = nullptr);
+                     const float* add = nullptr, float* stat_part = nullptr);
+int wino_stat_slots(const fd_conv_desc* d);
 bool wino_wgrad_ok(const fd_conv_desc* d);
 long wino_wgrad_ws_floats(const fd_conv_desc* d);
 int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st);

@@ -556,6 +556,9 @@ int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {
 }
 
 int fast_wgrad_finish_launch(const float* slabs, float* gw, int M, int C, int T, int splits, int accumulate, hipStream_t st) {
+#ifdef FD_ABLATE_NO_FINISH      // timing experiment only (wrong results): what the step would gain if the slab reductions cost nothing
+    return 0;
+#endif
     if (T == 9 && C % 32 == 0) {
         hipLaunchKernelGGL(k_wgrad_finish9, dim3(C / 32, M), dim3(288), 0, st, slabs, gw, M, C, splits, accumulate);
         hipError_t e9 = hipGetLastError();
@@ -570,6 +573,9 @@ int fast_wgrad_finish_launch(const float* slabs, float* gw, int M, int C, int T,
 
 int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, long total, long slab_stride, int splits, long out_cs,
                               int M, int act, hipStream_t st, const float* add) {
+#ifdef FD_ABLATE_NO_FINISH
+    return 0;
+#endif
     hipLaunchKernelGGL(k_splitk_finish, dim3(ew_blocks(total)), dim3(256), 0, st, slabs, Y, bias, total, slab_stride, splits, out_cs, M,
                        act, add);
     hipError_t e = hipGetLastError();

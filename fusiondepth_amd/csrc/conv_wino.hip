@@ -49,7 +49,8 @@ constexpr int LDU = WBM + 1, LDV = WBN, LDM = WBN + 1;
 // B operands are read: 8.7 KB per chunk instead of the 16.4 KB of four transformed components (the VGPR -> LDS store path is what
 // bounds the main loop, scripts/wino_ksweep.py), and 50.7 KB per workgroup = three workgroups per CU.
 constexpr int LDR = 2 * WBN + 8;
-constexpr int W_BUF_FLOATS = 4 * WBKC * LDU + WBKC * LDR;     // one operand buffer: U (four components) + raw activations
+constexpr int V_RAW_FLOATS = 9 * 64 * 4;                      // 16 rows x 136 = 2176 floats, rounded up to 9 wave-wide 16-byte DMAs
+constexpr int W_BUF_FLOATS = 4 * WBKC * LDU + V_RAW_FLOATS;   // one operand buffer: U (four components) + raw activations
 // double-buffered operands: 66 KB -> 2 workgroups per CU.  (A single-buffered variant - 33 KB, 4 per CU, two barriers per chunk - and a
 // one-chunk-deep register pipeline both measured the same; an 8-channel-chunk variant - 33 KB, 3 per CU - was 2-5 % faster alone
 // and 2 % slower inside the training step, where its extra resident waves take CUs from the other streams' kernels.)
@@ -85,8 +86,16 @@ struct WinoArgs {
     int M, C, Nb, H, W;
     int pad_mode, act;
     int xcd_swizzle;     // consecutive pixel tiles (vertical neighbours share input rows) go to the same XCD / L2
+    // optional: per-channel statistics of the output for the BatchNorm that follows (fd_conv2d_fwd_stats): [Nb][M][stat_slots][2] =
+    // (sum, sum of squares) over the 64 pixels of each (pixel tile, 32-pair half); needs tiles that do not straddle images
+    float* stat_part;
+    int stat_slots;
 };
 
+// VDMA: the raw activation rows go from global memory straight into LDS (buffer_load_dwordx4 ... lds; needs W % 4 == 0 so that a
+// lane's four pixels share an image row): no staging registers, no s_waitcnt + ds_write in the MFMA stream for them - the VGPR ->
+// LDS stores of the activations cost 0.9 of the 6.7 us per chunk-round of the register-staged loop (scripts/wino_ksweep.py).
+template <bool VDMA>
 __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -131,10 +140,31 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     const unsigned u_comp = 4u * (unsigned)g.M * 3u * (unsigned)g.C;     // bytes between components
     const __amdgpu_buffer_rsrc_t rsU = fd_make_rsrc(g.U), rsX = fd_make_rsrc(g.X);
 
+    // ---- VDMA: the raw buffer is ONE linear stream of 16 rows x 34 sixteen-byte pieces (pixels -4 .. 131 of the tile's flat pixel
+    //      range, row stride 136 floats); piece L = 64 * (wave + 4 q) + lane of DMA q belongs to row L / 34, piece L % 34.
+    //      Per lane and DMA, fixed for the whole tile: image row / byte offset of its four pixels inside channel 0.
+    const __amdgpu_buffer_rsrc_t rsXd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)(4u * (unsigned)g.Nb * (unsigned)g.C * hw), 0x00020000);
+    unsigned d_base[3] = {FD_OOB, FD_OOB, FD_OOB};
+    int d_y[3] = {0, 0, 0};
+    unsigned d_off[3] = {FD_OOB, FD_OOB, FD_OOB};
+    if (VDMA) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int L = 64 * (wave + 4 * q) + lane;
+            const int row = L / 34, seg = L - row * 34;
+            const int F = 2 * p0 - 4 + 4 * seg;                              // flat pixel index over (image, y, x)
+            const bool ok = row < WBKC && F >= 0 && F < g.Nb * (int)hw;
+            const int Fc = ok ? F : 0;
+            const int n = Fc / (int)hw, rem = Fc - n * (int)hw;
+            d_y[q] = rem / g.W;
+            d_base[q] = ok ? 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)row * hw + (unsigned)rem) : FD_OOB;
+        }
+    }
     float4 ru[4];
     f32x2 rmid[4];
     float rh[4];
     unsigned u_off = FD_OOB, mid_off = FD_OOB, h_off = FD_OOB;
+    unsigned d_soff = 0u;
     const unsigned c_step = 4u * 4u * hw;                                // 4 channel rows further
     int pc_ky, pc_c0;
     { pc_ky = ch_lo / cpt; pc_c0 = (ch_lo - pc_ky * cpt) * WBKC; }
@@ -151,11 +181,23 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
         const int ruse = refl ? rr_ : r;
         prep_ok = pvalid & live & (refl | inb);
         prep_base = 4u * (nbase + (unsigned)(pc_c0 + kr) * hw + (unsigned)(ruse * g.W + 2 * j0));
+        if (VDMA) {
+            d_soff = 4u * (unsigned)pc_c0 * hw;                          // wave-uniform: first channel of the chunk
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int yq = d_y[q] + pc_ky - 1;
+                const bool in_q = (unsigned)yq < (unsigned)g.H;
+                int yr = yq < 0 ? -yq : yq;
+                yr = yr >= g.H ? H2m2 - yr : yr;
+                const int dyq = (refl ? yr : yq) - d_y[q];
+                d_off[q] = (live & (refl | in_q)) ? d_base[q] + (unsigned)(dyq * g.W * 4) : FD_OOB;   // FD_OOB base + anything stays out of range
+            }
+        }
     };
     auto prep_b = [&]() __attribute__((always_inline)) {
         mid_off = prep_ok ? prep_base : FD_OOB;
         h_off = (prep_ok & halo_l) ? prep_base - 4u : ((prep_ok & halo_r) ? prep_base + 8u : FD_OOB);
-        if (FD_WINO_ABLATE & 16) { u_off = mid_off = h_off = FD_OOB; }                             // loads issue, no memory traffic
+        if (FD_WINO_ABLATE & 16) { u_off = mid_off = h_off = FD_OOB; d_off[0] = d_off[1] = d_off[2] = FD_OOB; }   // loads issue, no memory traffic
         pc_c0 += WBKC;
         const bool wrap = pc_c0 >= g.C;
         pc_c0 = wrap ? 0 : pc_c0;
@@ -176,7 +218,11 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
         *reinterpret_cast<f32x2*>(q + 4 + 2 * jn) = rmid[i];
         if (jn == 0 || jn == WBN - 1) q[h_col] = rh[i];
     };
-    if (tid < 2 * WBKC) smem[(tid >> 4) * W_BUF_FLOATS + 4 * WBKC * LDU + (tid & 15) * LDR] = 0.f;     // the zero cells
+    // DMA q of this wave -> the raw rows of buffer `buf` (LDS destination = wave-uniform base + 16 bytes x lane)
+    auto dma_v = [&](int buf, int q) __attribute__((always_inline)) {
+        float* dst = smem + buf * W_BUF_FLOATS + 4 * WBKC * LDU + (wave + 4 * q) * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsXd, (__attribute__((address_space(3))) void*)dst, 16, (int)d_off[q], (int)d_soff, 0, 0);
+    };
 
     // Wave w owns the 32 (channels) x 32 (pairs) block (w >> 1, w & 1) of the tile with ALL FOUR Winograd components: one
     // accumulator per component.  The four component products of an output therefore sit in the same lane and register, and the
@@ -186,8 +232,9 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     const int wm = wave >> 1, wn = wave & 1;
     // Columns of the raw row this lane's B operands come from: d1, d2 = the pair itself, d0 / d3 = its left / right neighbour
     // pixel - the halo cells for the tile's first / last pair - or, where the pair touches an image border, the padding value:
-    // the zero cell, or for reflection padding the mirror pixel (column -1 is column 1, column W is column W - 2).
+    // for reflection padding the mirror pixel (column -1 is column 1, column W is column W - 2), for zero padding the factor 0.
     int o12, o0, o3;
+    float ml, mr;                                                        // 0.0 where zero padding replaces d0 / d3
     {
         const int jp = 32 * wn + (lane & 31);
         const int pp = p0 + jp < Np ? p0 + jp : 0;
@@ -195,8 +242,10 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
         const int jj = rem % W2;
         const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
         o12 = 4 + 2 * jp;
-        o0 = le ? (refl ? o12 + 1 : 0) : o12 - 1;
-        o3 = re ? (refl ? o12 : 0) : o12 + 2;
+        o0 = (le && refl) ? o12 + 1 : o12 - 1;
+        o3 = (re && refl) ? o12 : o12 + 2;
+        ml = (le && !refl) ? 0.f : 1.f;
+        mr = (re && !refl) ? 0.f : 1.f;
     }
     f32x16 acc[4];
 #pragma unroll
@@ -224,18 +273,31 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
         if (FD_WINO_ABLATE & 8) { u_off = mid_off = h_off = FD_OOB; }
 #pragma unroll
         for (int t = 0; t < 4; ++t) load_u(t);
+        if (VDMA) {
+            dma_v(0, 0); dma_v(0, 1);
+            if (wave == 0) dma_v(0, 2);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { load_mid(i); load_h(i); }
+            for (int i = 0; i < 4; ++i) { load_mid(i); load_h(i); }
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) store_u(0, t);
+        if (!VDMA) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) store_v(0, i);
-        prep_a(ch_lo + 1 < ch_hi); prep_b();                     // chunk ch_lo + 1: loaded now, written to LDS during chunk ch_lo
+            for (int i = 0; i < 4; ++i) store_v(0, i);
+        }
+        prep_a(ch_lo + 1 < ch_hi); prep_b();                     // chunk ch_lo + 1
+        if (!VDMA) {                                             // ... loaded now, written to LDS during chunk ch_lo
 #pragma unroll
-        for (int t = 0; t < 4; ++t) load_u(t);
+            for (int t = 0; t < 4; ++t) load_u(t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { load_mid(i); load_h(i); }
-        prep_a(ch_lo + 2 < ch_hi); prep_b();                     // offsets of chunk ch_lo + 2, re-loaded during chunk ch_lo
+            for (int i = 0; i < 4; ++i) { load_mid(i); load_h(i); }
+            prep_a(ch_lo + 2 < ch_hi); prep_b();                 // offsets of chunk ch_lo + 2, re-loaded during chunk ch_lo
+        } else {
+            // VDMA: chunk ch + 1 is fetched DURING chunk ch (weights: k-steps 0-3 into registers, stored in k-steps 4-7; activations:
+            // three DMAs) with the offsets prepared one chunk earlier; the DMAs must have landed before anyone reads them
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         for (int ch = ch_lo; ch < ((FD_WINO_ABLATE & 1) ? ch_lo : ch_hi); ++ch) {
             const int cur = (ch - ch_lo) & 1;
@@ -252,7 +314,7 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
                 d0 = pr[k2 * LDR + o0]; d3 = pr[k2 * LDR + o3];
             };
             auto xform_b = [&](int nb) __attribute__((always_inline)) {   // (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-                bv[nb][0] = d0 - d12.y; bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = d12.x - d3;
+                bv[nb][0] = fmaf(d0, ml, -d12.y); bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = fmaf(-d3, mr, d12.x);
             };
 #pragma unroll
             for (int t = 0; t < 4; ++t) read_a(0, 0, t);
@@ -264,7 +326,10 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < NK) { read_b(2 * (kk + 1)); read_a(nb, 2 * (kk + 1), 0); read_a(nb, 2 * (kk + 1), 1); }
-                if (kk < LS && !(FD_WINO_ABLATE & (32 | 128))) store_u(cur ^ 1, kk);
+                if (!(FD_WINO_ABLATE & (32 | 128))) {
+                    if (!VDMA && kk < LS) store_u(cur ^ 1, kk);
+                    if (VDMA && kk >= LS) store_u(cur ^ 1, kk - LS);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -273,15 +338,23 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < LS && !(FD_WINO_ABLATE & (32 | 256))) store_v(cur ^ 1, kk);
+                if (!VDMA && kk < LS && !(FD_WINO_ABLATE & (32 | 256))) store_v(cur ^ 1, kk);
                 if (kk + 1 < NK) xform_b(nb);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < LS) { load_mid(kk); load_h(kk); }
-                if (kk == NK - 2) prep_a(ch + 3 < ch_hi);        // every load of chunk ch + 2 has been issued by now
+                if (VDMA) {
+                    if (kk < 2) dma_v(cur ^ 1, kk);
+                    if (kk == 2 && wave == 0) dma_v(cur ^ 1, 2);
+                    if (kk == NK - 2) prep_a(ch + 2 < ch_hi);    // every fetch of chunk ch + 1 has been issued by now
+                } else {
+                    if (kk < LS) { load_mid(kk); load_h(kk); }
+                    if (kk == NK - 2) prep_a(ch + 3 < ch_hi);    // every load of chunk ch + 2 has been issued by now
+                }
                 if (kk == NK - 1) prep_b();
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (VDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this chunk's DMAs (into the other buffer) have landed
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
@@ -320,6 +393,47 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
         }
         if (!(FD_WINO_ABLATE & 2) || o.x == 123.456f)
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsY, (int)off, 0, 0);
+        if (g.stat_part) { const float dd = o.x - o.y; acc[0][r] = o.x + o.y; acc[1][r] = 0.5f * dd * dd; }   // (sum, M2) of this row's two pixels
+    }
+    // ---- BatchNorm statistics of the tile (fd_conv2d_fwd_stats): (sum, M2 = sum of squared deviations from the partial's OWN
+    //      mean) over the 32 pairs of each half-wave for its 16 channel rows, by a transposing butterfly - after the steps 16, 8, 4,
+    //      2 a lane holds ONE row's partial, the step 1 completes it: 16 cross-lane moves per statistic instead of 80, fixed order
+    //      (deterministic).  Two halves of n elements each merge as M2 = M2a + M2b + (sa - sb)^2 / 2n (pairwise update of Chan
+    //      et al.): no E[x^2] - E[x]^2 anywhere, so a channel whose mean is many standard deviations from zero loses nothing.
+    if (g.stat_part && final_pass) {
+        float s1[16], s2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[r] = acc[0][r]; s2[r] = acc[1][r]; }
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int width = 8 >> step;                                   // rows kept by a lane after this step
+            const int xm = 16 >> step;                                     // lane distance of the exchange
+            const bool hi = (lane & xm) != 0;
+            const float inv2n = 0.25f / (float)(1 << step);                // each side holds n = 2 << step pixels
+#pragma unroll
+            for (int j = 0; j < width; ++j) {
+                const float k1 = hi ? s1[j + width] : s1[j], g1 = hi ? s1[j] : s1[j + width];
+                const float k2 = hi ? s2[j + width] : s2[j], g2 = hi ? s2[j] : s2[j + width];
+                const float o1 = __shfl_xor(g1, xm, 64), o2 = __shfl_xor(g2, xm, 64);
+                const float df = k1 - o1;
+                s1[j] = k1 + o1;
+                s2[j] = fmaf(df * df, inv2n, k2 + o2);
+            }
+        }
+        {
+            const float o1 = __shfl_xor(s1[0], 1, 64), o2 = __shfl_xor(s2[0], 1, 64);
+            const float df = s1[0] - o1;
+            s2[0] = fmaf(df * df, 1.0f / 64.0f, s2[0] + o2);                // n = 32 per side
+            s1[0] += o1;
+        }
+        // row held by this lane: bits (lane >> 4, lane >> 3, lane >> 2, lane >> 1) -> reg index, then the C/D layout above
+        const int rr = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int m = mbase + (rr & 3) + 8 * (rr >> 2);
+        if (!(lane & 1) && m < g.M) {
+            const int n = p0 / plane2, tile = (p0 - n * plane2) / WBN;     // the whole tile lies in image n (launcher's guarantee)
+            f32x2 v; v.x = s1[0]; v.y = s2[0];
+            *reinterpret_cast<f32x2*>(g.stat_part + (((size_t)n * g.M + m) * g.stat_slots + 2 * tile + wn) * 2) = v;
+        }
     }
 }
 
@@ -339,14 +453,20 @@ struct WinoWgradArgs {
     int slice_major;     // 1: grid x = pixel slice (XCD-aligned), z = (ky, c tile); 0: x = (ky, c tile), z = slice
 };
 constexpr int WGP = 16;                                          // pairs per chunk (GEMM-K 16 -> 8 MFMA k-steps)
-constexpr int WG_BUF_FLOATS = 4 * WGP * (LDU + LDU);             // A: [4][16][65], B: [4][16][65]
-constexpr int WG_LDS_FLOATS = (2 * WG_BUF_FLOATS > 4 * WBM * LDM) ? 2 * WG_BUF_FLOATS : 4 * WBM * LDM;
+// Both operands stay RAW in LDS, one row of the chunk's 32 pixels per channel: dY rows [0 .. 31] (+ 2 pad), X rows [0 .. 31] the
+// chunk's pixels, [32] the pixel right of the chunk, [33] the pixel left of it.  The transforms P = (y0, y0+y1, y0-y1, y1) and
+// Q = (d0-d2, d1+d2, d2-d1, d1-d3) are applied when the MFMA operands are read.  Row stride 34 floats: a lane (= channel) reads
+// 8-byte pairs at 34 i mod 64 - 32 different bank pairs; 17.4 KB per chunk and buffer instead of 33 KB of transformed components.
+constexpr int LDG = 2 * WGP + 2;
+constexpr int WG_BUF_FLOATS = (WBM + WBN) * LDG;                 // dY rows + X rows
+constexpr int WG_LDS_FLOATS = 2 * WG_BUF_FLOATS;
 
 __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, comp = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W2 = g.W >> 1;
-    const long plane2 = (long)g.H * W2, Np = (long)g.Nb * plane2;
+    const int plane2 = g.H * W2, Np = g.Nb * plane2;             // pixel pairs: < 2^29 (size guard of the entry point)
     const unsigned hw = (unsigned)(g.H * g.W);
     // grid (default): x = (kernel row, input-channel tile), y = output-channel tile, z = pixel slice.  The alternative
     // (slice_major: x = slice with the slice count a multiple of 8, so that all workgroups of a slice share an XCD / L2) measured
@@ -355,137 +475,161 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     const int bt = g.slice_major ? blockIdx.z : blockIdx.x, bs = g.slice_major ? blockIdx.x : blockIdx.z;
     const int ky = bt / ctiles, c0 = (bt - ky * ctiles) * WBN;
     const int m0 = blockIdx.y * WBM;
-    const long pp_lo = (long)bs * g.pairs_per_split;
-    const long pp_hi = pp_lo + g.pairs_per_split < Np ? pp_lo + g.pairs_per_split : Np;
-    const int nchunk = pp_hi > pp_lo ? (int)((pp_hi - pp_lo + WGP - 1) / WGP) : 0;
+    const int pp_lo = (int)((long)bs * g.pairs_per_split < Np ? (long)bs * g.pairs_per_split : Np);
+    const int pp_hi = (long)pp_lo + g.pairs_per_split < Np ? pp_lo + (int)g.pairs_per_split : Np;
+    const int nchunk = pp_hi > pp_lo ? (pp_hi - pp_lo + WGP - 1) / WGP : 0;
 
-    // loader: pair p of the chunk, rows rw + 16 i (dY rows = output channels, X rows = input channels)
+    // ---- loader: pair p of the chunk, rows rw + 16 i (dY rows = output channels, X rows = input channels)
     const int p = tid & 15, rw = tid >> 4;
-    unsigned a_row[4], b_row[4];                                 // element offsets of the 4 channel rows (clamped: never stored)
+    unsigned a_row[4], b_row[4];                                 // byte offsets of the 4 channel rows (clamped: never stored)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m0 + rw + 16 * i; m = m < g.M ? m : g.M - 1;
         int c = c0 + rw + 16 * i; c = c < g.C ? c : g.C - 1;
-        a_row[i] = (unsigned)m * hw; b_row[i] = (unsigned)c * hw;
+        a_row[i] = 4u * (unsigned)m * hw; b_row[i] = 4u * (unsigned)c * hw;
     }
     const bool refl = g.pad_mode == 1;
+    const int H2m2 = 2 * g.H - 2;
     const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY), rsX = fd_make_rsrc(g.X);
     f32x2 ra[4], rmid[4];
-    float rl[4], rr[4];
-    unsigned a_off = FD_OOB, mid_off = FD_OOB, l_off = FD_OOB, r_off = FD_OOB;
-    bool e_left = false, e_right = false;
-    long pc = pp_lo;                                             // first pair of the chunk being prepared
+    float rh[4];
+    unsigned a_off = FD_OOB, mid_off = FD_OOB, h_off = FD_OOB;
+    unsigned long edge_l = 0, edge_r = 0;                        // bit k: pair k of the prepared chunk sits at the left / right image border
+    int pc = pp_lo;                                              // first pair of the chunk being prepared
     auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
-        const long pg = pc + p;
+        const int pg = pc + p;
         const bool ok = live & (pg < pp_hi);
-        const long pq = ok ? pg : 0;
-        const int n = (int)(pq / plane2);
-        const int rem = (int)(pq - (long)n * plane2);
+        const int pq = ok ? pg : 0;
+        const int n = pq / plane2;
+        const int rem = pq - n * plane2;
         const int y = rem / W2, j = rem - y * W2;
         a_off = ok ? 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(y * g.W + 2 * j)) : FD_OOB;
-        int r = y + ky - 1;
+        const int r = y + ky - 1;
         const bool inb = (unsigned)r < (unsigned)g.H;
-        if (refl) r = r < 0 ? -r : (r >= g.H ? 2 * g.H - 2 - r : r);
+        int rr_ = r < 0 ? -r : r;
+        rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
+        const int ruse = refl ? rr_ : r;
         const bool okb = ok & (refl | inb);
-        const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(r * g.W + 2 * j));
-        e_left = j == 0; e_right = 2 * j + 2 >= g.W;
+        const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(ruse * g.W + 2 * j));
+        const bool e_left = j == 0, e_right = 2 * j + 2 >= g.W;
         mid_off = okb ? base : FD_OOB;
-        l_off = (okb & !e_left) ? base - 4u : FD_OOB;
-        r_off = (okb & !e_right) ? base + 8u : FD_OOB;
+        // the chunk's two halo pixels per channel row: pair 0 fetches its left neighbour, pair 15 its right neighbour (a pair at an
+        // image border has none: its readers substitute the padding value)
+        h_off = (okb & (p == 0) & !e_left) ? base - 4u : ((okb & (p == WGP - 1) & !e_right) ? base + 8u : FD_OOB);
+        // border flags of the 16 pairs, wave-uniform: lanes 0 .. 15 of every wave hold pairs 0 .. 15
+        edge_l = __ballot(e_left) & 0xffffUL;
+        edge_r = __ballot(e_right) & 0xffffUL;
         pc += WGP;
     };
-    // the edge flags belong to the chunk whose registers are in flight: latch them with the loads
-    bool s_left = false, s_right = false;
     auto load_row = [&](int i) __attribute__((always_inline)) {
-        ra[i] = fd_ldg64(rsY, a_off + 4u * a_row[i]);                     // FD_OOB + (< 2^31) stays out of range
-        rmid[i] = fd_ldg64(rsX, mid_off + 4u * b_row[i]);
-        rl[i] = fd_ldg32(rsX, l_off + 4u * b_row[i]);
-        rr[i] = fd_ldg32(rsX, r_off + 4u * b_row[i]);
+        ra[i] = fd_ldg64(rsY, a_off + a_row[i]);                          // FD_OOB + (< 2^31) stays out of range: reads 0
+        rmid[i] = fd_ldg64(rsX, mid_off + b_row[i]);
+        rh[i] = fd_ldg32(rsX, h_off + b_row[i]);
     };
+    const int h_col = p == 0 ? 2 * WGP + 1 : 2 * WGP;
     auto store_row = [&](int buf, int i) __attribute__((always_inline)) {
-        float* qa = smem + buf * WG_BUF_FLOATS + p * LDU + rw + 16 * i;
-        const float y0 = ra[i].x, y1 = ra[i].y;
-        qa[0] = y0; qa[WGP * LDU] = y0 + y1; qa[2 * WGP * LDU] = y0 - y1; qa[3 * WGP * LDU] = y1;
-        const float d1 = rmid[i].x, d2 = rmid[i].y;
-        const float d0 = (refl & s_left) ? d2 : rl[i];
-        const float d3 = (refl & s_right) ? d1 : rr[i];
-        float* qb = smem + buf * WG_BUF_FLOATS + 4 * WGP * LDU + p * LDU + rw + 16 * i;
-        qb[0] = d0 - d2; qb[WGP * LDU] = d1 + d2; qb[2 * WGP * LDU] = d2 - d1; qb[3 * WGP * LDU] = d1 - d3;
+        float* qa = smem + buf * WG_BUF_FLOATS + (rw + 16 * i) * LDG + 2 * p;
+        *reinterpret_cast<f32x2*>(qa) = ra[i];
+        float* qb = qa + WBM * LDG;
+        *reinterpret_cast<f32x2*>(qb) = rmid[i];
+        if (p == 0 || p == WGP - 1) qb[h_col - 2 * p] = rh[i];
     };
 
-    f32x16 acc[2][2];
+    // Wave w owns the 32 (output channels) x 32 (input channels) block (w >> 1, w & 1) of the tile with all four components (one
+    // accumulator each): the output transform dW = (M0 + (M1+M2)/2, (M1-M2)/2, (M1+M2)/2 - M3) is register arithmetic.
+    const int wm = wave >> 1, wn = wave & 1;
+    const int arow = lane >> 5, acol = lane & 31;
+    f32x16 acc[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     constexpr int NK = WGP / 2, LS = NK / 2;
-    const int arow = lane >> 5, acol = lane & 31;
+    // border flags of the chunk in LDS buffer `cur` (cl / cr) and of the chunk whose registers are in flight (nl / nr)
+    unsigned long cl = 0, cr = 0, nl = 0, nr = 0;
     if (nchunk > 0) {
         prep_chunk(true);
-        s_left = e_left; s_right = e_right;
+        cl = edge_l; cr = edge_r;
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_row(i);
 #pragma unroll
         for (int i = 0; i < 4; ++i) store_row(0, i);
+        prep_chunk(1 < nchunk);                                   // chunk 1: loaded now, written to LDS during chunk 0
+        nl = edge_l; nr = edge_r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_row(i);
+        prep_chunk(2 < nchunk);                                   // offsets of chunk 2, re-loaded during chunk 0
         __syncthreads();
         for (int ch = 0; ch < nchunk; ++ch) {
             const int cur = ch & 1;
-            prep_chunk(ch + 1 < nchunk);
-            s_left = e_left; s_right = e_right;
-            const float* pa = smem + cur * WG_BUF_FLOATS + comp * WGP * LDU + arow * LDU + acol;
-            const float* pb = pa + 4 * WGP * LDU;
-            float av[2][2], bv[2][2];
-            av[0][0] = pa[0]; av[0][1] = pa[32]; bv[0][0] = pb[0]; bv[0][1] = pb[32];
+            // operands of pair k = 2 kk + arow: A = P(dY row 32 wm + acol), B = Q(X row 32 wn + acol)
+            const float* pa = smem + cur * WG_BUF_FLOATS + (32 * wm + acol) * LDG + 2 * arow;
+            const float* pb = smem + cur * WG_BUF_FLOATS + (WBM + 32 * wn + acol) * LDG + 2 * arow;
+            // per lane: this half-wave's pair parity shifts the border masks by `arow`
+            const unsigned ml = (unsigned)(cl >> arow), mr = (unsigned)(cr >> arow);
+            float av[2][4], bv[2][4];
+            f32x2 yy, d12;
+            float d0, d3;
+            auto read_ops = [&](int kk2) __attribute__((always_inline)) {           // pair 2 kk2 + arow
+                yy = *reinterpret_cast<const f32x2*>(pa + 4 * kk2);
+                d12 = *reinterpret_cast<const f32x2*>(pb + 4 * kk2);
+                // left neighbour: pixel 2k - 1, for pair 0 the halo cell [33]; right neighbour: pixel 2k + 2 ([32] for pair 15)
+                d0 = (kk2 == 0) ? pb[arow ? -1 : 2 * WGP + 1] : pb[4 * kk2 - 1];
+                d3 = pb[4 * kk2 + 2];
+            };
+            auto xform = [&](int nb, int kk2) __attribute__((always_inline)) {
+                const bool le = (ml >> (2 * kk2)) & 1u, re = (mr >> (2 * kk2)) & 1u;
+                const float e0 = le ? (refl ? d12.y : 0.f) : d0;          // column -1 is column 1 (reflect) or 0
+                const float e3 = re ? (refl ? d12.x : 0.f) : d3;          // column W is column W - 2 (reflect) or 0
+                av[nb][0] = yy.x; av[nb][1] = yy.x + yy.y; av[nb][2] = yy.x - yy.y; av[nb][3] = yy.y;
+                bv[nb][0] = e0 - d12.y; bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = d12.x - e3;
+            };
+            read_ops(0); xform(0, 0);
 #pragma unroll
             for (int kk = 0; kk < NK; ++kk) {
                 const int cb = kk & 1, nb = cb ^ 1;
-                if (kk + 1 < NK) {
-                    av[nb][0] = pa[(kk + 1) * 2 * LDU]; av[nb][1] = pa[(kk + 1) * 2 * LDU + 32];
-                    bv[nb][0] = pb[(kk + 1) * 2 * LDU]; bv[nb][1] = pb[(kk + 1) * 2 * LDU + 32];
-                }
-                if (kk < LS) load_row(kk);
-                else store_row(cur ^ 1, kk - LS);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][i], bv[cb][j], acc[i][j], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) read_ops(kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < LS) store_row(cur ^ 1, kk);              // registers loaded one chunk ago -> the other buffer
+                __builtin_amdgcn_sched_barrier(0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) xform(nb, kk + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < LS) load_row(kk);                        // ... and re-loaded with the chunk after next
+                if (kk == LS) { cl = nl; cr = nr; nl = edge_l; nr = edge_r; }
+                if (kk == NK - 1) prep_chunk(ch + 3 < nchunk);
             }
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
         }
     }
 
-    // ---- output transform through LDS: sM[t][m][c] -> slab[z][m][ky*3 + kx][c]
-    float* sM = smem;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
-                sM[(comp * WBM + m) * LDM + j * 32 + acol] = acc[i][j][r];
-            }
-    __syncthreads();
-    const int cl = tid & 63, c = c0 + cl;
+    // ---- epilogue: slab[z][m][ky*3 + kx][c] from the four accumulators (C/D layout: column = lane & 31, row = (reg & 3) +
+    //      8 * (reg >> 2) + 4 * (lane >> 5))
+    const int c = c0 + 32 * wn + acol;
     if (c >= g.C) return;
     float* slab = g.slabs + (size_t)bs * ((size_t)g.M * 9 * g.C);
-#pragma unroll 4
-    for (int t = 0; t < 16; ++t) {
-        const int ml = (tid >> 6) + 4 * t, m = m0 + ml;
-        if (m >= g.M) break;
-        const float M0 = sM[(0 * WBM + ml) * LDM + cl], M1 = sM[(1 * WBM + ml) * LDM + cl];
-        const float M2 = sM[(2 * WBM + ml) * LDM + cl], M3 = sM[(3 * WBM + ml) * LDM + cl];
-        const float h = 0.5f * (M1 + M2);
-        float* o = slab + ((size_t)m * 9 + ky * 3) * g.C + c;
-        o[0] = M0 + h;
-        o[g.C] = 0.5f * (M1 - M2);
-        o[2 * (size_t)g.C] = h - M3;
+    const int mb = m0 + 32 * wm + 4 * arow;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m < g.M) {
+            const float M0 = acc[0][r], M1 = acc[1][r], M2 = acc[2][r], M3 = acc[3][r];
+            const float h = 0.5f * (M1 + M2);
+            float* o = slab + ((size_t)m * 9 + ky * 3) * g.C + c;
+            o[0] = M0 + h;
+            o[g.C] = 0.5f * (M1 - M2);
+            o[2 * (size_t)g.C] = h - M3;
+        }
     }
 }
 
@@ -522,10 +666,19 @@ int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStre
     return 0;
 }
 // y = act(conv3x3(x; U) + bias); d describes the convolution being computed (for a data gradient: Cin / Cout already swapped).
+// slots of BatchNorm partial sums per (image, channel) the kernel can emit for `d`, 0 if not (split-K, tiles across images)
+int wino_stat_slots(const fd_conv_desc* d) {
+    const long plane2 = (long)d->H * (d->W / 2);
+    if (!wino_fwd_ok(d) || plane2 % WBN != 0 || wino_splits(d, d->Cout, d->Cin) != 1 || d->act != 0) return 0;
+    return (int)(2 * plane2 / WBN);
+}
+
 int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st,
-                     const float* add) {
+                     const float* add, float* stat_part) {
     WinoArgs g = {};
     g.U = U; g.X = x; g.Y = y; g.bias = bias; g.slabs = ws; g.add = add;
+    g.stat_part = stat_part; g.stat_slots = stat_part ? wino_stat_slots(d) : 0;
+    if (stat_part && g.stat_slots == 0) { fd_set_error("wino conv: no statistics epilogue for this shape"); return -1; }
     g.M = d->Cout; g.C = d->Cin; g.Nb = d->N; g.H = d->H; g.W = d->W;
     g.pad_mode = d->pad_mode; g.act = d->act;
     const long out_total = (long)d->N * d->Cout * d->H * d->W;
@@ -534,12 +687,18 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
     if (sp > 1 && !ws) { fd_set_error("wino conv: split-K workspace missing"); return -1; }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int gx = fd_cdiv((long)d->N * d->H * (d->W / 2), WBN), gy = fd_cdiv(d->Cout, WBM);
     g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
-    hipLaunchKernelGGL(k_conv_wino, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+    static int dma_on = -1;
+    if (dma_on < 0) { const char* e = getenv("FD_WINO_DMA"); dma_on = e ? atoi(e) : 1; }
+    // direct-to-LDS activations need 16-byte pieces that stay inside one image row and a 16-byte aligned tensor
+    const bool vdma = dma_on && d->W % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    if (vdma) hipLaunchKernelGGL(k_conv_wino<true>, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+    else hipLaunchKernelGGL(k_conv_wino<false>, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
     FD_LAUNCH_CHECK("k_conv_wino");
     if (sp > 1) return fast_splitk_finish_launch(ws, y, bias, out_total, out_total, sp, (long)d->H * d->W, d->Cout, d->act, st, add);
     return 0;

@@ -743,7 +743,7 @@ _CONV_PLANS = {}
 
 
 class _ConvPlan:
-    __slots__ = ("d", "dp", "Ho", "Wo", "fwd_ws", "fwd_wt", "bwd_data_ws", "bwd_data_wt", "bwd_weight_ws")
+    __slots__ = ("d", "dp", "Ho", "Wo", "fwd_ws", "fwd_wt", "bwd_data_ws", "bwd_data_wt", "bwd_weight_ws", "stat_slots")
 
     def __init__(self, x, w, stride, pad, pad_mode, act, in_norm):
         self.d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
@@ -751,6 +751,7 @@ class _ConvPlan:
         self.Ho, self.Wo = _conv_out_hw(self.d)
         self.fwd_ws = query("fd_conv2d_fwd_ws_floats", self.dp)
         self.fwd_wt = query("fd_conv2d_fwd_wt_floats", self.dp)
+        self.stat_slots = query("fd_conv2d_fwd_stat_slots", self.dp)       # BatchNorm partial sums per (image, channel); 0: none
         self.bwd_data_ws = self.bwd_data_wt = self.bwd_weight_ws = None
 
     def data_sizes(self):
@@ -775,7 +776,10 @@ def _conv_plan(x, w, stride, pad, pad_mode, act, in_norm):
     return plan
 
 
-def _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+def _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm, want_stats=False):
+    """-> (x as float32, y, part): ``part`` [N, Cout, S, 2] holds the per-channel (sum, M2 about the slot's own mean) of y per pixel slot,
+    gathered in the convolution's epilogue for the BatchNorm that follows - or is None when ``want_stats`` is False or the
+    kernel chosen for this shape has no statistics epilogue."""
     cache_id = getattr(w, "_fd_cache_id", None)
     ctx.params = (w, bias)
     _note_use(w, bias)
@@ -787,10 +791,15 @@ def _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
     y = _empty((d.N, d.Cout, Ho, Wo), x)
     ws = _empty((nws,), x) if nws > 0 else None
     wt, ready = _weight_layout(w, cache_id, "f", nwt, d) if nwt > 0 else (None, 0)
-    call("fd_conv2d_fwd", plan.dp, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), stream())
+    part = None
+    if want_stats and plan.stat_slots > 0:
+        part = _empty((d.N, d.Cout, plan.stat_slots, 2), x)
+        call("fd_conv2d_fwd_stats", plan.dp, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), ptr(part), stream())
+    else:
+        call("fd_conv2d_fwd", plan.dp, ptr(x), ptr(w), ptr(bias), ptr(y), ptr(wt), ready, ptr(ws), stream())
     ctx.save_for_backward(x, w, y if act != 0 else None)
     ctx.desc, ctx.has_bias, ctx.cache_id, ctx.plan = d, bias is not None, cache_id, plan
-    return x, y
+    return x, y, part
 
 
 def _conv_backward(ctx, gy, gx_add=None):
@@ -845,6 +854,61 @@ class _Conv2d(torch.autograd.Function):
         return _conv_backward(ctx, gy) + (None, None, None, None, None)
 
 
+_NO_STATS = {}
+
+
+def _no_stats(like):
+    """Placeholder for "this convolution has no statistics epilogue" (autograd Functions return tensors)."""
+    t = _NO_STATS.get(like.device)
+    if t is None:
+        t = _NO_STATS[like.device] = torch.empty((0,), device=like.device)
+    return t
+
+
+class _Conv2dStats(torch.autograd.Function):
+    """conv2d that also returns the BatchNorm partial sums of its output (``fd_conv2d_fwd_stats``); an empty tensor when the
+    kernel chosen for the shape cannot produce them."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+        _, y, part = _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm, True)
+        part = part if part is not None else _no_stats(y)
+        ctx.mark_non_differentiable(part)
+        return y, part
+
+    @staticmethod
+    def backward(ctx, gy, _g_part):
+        return _conv_backward(ctx, gy) + (None, None, None, None, None)
+
+
+class _Conv2dTapStats(torch.autograd.Function):
+    """``_Conv2dTap`` + the BatchNorm partial sums of ``_Conv2dStats``."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+        xf, y, part = _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm, True)
+        part = part if part is not None else _no_stats(y)
+        ctx.mark_non_differentiable(part)
+        return y, xf.view_as(xf), part
+
+    @staticmethod
+    def backward(ctx, gy, g_tap, _g_part):
+        return _conv_backward(ctx, gy, g_tap) + (None, None, None, None, None)
+
+
+def conv2d_stats(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", tap=False):
+    """Convolution followed by a training-mode BatchNorm: -> (y, conv_stats[, x_tap]) where ``conv_stats`` goes to
+    ``batch_norm(..., conv_stats=)`` (None when this shape's kernel cannot gather them: batch_norm then makes its own pass)."""
+    args = (x, weight, bias, int(stride), int(pad), PAD_MODE[pad_mode], 0, False)
+    if tap and torch.is_grad_enabled() and x.requires_grad:
+        y, x_tap, part = _Conv2dTapStats.apply(*args)
+    else:
+        y, part = _Conv2dStats.apply(*args)
+        x_tap = x
+    part = part if part.numel() else None
+    return (y, part, x_tap) if tap else (y, part)
+
+
 class _Conv2dTap(torch.autograd.Function):
     """conv2d that also hands its input on: (y, x_tap) with x_tap == x.  A tensor that feeds a convolution and something else (the
     input of a ResNet block is also its residual branch) normally receives two gradients that autograd sums with an element-wise
@@ -853,7 +917,7 @@ class _Conv2dTap(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
-        xf, y = _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm)
+        xf, y, _ = _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm)
         return y, xf.view_as(xf)
 
     @staticmethod
@@ -900,7 +964,7 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", i
 
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, groups):
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, groups, conv_stats=None):
         ctx.params = (weight, bias)
         _note_use(weight, bias)
         ctx.groups = groups
@@ -911,9 +975,16 @@ class _BatchNorm(torch.autograd.Function):
         res = f32(residual) if residual is not None else None
         if training:
             mean, invstd = _empty((groups * C,), x), _empty((groups * C,), x)
-            ws = _empty((query("fd_bn_ws_floats", N, C, H, W, groups),), x)
-            call("fd_bn_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
-                 ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, groups, float(eps), float(momentum), int(relu), stream())
+            if conv_stats is not None and groups <= 16:
+                # statistics gathered by the producing convolution's epilogue: one launch, no statistics pass over x
+                assert conv_stats.shape[:2] == (N, C) and conv_stats.shape[3] == 2
+                call("fd_bn_train_fwd_parts", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
+                     ptr(mean), ptr(invstd), ptr(conv_stats), int(conv_stats.shape[2]), N, C, H, W, groups, float(eps),
+                     float(momentum), int(relu), stream())
+            else:
+                ws = _empty((query("fd_bn_ws_floats", N, C, H, W, groups),), x)
+                call("fd_bn_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
+                     ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, groups, float(eps), float(momentum), int(relu), stream())
             ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
         else:
             call("fd_bn_eval_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
@@ -939,7 +1010,7 @@ class _BatchNorm(torch.autograd.Function):
         if direct:
             gw = gb = None
             _grad_ready(ctx.params[0], ctx.params[1])
-        return gx, gw, gb, gres, None, None, None, None, None, None, None
+        return gx, gw, gb, gres, None, None, None, None, None, None, None, None
 
 
 _BN_GROUPS = [1]
@@ -978,9 +1049,10 @@ class bn_groups:
         _BN_GROUPS[0] = self.prev
 
 
-def batch_norm(x, bn, residual=None, relu=False):
+def batch_norm(x, bn, residual=None, relu=False, conv_stats=None):
     """nn.BatchNorm2d semantics (batch statistics + running-stat update in training mode) fused with the
-    optional residual add and ReLU.  ``bn`` is an ``nn.BatchNorm2d`` used as the parameter/buffer holder."""
+    optional residual add and ReLU.  ``bn`` is an ``nn.BatchNorm2d`` used as the parameter/buffer holder.
+    ``conv_stats``: the partial sums ``conv2d_stats`` returned for ``x`` (training mode only)."""
     training = bn.training
     groups = _BN_GROUPS[0] if training else 1
     if training and bn.num_batches_tracked is not None:
@@ -989,7 +1061,7 @@ def batch_norm(x, bn, residual=None, relu=False):
         else:
             bn.num_batches_tracked.add_(groups)
     return _BatchNorm.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, training, bn.momentum,
-                            bn.eps, relu, groups)
+                            bn.eps, relu, groups, conv_stats if training else None)
 
 
 class _MaxPool(torch.autograd.Function):

@@ -23,6 +23,25 @@ def _conv(x, conv, in_norm=False):
     return FD.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0], in_norm=in_norm)
 
 
+_CONV_STATS = os.environ.get("FD_CONV_STATS", "1") != "0"
+
+
+def _conv_bn(x, conv, bn, residual=None, relu=False, tap=False):
+    """bn(conv(x)) [+ residual] [ReLU].  In training mode the convolution's epilogue gathers the BatchNorm's partial sums where its
+    kernel can (FD.conv2d_stats), so the BatchNorm is ONE launch over the output instead of a statistics pass + an apply pass.
+    ``tap``: also return ``x`` routed through the convolution's autograd node (see ``_conv_tap``)."""
+    if bn.training and _CONV_STATS and torch.is_grad_enabled():
+        res = FD.conv2d_stats(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0],
+                              tap=tap and os.environ.get("FD_CONV_TAP", "1") != "0")
+        y, stats = res[0], res[1]
+        out = FD.batch_norm(y, bn, residual=residual, relu=relu, conv_stats=stats)
+        return (out, res[2]) if tap else out
+    if tap:
+        y, x = _conv_tap(x, conv)
+        return FD.batch_norm(y, bn, residual=residual, relu=relu), x
+    return FD.batch_norm(_conv(x, conv), bn, residual=residual, relu=relu)
+
+
 def _conv_tap(x, conv):
     """(conv(x), x): the block input is needed twice - by the first convolution and by the residual branch.  Taking the second
     use from the tap makes the residual gradient join the first convolution's data gradient inside that kernel
@@ -46,12 +65,11 @@ class BasicBlock(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
 
     def forward(self, x):
-        out, x = _conv_tap(x, self.conv1)
+        out, x = _conv_bn(x, self.conv1, self.bn1, relu=True, tap=True)
         identity = x
         if self.downsample is not None:
-            identity = FD.batch_norm(_conv(x, self.downsample[0]), self.downsample[1])
-        out = FD.batch_norm(out, self.bn1, relu=True)
-        return FD.batch_norm(_conv(out, self.conv2), self.bn2, residual=identity, relu=True)
+            identity = _conv_bn(x, self.downsample[0], self.downsample[1])
+        return _conv_bn(out, self.conv2, self.bn2, residual=identity, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -71,13 +89,12 @@ class Bottleneck(nn.Module):
                                             nn.BatchNorm2d(planes * 4))
 
     def forward(self, x):
-        out, x = _conv_tap(x, self.conv1)
+        out, x = _conv_bn(x, self.conv1, self.bn1, relu=True, tap=True)
         identity = x
         if self.downsample is not None:
-            identity = FD.batch_norm(_conv(x, self.downsample[0]), self.downsample[1])
-        out = FD.batch_norm(out, self.bn1, relu=True)
-        out = FD.batch_norm(_conv(out, self.conv2), self.bn2, relu=True)
-        return FD.batch_norm(_conv(out, self.conv3), self.bn3, residual=identity, relu=True)
+            identity = _conv_bn(x, self.downsample[0], self.downsample[1])
+        out = _conv_bn(out, self.conv2, self.bn2, relu=True)
+        return _conv_bn(out, self.conv3, self.bn3, residual=identity, relu=True)
 
 
 class _Stage(nn.Sequential):

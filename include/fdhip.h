@@ -216,6 +216,23 @@ long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d);
 long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d);
 int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
                   int wt_ready, float* ws, void* stream);
+/* BatchNorm statistics from the convolution's own epilogue.  Every ResNet convolution is followed by a training-mode BatchNorm
+ * (networks/resnet_encoder.py:95-101 -> torchvision BasicBlock / Bottleneck), whose first pass - per-channel sum and sum of
+ * squares of the convolution output - the convolution kernel can produce while the output tile is still in registers:
+ *   fd_conv2d_fwd_stat_slots  S = partial-sum slots per (image, output channel) the kernel chosen for `d` writes, or 0 when that
+ *                             kernel has no statistics epilogue (split-K launches, tiles that straddle images, fused activations):
+ *                             the caller then uses fd_bn_train_fwd, which makes its own statistics pass.
+ *   fd_conv2d_fwd_stats       fd_conv2d_fwd that also fills part [N][Cout][S][2] = (sum, M2) of y per slot of H*W/S pixels,
+ *                             M2 = sum of squared deviations from the slot's own mean (merged without cancellation).
+ *   fd_bn_train_fwd_parts     fd_bn_train_fwd (same semantics: per-group statistics, running statistics updated in group order)
+ *                             with the statistics taken from such partial sums - one launch, one pass over x less. */
+long fd_conv2d_fwd_stat_slots(const fd_conv_desc* d);
+int fd_conv2d_fwd_stats(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
+                        int wt_ready, float* ws, float* stat_part, void* stream);
+int fd_bn_train_fwd_parts(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                          float* running_mean, float* running_var, float* save_mean, float* save_invstd, const float* conv_part,
+                          int slots, int N, int C, int H, int W, int groups, float eps, float momentum, int relu, void* stream);
+
 /* Batched weight re-layout.  A training step re-derives the kernel-side copy of every conv weight once per optimiser
  * step; instead of one small launch per convolution inside fd_conv2d_fwd / fd_conv2d_bwd_data (wt_ready = 0) the caller can
  * collect the work of all its convolutions once and run it as ONE launch after each optimiser update, then call the

@@ -3,14 +3,22 @@
 means something: ``fusiondepth_amd.synthetic.make_scene_batch`` - a ground-truth depth field, frames -1 / +1 rendered through it
 with a ground-truth ego-motion, LiDAR returns sampled from it, ``depth_gt`` = the field at KITTI's 375x1242.
 
-    python tests/golden/make_absrel.py            # ~10 minutes on 8 cores
+    python tests/golden/make_absrel.py            # ~12 minutes on 8 cores
 
-50 optimiser steps of the CPU oracle trainer (ResNet-18, 192x640, --batch_size 2, Adam lr 1e-4) from the deterministic initial
-state of the trainer tests, one fresh scene batch per step; at steps 0, 10, .. 50 the monitoring metrics of
+20 optimiser steps of the CPU oracle trainer (ResNet-18, 192x640, --batch_size 2, the reference's default --learning_rate 1e-4 ->
+Adam lr 2.5e-5) from the deterministic initial state of the trainer tests, one fresh scene batch per step; at steps 0, 2, .. 20
+the monitoring metrics of
 ``Trainer.compute_depth_losses`` (bilinear to 375x1242, Garg crop, median scaling, clamp, layers.compute_depth_errors) on two
 held-out scene batches in eval mode.  Stored for a float32 AND a float64 run from the same state: the float64 one is the ground
-truth, their distance is what the reference's own arithmetic drifts by.  The test (tests/test_gpu_trainer.py) regenerates the
-inputs from the seeds below and runs the HIP trainer over the same 50 steps."""
+truth, their distance is what the reference's own arithmetic drifts by - from-scratch training with train-mode BatchNorm over two
+images and Adam's sign-like first updates is chaotic: the two runs agree to 4e-7 in AbsRel after 2 steps, 2e-4 after 4, 4e-3 after
+6 and 1e-2 after 20 (at Adam lr 1e-4 over 50 steps: 9e-2 after 20).  The test (tests/test_gpu_trainer.py)
+regenerates the inputs from the seeds below and runs the HIP trainer over the same 20 steps.
+
+How far apart may two CORRECT float32 implementations be?  One float32-vs-float64 pair is one draw of a chaotic process, so the
+fixture also holds ENSEMBLE float32 runs of the same oracle whose initial weights were each moved to a neighbouring float32 (one
+ulp, random direction): the spread of AbsRel over {float32, float64, one-ulp runs} at a checkpoint is the yardstick the test
+uses where it exceeds the north star's 0.001."""
 import os
 import sys
 
@@ -26,6 +34,7 @@ from oracle import scatter as OS, trainer as OT      # noqa: E402
 
 H, W, B, STEPS, EVERY, SEED, LR = 192, 640, 2, 20, 2, 3, 1e-4      # the reference default --learning_rate 1e-4 at --batch_size 2 -> Adam lr 2.5e-5 (trainer.py:38)
 TRAIN_SEED, VAL_SEEDS = 2000, (7001, 7002)
+ENSEMBLE = 3        # extra float32 runs whose initial weights are moved by ONE float32 ulp each (random direction)
 
 
 def scene_batch(seed):
@@ -69,9 +78,16 @@ def evaluate(ot, dtype):
     return acc / len(VAL_SEEDS)
 
 
-def run(dtype):
+def run(dtype, ulp_seed=None):
     opt = OT.default_opt(height=H, width=W, batch_size=B, num_layers=18, learning_rate=LR)
     m = models(opt)
+    if ulp_seed is not None:        # the same reference, one rounding away: every weight to a neighbouring float32
+        gen = torch.Generator().manual_seed(ulp_seed)
+        with torch.no_grad():
+            for net in m.values():
+                for prm in net.parameters():
+                    up = torch.rand(prm.shape, generator=gen) < 0.5
+                    prm.copy_(torch.nextafter(prm, torch.where(up, torch.full_like(prm, float("inf")), torch.full_like(prm, -float("inf")))))
     if dtype == torch.float64:
         m = {k: net.double() for k, net in m.items()}
     ot = OT.OracleTrainer(opt, models=m)
@@ -92,10 +108,18 @@ def run(dtype):
 
 if __name__ == "__main__":
     torch.set_num_threads(max(1, os.cpu_count() or 1))
-    out = {"steps": np.int64(STEPS), "every": np.int64(EVERY)}
-    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
-        out["%s/loss" % tag], out["%s/metrics" % tag] = run(dt)
-    np.savez_compressed(os.path.join(HERE, "absrel_r18_192x640_b2.npz"), **out)
+    path = os.path.join(HERE, "absrel_r18_192x640_b2.npz")
+    if "--ensemble-only" in sys.argv:      # keep the float32 / float64 runs of the existing fixture, (re)make the perturbed ones
+        out = dict(np.load(path))
+    else:
+        out = {"steps": np.int64(STEPS), "every": np.int64(EVERY)}
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            out["%s/loss" % tag], out["%s/metrics" % tag] = run(dt)
+    for k in range(ENSEMBLE):
+        out["f32p%d/loss" % k], out["f32p%d/metrics" % k] = run(torch.float32, ulp_seed=500 + k)
+        print("one-ulp run %d |abs_rel - f32|:" % k, np.abs(out["f32p%d/metrics" % k][:, 0] - out["f32/metrics"][:, 0]))
+    out["ensemble"] = np.int64(ENSEMBLE)
+    np.savez_compressed(path, **out)
     print("abs_rel f32:", out["f32/metrics"][:, 0])
     print("abs_rel f64:", out["f64/metrics"][:, 0])
     print("|f32 - f64|:", np.abs(out["f32/metrics"][:, 0] - out["f64/metrics"][:, 0]))

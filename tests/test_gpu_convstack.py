@@ -470,6 +470,127 @@ def test_grouped_batchnorm_equals_separate_passes(FD, N, C, H, W, G, res):
     assert int(bn_g.num_batches_tracked) == int(bn_o.num_batches_tracked) == G
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W,G,res", [
+    (6, 64, 64, 48, 160, 2, True),      # the step's layer1 plane: 60 tiles per image, grouped, residual + ReLU
+    (12, 128, 128, 24, 80, 3, False),   # layer2: 15 tiles per image, 2 channel tiles, three groups
+    (8, 128, 64, 48, 160, 1, True),     # one group
+])
+def test_conv_epilogue_statistics_feed_batchnorm(FD, N, Cin, Cout, H, W, G, res):
+    """fd_conv2d_fwd_stats + fd_bn_train_fwd_parts (BatchNorm statistics gathered in the convolution's epilogue, one BatchNorm
+    launch) == fd_conv2d_fwd + fd_bn_train_fwd (statistics pass + apply pass), and both == torch's conv2d + BatchNorm2d in float64:
+    outputs, running statistics after the grouped in-order updates, and every gradient.  Reference ops: torchvision BasicBlock
+    (conv3x3 -> BatchNorm2d -> [+ identity] -> ReLU) as driven by networks/resnet_encoder.py:95-101."""
+    rng = np.random.RandomState(N * 1000 + Cin)
+    x = torch.from_numpy((rng.randn(N, Cin, H, W) + 0.5).astype(np.float32))
+    w = torch.from_numpy((rng.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32))
+    r = torch.from_numpy(rng.randn(N, Cout, H, W).astype(np.float32)) if res else None
+    cot = torch.from_numpy(rng.randn(N, Cout, H, W).astype(np.float32))
+    bn_ref = gin.fill_params(torch.nn.BatchNorm2d(Cout), 7)
+    Ng = N // G
+
+    def hip(use_stats):
+        bn = torch.nn.BatchNorm2d(Cout)
+        bn.load_state_dict(bn_ref.state_dict())
+        bn.cuda()
+        xg, wg = dev(x).requires_grad_(True), dev(w).requires_grad_(True)
+        rg = dev(r).requires_grad_(True) if res else None
+        with FD.bn_groups(G):
+            if use_stats:
+                y, stats = FD.conv2d_stats(xg, wg, None, 1, 1)
+                assert stats is not None and tuple(stats.shape) == (N, Cout, 2 * (H * W // 2) // 64, 2)
+                out = FD.batch_norm(y, bn, residual=rg, relu=True, conv_stats=stats)
+            else:
+                out = FD.batch_norm(FD.conv2d(xg, wg, None, 1, 1), bn, residual=rg, relu=True)
+        gr = torch.autograd.grad((out * dev(cot)).sum(), [xg, wg, bn.weight, bn.bias] + ([rg] if res else []))
+        return out, gr, bn
+
+    out_s, gr_s, bn_s = hip(True)
+    out_p, gr_p, bn_p = hip(False)
+    # float64 ground truth, group by group
+    bn64 = torch.nn.BatchNorm2d(Cout).double()
+    bn64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn_ref.state_dict().items()})
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    r64 = r.double().requires_grad_(True) if res else None
+    outs = []
+    for g in range(G):
+        y = bn64(F.conv2d(x64[g * Ng:(g + 1) * Ng], w64, None, 1, 1))
+        if res:
+            y = y + r64[g * Ng:(g + 1) * Ng]
+        outs.append(F.relu(y))
+    out64 = torch.cat(outs, 0)
+    gr64 = torch.autograd.grad((out64 * cot.double()).sum(), [x64, w64, bn64.weight, bn64.bias] + ([r64] if res else []))
+    from conftest import assert_mostly_close
+    names = ["gx", "gw", "g gamma", "g beta", "g residual"]
+    for name, out, gr, bn in (("epilogue statistics", out_s, gr_s, bn_s), ("statistics pass", out_p, gr_p, bn_p)):
+        relclose(cpu(out), out64.detach().numpy(), name + ": output", arel=2e-5)
+        relclose(cpu(bn.running_mean), bn64.running_mean.numpy(), name + ": running_mean")
+        relclose(cpu(bn.running_var), bn64.running_var.numpy(), name + ": running_var")
+        for a, b, nm in zip(gr, gr64, names):
+            b = b.numpy()
+            # An output within float32 rounding of 0 takes the other side of the ReLU than in float64: its gradient (and through
+            # the 3x3 window that of its neighbours) flips by O(1) - a few 1e-4 of the entries at these sizes; the parameter
+            # gradients are sums over all pixels and move by those flipped entries (a percent of their largest value).
+            if nm in ("gx", "g residual"):
+                assert_mostly_close(cpu(a), b, rtol=2e-4, atol=2e-4 * np.abs(b).max(), what="%s: %s" % (name, nm), max_bad_frac=2e-3)
+            else:
+                relclose(cpu(a), b, "%s: %s" % (name, nm), rtol=1e-3, arel=2e-2)
+    # the two HIP paths differ only in the summation order of the statistics (1e-7 relative in mean / variance)
+    relclose(cpu(out_s), cpu(out_p), "epilogue statistics vs statistics pass: output", arel=2e-6)
+    for a, b, nm in zip(gr_s, gr_p, names):
+        if nm in ("gx", "g residual"):
+            assert_mostly_close(cpu(a), cpu(b), rtol=2e-4, atol=2e-4 * float(b.abs().max()), what="two paths: " + nm, max_bad_frac=1e-3)
+        else:
+            relclose(cpu(a), cpu(b), "two paths: " + nm, rtol=1e-3, arel=5e-3)
+
+
+def test_batchnorm_statistics_of_a_near_constant_map(FD):
+    """The beam encoders see a sparse LiDAR image: after input normalisation and a zero-padded convolution the map is one constant
+    (a different one along the border) plus sparse spikes, i.e. the channel mean sits 10 - 100 standard deviations from zero and
+    from the corner pixel.  Single-pass E[d^2] - E[d]^2 statistics shifted by the corner pixel (rounds 1-2) lost 3 digits of the
+    variance there (2.4e-4 on the beam encoder's first feature at 1216x352).  Both statistics paths - fd_bn_train_fwd's own pass and
+    the convolution-epilogue partials of fd_conv2d_fwd_stats - against float64 BatchNorm2d on such a map, bound 2e-5."""
+    rng = np.random.RandomState(11)
+    N, C, H, W = 2, 64, 96, 320
+    x = np.full((N, C, H, W), -2.0, np.float32)                          # (0 - 0.45) / 0.225
+    hit = rng.rand(N, 1, H, W) < 0.03
+    x = np.where(hit, (rng.rand(N, C, H, W) * 4 - 2).astype(np.float32), x).astype(np.float32)
+    x = torch.from_numpy(x)
+    w = torch.from_numpy((np.abs(rng.randn(C, C, 3, 3)) * np.sqrt(2.0 / (9 * C))).astype(np.float32))    # same-sign taps: |mean| >> std
+    bn_ref = gin.fill_params(torch.nn.BatchNorm2d(C), 9)
+    bn64 = torch.nn.BatchNorm2d(C).double()
+    bn64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn_ref.state_dict().items()})
+    y64 = F.conv2d(x.double(), w.double(), None, 1, 1)
+    ratio = float((y64.mean((0, 2, 3)).abs() / y64.std((0, 2, 3))).median())
+    assert ratio > 8, ratio                                              # the premise of the test
+    out64 = bn64(y64)
+    for use_stats in (True, False):
+        bn = torch.nn.BatchNorm2d(C)
+        bn.load_state_dict(bn_ref.state_dict())
+        bn.cuda()
+        with torch.no_grad():
+            if use_stats:
+                y, stats = FD.conv2d_stats(dev(x), dev(w), None, 1, 1)
+                assert stats is not None
+                out = FD.batch_norm(y, bn, conv_stats=stats)
+            else:
+                out = FD.batch_norm(FD.conv2d(dev(x), dev(w), None, 1, 1), bn)
+        name = "near-constant map, " + ("epilogue statistics" if use_stats else "statistics pass")
+        relclose(cpu(out), out64.detach().numpy(), name + ": output", arel=2e-5)
+        relclose(cpu(bn.running_var), bn64.running_var.numpy(), name + ": running_var", rtol=2e-5, arel=2e-5)
+        relclose(cpu(bn.running_mean), bn64.running_mean.numpy(), name + ": running_mean", rtol=2e-6, arel=2e-6)
+
+
+def test_conv_epilogue_statistics_decline_unsupported_shapes(FD):
+    """Shapes whose kernel has no statistics epilogue (tiles straddling images, split-K, strided / 1x1 convolutions on the direct
+    kernel): conv2d_stats returns None and batch_norm makes its own statistics pass."""
+    for (N, Cin, Cout, H, W, k, s, p) in [(2, 64, 64, 6, 20, 3, 1, 1), (2, 64, 128, 16, 32, 3, 2, 1), (2, 64, 64, 16, 32, 1, 1, 0)]:
+        x = torch.randn(N, Cin, H, W, device="cuda")
+        w = torch.randn(Cout, Cin, k, k, device="cuda") * 0.05
+        y, stats = FD.conv2d_stats(x, w, None, s, p)
+        assert stats is None
+        assert torch.equal(y, FD.conv2d(x, w, None, s, p))
+
+
 # ------------------------------------------------------------------------------------------------ Winograd F(2,3) path
 def _wino_conv(x, w, bias, reflect, act=0):
     import ctypes

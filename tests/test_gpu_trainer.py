@@ -83,7 +83,7 @@ def _to64(inp):
     return {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
 
 
-def _check_forward_against_float64(tag, outs_g, losses_g, ot, inp, noise, keys):
+def _check_forward_against_float64(tag, outs_g, losses_g, ot, inp, noise, keys, floor=1e-4):
     """One training forward of the HIP trainer against GROUND TRUTH = the oracle's graph in float64, tensor by tensor (worst
     element-wise relative error) and loss by loss.  Bound: the north-star 1e-4, or twice the error the reference's own float32
     arithmetic (the float32 oracle, same weights) shows on that tensor - whichever is larger.  A 10x regression cannot pass: the
@@ -95,7 +95,7 @@ def _check_forward_against_float64(tag, outs_g, losses_g, ot, inp, noise, keys):
     for key in keys:
         r64 = o64[key].numpy()
         e_hip, e_ref = _rel_err(outs_g[key].detach().cpu().numpy(), r64), _rel_err(o32[key].numpy(), r64)
-        bound = max(1e-4, 2 * e_ref)
+        bound = max(floor, 2 * e_ref)
         conftest.report("%s %s" % (tag, key), e_hip, bound, "(float32 oracle %.2e)" % e_ref)
         assert e_hip <= bound, "%s %s: HIP %.3g vs float64, float32 oracle %.3g" % (tag, key, e_hip, e_ref)
     for k in l64:
@@ -176,6 +176,8 @@ def test_other_baseline_configs_match_oracle(layers, H, W, B):
             saved = {k: {n: b.clone() for n, b in m.named_buffers()} for k, m in tr.models.items()}
             outs_g, losses_g = tr.process_batch(ginp)
             ot0 = _make_oracle(opt)          # same initial weights as the pair above (the oracle has already stepped)
+            # (round 3: this bound caught the BatchNorm statistics shift - 1.1e-4 / 1.9e-4 at 1024x320 and 1216x352 before the
+            # median-of-9 shift of norm.hip, 3e-5 = the float32 oracle's own error after it)
             _check_forward_against_float64("R%d %dx%d b%d step0" % (layers, W, H, B), outs_g, losses_g, ot0, inp, noise,
                                            [("disp", s) for s in range(4)])
             tr.flat.zero_grad()
@@ -200,18 +202,20 @@ def test_other_baseline_configs_match_oracle(layers, H, W, B):
 
 def test_absrel_after_equal_steps_vs_oracle_fixture(golden):
     """The north star's AbsRel clause (BASELINE.json: "AbsRel within 0.001 of the reference after equal steps"; metric =
-    trainer.py:598-630 / evaluate_depth.py:42-60): 50 optimiser steps of the HIP trainer and of the CPU oracle from the same initial
+    trainer.py:598-630 / evaluate_depth.py:42-60): 20 optimiser steps of the HIP trainer and of the CPU oracle from the same initial
     state on the same scene batches (tests/golden/make_absrel.py: a consistent synthetic scene with a ground-truth depth field, so
-    AbsRel lies in a meaningful range instead of ~1 against random ground truth), AbsRel of the held-out scenes at steps 0, 10 .. 50.
-    The fixture holds the oracle's float32 AND float64 runs: float64 is ground truth, |float32 - float64| is what the reference's
-    own arithmetic drifts by through 50 Adam steps.  Bound at every checkpoint: |AbsRel_HIP - AbsRel_oracle32| <= 0.001 absolute, or
-    twice that drift where the reference itself cannot hold 0.001; all values go to the terminal summary."""
+    AbsRel lies in a meaningful range - 0.31 .. 0.60 - instead of ~1 against random ground truth), AbsRel of the held-out scenes
+    after 0, 2, .. 20 steps.  The fixture holds the oracle's float32 AND float64 runs: float64 is ground truth, |float32 - float64|
+    is what the reference's own arithmetic drifts by (from-scratch training is chaotic: 4e-7 after 2 steps, 2e-4 after 4, 4e-3
+    after 6, 1e-2 after 20 - beyond step 4 the reference cannot hold 0.001 against ITSELF in float64).  Bound at every checkpoint:
+    |AbsRel_HIP - AbsRel_oracle32| <= 0.001 absolute, or twice that drift where it exceeds 0.001; all values go to the terminal
+    summary."""
     import conftest
     import make_absrel as MA
     g = golden("absrel_r18_192x640_b2")
     opt = _opts(height=MA.H, width=MA.W, batch_size=MA.B, learning_rate=MA.LR)
     tr, _ = _make_pair(opt)
-    assert abs(tr.lr - 1e-4) < 1e-12 and tr.accumulate_step == 1 and int(g["steps"]) == MA.STEPS
+    assert abs(tr.lr - 2.5e-5) < 1e-12 and tr.accumulate_step == 1 and int(g["steps"]) == MA.STEPS      # 1e-4 * (batch 2 / 8), trainer.py:38
     val = []
     for seed in MA.VAL_SEEDS:
         inp, _ = MA.scene_batch(seed)
