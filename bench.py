@@ -110,7 +110,7 @@ def roofline_probes(args, tr, batch):
     # HBM bytes per launch: rocprofv3 --pmc passes cannot run inside this process, so the number comes from the committed passes of
     # this exact kernel and shape (scripts/pmc_probe.sh) - and only while the kernel source is the one that was profiled.
     traffic, traffic_src = None, None
-    for name in ("round2_pmc_probe_wino.json", "round1_pmc_probe_wino.json"):
+    for name in ("round3_pmc_probe_wino.json", "round2_pmc_probe_wino.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -156,16 +156,18 @@ def roofline_probes(args, tr, batch):
     ms = graph_time_ms(loss_fwd_bwd, launches=5)
     byts = LOSS_BYTES_PER_PIXEL * H * W * B
     loss_traffic, loss_traffic_src = None, None
-    pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_loss.json")
-    if os.path.exists(pmc_path):
+    sha = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fusiondepth_amd", "csrc",
+                                           "photometric_ms.hip"), "rb").read()).hexdigest()
+    for name in ("round3_pmc_loss.json", "round2_pmc_loss.json"):
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        if not os.path.exists(pmc_path):
+            continue
         pmc = json.load(open(pmc_path))
-        sha = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fusiondepth_amd", "csrc",
-                                               "photometric_ms.hip"), "rb").read()).hexdigest()
         if pmc.get("source_sha256") == sha and pmc.get("batch") == B and (H, W) == (192, 640):
-            loss_traffic, loss_traffic_src = pmc["traffic_bytes_per_launch"], "round2_pmc_loss.json"
-        else:
-            print("[bench] profiles/round2_pmc_loss.json was measured on a different photometric_ms.hip / batch / size: "
-                  "roofline_loss_path.traffic left null - re-run scripts/pmc_loss_ms.sh", file=sys.stderr, flush=True)
+            loss_traffic, loss_traffic_src = pmc["traffic_bytes_per_launch"], name
+            break
+        print("[bench] profiles/%s was measured on a different photometric_ms.hip / batch / size: roofline_loss_path.traffic "
+              "left null unless an older record matches - re-run scripts/pmc_loss_ms.sh" % name, file=sys.stderr, flush=True)
     out["roofline_loss_path"] = {"bound": "hbm", "kernel": "k_photo_ms (4 scales, forward + unit gradients) + k_photo_ms_fin + "
                                  "k_photo_ms_bwd (+ projection-matrix and loss-combination launches), batch %d" % B,
                                  "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",

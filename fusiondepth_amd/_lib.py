@@ -153,9 +153,19 @@ def last_error():
     return load().fd_last_error().decode()
 
 
+# FD_HOST_DELAY_US=x: busy-wait x microseconds before every entry-point call - the experiment behind DESIGN.md's "the step is
+# GPU-bound": up to 16 us per call (about +11 ms of host work per step) leaves ms_per_step unchanged (profiles/README.md, round 3)
+_HOST_DELAY_US = float(os.environ.get("FD_HOST_DELAY_US", "0"))
+
+
 def call(name, *args):
     """Invoke an ``int``-returning entry point and raise RuntimeError on a non-zero status."""
     lib = load()
+    if _HOST_DELAY_US:
+        import time
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e6 < _HOST_DELAY_US:
+            pass
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError("%s failed (status %d): %s" % (name, rc, lib.fd_last_error().decode()))

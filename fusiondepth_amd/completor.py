@@ -75,7 +75,7 @@ class Completor(Trainer):
         pred = torch.clamp(pred * (torch.median(gt) / torch.median(pred)), min=1e-3, max=80)
         errs = FD.depth_errors(gt * 1000.0, pred * 1000.0)
         for i, metric in enumerate(self.depth_metric_names):
-            v = np.array(errs[i].cpu())
+            v = errs[i].detach().cpu().numpy()
             losses[metric] = losses.get(metric, 0.0) + v if accumulate else v
 
     def val(self, batches, save_best=True):

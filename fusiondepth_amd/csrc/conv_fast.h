@@ -24,6 +24,14 @@ struct FastGemmArgs {
                          // the residual branch of a ResNet block joins the data gradient in the epilogue)
 };
 
+// the fields in which the problems of one grouped launch differ (fast_gemm_group_launch)
+struct FastGemmGroup {
+    const float* A[4];
+    int NY[4], NX[4], oy[4], ox[4], ooy[4], oox[4], T[4], TB[4], K[4];
+    int first_bx[5];
+    int n;
+};
+
 struct FastWgradArgs {
     const float* dY; const float* X; float* slabs;   // slabs [splits][M][T][C]
     int M, C, T, TB;
@@ -36,6 +44,7 @@ struct FastWgradArgs {
 
 long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out);
 int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st);
+int fast_gemm_group_launch(const FastGemmArgs& a, const FastGemmGroup& q, hipStream_t st);
 int fast_weight_relayout(const float* W, float* A2, int Co, int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh, int kw0,
                          int dkw, int mode, hipStream_t st);
 int fast_wgrad_splits(int M, int C, int T, long Np);

@@ -35,8 +35,10 @@ __device__ __forceinline__ int refl_idx(int i, int n) {
     return i >= n ? 2 * n - 2 - i : i;
 }
 
+// The kernel body; `bx` = pixel tile of problem `g`, `ntx` = its number of pixel tiles (k_conv_fast: the grid's x extent;
+// k_conv_fast_grp: the x range of one of several problems that share a launch).
 template <int WAVES_M, int WAVES_N, int WM, int WN, int BKC>
-__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmArgs g) {
+__device__ __forceinline__ void conv_fast_body(const FastGemmArgs& g, int bx, int ntx) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
     constexpr int LDA = BM + 1, LDB = BN;
@@ -53,8 +55,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    int bx = blockIdx.x;
-    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    if (g.xcd_swizzle) { const int per = ntx >> 3; bx = (bx & 7) * per + (bx >> 3); }
     const int m0 = blockIdx.y * BM;
     const long p0 = (long)bx * BN;
     const int plane = g.NY * g.NX;
@@ -223,6 +224,24 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmAr
                 }
             }
     }
+}
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BKC>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast(FastGemmArgs g) {
+    conv_fast_body<WAVES_M, WAVES_N, WM, WN, BKC>(g, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Several problems that differ only in the fields of FastGemmGroup - the output-parity classes of a stride-2 data gradient: each
+// class alone has too few tiles to fill 256 CUs (92 workgroups for ResNet layer4.0 at batch 24) and they do not depend on each
+// other, so ONE launch runs them side by side: grid x = the concatenated pixel tiles of the classes.  No split-K (gridDim.z = 1).
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BKC>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast_grp(FastGemmArgs g, FastGemmGroup q) {
+    int j = 0;
+    while (j + 1 < q.n && (int)blockIdx.x >= q.first_bx[j + 1]) ++j;
+    g.A = q.A[j]; g.NY = q.NY[j]; g.NX = q.NX[j]; g.oy = q.oy[j]; g.ox = q.ox[j]; g.ooy = q.ooy[j]; g.oox = q.oox[j];
+    g.T = q.T[j]; g.TB = q.TB[j]; g.K = q.K[j];
+    g.xcd_swizzle = 0;
+    conv_fast_body<WAVES_M, WAVES_N, WM, WN, BKC>(g, (int)blockIdx.x - q.first_bx[j], q.first_bx[j + 1] - q.first_bx[j]);
 }
 
 // Y[i] = act(sum_z slabs[z][i] + bias[channel(i)])   (fixed z order => deterministic)
@@ -531,6 +550,39 @@ long fast_splitk_slab_floats(const FastGemmArgs& a, int* splits_out) {
     const FastChoice ch = choose_config(probe);
     if (splits_out) *splits_out = ch.splits;
     return ch.splits > 1 ? (long)ch.splits * a.out_total : 0;
+}
+
+namespace {
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BKC>
+void launch_grp(const FastGemmArgs& a, const FastGemmGroup& q, hipStream_t st) {
+    constexpr int BM = WAVES_M * 32 * WM, BN = WAVES_N * 32 * WN;
+    FastGemmGroup grp = q;
+    int gx = 0;
+    for (int j = 0; j < q.n; ++j) { grp.first_bx[j] = gx; gx += fd_cdiv((long)a.Nb * q.NY[j] * q.NX[j], BN); }
+    grp.first_bx[q.n] = gx;
+    const size_t lds = sizeof(float) * 2 * BKC * ((BM + 1) + BN);
+    auto kern = k_conv_fast_grp<WAVES_M, WAVES_N, WM, WN, BKC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx, fd_cdiv(a.M, BM), 1), dim3(64 * WAVES_M * WAVES_N), lds, st, a, grp);
+}
+}  // namespace
+
+// `a` holds what the problems share; q their differences (q.first_bx is filled here).  Same tile configuration rule as
+// fast_gemm_launch (64x128, or 32x256 for <= 32 output channels); no split-K.
+int fast_gemm_group_launch(const FastGemmArgs& a, const FastGemmGroup& q, hipStream_t st) {
+    if ((double)a.Nb * a.C * a.Hi * a.Wi * 4.0 >= 2147483648.0) { fd_set_error("conv: tensor exceeds the 2 GiB addressing range of the fast path"); return -1; }
+    for (int j = 0; j < q.n; ++j)
+        if ((double)a.M * q.K[j] * 4.0 >= 2147483648.0) { fd_set_error("conv: weights exceed the 2 GiB addressing range of the fast path"); return -1; }
+    const bool b32 = a.C % 32 == 0;
+    if (a.M > 32) { if (b32) launch_grp<2, 2, 1, 2, 32>(a, q, st); else launch_grp<2, 2, 1, 2, 16>(a, q, st); }
+    else { if (b32) launch_grp<1, 4, 1, 2, 32>(a, q, st); else launch_grp<1, 4, 1, 2, 16>(a, q, st); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { fd_set_error("k_conv_fast_grp launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
 }
 
 int fast_gemm_launch(const FastGemmArgs& a, hipStream_t st) {

@@ -451,8 +451,13 @@ struct WinoWgradArgs {
     int pad_mode;
     long pairs_per_split;
     int slice_major;     // 1: grid x = pixel slice (XCD-aligned), z = (ky, c tile); 0: x = (ky, c tile), z = slice
+    int adv_n, adv_y, adv_j;   // one chunk of WGP pairs = adv_n images + adv_y rows + adv_j pairs (host: divisions once per launch)
 };
 constexpr int WGP = 16;                                          // pairs per chunk (GEMM-K 16 -> 8 MFMA k-steps)
+#ifndef FD_WGRAD_ABLATE       // timing experiments only (wrong results), scripts/build_ablation.sh: 1 no global loads in the loop,
+#define FD_WGRAD_ABLATE 0     // 2 no LDS stores, 4 no border masks, 8 no chunk index arithmetic, 16 no barrier, 32 no operand
+#endif                        // transforms, 64 no operand reads
+
 // Both operands stay RAW in LDS, one row of the chunk's 32 pixels per channel: dY rows [0 .. 31] (+ 2 pad), X rows [0 .. 31] the
 // chunk's pixels, [32] the pixel right of the chunk, [33] the pixel left of it.  The transforms P = (y0, y0+y1, y0-y1, y1) and
 // Q = (d0-d2, d1+d2, d2-d1, d1-d3) are applied when the MFMA operands are read.  Row stride 34 floats: a lane (= channel) reads
@@ -472,9 +477,22 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     // (slice_major: x = slice with the slice count a multiple of 8, so that all workgroups of a slice share an XCD / L2) measured
     // slightly slower in the training step and is kept as a tuning switch (FD_WINO_WGRAD_MAP=1).
     const int ctiles = (g.C + WBN - 1) / WBN;
-    const int bt = g.slice_major ? blockIdx.z : blockIdx.x, bs = g.slice_major ? blockIdx.x : blockIdx.z;
+    int bt, bs, by;
+    if (g.slice_major == 2) {
+        // 1-D grid, XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs, so id L runs on XCD L % 8.  All (kernel row,
+        // c tile, m tile) workgroups of one pixel slice get ids 8 apart - same XCD, dispatched back to back - and find the slice's
+        // dY / X rows in that XCD's L2 (the 3 kernel rows alone re-read both operands: 3x the HBM traffic when they sit on 3 XCDs).
+        const int mtiles = (g.M + WBM - 1) / WBM, nt = 3 * ctiles * mtiles;
+        const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
+        const int t = k % nt;
+        bs = (k / nt) * 8 + xcd;
+        by = t / (3 * ctiles);
+        bt = t - by * 3 * ctiles;
+    } else {
+        bt = g.slice_major ? blockIdx.z : blockIdx.x; bs = g.slice_major ? blockIdx.x : blockIdx.z; by = blockIdx.y;
+    }
     const int ky = bt / ctiles, c0 = (bt - ky * ctiles) * WBN;
-    const int m0 = blockIdx.y * WBM;
+    const int m0 = by * WBM;
     const int pp_lo = (int)((long)bs * g.pairs_per_split < Np ? (long)bs * g.pairs_per_split : Np);
     const int pp_hi = (long)pp_lo + g.pairs_per_split < Np ? pp_lo + (int)g.pairs_per_split : Np;
     const int nchunk = pp_hi > pp_lo ? (pp_hi - pp_lo + WGP - 1) / WGP : 0;
@@ -496,13 +514,19 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     unsigned a_off = FD_OOB, mid_off = FD_OOB, h_off = FD_OOB;
     unsigned long edge_l = 0, edge_r = 0;                        // bit k: pair k of the prepared chunk sits at the left / right image border
     int pc = pp_lo;                                              // first pair of the chunk being prepared
+    // (image, row, pair in row) of this thread's pair of the chunk being prepared: divided out once, then advanced by one chunk per
+    // call with two carries - the two integer divisions per chunk of the first version were 15 % of the kernel (ablation, profiles/)
+    int cn, cy, cj;
+    {
+        const int pq = pp_lo + p;
+        cn = pq / plane2;
+        const int rem = pq - cn * plane2;
+        cy = rem / W2; cj = rem - cy * W2;
+    }
     auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
         const int pg = pc + p;
         const bool ok = live & (pg < pp_hi);
-        const int pq = ok ? pg : 0;
-        const int n = pq / plane2;
-        const int rem = pq - n * plane2;
-        const int y = rem / W2, j = rem - y * W2;
+        const int n = cn, y = cy, j = cj;
         a_off = ok ? 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(y * g.W + 2 * j)) : FD_OOB;
         const int r = y + ky - 1;
         const bool inb = (unsigned)r < (unsigned)g.H;
@@ -520,6 +544,14 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         edge_l = __ballot(e_left) & 0xffffUL;
         edge_r = __ballot(e_right) & 0xffffUL;
         pc += WGP;
+        // advance (cn, cy, cj) by one chunk (values past the slice are never used: `ok` is false there)
+        cj += g.adv_j;
+        const bool c1 = cj >= W2;
+        cj -= c1 ? W2 : 0;
+        cy += g.adv_y + (c1 ? 1 : 0);
+        const bool c2 = cy >= g.H;
+        cy -= c2 ? g.H : 0;
+        cn += g.adv_n + (c2 ? 1 : 0);
     };
     auto load_row = [&](int i) __attribute__((always_inline)) {
         ra[i] = fd_ldg64(rsY, a_off + a_row[i]);                          // FD_OOB + (< 2^31) stays out of range: reads 0
@@ -566,8 +598,7 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
             // operands of pair k = 2 kk + arow: A = P(dY row 32 wm + acol), B = Q(X row 32 wn + acol)
             const float* pa = smem + cur * WG_BUF_FLOATS + (32 * wm + acol) * LDG + 2 * arow;
             const float* pb = smem + cur * WG_BUF_FLOATS + (WBM + 32 * wn + acol) * LDG + 2 * arow;
-            // per lane: this half-wave's pair parity shifts the border masks by `arow`
-            const unsigned ml = (unsigned)(cl >> arow), mr = (unsigned)(cr >> arow);
+            const unsigned long ccl = cl, ccr = cr;                      // this chunk's flags (cl / cr move on in mid-chunk)
             float av[2][4], bv[2][4];
             f32x2 yy, d12;
             float d0, d3;
@@ -578,10 +609,22 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
                 d0 = (kk2 == 0) ? pb[arow ? -1 : 2 * WGP + 1] : pb[4 * kk2 - 1];
                 d3 = pb[4 * kk2 + 2];
             };
+            // Border pairs: column -1 is column 1 (reflect) or 0, column W is column W - 2 (reflect) or 0.  The flags are wave-uniform
+            // per half-wave (lanes 0-31 hold pair 2 kk2, lanes 32-63 pair 2 kk2 + 1), so the select is ONE v_cndmask with a scalar
+            // lane mask built on the scalar unit - the per-lane bit tests of the first version were 8 % of the kernel.
+            auto lane_mask = [&](unsigned long bits, int kk2) __attribute__((always_inline)) -> unsigned long {
+                const unsigned long t = bits >> (2 * kk2);
+                return ((t & 1UL) ? 0x00000000ffffffffUL : 0UL) | ((t & 2UL) ? 0xffffffff00000000UL : 0UL);
+            };
             auto xform = [&](int nb, int kk2) __attribute__((always_inline)) {
-                const bool le = (ml >> (2 * kk2)) & 1u, re = (mr >> (2 * kk2)) & 1u;
-                const float e0 = le ? (refl ? d12.y : 0.f) : d0;          // column -1 is column 1 (reflect) or 0
-                const float e3 = re ? (refl ? d12.x : 0.f) : d3;          // column W is column W - 2 (reflect) or 0
+                float e0, e3;
+                if (FD_WGRAD_ABLATE & 4) { e0 = d0; e3 = d3; }
+                else {
+                    const unsigned long sl = lane_mask(ccl, kk2), sr = lane_mask(ccr, kk2);
+                    const float padl = refl ? d12.y : 0.f, padr = refl ? d12.x : 0.f;
+                    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(e0) : "v"(d0), "v"(padl), "s"(sl));
+                    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(e3) : "v"(d3), "v"(padr), "s"(sr));
+                }
                 av[nb][0] = yy.x; av[nb][1] = yy.x + yy.y; av[nb][2] = yy.x - yy.y; av[nb][3] = yy.y;
                 bv[nb][0] = e0 - d12.y; bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = d12.x - e3;
             };
@@ -592,24 +635,24 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < NK) read_ops(kk + 1);
+                if (kk + 1 < NK && !(FD_WGRAD_ABLATE & 64)) read_ops(kk + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < LS) store_row(cur ^ 1, kk);              // registers loaded one chunk ago -> the other buffer
+                if (kk < LS && !(FD_WGRAD_ABLATE & 2)) store_row(cur ^ 1, kk);              // registers loaded one chunk ago -> the other buffer
                 __builtin_amdgcn_sched_barrier(0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < NK) xform(nb, kk + 1);
+                if (kk + 1 < NK) { if (!(FD_WGRAD_ABLATE & 32)) xform(nb, kk + 1); else { for (int t = 0; t < 4; ++t) { av[nb][t] = av[cb][t]; bv[nb][t] = bv[cb][t]; } } }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < LS) load_row(kk);                        // ... and re-loaded with the chunk after next
+                if (kk < LS && !(FD_WGRAD_ABLATE & 1)) load_row(kk);                        // ... and re-loaded with the chunk after next
                 if (kk == LS) { cl = nl; cr = nr; nl = edge_l; nr = edge_r; }
-                if (kk == NK - 1) prep_chunk(ch + 3 < nchunk);
+                if (kk == NK - 1 && !(FD_WGRAD_ABLATE & 8)) prep_chunk(ch + 3 < nchunk);
             }
             __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
+            if (!(FD_WGRAD_ABLATE & 16)) __syncthreads();
         }
     }
 
@@ -745,17 +788,25 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
     long pps = (Np + sp - 1) / sp;
     pps = (pps + WGP - 1) / WGP * WGP;
     g.pairs_per_split = pps;
+    {
+        const int W2 = d->W / 2, plane2 = d->H * W2;
+        g.adv_n = WGP / plane2;
+        const int rem = WGP - g.adv_n * plane2;
+        g.adv_y = rem / W2; g.adv_j = rem - g.adv_y * W2;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     static int slice_major = -1;
-    if (slice_major < 0) { const char* e = getenv("FD_WINO_WGRAD_MAP"); slice_major = e ? atoi(e) : 0; }     // measured: 450-452 (0) vs 447-449 (1) images/s
+    if (slice_major < 0) { const char* e = getenv("FD_WINO_WGRAD_MAP"); slice_major = e ? atoi(e) : 2; }     // 2 (XCD-aware 1-D grid): layer1 HBM traffic 157 -> 76 MB per launch, step -0.5 %; 1 measured slower than 0
     g.slice_major = slice_major;
     const int nt = 3 * fd_cdiv(d->Cin, WBN);
-    hipLaunchKernelGGL(k_wgrad_wino, slice_major ? dim3(sp, fd_cdiv(d->Cout, WBM), nt) : dim3(nt, fd_cdiv(d->Cout, WBM), sp), dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st,
-                       g);
+    const int mt = fd_cdiv(d->Cout, WBM);
+    if (slice_major == 2 && sp % 8 != 0) g.slice_major = 0;               // the XCD map needs whole groups of 8 slices
+    const dim3 grid = g.slice_major == 2 ? dim3((unsigned)(nt * mt * sp)) : (g.slice_major ? dim3(sp, mt, nt) : dim3(nt, mt, sp));
+    hipLaunchKernelGGL(k_wgrad_wino, grid, dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st, g);
     FD_LAUNCH_CHECK("k_wgrad_wino");
     return fast_wgrad_finish_launch(ws, gw, d->Cout, d->Cin, 9, sp, accumulate, st);
 }

@@ -874,6 +874,7 @@ class _Conv2dStats(torch.autograd.Function):
         _, y, part = _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm, True)
         part = part if part is not None else _no_stats(y)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)      # no zero-filled "gradient" of `part` (one fill launch per convolution otherwise)
         return y, part
 
     @staticmethod
@@ -889,6 +890,7 @@ class _Conv2dTapStats(torch.autograd.Function):
         xf, y, part = _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm, True)
         part = part if part is not None else _no_stats(y)
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)
         return y, xf.view_as(xf), part
 
     @staticmethod

@@ -889,7 +889,7 @@ class Trainer:
         pred = torch.clamp(pred * (torch.median(gt) / torch.median(pred)), min=1e-3, max=80)
         errs = FD.depth_errors(gt, pred)
         for i, metric in enumerate(self.depth_metric_names):
-            v = np.array(errs[i].cpu())
+            v = errs[i].detach().cpu().numpy()
             losses[metric] = losses.get(metric, 0.0) + v if accumulate else v
 
     def val_metrics(self, batches):

@@ -14,6 +14,12 @@ SHAPES = [  # name, Cin, H, W, Cout, K, stride, pad, mode
     ("upconv(0,1) 16->16 @192x640 refl", 16, 192, 640, 16, 3, 1, 1, "reflect"),
     ("upconv(1,1) 96->32 @96x320 refl", 96, 96, 320, 32, 3, 1, 1, "reflect"),
     ("layer2.0 3x3 s2 64->128 @48x160", 64, 48, 160, 128, 3, 2, 1, "zero"),
+    ("layer3.0 3x3 s2 128->256 @24x80", 128, 24, 80, 256, 3, 2, 1, "zero"),
+    ("layer4.0 3x3 s2 256->512 @12x40", 256, 12, 40, 512, 3, 2, 1, "zero"),
+    ("layer2.0 down 1x1 s2 64->128 @48x160", 64, 48, 160, 128, 1, 2, 0, "zero"),
+    ("upconv(1,0) 64->32 @48x160 refl", 64, 48, 160, 32, 3, 1, 1, "reflect"),
+    ("upconv(2,1) 128->64 @48x160 refl", 128, 48, 160, 64, 3, 1, 1, "reflect"),
+    ("upconv(4,0) 512->256 @6x20 refl", 512, 6, 20, 256, 3, 1, 1, "reflect"),
 ]
 def timeit(fn, n):
     fn(); torch.cuda.synchronize()

@@ -46,3 +46,18 @@ print("\nTime with exactly one kernel in flight, by kernel:\n\n| kernel | ms per
 for n, dt in alone.most_common(14):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)[:70]
     print("| `%s` | %.2f |" % (n, dt / steps / 1e6))
+
+# ---- per stream: kernel time per step (a lower bound of the step = the busiest stream's chain) and its first / last kernel
+per = collections.defaultdict(lambda: [0.0, 0, None, None])
+for n, s, e, st in rows:
+    if s >= lo and e <= hi:
+        q = per[st]
+        q[0] += e - s; q[1] += 1
+print("\nKernel time per HIP stream (sum of kernel durations, per step):\n\n| stream | ms per step | launches per step | top kernels (ms per step) |\n|---|---:|---:|---|")
+for st, q in sorted(per.items(), key=lambda kv: -kv[1][0]):
+    top = collections.Counter()
+    for n, s, e, st2 in rows:
+        if st2 == st and s >= lo and e <= hi:
+            nn = re.sub(r"\(anonymous namespace\)::", "", n); nn = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", nn); nn = re.sub(r"^void ", "", nn)[:28]
+            top[nn] += e - s
+    print("| %s | %.2f | %.0f | %s |" % (st, q[0] / steps / 1e6, q[1] / steps, ", ".join("%s %.2f" % (k, v / steps / 1e6) for k, v in top.most_common(5))))
