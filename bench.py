@@ -311,6 +311,8 @@ def main():
     # A pool of distinct step batches, resident in HBM.  The reference's loader yields the step's 12 images as 2 micro-batches of 6;
     # the stacked step consumes them as one batch: concatenate once, outside the timed region.
     n_pool = args.pool if args.pool > 0 else min(48, args.steps + max(args.warmup, 2) + 4)
+    if args.probe_only:
+        n_pool = 1                           # the probes need one batch (and the profile of --probe_only stays free of generator kernels)
     pool = []
     for i in range(n_pool):
         mbs_i = [synthetic.make_scene_batch(tr.batch_size, args.height, args.width, seed=1234 + 1009 * rank + 17 * i + j, clutter=0.5)

@@ -1,9 +1,11 @@
 // BatchNorm2d (training-mode batch statistics) fused with the residual add + ReLU tail of the ResNet blocks.
 // Reference: torchvision ResNet BasicBlock/Bottleneck as driven by networks/resnet_encoder.py:95-101 in
 // train mode (trainer.py:207-211).  HBM-bound: forward = 1 statistics pass + 1 apply pass, backward = 1
-// reduction pass + 1 apply pass; statistics use shifted single-pass sums (shift = median of 9 samples of the
-// channel) so var = E[(x-k)^2] - E[x-k]^2 does not cancel catastrophically.  Deterministic: per-(channel,
-// slice) partials are combined in slice order by every consumer.
+// reduction pass + 1 apply pass; statistics use shifted single-pass sums (large planes: shift = median of 9
+// samples of the channel, stored with the partial sums; small planes: first element, with an exact second pass over the
+// registers when it turns out to be far from the mean; conv-epilogue partials: Chan-merged (sum, M2)) so var =
+// E[(x-k)^2] - E[x-k]^2 does not cancel catastrophically.  Deterministic: per-(channel, slice) partials are combined in
+// slice order by every consumer.
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include <stdint.h>
@@ -71,8 +73,8 @@ __device__ __forceinline__ float bn_shift(const float* __restrict__ plane, long 
 // is exactly what G separate forward passes over the sub-batches would compute (the pose encoders see frames -1 and +1
 // as two passes in the reference; here they are one launch with G = 2).
 template <bool VEC>
-__global__ void __launch_bounds__(NT) k_bn_stats(const float* __restrict__ x, float* __restrict__ part, int N, int C,
-                                                 long HW, int splits) {
+__global__ void __launch_bounds__(NT) k_bn_stats(const float* __restrict__ x, float* __restrict__ part, float* __restrict__ shifts,
+                                                 int N, int C, long HW, int splits) {
     __shared__ float red[4 * 2];
     const int c = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
     const long n0 = (long)g * N;
@@ -90,15 +92,18 @@ __global__ void __launch_bounds__(NT) k_bn_stats(const float* __restrict__ x, fl
     });
     const float r = fd_block_sum_n<2, 4>(acc, red);
     if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
+    // the apply pass reads the shift instead of re-deriving it in every workgroup (nine scattered loads + the sorting network
+    // in front of each of its ~10^4 workgroups cost 0.27 ms per training step)
+    if (threadIdx.x == 0 && s == 0) shifts[(long)g * C + c] = shift;
 }
 
 struct BnStat { float mean, var; };
-__device__ __forceinline__ BnStat bn_finalize(const float* __restrict__ part, const float* __restrict__ x, int c, int C,
-                                              int g, int Ng, long HW, int splits, float M) {
+__device__ __forceinline__ BnStat bn_finalize(const float* __restrict__ part, const float* __restrict__ shifts, int c, int C,
+                                              int g, int splits, float M) {
     float s1 = 0.f, s2 = 0.f;
     const long pb = ((long)g * C + c) * splits;
     for (int s = 0; s < splits; ++s) { s1 += part[(pb + s) * 2]; s2 += part[(pb + s) * 2 + 1]; }
-    const float shift = bn_shift(x + ((long)g * Ng * C + c) * HW, HW);
+    const float shift = shifts[(long)g * C + c];
     const float m = s1 / M;
     BnStat st;
     st.mean = shift + m;
@@ -113,12 +118,12 @@ __global__ void __launch_bounds__(NT) k_bn_apply_train(const float* __restrict__
                                                        float* __restrict__ y, float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, float* __restrict__ save_mean,
                                                        float* __restrict__ save_invstd, const float* __restrict__ part,
-                                                       int N, int C, long HW, int splits, float eps, float momentum,
-                                                       int relu, int G) {
+                                                       const float* __restrict__ shifts, int N, int C, long HW, int splits,
+                                                       float eps, float momentum, int relu, int G) {
     // N = samples per group; blockIdx.y enumerates (sample, channel) over all G*N samples
     const int nc = blockIdx.y, c = nc % C, n = nc / C, g = n / N;
     const float M = (float)N * (float)HW;
-    const BnStat st = bn_finalize(part, x, c, C, g, N, HW, splits, M);
+    const BnStat st = bn_finalize(part, shifts, c, C, g, splits, M);
     const float invstd = 1.0f / sqrtf(st.var + eps);
     if (blockIdx.x == 0 && n == g * N && threadIdx.x == 0) {   // once per (group, channel)
         save_mean[g * C + c] = st.mean;
@@ -129,7 +134,7 @@ __global__ void __launch_bounds__(NT) k_bn_apply_train(const float* __restrict__
         // consecutive forward passes would have applied them
         float rm = running_mean[c], rv = running_var[c];
         for (int gg = 0; gg < G; ++gg) {
-            const BnStat sg = bn_finalize(part, x, c, C, gg, N, HW, splits, M);
+            const BnStat sg = bn_finalize(part, shifts, c, C, gg, splits, M);
             const float unbiased = M > 1.f ? sg.var * (M / (M - 1.f)) : sg.var;
             rm = (1.f - momentum) * rm + momentum * sg.mean;
             rv = (1.f - momentum) * rv + momentum * unbiased;
@@ -280,6 +285,9 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_reduce(const float* __restrict__ 
     });
     const float r = fd_block_sum_n<2, 4>(acc, red);
     if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
+    // the apply pass reads the shift instead of re-deriving it in every workgroup (nine scattered loads + the sorting network
+    // in front of each of its ~10^4 workgroups cost 0.27 ms per training step)
+    if (threadIdx.x == 0 && s == 0) shifts[(long)g * C + c] = shift;
 }
 
 template <bool VEC>
@@ -370,7 +378,11 @@ __global__ void __launch_bounds__(NT) k_bn_train_small(const float* __restrict__
     const float M = (float)N * (float)(4 * q);
     const float wc = weight ? weight[c] : 1.f, bc = bias ? bias[c] : 0.f;
     for (int g = 0; g < G; ++g) {
-        const float shift = bn_shift(x + ((long)g * N * C + c) * 4 * q, 4L * q);
+        // The whole (group, channel) sits in registers.  First try: single-pass sums shifted by the plane's first element (one
+        // broadcast load that travels with the data).  If that shift turns out to sit more than 4 standard deviations from the mean
+        // (var = E[d^2] - E[d]^2 then loses eps * 16 and more) the deviations are summed again from the registers around the now
+        // known mean - exact two-pass statistics, a workgroup-uniform branch taken for the rare channel that needs it.
+        const float shift = x[((long)g * N * C + c) * 4 * q];
         float4 v[SMALL_K];
         long off[SMALL_K];
         float s1 = 0.f, s2 = 0.f;
@@ -389,7 +401,19 @@ __global__ void __launch_bounds__(NT) k_bn_train_small(const float* __restrict__
         }
         block_sum2(s1, s2, red);
         const float m = s1 / M;
-        const float mean = shift + m, var = fmaxf(s2 / M - m * m, 0.f);
+        const float mean = shift + m;
+        float var = fmaxf(s2 / M - m * m, 0.f);
+        if (m * m > 16.f * var) {                                   // uniform: s1, s2 are broadcast values
+            float t2 = 0.f, dummy = 0.f;
+#pragma unroll
+            for (int k = 0; k < SMALL_K; ++k) {
+                if (off[k] < 0) continue;
+                const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+                t2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            block_sum2(t2, dummy, red);
+            var = t2 / M;
+        }
         const float invstd = 1.0f / sqrtf(var + eps);
         if (threadIdx.x == 0) {
             save_mean[g * C + c] = mean; save_invstd[g * C + c] = invstd;
@@ -489,7 +513,7 @@ inline int plane_blocks(long HW) {
 
 extern "C" long fd_bn_ws_floats(int N, int C, int H, int W, int groups) {
     if (groups < 1 || N % groups) return 0;
-    return (long)groups * C * bn_splits(N / groups, C, (long)H * W, groups) * 2;
+    return (long)groups * C * (bn_splits(N / groups, C, (long)H * W, groups) * 2 + 1);      // partial sums + one shift per (group, channel)
 }
 
 extern "C" int fd_bn_train_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
@@ -518,11 +542,13 @@ extern "C" int fd_bn_train_fwd(const float* x, const float* weight, const float*
     auto stats = vec ? k_bn_stats<true> : k_bn_stats<false>;
     auto apply = vec ? k_bn_apply_train<true> : k_bn_apply_train<false>;
 #ifndef FD_ABLATE_NO_BN_STATS    // timing experiment only: the apply pass then normalises with whatever the workspace holds
-    hipLaunchKernelGGL(stats, dim3(C, sp, groups), dim3(NT), 0, st, x, ws, Ng, C, HW, sp);
+    float* shifts = ws + (long)groups * C * sp * 2;              // [group][channel], behind the partial sums
+    hipLaunchKernelGGL(stats, dim3(C, sp, groups), dim3(NT), 0, st, x, ws, shifts, Ng, C, HW, sp);
     FD_LAUNCH_CHECK("fd_bn_train_fwd(stats)");
 #endif
     hipLaunchKernelGGL(apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, weight, bias, residual, y,
-                       running_mean, running_var, save_mean, save_invstd, ws, Ng, C, HW, sp, eps, momentum, relu, groups);
+                       running_mean, running_var, save_mean, save_invstd, ws, ws + (long)groups * C * sp * 2, Ng, C, HW, sp, eps, momentum,
+                       relu, groups);
     FD_LAUNCH_CHECK("fd_bn_train_fwd(apply)");
     return 0;
 }

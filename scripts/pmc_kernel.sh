@@ -14,15 +14,19 @@ for grp in "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_GUI_ACTIVE WRITE_SIZE" \
   echo "pass $i rc=$? ($grp)"
 done
 python - "$TAG" "$MATCH" "$SKIP" "$*" > $R/gpurun_out/${TAG}_pmc.md <<'PY'
-import csv, glob, sys, collections
+import csv, glob, re, sys, collections
 tag, match, skip, cmd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)
+    return re.sub(r"^void ", "", n)[:60]
 acc = collections.defaultdict(lambda: collections.defaultdict(list)); dur = collections.defaultdict(list)
 for i in range(1, 6):
     for f in glob.glob("/tmp/pk_%s_%d/**/*counter_collection.csv" % (tag, i), recursive=True):
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"]:
-                per[r["Kernel_Name"].split("(")[0][-48:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, d in per.items():
             for c, v in d.items():
                 acc[k][c] = v[skip:]
@@ -30,7 +34,7 @@ for i in range(1, 6):
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"]:
-                per[r["Kernel_Name"].split("(")[0][-48:]].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+                per[short(r["Kernel_Name"])].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
         for k, v in per.items():
             dur[k] += v[skip:]
 print("# PMC counters of kernels matching `%s`\n\ncommand: `%s`; rocprofv3 --pmc, one group per pass, --kernel-trace only (scripts/pmc_kernel.sh); "

@@ -11,3 +11,4 @@ python $R/scripts/rocprof_summary.py $DB 8 50 k_adam_dev > $R/gpurun_out/${TAG}_
 head -60 $R/gpurun_out/${TAG}_bench_kernel_stats.md
 python $R/scripts/rocprof_timeline.py $DB > $R/gpurun_out/${TAG}_bench_timeline.md
 cat $R/gpurun_out/${TAG}_bench_timeline.md
+python $R/scripts/rocprof_top.py $DB 7 > $R/gpurun_out/${TAG}_bench_top_dispatches.md
