@@ -16,6 +16,7 @@
 #include "fd_common.h"
 #include "conv_fast.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -95,8 +96,12 @@ struct WinoArgs {
 // VDMA: the raw activation rows go from global memory straight into LDS (buffer_load_dwordx4 ... lds; needs W % 4 == 0 so that a
 // lane's four pixels share an image row): no staging registers, no s_waitcnt + ds_write in the MFMA stream for them - the VGPR ->
 // LDS stores of the activations cost 0.9 of the 6.7 us per chunk-round of the register-staged loop (scripts/wino_ksweep.py).
-template <bool VDMA>
-__global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
+// STATS: the epilogue also reduces the tile to the BatchNorm partial sums (g.stat_part != nullptr).  A template flag, not a run-time
+// test: with `if (g.stat_part)` around writes into the accumulator array the compiler kept BOTH versions of every remaining
+// accumulator alive and emitted two v_accvgpr_read + a v_cndmask per accumulator and ROW - 700 of the 1 430 vector instructions of
+// the epilogue, 15 % of the kernel's time on the layer1 shape (profiles/round3_experiments.md).
+template <bool VDMA, bool STATS>
+__global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))) k_conv_wino(WinoArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,34 +381,49 @@ __global__ void __launch_bounds__(WNT) k_conv_wino(WinoArgs g) {
     const __amdgpu_buffer_rsrc_t rsAdd = fd_make_rsrc(g.add ? g.add : g.Y);
     const bool has_add = final_pass && g.add;
     const int mbase = m0 + 32 * wm + 4 * arow;
+    // the 16 bias values of this lane's rows: one batch of loads in front of the row loop (a load + wait per row serialised 16
+    // memory latencies in the epilogue of every biased - i.e. every decoder - convolution)
+    float bias_r[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = mbase + (r & 3) + 8 * (r >> 2);
-        const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hw : FD_OOB;       // out of range: the store is dropped
-        f32x2 o;
-        o.x = (acc[0][r] + acc[1][r]) + acc[2][r];
-        o.y = (acc[1][r] - acc[2][r]) - acc[3][r];
-        if (final_pass) {
-            const float b = (g.bias && m < g.M) ? g.bias[m] : 0.f;
-            o.x = wino_act(o.x + b, g.act); o.y = wino_act(o.y + b, g.act);
-            if (has_add) {
-                const f32x2 a2 = fd_ldg64(rsAdd, off);
-                o.x += a2.x; o.y += a2.y;
-            }
+    for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
+    if (final_pass && g.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            bias_r[r] = g.bias[m < g.M ? m : g.M - 1];
         }
-        if (!(FD_WINO_ABLATE & 2) || o.x == 123.456f)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsY, (int)off, 0, 0);
-        if (g.stat_part) { const float dd = o.x - o.y; acc[0][r] = o.x + o.y; acc[1][r] = 0.5f * dd * dd; }   // (sum, M2) of this row's two pixels
     }
+    float s1[16], s2[16];                       // STATS: (sum, M2) of each row's two pixels
+    auto rows = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;            // 0: none (compile-time), -1: g.act at run time
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hw : FD_OOB;       // out of range: the store is dropped
+            f32x2 o;
+            o.x = (acc[0][r] + acc[1][r]) + acc[2][r];
+            o.y = (acc[1][r] - acc[2][r]) - acc[3][r];
+            if (final_pass) {
+                o.x += bias_r[r]; o.y += bias_r[r];
+                if (ACT != 0) { o.x = wino_act(o.x, g.act); o.y = wino_act(o.y, g.act); }
+                if (has_add) {
+                    const f32x2 a2 = fd_ldg64(rsAdd, off);
+                    o.x += a2.x; o.y += a2.y;
+                }
+            }
+            if (!(FD_WINO_ABLATE & 2) || o.x == 123.456f)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsY, (int)off, 0, 0);
+            if (STATS) { const float dd = o.x - o.y; s1[r] = o.x + o.y; s2[r] = 0.5f * dd * dd; }
+        }
+    };
+    if (g.act == 0 || !final_pass) rows(std::integral_constant<int, 0>{});
+    else rows(std::integral_constant<int, -1>{});
     // ---- BatchNorm statistics of the tile (fd_conv2d_fwd_stats): (sum, M2 = sum of squared deviations from the partial's OWN
     //      mean) over the 32 pairs of each half-wave for its 16 channel rows, by a transposing butterfly - after the steps 16, 8, 4,
     //      2 a lane holds ONE row's partial, the step 1 completes it: 16 cross-lane moves per statistic instead of 80, fixed order
     //      (deterministic).  Two halves of n elements each merge as M2 = M2a + M2b + (sa - sb)^2 / 2n (pairwise update of Chan
     //      et al.): no E[x^2] - E[x]^2 anywhere, so a channel whose mean is many standard deviations from zero loses nothing.
-    if (g.stat_part && final_pass) {
-        float s1[16], s2[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s1[r] = acc[0][r]; s2[r] = acc[1][r]; }
+    if (STATS && final_pass) {
 #pragma unroll
         for (int step = 0; step < 4; ++step) {
             const int width = 8 >> step;                                   // rows kept by a lane after this step
@@ -730,8 +750,10 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
     if (sp > 1 && !ws) { fd_set_error("wino conv: split-K workspace missing"); return -1; }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const int gx = fd_cdiv((long)d->N * d->H * (d->W / 2), WBN), gy = fd_cdiv(d->Cout, WBM);
@@ -740,8 +762,9 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
     if (dma_on < 0) { const char* e = getenv("FD_WINO_DMA"); dma_on = e ? atoi(e) : 1; }
     // direct-to-LDS activations need 16-byte pieces that stay inside one image row and a 16-byte aligned tensor
     const bool vdma = dma_on && d->W % 4 == 0 && ((uintptr_t)x & 15) == 0;
-    if (vdma) hipLaunchKernelGGL(k_conv_wino<true>, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
-    else hipLaunchKernelGGL(k_conv_wino<false>, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+    const bool stats = g.stat_part != nullptr;
+    auto kern = vdma ? (stats ? k_conv_wino<true, true> : k_conv_wino<true, false>) : (stats ? k_conv_wino<false, true> : k_conv_wino<false, false>);
+    hipLaunchKernelGGL(kern, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
     FD_LAUNCH_CHECK("k_conv_wino");
     if (sp > 1) return fast_splitk_finish_launch(ws, y, bias, out_total, out_total, sp, (long)d->H * d->W, d->Cout, d->act, st, add);
     return 0;

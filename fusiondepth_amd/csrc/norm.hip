@@ -92,8 +92,7 @@ __global__ void __launch_bounds__(NT) k_bn_stats(const float* __restrict__ x, fl
     });
     const float r = fd_block_sum_n<2, 4>(acc, red);
     if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
-    // the apply pass reads the shift instead of re-deriving it in every workgroup (nine scattered loads + the sorting network
-    // in front of each of its ~10^4 workgroups cost 0.27 ms per training step)
+    // the apply pass reads the shift instead of re-deriving it (nine scattered loads + the sorting network) in every workgroup
     if (threadIdx.x == 0 && s == 0) shifts[(long)g * C + c] = shift;
 }
 
@@ -285,9 +284,6 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_reduce(const float* __restrict__ 
     });
     const float r = fd_block_sum_n<2, 4>(acc, red);
     if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
-    // the apply pass reads the shift instead of re-deriving it in every workgroup (nine scattered loads + the sorting network
-    // in front of each of its ~10^4 workgroups cost 0.27 ms per training step)
-    if (threadIdx.x == 0 && s == 0) shifts[(long)g * C + c] = shift;
 }
 
 template <bool VEC>
