@@ -486,6 +486,7 @@ constexpr int LDG = 2 * WGP + 2;
 constexpr int WG_BUF_FLOATS = (WBM + WBN) * LDG;                 // dY rows + X rows
 constexpr int WG_LDS_FLOATS = 2 * WG_BUF_FLOATS;
 
+template <bool REFL>      // reflection (decoder) or zero (ResNet trunk) padding: a template flag keeps the border selects out of the trunk's loop
 __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -526,7 +527,7 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         int c = c0 + rw + 16 * i; c = c < g.C ? c : g.C - 1;
         a_row[i] = 4u * (unsigned)m * hw; b_row[i] = 4u * (unsigned)c * hw;
     }
-    const bool refl = g.pad_mode == 1;
+    constexpr bool refl = REFL;
     const int H2m2 = 2 * g.H - 2;
     const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY), rsX = fd_make_rsrc(g.X);
     f32x2 ra[4], rmid[4];
@@ -819,7 +820,8 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     static int slice_major = -1;
@@ -829,7 +831,8 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
     const int mt = fd_cdiv(d->Cout, WBM);
     if (slice_major == 2 && sp % 8 != 0) g.slice_major = 0;               // the XCD map needs whole groups of 8 slices
     const dim3 grid = g.slice_major == 2 ? dim3((unsigned)(nt * mt * sp)) : (g.slice_major ? dim3(sp, mt, nt) : dim3(nt, mt, sp));
-    hipLaunchKernelGGL(k_wgrad_wino, grid, dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st, g);
+    if (d->pad_mode == 1) hipLaunchKernelGGL(k_wgrad_wino<true>, grid, dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st, g);
+    else hipLaunchKernelGGL(k_wgrad_wino<false>, grid, dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st, g);
     FD_LAUNCH_CHECK("k_wgrad_wino");
     return fast_wgrad_finish_launch(ws, gw, d->Cout, d->Cin, 9, sp, accumulate, st);
 }
