@@ -478,12 +478,17 @@ constexpr int WGP = 16;                                          // pairs per ch
 #define FD_WGRAD_ABLATE 0     // 2 no LDS stores, 4 no border masks, 8 no chunk index arithmetic, 16 no barrier, 32 no operand
 #endif                        // transforms, 64 no operand reads
 
-// Both operands stay RAW in LDS, one row of the chunk's 32 pixels per channel: dY rows [0 .. 31] (+ 2 pad), X rows [0 .. 31] the
-// chunk's pixels, [32] the pixel right of the chunk, [33] the pixel left of it.  The transforms P = (y0, y0+y1, y0-y1, y1) and
-// Q = (d0-d2, d1+d2, d2-d1, d1-d3) are applied when the MFMA operands are read.  Row stride 34 floats: a lane (= channel) reads
-// 8-byte pairs at 34 i mod 64 - 32 different bank pairs; 17.4 KB per chunk and buffer instead of 33 KB of transformed components.
-constexpr int LDG = 2 * WGP + 2;
-constexpr int WG_BUF_FLOATS = (WBM + WBN) * LDG;                 // dY rows + X rows
+// Both operands stay RAW in LDS and the transforms P = (y0, y0+y1, y0-y1, y1), Q = (d0-d2, d1+d2, d2-d1, d1-d3) are applied when the
+// MFMA operands are read.  dY: one row of the chunk's 32 pixels per output channel (stride 34 floats: a lane (= channel) reads
+// 8-byte pairs at 34 i mod 64 - 32 different bank pairs).  X: per input channel and PAIR the four pixels (d0, d1, d2, d3) the pair's
+// products need, i.e. every pair carries its own left / right neighbour pixel (stride 68 floats: 16-byte reads at 4 i mod 64 banks).
+// The loader thread of a pair knows whether it touches an image border and writes the padding value (0, or the mirror pixel) into
+// d0 / d3 itself, so the readers need no border flags, no neighbour-cell reads and no halo cells: the round-3a layout (one raw
+// 34-float row per channel, flags as scalar lane masks) spent 10 scalar + 2 vector instructions and 2 extra LDS reads per k-step on
+// them.  26 KB per chunk and buffer, 52 KB per workgroup: three workgroups per CU.
+constexpr int LDG = 2 * WGP + 2;                                 // dY row stride
+constexpr int LDX = 4 * WGP + 4;                                 // X row stride: 16 pairs x (d0, d1, d2, d3) + 4
+constexpr int WG_BUF_FLOATS = WBM * LDG + WBN * LDX;             // dY rows + X rows
 constexpr int WG_LDS_FLOATS = 2 * WG_BUF_FLOATS;
 
 template <bool REFL>      // reflection (decoder) or zero (ResNet trunk) padding: a template flag keeps the border selects out of the trunk's loop
@@ -529,11 +534,13 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     }
     constexpr bool refl = REFL;
     const int H2m2 = 2 * g.H - 2;
-    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY), rsX = fd_make_rsrc(g.X);
-    f32x2 ra[4], rmid[4];
-    float rh[4];
-    unsigned a_off = FD_OOB, mid_off = FD_OOB, h_off = FD_OOB;
-    unsigned long edge_l = 0, edge_r = 0;                        // bit k: pair k of the prepared chunk sits at the left / right image border
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY);
+    // X with its true size: the 16-byte load of a pair may reach one pixel past the tensor's last one - that lane reads 0.0
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)(4u * (unsigned)g.Nb * (unsigned)g.C * hw), 0x00020000);
+    f32x2 ra[4];
+    float4 rx[4];
+    unsigned a_off = FD_OOB, x_off = FD_OOB;
+    int pf = 0, rf = 0;          // bit 0 / 1: the pair of the PREPARED chunk (pf) / of the chunk whose data sit in ra, rx (rf) starts / ends an image row
     int pc = pp_lo;                                              // first pair of the chunk being prepared
     // (image, row, pair in row) of this thread's pair of the chunk being prepared: divided out once, then advanced by one chunk per
     // call with two carries - the two integer divisions per chunk of the first version were 15 % of the kernel (ablation, profiles/)
@@ -557,13 +564,9 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         const bool okb = ok & (refl | inb);
         const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(ruse * g.W + 2 * j));
         const bool e_left = j == 0, e_right = 2 * j + 2 >= g.W;
-        mid_off = okb ? base : FD_OOB;
-        // the chunk's two halo pixels per channel row: pair 0 fetches its left neighbour, pair 15 its right neighbour (a pair at an
-        // image border has none: its readers substitute the padding value)
-        h_off = (okb & (p == 0) & !e_left) ? base - 4u : ((okb & (p == WGP - 1) & !e_right) ? base + 8u : FD_OOB);
-        // border flags of the 16 pairs, wave-uniform: lanes 0 .. 15 of every wave hold pairs 0 .. 15
-        edge_l = __ballot(e_left) & 0xffffUL;
-        edge_r = __ballot(e_right) & 0xffffUL;
+        // four pixels from column 2j - 1 on; a pair at the left border has no such column: it loads from 2j and shifts (store_row)
+        x_off = okb ? (e_left ? base : base - 4u) : FD_OOB;
+        pf = (e_left ? 1 : 0) | (e_right ? 2 : 0);
         pc += WGP;
         // advance (cn, cy, cj) by one chunk (values past the slice are never used: `ok` is false there)
         cj += g.adv_j;
@@ -576,16 +579,20 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     };
     auto load_row = [&](int i) __attribute__((always_inline)) {
         ra[i] = fd_ldg64(rsY, a_off + a_row[i]);                          // FD_OOB + (< 2^31) stays out of range: reads 0
-        rmid[i] = fd_ldg64(rsX, mid_off + b_row[i]);
-        rh[i] = fd_ldg32(rsX, h_off + b_row[i]);
+        rx[i] = fd_ldg128(rsX, x_off + b_row[i]);
     };
-    const int h_col = p == 0 ? 2 * WGP + 1 : 2 * WGP;
     auto store_row = [&](int buf, int i) __attribute__((always_inline)) {
         float* qa = smem + buf * WG_BUF_FLOATS + (rw + 16 * i) * LDG + 2 * p;
         *reinterpret_cast<f32x2*>(qa) = ra[i];
-        float* qb = qa + WBM * LDG;
-        *reinterpret_cast<f32x2*>(qb) = rmid[i];
-        if (p == 0 || p == WGP - 1) qb[h_col - 2 * p] = rh[i];
+        // (d0, d1, d2, d3) of the pair; column -1 is column 1 (reflect) or 0, column W is column W - 2 (reflect) or 0
+        const bool L = rf & 1, R = rf & 2;
+        float4 d;
+        d.y = L ? rx[i].x : rx[i].y;
+        d.z = L ? rx[i].y : rx[i].z;
+        d.w = L ? rx[i].z : rx[i].w;
+        d.x = L ? (refl ? d.z : 0.f) : rx[i].x;
+        d.w = R ? (refl ? d.y : 0.f) : d.w;
+        *reinterpret_cast<float4*>(smem + buf * WG_BUF_FLOATS + WBM * LDG + (rw + 16 * i) * LDX + 4 * p) = d;
     };
 
     // Wave w owns the 32 (output channels) x 32 (input channels) block (w >> 1, w & 1) of the tile with all four components (one
@@ -599,17 +606,15 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     constexpr int NK = WGP / 2, LS = NK / 2;
-    // border flags of the chunk in LDS buffer `cur` (cl / cr) and of the chunk whose registers are in flight (nl / nr)
-    unsigned long cl = 0, cr = 0, nl = 0, nr = 0;
     if (nchunk > 0) {
         prep_chunk(true);
-        cl = edge_l; cr = edge_r;
+        rf = pf;
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_row(i);
 #pragma unroll
         for (int i = 0; i < 4; ++i) store_row(0, i);
         prep_chunk(1 < nchunk);                                   // chunk 1: loaded now, written to LDS during chunk 0
-        nl = edge_l; nr = edge_r;
+        rf = pf;
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_row(i);
         prep_chunk(2 < nchunk);                                   // offsets of chunk 2, re-loaded during chunk 0
@@ -618,38 +623,19 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
             const int cur = ch & 1;
             // operands of pair k = 2 kk + arow: A = P(dY row 32 wm + acol), B = Q(X row 32 wn + acol)
             const float* pa = smem + cur * WG_BUF_FLOATS + (32 * wm + acol) * LDG + 2 * arow;
-            const float* pb = smem + cur * WG_BUF_FLOATS + (WBM + 32 * wn + acol) * LDG + 2 * arow;
-            const unsigned long ccl = cl, ccr = cr;                      // this chunk's flags (cl / cr move on in mid-chunk)
+            const float* pb = smem + cur * WG_BUF_FLOATS + WBM * LDG + (32 * wn + acol) * LDX + 4 * arow;
             float av[2][4], bv[2][4];
-            f32x2 yy, d12;
-            float d0, d3;
+            f32x2 yy;
+            float4 dd;
             auto read_ops = [&](int kk2) __attribute__((always_inline)) {           // pair 2 kk2 + arow
                 yy = *reinterpret_cast<const f32x2*>(pa + 4 * kk2);
-                d12 = *reinterpret_cast<const f32x2*>(pb + 4 * kk2);
-                // left neighbour: pixel 2k - 1, for pair 0 the halo cell [33]; right neighbour: pixel 2k + 2 ([32] for pair 15)
-                d0 = (kk2 == 0) ? pb[arow ? -1 : 2 * WGP + 1] : pb[4 * kk2 - 1];
-                d3 = pb[4 * kk2 + 2];
+                dd = *reinterpret_cast<const float4*>(pb + 8 * kk2);
             };
-            // Border pairs: column -1 is column 1 (reflect) or 0, column W is column W - 2 (reflect) or 0.  The flags are wave-uniform
-            // per half-wave (lanes 0-31 hold pair 2 kk2, lanes 32-63 pair 2 kk2 + 1), so the select is ONE v_cndmask with a scalar
-            // lane mask built on the scalar unit - the per-lane bit tests of the first version were 8 % of the kernel.
-            auto lane_mask = [&](unsigned long bits, int kk2) __attribute__((always_inline)) -> unsigned long {
-                const unsigned long t = bits >> (2 * kk2);
-                return ((t & 1UL) ? 0x00000000ffffffffUL : 0UL) | ((t & 2UL) ? 0xffffffff00000000UL : 0UL);
-            };
-            auto xform = [&](int nb, int kk2) __attribute__((always_inline)) {
-                float e0, e3;
-                if (FD_WGRAD_ABLATE & 4) { e0 = d0; e3 = d3; }
-                else {
-                    const unsigned long sl = lane_mask(ccl, kk2), sr = lane_mask(ccr, kk2);
-                    const float padl = refl ? d12.y : 0.f, padr = refl ? d12.x : 0.f;
-                    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(e0) : "v"(d0), "v"(padl), "s"(sl));
-                    asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(e3) : "v"(d3), "v"(padr), "s"(sr));
-                }
+            auto xform = [&](int nb) __attribute__((always_inline)) {
                 av[nb][0] = yy.x; av[nb][1] = yy.x + yy.y; av[nb][2] = yy.x - yy.y; av[nb][3] = yy.y;
-                bv[nb][0] = e0 - d12.y; bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = d12.x - e3;
+                bv[nb][0] = dd.x - dd.z; bv[nb][1] = dd.y + dd.z; bv[nb][2] = dd.z - dd.y; bv[nb][3] = dd.y - dd.w;
             };
-            read_ops(0); xform(0, 0);
+            read_ops(0); xform(0);
 #pragma unroll
             for (int kk = 0; kk < NK; ++kk) {
                 const int cb = kk & 1, nb = cb ^ 1;
@@ -664,12 +650,12 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < NK) { if (!(FD_WGRAD_ABLATE & 32)) xform(nb, kk + 1); else { for (int t = 0; t < 4; ++t) { av[nb][t] = av[cb][t]; bv[nb][t] = bv[cb][t]; } } }
+                if (kk + 1 < NK) { if (!(FD_WGRAD_ABLATE & 32)) xform(nb); else { for (int t = 0; t < 4; ++t) { av[nb][t] = av[cb][t]; bv[nb][t] = bv[cb][t]; } } }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk < LS && !(FD_WGRAD_ABLATE & 1)) load_row(kk);                        // ... and re-loaded with the chunk after next
-                if (kk == LS) { cl = nl; cr = nr; nl = edge_l; nr = edge_r; }
+                if (kk == LS) rf = pf;                                                      // the flags travel with the registers
                 if (kk == NK - 1 && !(FD_WGRAD_ABLATE & 8)) prep_chunk(ch + 3 < nchunk);
             }
             __builtin_amdgcn_sched_barrier(0);
