@@ -666,20 +666,21 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     // ---- epilogue: slab[z][m][ky*3 + kx][c] from the four accumulators (C/D layout: column = lane & 31, row = (reg & 3) +
     //      8 * (reg >> 2) + 4 * (lane >> 5))
     const int c = c0 + 32 * wn + acol;
-    if (c >= g.C) return;
-    float* slab = g.slabs + (size_t)bs * ((size_t)g.M * 9 * g.C);
+    // this slice's slab through a buffer resource: 32-bit offsets (a slab is M * 9 * C floats < 2^29), rows / columns past the tensor
+    // are dropped by an out-of-range offset instead of a branch per row
+    const __amdgpu_buffer_rsrc_t rsS = fd_make_rsrc(g.slabs + (size_t)bs * ((size_t)g.M * 9 * g.C));
     const int mb = m0 + 32 * wm + 4 * arow;
+    const unsigned col = (c < g.C) ? 4u * (unsigned)(ky * 3 * g.C + c) : FD_OOB;
+    const unsigned row_step = 4u * 9u * (unsigned)g.C, kx_step = 4u * (unsigned)g.C;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
-        if (m < g.M) {
-            const float M0 = acc[0][r], M1 = acc[1][r], M2 = acc[2][r], M3 = acc[3][r];
-            const float h = 0.5f * (M1 + M2);
-            float* o = slab + ((size_t)m * 9 + ky * 3) * g.C + c;
-            o[0] = M0 + h;
-            o[g.C] = 0.5f * (M1 - M2);
-            o[2 * (size_t)g.C] = h - M3;
-        }
+        const unsigned off = (m < g.M) ? col + (unsigned)m * row_step : FD_OOB;        // FD_OOB + (< 2^31) stays out of range
+        const float M0 = acc[0][r], M1 = acc[1][r], M2 = acc[2][r], M3 = acc[3][r];
+        const float h = 0.5f * (M1 + M2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, M0 + h), rsS, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 0.5f * (M1 - M2)), rsS, (int)(off + kx_step), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h - M3), rsS, (int)(off + 2u * kx_step), 0, 0);
     }
 }
 
