@@ -13,6 +13,7 @@
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include "conv_fast.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -23,12 +24,15 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == 1) return v > 0.f ? v : 0.f;
+// ELU / sigmoid / tanh: ONE out-of-line copy (the unrolled epilogues would otherwise inline three libm routines per accumulator)
+__device__ __attribute__((noinline)) float act_apply_slow(float v, int act) {
     if (act == 2) return v > 0.f ? v : expm1f(v);
     if (act == 3) return 1.0f / (1.0f + expf(-v));
-    if (act == 4) return tanhf(v);
-    return v;
+    return tanhf(v);
+}
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act >= 2) return act_apply_slow(v, act);
+    return act == 1 ? (v > 0.f ? v : 0.f) : v;
 }
 __device__ __forceinline__ int refl_idx(int i, int n) {
     i = i < 0 ? -i : i;
@@ -194,36 +198,75 @@ __device__ __forceinline__ void conv_fast_body(const FastGemmArgs& g, int bx, in
         }
     }
 
-    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).
+    //      Output, residual and bias go through buffer resources with 32-bit byte offsets (every tensor of this path is < 2 GiB: the
+    //      launchers check): a row >= M or a pixel past the end gets an out-of-range offset instead of a branch, the bias values of
+    //      the lane's rows are fetched in one batch in front of the row loop, and the activation switch sits outside it (the first
+    //      version - a bias load + wait, an inlined libm switch and 64-bit address arithmetic per accumulator - executed ~1 150 vector
+    //      instructions per wave and tile, more than the chunk loop of a 3x3 layer).
     const bool final_pass = nsplit == 1;
-    float* Y = final_pass ? g.Y : g.slabs + (size_t)blockIdx.z * g.slab_stride;
-    const float* bias = g.bias;
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(final_pass ? g.Y : g.slabs + (size_t)blockIdx.z * g.slab_stride);
+    const __amdgpu_buffer_rsrc_t rsAdd = fd_make_rsrc(g.add ? g.add : g.Y);
+    const bool has_add = final_pass && g.add;
+    const unsigned cs4 = 4u * (unsigned)g.out_cs;
+    float bias_r[WM][16];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const long p = p0 + wave_n * 32 * WN + j * 32 + acol;
-        if (p >= Np) continue;
-        const int n = (int)(p / plane);
-        const int rem = (int)(p - (long)n * plane);
-        const int y = rem / g.NX, x = rem - y * g.NX;
-        const long po = (long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox);
-        float* yo = Y + po;
-        const float* ao = (final_pass && g.add) ? g.add + po : nullptr;
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias_r[i][r] = 0.f;
+    if (final_pass && g.bias) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
-                if (m < g.M) {
-                    float v = acc[i][j][r];
-                    if (final_pass) {
-                        if (bias) v += bias[m];
-                        v = act_apply(v, g.act);
-                        if (ao) v += ao[(long)m * g.out_cs];
-                    }
-                    yo[(long)m * g.out_cs] = v;
-                }
+                bias_r[i][r] = g.bias[m < g.M ? m : g.M - 1];
             }
     }
+    auto rows = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;                  // 0: none (compile time), -1: g.act at run time
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const long p = p0 + wave_n * 32 * WN + j * 32 + acol;
+            unsigned pix = FD_OOB;
+            if (p < Np) {
+                const int n = (int)(p / plane);
+                const int rem = (int)(p - (long)n * plane);
+                const int y = rem / g.NX, x = rem - y * g.NX;
+                pix = 4u * (unsigned)((long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox));
+            }
+            unsigned off[WM][16];
+            float addv[WM][16];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wave_m * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                    off[i][r] = (m < g.M) ? pix + (unsigned)m * cs4 : FD_OOB;              // FD_OOB + (< 2^31) stays out of range
+                    addv[i][r] = 0.f;
+                }
+            if (has_add) {                                   // the second gradient of this tensor: all loads in flight, one wait
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) addv[i][r] = fd_ldg32(rsAdd, off[i][r]);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (final_pass) {
+                        v += bias_r[i][r];
+                        if (ACT != 0) v = act_apply(v, g.act);
+                        v += addv[i][r];
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, (int)off[i][r], 0, 0);
+                }
+        }
+    };
+    if (g.act == 0 || !final_pass) rows(std::integral_constant<int, 0>{});
+    else rows(std::integral_constant<int, -1>{});
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int BKC>
