@@ -837,11 +837,58 @@ def _conv_backward(ctx, gy, gx_add=None):
         gw = tw if direct else torch.empty_like(w)
         gb = (tb if direct else _empty((d.Cout,), x)) if ctx.has_bias else None
         ws = _empty((plan.weight_ws(),), x)
+        if direct and getattr(ctx.params[0], "_fd_side_wgrad", False):
+            # a layer of the decoder's serial chain (enable_side_wgrad): its weight gradient is a leaf of the backward graph - it
+            # runs on a side stream beside the data gradients of the following layers; the gradient-ready notification is given
+            # with that stream current, so that a data-parallel bucket is ordered behind the kernel that really finishes it
+            side = _wgrad_stream()                     # ordered after everything queued so far (gy is complete)
+            with torch.cuda.stream(side):
+                call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), 1, stream())
+                _grad_ready(ctx.params[0], ctx.params[1] if ctx.has_bias else None)
+            _WGRAD_KEEPALIVE.append((x, gy, ws))
+            return gx, None, None
         call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws), int(direct), stream())
         if direct:
             gw = gb = None          # already accumulated in place
             _grad_ready(ctx.params[0], ctx.params[1] if ctx.has_bias else None)
     return gx, gw, gb
+
+
+# ---- weight gradients of the decoder on a side stream -----------------------------------------------------------------------
+# Decoder -> loss -> decoder is the serial section of the step: one kernel at a time on the main stream, at batch 12 and 16-128
+# channels, while the encoder streams have little or nothing to run.  In a conv's backward only the data gradient feeds the next
+# layer; the weight gradient (+ its slab reduction + the bias sums) is a leaf, so for parameters marked by ``enable_side_wgrad`` it
+# is issued on ONE side stream per issuing stream.  The tensors those kernels read are kept alive until ``join_wgrad_streams``
+# (the caching allocator would otherwise hand their memory to later kernels of the issuing stream).  Round 2's FD_ASYNC_WGRAD did
+# this for EVERY convolution - slower (the encoders' streams already fill the chip) and its notifications were given on the wrong
+# stream; this is the decoder only, opt-in per parameter.
+_WGRAD_STREAMS = {}
+_WGRAD_KEEPALIVE = []
+
+
+def enable_side_wgrad(params, on=True):
+    for p in params:
+        if p.dim() == 4:
+            p._fd_side_wgrad = bool(on)
+
+
+def join_wgrad_streams():
+    """Order every side-stream weight gradient before what follows on the current stream (optimiser / all-reduce)."""
+    if not _WGRAD_STREAMS:
+        return
+    cur = torch.cuda.current_stream()
+    for st in _WGRAD_STREAMS.values():
+        cur.wait_stream(st)
+    _WGRAD_KEEPALIVE.clear()
+
+
+def _wgrad_stream():
+    cur = torch.cuda.current_stream()
+    st = _WGRAD_STREAMS.get(cur.cuda_stream)
+    if st is None:
+        st = _WGRAD_STREAMS[cur.cuda_stream] = torch.cuda.Stream()
+    st.wait_stream(cur)
+    return st
 
 
 class _Conv2d(torch.autograd.Function):

@@ -174,6 +174,10 @@ class Trainer:
         FD.evict_dead_weight_layouts()         # cached layouts / re-layout plan of trainers that no longer exist
         FD.enable_weight_cache(self.parameters_to_train)
         FD.enable_direct_grad(self.parameters_to_train)
+        # the depth decoder is the serial section of the step: its weight gradients leave the main stream (functional.enable_side_wgrad)
+        for k in os.environ.get("FD_SIDE_WGRAD", "depth").split(","):
+            if k in self.models:
+                FD.enable_side_wgrad(self.models[k].parameters())
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.adam_step_count = 0
@@ -499,6 +503,7 @@ class Trainer:
         cur = torch.cuda.current_stream()
         for st in self._streams:
             cur.wait_stream(st)
+        FD.join_wgrad_streams()
 
     def _fork(self, idx):
         """Side stream #idx, ordered after everything already queued on the current stream."""
