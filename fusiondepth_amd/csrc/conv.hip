@@ -519,6 +519,46 @@ __global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* _
     }
 }
 
+// Reflect-padded data gradient without the padded-grid round trip: the interior of the padded grid IS the zero-padded data gradient
+// (written straight to gx by the convolution kernel), only the one-pixel ring needs the adjoint of ReflectionPad2d(1).  The ring
+// arrives as four strips per (image, channel) - top [W+2], bottom [W+2], left [H], right [H] (padded rows 1 .. H) - and folds as
+//   gx[1][x] += top[x+1], gx[H-2][x] += bottom[x+1], gx[y][1] += left[y], gx[y][W-2] += right[y],
+// the corners top[0] / top[W+1] / bottom[0] / bottom[W+1] going to (1,1) / (1,W-2) / (H-2,1) / (H-2,W-2).  One thread per target pixel
+// (rows 1 / H-2, columns 1 / W-2) sums every strip value that maps to it in a fixed order: deterministic, also when H - 2 == 1.
+__global__ void __launch_bounds__(256) k_reflect_ring_fold(const float* __restrict__ ring, float* __restrict__ gx, long planes, int H,
+                                                           int W) {
+    const int rows2 = (H - 2 != 1) ? 2 : 1, cols2 = (W - 2 != 1) ? 2 : 1;     // distinct target rows / columns
+    const int nrow_t = rows2 * W, ncol_t = (H - rows2) * cols2, nt = nrow_t + ncol_t;
+    const long ring_plane = 2L * (W + 2) + 2L * H;
+    const long total = planes * nt;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pl = i / nt;
+        const int t = (int)(i - pl * nt);
+        int y, x;
+        if (t < nrow_t) { const int r = t / W; x = t - r * W; y = r == 0 ? 1 : H - 2; }
+        else {
+            const int q = t - nrow_t, k = q / (H - rows2), j = q - k * (H - rows2);
+            x = k == 0 ? 1 : W - 2;
+            const int r_lo = (rows2 == 2 && H - 2 < 1) ? H - 2 : 1, r_hi = (rows2 == 2 && H - 2 < 1) ? 1 : H - 2;   // sorted target rows
+            y = j;
+            if (y >= r_lo) ++y;
+            if (rows2 == 2 && y >= r_hi) ++y;
+        }
+        const float* top = ring + pl * ring_plane;
+        const float* bot = top + (W + 2);
+        const float* lef = bot + (W + 2);
+        const float* rig = lef + H;
+        // padded rows {0 if y == 1, H+1 if y == H-2} x padded columns {x+1, 0 if x == 1, W+1 if x == W-2}; padded row y+1 x
+        // padded columns {0 if x == 1, W+1 if x == W-2}
+        float s = 0.f;
+        if (y == 1) { s += top[x + 1]; if (x == 1) s += top[0]; if (x == W - 2) s += top[W + 1]; }
+        if (y == H - 2) { s += bot[x + 1]; if (x == 1) s += bot[0]; if (x == W - 2) s += bot[W + 1]; }
+        if (x == 1) s += lef[y];
+        if (x == W - 2) s += rig[y];
+        gx[pl * (long)H * W + (long)y * W + x] += s;
+    }
+}
+
 // Adjoint of ReflectionPad2d(1): fold the gradient on the padded grid [H+2][W+2] back onto [H][W].
 __global__ void k_reflect_fold(const float* __restrict__ gp, float* __restrict__ gx, long planes, int H, int W) {
     const int Wp = W + 2;
@@ -832,6 +872,12 @@ extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
         f.osy = 1; f.osx = 1;
         f.out_total = (long)d->N * d->Cin * f.NY * f.NX;
         slabs = fast_splitk_slab_floats(f, nullptr);
+        if (d->pad_mode == 1) {                        // the interior-plus-ring path runs the H x W problem: its own split count
+            f.NY = d->H; f.NX = d->W;
+            f.out_total = (long)d->N * d->Cin * f.NY * f.NX;
+            const long s2 = fast_splitk_slab_floats(f, nullptr);
+            slabs = s2 > slabs ? s2 : slabs;
+        }
     }
     return wt + padded + slabs;
 }
@@ -919,6 +965,49 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
     if (d->stride == 1) {
         g.sy = 1; g.da = 1; g.sx = 1; g.db = 1;
         g.osy = 1; g.ooy = 0; g.osx = 1; g.oox = 0;
+        static int ring_on = -1;
+        if (ring_on < 0) { const char* e = getenv("FD_REFLECT_RING"); ring_on = e ? atoi(e) : 1; }
+        if (d->pad_mode == 1 && fast && ring_on && KH == 3 && KW == 3 && d->pad == 1 && d->H >= 2 && d->W >= 2 &&
+            (long)d->H * d->W >= (ring_on > 1 ? ring_on : 16384)) {      // smaller planes (measured up to 48 x 160): four thin launches + their fold cost more than the fold pass
+            // Reflect padding, 3x3: (1) the interior of the padded grid = the zero-padded data gradient, straight into gx (with the
+            // second gradient of the tensor, if any, in the epilogue); (2) the ring's four strips as ONE grouped launch of thin
+            // problems into a small buffer; (3) k_reflect_ring_fold.  The padded-grid gradient + k_reflect_fold of rounds 1-2 wrote
+            // and re-read the whole (H+2) x (W+2) tensor on the decoder's serial chain (0.65 ms per training step).
+            g.NY = d->H; g.NX = d->W; g.oy = -1; g.ox = -1;
+            g.Y = gx; g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin;
+            add_in_kernel = false;       // a second gradient of the tensor (not used by the decoder) is added after the fold, so
+                                         // that the sum keeps the order (interior + ring) + other of the fold path, bit for bit
+            if (int rc = run(KH, KW, KH - 1, -1, KW - 1, -1, true)) return rc;
+            const int Hp = d->H, Wp2 = d->W + 2;
+            const long ring_plane = 2L * Wp2 + 2L * Hp;
+            float* ring = gpad;                                   // [N][Cin][top W+2 | bottom W+2 | left H | right H]
+            FastGemmArgs f = {};
+            FastGemmGroup q = {};
+            f.A = wt; f.X = gy; f.Y = ring; f.bias = nullptr;
+            f.M = d->Cin; f.C = d->Cout; f.T = 9; f.TB = 3; f.K = 9 * d->Cout;
+            f.Nb = d->N; f.Hi = s.Ho; f.Wi = s.Wo;
+            f.sy = 1; f.da = 1; f.sx = 1; f.db = 1; f.pad_mode = 0;       // the flip is in the weight layout (kh0 = 2, dkh = -1)
+            f.osy = 1; f.osx = 1; f.ooy = 0; f.oox = 0;
+            f.out_total = (long)d->N * d->Cin * ring_plane; f.slab_stride = f.out_total; f.slabs = nullptr; f.add = nullptr;
+            q.n = 4; q.own_out = 1;
+            const int ny[4] = {1, 1, Hp, Hp}, nx[4] = {Wp2, Wp2, 1, 1};
+            const int oy4[4] = {-2, -2 + d->H + 1, -1, -1}, ox4[4] = {-2, -2, -2, -2 + d->W + 1};
+            const long yoff[4] = {0, Wp2, 2L * Wp2, 2L * Wp2 + Hp};
+            for (int j = 0; j < 4; ++j) {
+                q.A[j] = wt; q.NY[j] = ny[j]; q.NX[j] = nx[j]; q.oy[j] = oy4[j]; q.ox[j] = ox4[j]; q.ooy[j] = 0; q.oox[j] = 0;
+                q.T[j] = 9; q.TB[j] = 3; q.K[j] = 9 * d->Cout;
+                q.y_off[j] = yoff[j]; q.out_w[j] = nx[j]; q.out_cs[j] = ring_plane; q.out_ns[j] = ring_plane * d->Cin;
+            }
+            f.NY = q.NY[0]; f.NX = q.NX[0]; f.oy = q.oy[0]; f.ox = q.ox[0];
+            f.out_w = q.out_w[0]; f.out_cs = q.out_cs[0]; f.out_ns = q.out_ns[0];
+            if (int rc = fast_gemm_group_launch(f, q, st)) return rc;
+            const long planes = (long)d->N * d->Cin;
+            const int rows2 = (d->H - 2 != 1) ? 2 : 1, cols2 = (d->W - 2 != 1) ? 2 : 1;
+            const long targets = planes * ((long)rows2 * d->W + (long)(d->H - rows2) * cols2);
+            hipLaunchKernelGGL(k_reflect_ring_fold, dim3((unsigned)ew_blocks(targets)), dim3(256), 0, st, ring, gx, planes, d->H, d->W);
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(ring fold)");
+            return add_after();
+        }
         if (d->pad_mode == 1) {   // gradient on the reflect-padded grid, then fold (adjoint of ReflectionPad2d(1))
             g.NY = d->H + 2; g.NX = d->W + 2; g.oy = -(KH - 1); g.ox = -(KW - 1);
             g.Y = gpad; g.out_w = d->W + 2;

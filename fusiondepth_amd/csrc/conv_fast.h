@@ -28,6 +28,11 @@ struct FastGemmArgs {
 struct FastGemmGroup {
     const float* A[4];
     int NY[4], NX[4], oy[4], ox[4], ooy[4], oox[4], T[4], TB[4], K[4];
+    // output map per problem (used when own_out != 0: the problems write to different places of the buffer Y, e.g. the four sides
+    // of a padded grid's ring): Y + y_off[j] floats, row width out_w[j], channel stride out_cs[j], image stride out_ns[j]
+    long y_off[4], out_ns[4], out_cs[4];
+    int out_w[4];
+    int own_out;
     int first_bx[5];
     int n;
 };

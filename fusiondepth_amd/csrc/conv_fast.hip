@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_conv_fast_grp(FastGe
     while (j + 1 < q.n && (int)blockIdx.x >= q.first_bx[j + 1]) ++j;
     g.A = q.A[j]; g.NY = q.NY[j]; g.NX = q.NX[j]; g.oy = q.oy[j]; g.ox = q.ox[j]; g.ooy = q.ooy[j]; g.oox = q.oox[j];
     g.T = q.T[j]; g.TB = q.TB[j]; g.K = q.K[j];
+    if (q.own_out) { g.Y += q.y_off[j]; g.out_ns = q.out_ns[j]; g.out_cs = q.out_cs[j]; g.out_w = q.out_w[j]; }
     g.xcd_swizzle = 0;
     conv_fast_body<WAVES_M, WAVES_N, WM, WN, BKC>(g, (int)blockIdx.x - q.first_bx[j], q.first_bx[j + 1] - q.first_bx[j]);
 }

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-( time timeout 2000 python -m pytest tests -q -m gpu -x --durations=5 ) > gpurun_out/r3_tests10.log 2>&1
-grep -n "passed\|failed\|FAILED\|Error" gpurun_out/r3_tests10.log | tail -5
-python scripts/determinism_check.py 2>&1 | tail -6
+run() { echo -n "[$1] : "; ( env $1 timeout 300 python bench.py --steps 20 --warmup 5 --no_roofline --no_cpu_baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | tr '\n' ' ' ); echo; }
+for i in 1 2 3; do
+  run "FD_REFLECT_RING=0"
+  run "FD_REFLECT_RING=1"
+done
