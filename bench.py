@@ -364,11 +364,14 @@ def main():
     if launch == "auto":
         # Both launch paths run the same kernels on the same streams; which one keeps the GPU busier depends on the host
         # (Python issue rate vs hipGraphLaunch cost per node).  Decide inside the untimed warm-up, identically on all ranks.
-        eager_step()                                         # allocator / autotune warm-up
-        t_eager = timed(eager_step, 2)
-        graph_step(); graph_step()                           # eager warm-up on the capture stream + capture
-        t_graph = timed(graph_step, 2)
-        launch = "eager" if t_eager <= t_graph else "graph"
+        # Best of three single steps each, after the path's own warm-up: the first steps of either path pay for allocator growth,
+        # lazily built weight layouts and the side-stream setup (one slow trial step once made this choose the slower path).
+        for _ in range(3):
+            eager_step()
+        t_eager = min(timed(eager_step, 1) for _ in range(3))
+        graph_step(); graph_step(); graph_step()             # eager warm-up on the capture stream + capture + first replay
+        t_graph = min(timed(graph_step, 1) for _ in range(3))
+        launch = "graph" if t_graph < 0.97 * t_eager else "eager"
         if rank == 0:
             print("[bench] warm-up: eager %.2f ms/step, hipGraph replay %.2f ms/step -> %s" % (1e3 * t_eager, 1e3 * t_graph, launch),
                   file=sys.stderr, flush=True)

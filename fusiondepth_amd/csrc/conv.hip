@@ -965,8 +965,8 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
     if (d->stride == 1) {
         g.sy = 1; g.da = 1; g.sx = 1; g.db = 1;
         g.osy = 1; g.ooy = 0; g.osx = 1; g.oox = 0;
-        static int ring_on = -1;
-        if (ring_on < 0) { const char* e = getenv("FD_REFLECT_RING"); ring_on = e ? atoi(e) : 1; }
+        int ring_on = 1;                       // read per call (reflect-padded layers only: 20 calls per step), so that tests can switch it
+        if (d->pad_mode == 1) { const char* e = getenv("FD_REFLECT_RING"); ring_on = e ? atoi(e) : 1; }
         if (d->pad_mode == 1 && fast && ring_on && KH == 3 && KW == 3 && d->pad == 1 && d->H >= 2 && d->W >= 2 &&
             (long)d->H * d->W >= (ring_on > 1 ? ring_on : 16384)) {      // smaller planes (measured up to 48 x 160): four thin launches + their fold cost more than the fold pass
             // Reflect padding, 3x3: (1) the interior of the padded grid = the zero-padded data gradient, straight into gx (with the

@@ -581,13 +581,15 @@ def test_batchnorm_statistics_of_a_near_constant_map(FD):
 
 
 @pytest.mark.parametrize("N,Ci,Co,H,W", [(2, 64, 32, 3, 6), (1, 128, 64, 2, 4), (2, 96, 32, 5, 8), (1, 16, 16, 4, 10), (2, 64, 64, 12, 40),
-                                         (1, 32, 48, 3, 3), (1, 512, 256, 6, 20), (2, 32, 16, 7, 5)])
-def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W):
+                                         (1, 32, 48, 3, 3), (1, 512, 256, 6, 20), (2, 32, 16, 7, 5),
+                                         (2, 96, 32, 96, 320), (1, 16, 16, 192, 640), (1, 288, 32, 96, 320)])      # >= 16 384 pixels: the ring path by default
+def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W, monkeypatch):
     """conv3x3(ReflectionPad2d(1)(x)) - every DepthDecoder convolution (networks/depth_decoder.py, layers.py Conv3x3): its data
     gradient = the zero-padded data gradient written straight to gx + the padded grid's one-pixel ring (four strips, one grouped
     launch) folded back onto rows 1 / H-2 and columns 1 / W-2 (k_reflect_ring_fold), including images so small that the two target
     rows / columns coincide (H = 3) or are the border itself (H = 2), odd sizes, and a second gradient joining at the input
     (conv2d_tap).  Against torch's float64 autograd of F.pad(mode="reflect") + conv2d."""
+    monkeypatch.setenv("FD_REFLECT_RING", "2")        # planes from 2 pixels on (default: from 16 384 - smaller ones keep the fold pass)
     g = torch.Generator().manual_seed(N * 131 + H)
     x = torch.randn(N, Ci, H, W, generator=g)
     w = torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5
@@ -600,6 +602,10 @@ def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W)
     relclose(cpu(y), y64.detach().numpy(), "forward", arel=2e-6)
     gx = torch.autograd.grad((y * dev(cot)).sum(), xg)[0]
     relclose(cpu(gx), gx64, "data gradient", arel=3e-6)
+    monkeypatch.setenv("FD_REFLECT_RING", "0")        # the fold path gives the same gradient up to the order of the ring's additions
+    gx_fold = torch.autograd.grad((FD.conv2d(xg, dev(w), None, 1, 1, "reflect") * dev(cot)).sum(), xg)[0]
+    relclose(cpu(gx), cpu(gx_fold), "ring path vs fold path", arel=1e-6)
+    monkeypatch.setenv("FD_REFLECT_RING", "2")
     xg2 = dev(x).requires_grad_(True)
     y2, xt = FD.conv2d_tap(xg2, dev(w), None, 1, 1, "reflect")
     gx2 = torch.autograd.grad((y2 * dev(cot)).sum() + (xt * xt).sum(), xg2)[0]
