@@ -492,6 +492,52 @@ def test_gradients_are_run_to_run_identical_under_gpu_contention(interleave):
             assert torch.equal(g, ref), "repetition %d: %d gradient entries differ" % (rep, int((g != ref).sum()))
 
 
+def test_decoder_weight_gradients_on_the_side_stream_are_bit_identical(monkeypatch):
+    """functional.enable_side_wgrad (default for the depth decoder): its weight gradients, slab reductions and bias sums run on a side
+    stream beside the data gradients of the following layers.  Same kernels, same accumulation targets: the gradient buffer after a
+    backward pass must equal the all-on-one-stream result bit for bit, also under background GPU load (a tensor freed or reused on
+    the main stream while the side stream still reads it would show up here), and the side stream must really have been used."""
+    from fusiondepth_amd import functional as FD
+    from fusiondepth_amd.trainer import Trainer
+    B, H, W = 2, 64, 96
+    inp, noise = _batch(B, H, W, 991)
+    ginp = {k: v.cuda() for k, v in inp.items()}
+    ginp["_noise"] = [n.cuda() for n in noise]
+    grads = {}
+    bg = torch.cuda.Stream()
+    junk = [torch.randn(s, s, device="cuda") for s in (512, 2048)]
+    for mode in ("none", "depth"):
+        monkeypatch.setenv("FD_SIDE_WGRAD", mode)
+        torch.manual_seed(4321)                                  # the same initial weights for both trainers
+        tr = Trainer(_opts(batch_size=B), verbose=False)
+        marked = [p for p in tr.models["depth"].parameters() if getattr(p, "_fd_side_wgrad", False)]
+        assert (len(marked) > 0) == (mode == "depth")
+        for rep in range(3):
+            tr.flat.zero_grad()
+            saved = {k: {n: b.clone() for n, b in m.named_buffers()} for k, m in tr.models.items()}
+            torch.cuda.synchronize()
+            with torch.cuda.stream(bg):
+                for i in range(10 + 9 * rep):
+                    junk[i % 2] @ junk[i % 2]
+            outputs, losses = tr.process_batch(ginp, groups=tr.accumulate_step)
+            losses["loss"].backward()
+            if mode == "depth":
+                assert len(FD._WGRAD_KEEPALIVE) >= len(marked) // 2          # the side stream has pending work to be joined
+            tr._join_side_streams()
+            assert not FD._WGRAD_KEEPALIVE
+            torch.cuda.synchronize()
+            g = tr.flat.flat_grad.clone()
+            with torch.no_grad():
+                for k, m in tr.models.items():
+                    for n, b in m.named_buffers():
+                        b.copy_(saved[k][n])
+            if mode in grads:
+                assert torch.equal(g, grads[mode]), "%s, repetition %d" % (mode, rep)
+            grads[mode] = g
+    assert float(grads["none"].abs().max()) > 0
+    assert torch.equal(grads["none"], grads["depth"]), "%d gradient entries differ" % int((grads["none"] != grads["depth"]).sum())
+
+
 def test_training_trajectory_is_reproducible_across_runs():
     """Three optimiser steps (forward, backward, Adam, batched weight re-layout, stream forks / joins across step boundaries)
     repeated from the same initial state under background GPU load land on bit-identical parameters."""
