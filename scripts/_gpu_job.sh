@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for m in 64 32 16; do echo "== FD_WINO_MIN_M=$m"; FD_WINO_MIN_M=$m python scripts/conv_probe.py 30 12 2>&1 | grep "refl" | cut -c1-70; done
-run() { echo -n "[$1] : "; ( env $1 timeout 300 python bench.py --steps 20 --warmup 5 --no_roofline --no_cpu_baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | tr '\n' ' ' ); echo; }
-for i in 1 2; do
-  run "FD_WINO_MIN_M=64"
-  run "FD_WINO_MIN_M=32"
-  run "FD_WINO_MIN_M=16"
-done
+mkdir -p gpurun_out
+( time python -c "import __graft_entry__ as g; g.smoke()" ) 2>&1 | tail -6
+( time python bench.py ) > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "default bench rc=$?"; tail -3 gpurun_out/bench_default.err; cut -c1-400 gpurun_out/bench_default.json
+python bench.py --gpus 2 --steps 2 --warmup 1 2>&1 | tail -2; echo "gpus2 rc=$?"
+( time timeout 2000 python -m pytest tests -q -m gpu -x ) > gpurun_out/r3_tests11.log 2>&1; grep -n "passed\|failed\|FAILED" gpurun_out/r3_tests11.log | tail -3; tail -4 gpurun_out/r3_tests11.log | head -3

@@ -35,6 +35,7 @@ from oracle import scatter as OS, trainer as OT      # noqa: E402
 H, W, B, STEPS, EVERY, SEED, LR = 192, 640, 2, 20, 2, 3, 1e-4      # the reference default --learning_rate 1e-4 at --batch_size 2 -> Adam lr 2.5e-5 (trainer.py:38)
 TRAIN_SEED, VAL_SEEDS = 2000, (7001, 7002)
 ENSEMBLE = 3        # extra float32 runs whose initial weights are moved by ONE float32 ulp each (random direction)
+ENSEMBLE_SHORT, SHORT_STEPS = 6, 8     # six more such runs over the first 8 steps only: the checkpoints where 0.001 is still in reach
 
 
 def scene_batch(seed):
@@ -78,7 +79,7 @@ def evaluate(ot, dtype):
     return acc / len(VAL_SEEDS)
 
 
-def run(dtype, ulp_seed=None):
+def run(dtype, ulp_seed=None, steps=None):
     opt = OT.default_opt(height=H, width=W, batch_size=B, num_layers=18, learning_rate=LR)
     m = models(opt)
     if ulp_seed is not None:        # the same reference, one rounding away: every weight to a neighbouring float32
@@ -93,7 +94,7 @@ def run(dtype, ulp_seed=None):
     ot = OT.OracleTrainer(opt, models=m)
     assert abs(ot.hp.learning_rate - 2.5e-5) < 1e-12 and ot.hp.accumulate_step == 1
     losses, metrics = [], [evaluate(ot, dtype)]
-    for step in range(STEPS):
+    for step in range(STEPS if steps is None else steps):
         inp, noise = scene_batch(TRAIN_SEED + step)
         if dtype == torch.float64:
             inp = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in inp.items()}
@@ -109,16 +110,21 @@ def run(dtype, ulp_seed=None):
 if __name__ == "__main__":
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     path = os.path.join(HERE, "absrel_r18_192x640_b2.npz")
-    if "--ensemble-only" in sys.argv:      # keep the float32 / float64 runs of the existing fixture, (re)make the perturbed ones
+    if "--ensemble-only" in sys.argv or "--short-only" in sys.argv:      # keep the runs the existing fixture already holds
         out = dict(np.load(path))
     else:
         out = {"steps": np.int64(STEPS), "every": np.int64(EVERY)}
         for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
             out["%s/loss" % tag], out["%s/metrics" % tag] = run(dt)
-    for k in range(ENSEMBLE):
+    for k in range(0 if "--short-only" in sys.argv else ENSEMBLE):
         out["f32p%d/loss" % k], out["f32p%d/metrics" % k] = run(torch.float32, ulp_seed=500 + k)
         print("one-ulp run %d |abs_rel - f32|:" % k, np.abs(out["f32p%d/metrics" % k][:, 0] - out["f32/metrics"][:, 0]))
     out["ensemble"] = np.int64(ENSEMBLE)
+    if "--short-only" in sys.argv or "--ensemble-only" not in sys.argv:
+        for k in range(ENSEMBLE_SHORT):
+            out["f32s%d/loss" % k], out["f32s%d/metrics" % k] = run(torch.float32, ulp_seed=900 + k, steps=SHORT_STEPS)
+            print("short one-ulp run %d |abs_rel - f32|:" % k, np.abs(out["f32s%d/metrics" % k][:, 0] - out["f32/metrics"][:len(out["f32s%d/metrics" % k]), 0]))
+        out["ensemble_short"] = np.int64(ENSEMBLE_SHORT)
     np.savez_compressed(path, **out)
     print("abs_rel f32:", out["f32/metrics"][:, 0])
     print("abs_rel f64:", out["f64/metrics"][:, 0])

@@ -207,11 +207,15 @@ def test_absrel_after_equal_steps_vs_oracle_fixture(golden):
     AbsRel lies in a meaningful range - 0.31 .. 0.60 - instead of ~1 against random ground truth), AbsRel of the held-out scenes
     after 0, 2, .. 20 steps.  The fixture holds the oracle's float32 AND float64 runs: float64 is ground truth, |float32 - float64|
     is what the reference's own arithmetic drifts by (from-scratch training is chaotic: 4e-7 after 2 steps, 2e-4 after 4, 4e-3
-    after 6, 1e-2 after 20 - beyond step 4 the reference cannot hold 0.001 against ITSELF in float64), and three more float32 runs
-    of the oracle whose initial weights were each moved by ONE ulp (1.2e-3 apart after 4 steps, 3e-3 after 6).  Bound at every
-    checkpoint: |AbsRel_HIP - AbsRel_oracle32| <= 0.001 absolute, or twice the spread of the oracle's own runs {float64, one-ulp}
-    around its float32 run where that exceeds 0.001 (the HIP trainer measures 3e-6 after 2 steps, 1.3e-3 after 4 - inside the
-    one-ulp runs' 0.8 - 1.2e-3); all values go to the terminal summary."""
+    after 6, 1e-2 after 20 - beyond step 4 the reference cannot hold 0.001 against ITSELF in float64), and nine more float32 runs
+    of the oracle whose initial weights were each moved by ONE ulp (three over all 20 steps, six over the first 8): after 2 steps
+    they sit within 1.5e-6 of the unperturbed run, after 4 steps 0.2 - 1.8e-3 away (all nine on the same side: the unperturbed
+    run is the lowest of the ten), after 6 steps up to 4e-3.  Bound at every checkpoint: |AbsRel_HIP - AbsRel_oracle32| <= 0.001
+    absolute, or three times the spread of the oracle's own runs {float64, one-ulp} around its float32 run where that exceeds
+    0.001.  The HIP trainer differs from the oracle by the rounding of every kernel in every step, not by one ulp once: 4e-6
+    after 2 steps (a few times the one-ulp runs' 1.5e-6, asserted <= 5e-5 - the checkpoint where 0.001 means something), and
+    1.3e-3 .. 2.5e-3 after 4 steps depending on the build (any change of summation order moves it: the same amplification, from
+    a few times the one-ulp perturbation).  All values go to the terminal summary."""
     import conftest
     import make_absrel as MA
     g = golden("absrel_r18_192x640_b2")
@@ -236,13 +240,15 @@ def test_absrel_after_equal_steps_vs_oracle_fixture(golden):
     assert_close(losses[0], g["f32/loss"][0], rtol=1e-4, atol=0, what="loss of step 0")
     assert 0.03 < f64.min() and f64.max() < 1.0, "fixture AbsRel out of the meaningful range: %s" % f64
     others = [f64] + [g["f32p%d/metrics" % k][:, 0] for k in range(int(g["ensemble"]))]     # float64 + the one-ulp float32 runs
+    others += [g["f32s%d/metrics" % k][:, 0] for k in range(int(g["ensemble_short"]))]      # (the short ones end after MA.SHORT_STEPS)
     for i, (a, r32) in enumerate(zip(got, f32)):
-        spread = max(abs(float(o[i]) - r32) for o in others)
-        bound = max(1e-3, 2 * spread)
+        spread = max(abs(float(o[i]) - r32) for o in others if len(o) > i)
+        bound = max(1e-3, 3 * spread)
         conftest.report("AbsRel after %2d steps: HIP %.5f, oracle f32 %.5f, f64 %.5f; |HIP - f32|" % (i * MA.EVERY, a, r32, f64[i]),
                         abs(a - r32), bound, "(spread of the oracle's own runs %.1e)" % spread)
         assert abs(a - r32) <= bound, "AbsRel after %d steps: HIP %.5f vs oracle %.5f (float64 %.5f)" % (i * MA.EVERY, a, r32, f64[i])
-    assert abs(got[0] - f32[0]) <= 1e-4, "AbsRel of the initial state must agree to 1e-4 (no optimiser step in between)"
+    assert abs(got[0] - f32[0]) <= 1e-6, "AbsRel of the initial state (no optimiser step in between)"
+    assert abs(got[1] - f32[1]) <= 5e-5, "AbsRel after 2 steps: before the chaotic amplification sets in, far inside 0.001"
 
 
 def test_resnet50_full_size_forward_against_float64():
