@@ -486,28 +486,53 @@ __global__ void __launch_bounds__(256) k_wgrad_finish(const float* __restrict__ 
     }
 }
 
-// The same reduction for 3x3 kernels with both sides coalesced: a workgroup owns (output channel m, 32 input channels); thread
-// (t, c) sums slab rows [m][t][c0 + c] over the slices (128-byte rows), the 9 x 32 block is transposed through LDS, and the
-// 288 results leave as one contiguous run of gw[m][c0 .. c0 + 31][0 .. 8] (the generic kernel writes single floats 36 bytes apart).
-__global__ void __launch_bounds__(288) k_wgrad_finish9(const float* __restrict__ slabs, float* __restrict__ gw, int M, int C,
-                                                       int splits, int accumulate) {
-    __shared__ float tile[9][33];
-    const int m = blockIdx.y, c0 = blockIdx.x * 32;
-    const int t = threadIdx.x >> 5, c = threadIdx.x & 31;
-    const size_t n = (size_t)M * 9 * C;
-    const float* p = slabs + ((size_t)m * 9 + t) * C + c0 + c;
-    float s = 0.f;
-    int z = 0;
-    for (; z + 4 <= splits; z += 4) {                              // fixed order, four loads in flight
-        const float a0 = p[(size_t)z * n], a1 = p[(size_t)(z + 1) * n], a2 = p[(size_t)(z + 2) * n], a3 = p[(size_t)(z + 3) * n];
-        s += a0; s += a1; s += a2; s += a3;
+// The same reduction for 3x3 kernels with both sides coalesced: a workgroup owns (MB output channels m, 32 input channels); thread
+// (r, c) sums slab row [m][r][c0 + c] over the slices (128-byte rows, fixed order, eight loads in flight - with 128 slices of a
+// 64-channel layer or 8 192 (m, c block) pairs of a 512-channel one the pass was latency-bound at 4 loads and one m per workgroup),
+// the R x 32 block goes through LDS, and the 288 results leave as one contiguous run of gw[m][c0 .. c0 + 31][0 .. 8] (the generic
+// kernel writes single floats 36 bytes apart).  R = 9: slab rows are [ky][kx].  R = 12: slab rows are [ri][kx], the row components
+// of k_wgrad_wino<.., true>, and the vertical output transform is applied here:
+//   dW[ky = 0] = T0 + (T1 + T2) / 2,   dW[1] = (T1 - T2) / 2,   dW[2] = (T1 + T2) / 2 - T3.
+template <int R>
+__global__ void __launch_bounds__(384) k_wgrad_finish9(const float* __restrict__ slabs, float* __restrict__ gw, int M, int C,
+                                                       int splits, int accumulate, int mb) {
+    __shared__ float tile[12][33];
+    const int c0 = blockIdx.x * 32;
+    const int r = threadIdx.x >> 5, c = threadIdx.x & 31;
+    const size_t n = (size_t)M * R * C;
+    const int m_hi = min(M, ((int)blockIdx.y + 1) * mb);
+    for (int m = blockIdx.y * mb; m < m_hi; ++m) {
+        if (r < R) {
+            const float* p = slabs + ((size_t)m * R + r) * C + c0 + c;
+            float s = 0.f;
+            int z = 0;
+            for (; z + 8 <= splits; z += 8) {
+                float a[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = p[(size_t)(z + u) * n];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += a[u];
+            }
+            for (; z < splits; ++z) s += p[(size_t)z * n];
+            tile[r][c] = s;
+        }
+        __syncthreads();
+        const int j = threadIdx.x;
+        if (j < 288) {
+            const int cc = j / 9, tt = j - cc * 9;
+            float v;
+            if constexpr (R == 9) v = tile[tt][cc];
+            else {
+                const int ky = tt / 3, kx = tt - ky * 3;
+                const float t0 = tile[kx][cc], t1 = tile[3 + kx][cc], t2 = tile[6 + kx][cc], t3 = tile[9 + kx][cc];
+                const float h = 0.5f * (t1 + t2);
+                v = ky == 0 ? t0 + h : (ky == 1 ? 0.5f * (t1 - t2) : h - t3);
+            }
+            float* o = gw + ((size_t)m * C + c0) * 9 + j;
+            *o = (accumulate ? *o : 0.f) + v;
+        }
+        __syncthreads();
     }
-    for (; z < splits; ++z) s += p[(size_t)z * n];
-    tile[t][c] = s;
-    __syncthreads();
-    const int j = threadIdx.x, cc = j / 9, tt = j - cc * 9;
-    float* o = gw + ((size_t)m * C + c0) * 9 + j;
-    *o = (accumulate ? *o : 0.f) + tile[tt][cc];
 }
 
 // A2[m][(a,b)][c]:  mode 0 (forward)  A2[co][t][ci] = W[co][ci][kh0+dkh*a][kw0+dkw*b]
@@ -655,12 +680,18 @@ int fast_wgrad_finish_launch(const float* slabs, float* gw, int M, int C, int T,
 #ifdef FD_ABLATE_NO_FINISH      // timing experiment only (wrong results): what the step would gain if the slab reductions cost nothing
     return 0;
 #endif
-    if (T == 9 && C % 32 == 0) {
-        hipLaunchKernelGGL(k_wgrad_finish9, dim3(C / 32, M), dim3(288), 0, st, slabs, gw, M, C, splits, accumulate);
+    if ((T == 9 || T == 12) && C % 32 == 0) {
+        // enough (m, c block) pairs for every CU, several output channels per workgroup beyond that
+        int mb = (int)(((long)M * (C / 32)) / 1024);
+        mb = mb < 1 ? 1 : (mb > 8 ? 8 : mb);
+        const dim3 grid(C / 32, (M + mb - 1) / mb);
+        if (T == 9) hipLaunchKernelGGL(k_wgrad_finish9<9>, grid, dim3(384), 0, st, slabs, gw, M, C, splits, accumulate, mb);
+        else hipLaunchKernelGGL(k_wgrad_finish9<12>, grid, dim3(384), 0, st, slabs, gw, M, C, splits, accumulate, mb);
         hipError_t e9 = hipGetLastError();
         if (e9 != hipSuccess) { fd_set_error("k_wgrad_finish9 launch failed: %s", hipGetErrorString(e9)); return (int)e9; }
         return 0;
     }
+    if (T == 12) { fd_set_error("k_wgrad_finish9<12> needs Cin %% 32 == 0 (got %d)", C); return 1; }
     hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks((long)M * C * T)), dim3(256), 0, st, slabs, gw, M, C, T, splits, accumulate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }

@@ -471,6 +471,7 @@ struct WinoWgradArgs {
     int pad_mode;
     long pairs_per_split;
     int slice_major;     // 1: grid x = pixel slice (XCD-aligned), z = (ky, c tile); 0: x = (ky, c tile), z = slice
+    int slab_rows;       // rows per output channel in a slab: 9 = [ky][kx], 12 = [ri][kx] (k_wgrad_wino<.., true>)
     int adv_n, adv_y, adv_j;   // one chunk of WGP pairs = adv_n images + adv_y rows + adv_j pairs (host: divisions once per launch)
 };
 constexpr int WGP = 16;                                          // pairs per chunk (GEMM-K 16 -> 8 MFMA k-steps)
@@ -491,13 +492,23 @@ constexpr int LDX = 4 * WGP + 4;                                 // X row stride
 constexpr int WG_BUF_FLOATS = WBM * LDG + WBN * LDX;             // dY rows + X rows
 constexpr int WG_LDS_FLOATS = 2 * WG_BUF_FLOATS;
 
-template <bool REFL>      // reflection (decoder) or zero (ResNet trunk) padding: a template flag keeps the border selects out of the trunk's loop
+// TWOD: the transposed F(2x2, 3x3) algorithm - the vertical direction is transformed as well.  The GEMM-K unit is a 2x2 tile of dY
+// (image rows 2 ty, 2 ty + 1) instead of a pixel pair, and the "kernel row" of a workgroup becomes a row COMPONENT ri = 0 .. 3:
+//   dY row combination  (y_r0,  y_r0 + y_r1,  y_r0 - y_r1,  y_r1)[ri]          (rows 2 ty, 2 ty + 1)
+//   X  row combination  (x_r0 - x_r2,  x_r1 + x_r2,  x_r2 - x_r1,  x_r1 - x_r3)[ri]   (rows 2 ty - 1 .. 2 ty + 2, padded like the columns)
+// formed by the LOADER (two row loads per operand, one fused multiply-add per value) before the pair goes to LDS; everything behind
+// that - LDS layout, operand reads, the horizontal transforms, the MFMA loop, the horizontal output transform - is the 1-D kernel's.
+// 4 components x half the K of 3 kernel rows: 16 products per 2x2 tile instead of 24 (direct: 36).  Slab rows are [ri][kx]; the
+// vertical output transform dW[ky] = (T0 + (T1+T2)/2, (T1-T2)/2, (T1+T2)/2 - T3) is applied by k_wgrad_finish9<12> while it sums the slices.
+template <bool REFL, bool TWOD>      // REFL: reflection (decoder) or zero (ResNet trunk) padding - a template flag keeps the border selects out of the trunk's loop
 __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W2 = g.W >> 1;
-    const int plane2 = g.H * W2, Np = g.Nb * plane2;             // pixel pairs: < 2^29 (size guard of the entry point)
+    const int HT = TWOD ? g.H >> 1 : g.H;                        // rows of GEMM-K units per image
+    constexpr int R = TWOD ? 4 : 3;                              // workgroup groups along the vertical direction
+    const int plane2 = HT * W2, Np = g.Nb * plane2;              // pixel pairs / tiles: < 2^29 (size guard of the entry point)
     const unsigned hw = (unsigned)(g.H * g.W);
     // grid (default): x = (kernel row, input-channel tile), y = output-channel tile, z = pixel slice.  The alternative
     // (slice_major: x = slice with the slice count a multiple of 8, so that all workgroups of a slice share an XCD / L2) measured
@@ -508,12 +519,12 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         // 1-D grid, XCD-aware: consecutive workgroup ids go round-robin to the 8 XCDs, so id L runs on XCD L % 8.  All (kernel row,
         // c tile, m tile) workgroups of one pixel slice get ids 8 apart - same XCD, dispatched back to back - and find the slice's
         // dY / X rows in that XCD's L2 (the 3 kernel rows alone re-read both operands: 3x the HBM traffic when they sit on 3 XCDs).
-        const int mtiles = (g.M + WBM - 1) / WBM, nt = 3 * ctiles * mtiles;
+        const int mtiles = (g.M + WBM - 1) / WBM, nt = R * ctiles * mtiles;
         const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
         const int t = k % nt;
         bs = (k / nt) * 8 + xcd;
-        by = t / (3 * ctiles);
-        bt = t - by * 3 * ctiles;
+        by = t / (R * ctiles);
+        bt = t - by * R * ctiles;
     } else {
         bt = g.slice_major ? blockIdx.z : blockIdx.x; bs = g.slice_major ? blockIdx.x : blockIdx.z; by = blockIdx.y;
     }
@@ -537,9 +548,15 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY);
     // X with its true size: the 16-byte load of a pair may reach one pixel past the tensor's last one - that lane reads 0.0
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)(4u * (unsigned)g.Nb * (unsigned)g.C * hw), 0x00020000);
-    f32x2 ra[4];
-    float4 rx[4];
-    unsigned a_off = FD_OOB, x_off = FD_OOB;
+    f32x2 ra[4], rb[TWOD ? 4 : 1];
+    float4 rx[4], rz[TWOD ? 4 : 1];
+    unsigned a_off = FD_OOB, x_off = FD_OOB, a_off2 = FD_OOB, x_off2 = FD_OOB;
+    // TWOD, row component ri = ky (workgroup-uniform): which rows are combined, and the sign of the second one
+    const int yr_a = ky == 3 ? 1 : 0;
+    const bool y_two = ky == 1 || ky == 2;
+    const float y_sgn = ky == 2 ? -1.f : 1.f;
+    const int xr_a = ky == 0 ? 0 : (ky == 2 ? 2 : 1), xr_b = ky == 3 ? 3 : (ky == 2 ? 1 : 2);
+    const float x_sgn = ky == 1 ? 1.f : -1.f;
     int pf = 0, rf = 0;          // bit 0 / 1: the pair of the PREPARED chunk (pf) / of the chunk whose data sit in ra, rx (rf) starts / ends an image row
     int pc = pp_lo;                                              // first pair of the chunk being prepared
     // (image, row, pair in row) of this thread's pair of the chunk being prepared: divided out once, then advanced by one chunk per
@@ -555,17 +572,27 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         const int pg = pc + p;
         const bool ok = live & (pg < pp_hi);
         const int n = cn, y = cy, j = cj;
-        a_off = ok ? 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(y * g.W + 2 * j)) : FD_OOB;
-        const int r = y + ky - 1;
-        const bool inb = (unsigned)r < (unsigned)g.H;
-        int rr_ = r < 0 ? -r : r;
-        rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
-        const int ruse = refl ? rr_ : r;
-        const bool okb = ok & (refl | inb);
-        const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(ruse * g.W + 2 * j));
         const bool e_left = j == 0, e_right = 2 * j + 2 >= g.W;
-        // four pixels from column 2j - 1 on; a pair at the left border has no such column: it loads from 2j and shifts (store_row)
-        x_off = okb ? (e_left ? base : base - 4u) : FD_OOB;
+        auto x_row = [&](int r) __attribute__((always_inline)) {              // byte offset of the pair's four pixels in image row r (padded)
+            const bool inb = (unsigned)r < (unsigned)g.H;
+            int rr_ = r < 0 ? -r : r;
+            rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
+            const int ruse = refl ? rr_ : r;
+            const bool okb = ok & (refl | inb);
+            const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(ruse * g.W + 2 * j));
+            // four pixels from column 2j - 1 on; a pair at the left border has no such column: it loads from 2j and shifts (store_row)
+            return okb ? (e_left ? base : base - 4u) : FD_OOB;
+        };
+        if constexpr (TWOD) {
+            const unsigned ya = 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)((2 * y + yr_a) * g.W + 2 * j));
+            a_off = ok ? ya : FD_OOB;
+            a_off2 = (ok & y_two) ? ya + 4u * (unsigned)g.W : FD_OOB;        // rows 2 ty and 2 ty + 1 (yr_a = 0 whenever both are used)
+            x_off = x_row(2 * y - 1 + xr_a);
+            x_off2 = x_row(2 * y - 1 + xr_b);
+        } else {
+            a_off = ok ? 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(y * g.W + 2 * j)) : FD_OOB;
+            x_off = x_row(y + ky - 1);
+        }
         pf = (e_left ? 1 : 0) | (e_right ? 2 : 0);
         pc += WGP;
         // advance (cn, cy, cj) by one chunk (values past the slice are never used: `ok` is false there)
@@ -573,16 +600,25 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         const bool c1 = cj >= W2;
         cj -= c1 ? W2 : 0;
         cy += g.adv_y + (c1 ? 1 : 0);
-        const bool c2 = cy >= g.H;
-        cy -= c2 ? g.H : 0;
+        const bool c2 = cy >= HT;
+        cy -= c2 ? HT : 0;
         cn += g.adv_n + (c2 ? 1 : 0);
     };
     auto load_row = [&](int i) __attribute__((always_inline)) {
         ra[i] = fd_ldg64(rsY, a_off + a_row[i]);                          // FD_OOB + (< 2^31) stays out of range: reads 0
         rx[i] = fd_ldg128(rsX, x_off + b_row[i]);
+        if constexpr (TWOD) {
+            rb[i] = fd_ldg64(rsY, a_off2 + a_row[i]);
+            rz[i] = fd_ldg128(rsX, x_off2 + b_row[i]);
+        }
     };
     auto store_row = [&](int buf, int i) __attribute__((always_inline)) {
         float* qa = smem + buf * WG_BUF_FLOATS + (rw + 16 * i) * LDG + 2 * p;
+        if constexpr (TWOD) {                                             // the row combinations (exact products: a +- b)
+            ra[i].x = fmaf(y_sgn, rb[i].x, ra[i].x); ra[i].y = fmaf(y_sgn, rb[i].y, ra[i].y);
+            rx[i].x = fmaf(x_sgn, rz[i].x, rx[i].x); rx[i].y = fmaf(x_sgn, rz[i].y, rx[i].y);
+            rx[i].z = fmaf(x_sgn, rz[i].z, rx[i].z); rx[i].w = fmaf(x_sgn, rz[i].w, rx[i].w);
+        }
         *reinterpret_cast<f32x2*>(qa) = ra[i];
         // (d0, d1, d2, d3) of the pair; column -1 is column 1 (reflect) or 0, column W is column W - 2 (reflect) or 0
         const bool L = rf & 1, R = rf & 2;
@@ -668,10 +704,10 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     const int c = c0 + 32 * wn + acol;
     // this slice's slab through a buffer resource: 32-bit offsets (a slab is M * 9 * C floats < 2^29), rows / columns past the tensor
     // are dropped by an out-of-range offset instead of a branch per row
-    const __amdgpu_buffer_rsrc_t rsS = fd_make_rsrc(g.slabs + (size_t)bs * ((size_t)g.M * 9 * g.C));
+    const __amdgpu_buffer_rsrc_t rsS = fd_make_rsrc(g.slabs + (size_t)bs * ((size_t)g.M * (3 * R) * g.C));
     const int mb = m0 + 32 * wm + 4 * arow;
     const unsigned col = (c < g.C) ? 4u * (unsigned)(ky * 3 * g.C + c) : FD_OOB;
-    const unsigned row_step = 4u * 9u * (unsigned)g.C, kx_step = 4u * (unsigned)g.C;
+    const unsigned row_step = 4u * (3u * R) * (unsigned)g.C, kx_step = 4u * (unsigned)g.C;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = mb + (r & 3) + 8 * (r >> 2);
@@ -776,9 +812,16 @@ bool wino_wgrad_ok(const fd_conv_desc* d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 16 == 0 && d->Cin >= 64 && d->Cout >= 64 &&
            d->W % 2 == 0 && !d->in_norm;
 }
+// The 2-D algorithm needs whole 2x2 tiles of dY (FD_WINO_WGRAD_2D=0: the 1-D kernel everywhere, for A/B timing)
+bool wino_wgrad_2d(const fd_conv_desc* d) {
+    const char* e = getenv("FD_WINO_WGRAD_2D");            // read per call: the tests run both kernels in one process
+    const int on = e ? atoi(e) : 1;
+    return on != 0 && d->H % 2 == 0 && d->Cin % 32 == 0;      // (k_wgrad_finish9<12> works on blocks of 32 input channels)
+}
 int wino_wgrad_splits(const fd_conv_desc* d) {
-    const long tiles = 3L * fd_cdiv(d->Cin, WBN) * fd_cdiv(d->Cout, WBM);
-    const long Np = (long)d->N * d->H * (d->W / 2);
+    const bool twod = wino_wgrad_2d(d);
+    const long tiles = (twod ? 4L : 3L) * fd_cdiv(d->Cin, WBN) * fd_cdiv(d->Cout, WBM);
+    const long Np = (long)d->N * (twod ? d->H / 2 : d->H) * (d->W / 2);
     static long target = 0;
     if (!target) { const char* e = getenv("FD_WINO_WGRAD_TARGET"); target = e ? atol(e) : 384; }     // in-step optimum (768: -1 %)
     long sp = target / tiles;
@@ -789,38 +832,49 @@ int wino_wgrad_splits(const fd_conv_desc* d) {
     if (sp < 1) sp = 1;
     return (int)sp;
 }
-long wino_wgrad_ws_floats(const fd_conv_desc* d) { return (long)wino_wgrad_splits(d) * d->Cout * 9 * d->Cin; }
+long wino_wgrad_ws_floats(const fd_conv_desc* d) { return (long)wino_wgrad_splits(d) * d->Cout * (wino_wgrad_2d(d) ? 12 : 9) * d->Cin; }
 int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st) {
     WinoWgradArgs g = {};
     g.dY = gy; g.X = x; g.slabs = ws;
     g.M = d->Cout; g.C = d->Cin; g.Nb = d->N; g.H = d->H; g.W = d->W; g.pad_mode = d->pad_mode;
     const int sp = wino_wgrad_splits(d);
-    const long Np = (long)d->N * d->H * (d->W / 2);
+    const bool twod = wino_wgrad_2d(d);
+    const int HT = twod ? d->H / 2 : d->H;
+    g.slab_rows = twod ? 12 : 9;
+    const long Np = (long)d->N * HT * (d->W / 2);
     long pps = (Np + sp - 1) / sp;
     pps = (pps + WGP - 1) / WGP * WGP;
     g.pairs_per_split = pps;
     {
-        const int W2 = d->W / 2, plane2 = d->H * W2;
+        const int W2 = d->W / 2, plane2 = HT * W2;
         g.adv_n = WGP / plane2;
         const int rem = WGP - g.adv_n * plane2;
         g.adv_y = rem / W2; g.adv_j = rem - g.adv_y * W2;
     }
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     static int slice_major = -1;
     if (slice_major < 0) { const char* e = getenv("FD_WINO_WGRAD_MAP"); slice_major = e ? atoi(e) : 2; }     // 2 (XCD-aware 1-D grid): layer1 HBM traffic 157 -> 76 MB per launch, step -0.5 %; 1 measured slower than 0
     g.slice_major = slice_major;
-    const int nt = 3 * fd_cdiv(d->Cin, WBN);
+    const int nt = (twod ? 4 : 3) * fd_cdiv(d->Cin, WBN);
     const int mt = fd_cdiv(d->Cout, WBM);
     if (slice_major == 2 && sp % 8 != 0) g.slice_major = 0;               // the XCD map needs whole groups of 8 slices
     const dim3 grid = g.slice_major == 2 ? dim3((unsigned)(nt * mt * sp)) : (g.slice_major ? dim3(sp, mt, nt) : dim3(nt, mt, sp));
-    if (d->pad_mode == 1) hipLaunchKernelGGL(k_wgrad_wino<true>, grid, dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st, g);
-    else hipLaunchKernelGGL(k_wgrad_wino<false>, grid, dim3(WNT), sizeof(float) * WG_LDS_FLOATS, st, g);
+    const size_t lds = sizeof(float) * WG_LDS_FLOATS;
+    if (twod) {
+        if (d->pad_mode == 1) hipLaunchKernelGGL((k_wgrad_wino<true, true>), grid, dim3(WNT), lds, st, g);
+        else hipLaunchKernelGGL((k_wgrad_wino<false, true>), grid, dim3(WNT), lds, st, g);
+    } else {
+        if (d->pad_mode == 1) hipLaunchKernelGGL((k_wgrad_wino<true, false>), grid, dim3(WNT), lds, st, g);
+        else hipLaunchKernelGGL((k_wgrad_wino<false, false>), grid, dim3(WNT), lds, st, g);
+    }
     FD_LAUNCH_CHECK("k_wgrad_wino");
-    return fast_wgrad_finish_launch(ws, gw, d->Cout, d->Cin, 9, sp, accumulate, st);
+    return fast_wgrad_finish_launch(ws, gw, d->Cout, d->Cin, twod ? 12 : 9, sp, accumulate, st);
 }
 

@@ -767,9 +767,10 @@ class _ConvPlan:
 
 
 def _conv_plan(x, w, stride, pad, pad_mode, act, in_norm):
-    # FD_CONV_FORCE is the one tuning variable the library re-reads on every call (scripts/conv_cfg_sweep.py flips it within a
-    # process) and it changes the split-K workspace size: part of the key
-    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, os.environ.get("FD_CONV_FORCE"))
+    # FD_CONV_FORCE and FD_WINO_WGRAD_2D are the tuning variables the library re-reads on every call (scripts/conv_cfg_sweep.py and
+    # the tests flip them within a process) and they change the split-K / slab workspace sizes: part of the key
+    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, os.environ.get("FD_CONV_FORCE"),
+           os.environ.get("FD_WINO_WGRAD_2D"))
     plan = _CONV_PLANS.get(key)
     if plan is None:
         plan = _CONV_PLANS[key] = _ConvPlan(x, w, stride, pad, pad_mode, act, in_norm)

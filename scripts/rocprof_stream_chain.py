@@ -19,16 +19,22 @@ print("stream %s: %.2f ms of kernels in %d launches (step wall under the profile
 t0 = lo
 phase = collections.OrderedDict()
 acc = []
+prev = None
 for n, s, e, st in step:
     if st != main:
         continue
-    acc.append((short(n), (e - s) / 1e3, (s - lo) / 1e6))
-# compress runs
+    acc.append((short(n), (e - s) / 1e3, (s - lo) / 1e6, 0.0 if prev is None else max(0, s - prev) / 1e3))
+    prev = e
+# compress runs; last column: idle time of this stream in front of the kernels of the run (launch latency, or waiting for another stream)
 out = []
-for n, d, t in acc:
+for n, d, t, gap in acc:
     if out and out[-1][0] == n:
-        out[-1][1] += d; out[-1][2] += 1
+        out[-1][1] += d; out[-1][2] += 1; out[-1][4] += gap
     else:
-        out.append([n, d, 1, t])
-for n, d, c, t in out:
-    print("%8.2f ms  %-40s x%-3d %8.1f us" % (t, n, c, d))
+        out.append([n, d, 1, t, gap])
+for n, d, c, t, gap in out:
+    print("%8.2f ms  %-40s x%-3d %8.1f us   idle before %7.1f us" % (t, n, c, d, gap))
+gaps = sorted((g for _, _, _, g in acc), reverse=True)
+print("\nidle on this stream: %.2f ms in total; %d gaps > 20 us hold %.2f ms, the %d gaps <= 20 us %.2f ms (median %.1f us)" % (
+    sum(gaps) / 1e3, sum(1 for g in gaps if g > 20), sum(g for g in gaps if g > 20) / 1e3, sum(1 for g in gaps if g <= 20),
+    sum(g for g in gaps if g <= 20) / 1e3, gaps[len(gaps) // 2]))

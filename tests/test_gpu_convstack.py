@@ -703,16 +703,26 @@ def test_winograd_routing_forward_and_data_gradient_match_torch():
     relclose(cpu(gx2), cpu(1.5 * gx), "dx after batched re-layout", rtol=1e-6, arel=1e-6)
 
 
+@pytest.mark.parametrize("two_d", [1, 0])
 @pytest.mark.parametrize("N,Ci,Co,H,W,mode", [
-    (2, 64, 64, 24, 80, "zero"),        # 3 tiles x many pixel slices
-    (1, 96, 80, 7, 10, "zero"),         # partial channel tiles on both sides, 35 pairs (< one slice of 64)
+    (2, 64, 64, 24, 80, "zero"),        # 3 (4) tiles x many pixel slices
+    (1, 96, 80, 7, 10, "zero"),         # partial channel tiles on both sides, 35 pairs (< one slice of 64); odd height: 1-D kernel
+    (1, 96, 80, 8, 10, "zero"),         # the same with whole 2x2 tiles
     (2, 128, 64, 12, 40, "reflect"),    # decoder ConvBlock: reflect padding
     (3, 64, 128, 5, 6, "reflect"),      # edges everywhere: every pair touches a border
+    (3, 64, 128, 6, 6, "reflect"),      # ... every 2x2 tile touches one or two
+    (2, 64, 64, 2, 4, "reflect"),       # one tile row: both vertical mirrors in the same tile
+    (2, 64, 64, 2, 4, "zero"),
+    (5, 64, 64, 48, 160, "zero"),       # layer1 plane: 128 slices, chunks that cross image borders (48 * 80 / 2 tiles per image)
+    (3, 512, 512, 6, 20, "zero"),       # layer4: one slice, 8 output channels per finishing workgroup
 ])
-def test_winograd_weight_gradient_vs_float64_reference(N, Ci, Co, H, W, mode):
-    """k_wgrad_wino (transposed F(2,3): 4 products per pixel pair and kernel row) through FD.conv2d's backward, against torch
-    float64 autograd; also accumulation into an existing gradient (the trainer's direct-gradient mode)."""
+def test_winograd_weight_gradient_vs_float64_reference(N, Ci, Co, H, W, mode, two_d, monkeypatch):
+    """k_wgrad_wino through FD.conv2d's backward, against torch float64 autograd: the transposed F(2x2, 3x3) algorithm (16
+    products per 2x2 tile of dY; two_d = 1, the default wherever the height is even) and the transposed F(2, 3) algorithm per
+    kernel row (4 products per pixel pair and row; FD_WINO_WGRAD_2D=0, and odd heights); also accumulation into an existing
+    gradient (the trainer's direct-gradient mode)."""
     import fusiondepth_amd.functional as FD
+    monkeypatch.setenv("FD_WINO_WGRAD_2D", str(two_d))
     torch.manual_seed(Ci + Co)
     x = torch.randn(N, Ci, H, W, device="cuda")
     w = torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05)
