@@ -479,6 +479,22 @@ __global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* _
                 float* o = j.dst + ((size_t)(ci0 + c) * 3 + ky) * Co + co0 + r;
                 o[0] = g0; o[n] = 0.5f * (g0 + g1 + g2); o[2 * n] = 0.5f * (g0 - g1 + g2); o[3 * n] = g2;
             }
+        } else if (j.mode == 5 || j.mode == 6) {         // F(2x2, 3x3): U2[t][co][ri][ci] (5) / [t][ci][ri][co] of the flipped kernel (6)
+            const bool dg = j.mode == 6;
+            const size_t n = (size_t)Co * 4 * Ci;
+            for (unsigned i = threadIdx.x; i < nco * 4 * nci; i += 256) {
+                unsigned r, c, ri;
+                if (!dg) { c = i % nci; const unsigned q = i / nci; ri = q % 4; r = q / 4; }
+                else { r = i % nco; const unsigned q = i / nco; ri = q % 4; c = q / 4; }
+                float v[3];
+                for (unsigned b = 0; b < 3; ++b) {
+                    const unsigned kb = dg ? 2 - b : b;
+                    const float g0 = tile[r][c * 9 + (dg ? 6 : 0) + kb], g1 = tile[r][c * 9 + 3 + kb], g2 = tile[r][c * 9 + (dg ? 0 : 6) + kb];
+                    v[b] = ri == 0 ? g0 : (ri == 3 ? g2 : (ri == 1 ? 0.5f * (g0 + g1 + g2) : 0.5f * (g0 - g1 + g2)));
+                }
+                float* o = dg ? j.dst + ((size_t)(ci0 + c) * 4 + ri) * Co + co0 + r : j.dst + ((size_t)(co0 + r) * 4 + ri) * Ci + ci0 + c;
+                o[0] = v[0]; o[n] = 0.5f * (v[0] + v[1] + v[2]); o[2 * n] = 0.5f * (v[0] - v[1] + v[2]); o[3 * n] = v[2];
+            }
         } else if (j.mode == 1) {                        // dst[(ci * T + t) * Co + co], co fastest
             for (unsigned i = threadIdx.x; i < nci * T * nco; i += 256) {
                 const unsigned r = i % nco, q = i / nco, t = q % T, c = q / T;
@@ -772,7 +788,7 @@ void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
 
 extern "C" long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d) {
     if (!d || !fast_fwd_ok(d)) return 0;
-    if (wino_use_fwd(d)) return align4(wino_wt_floats(d->Cout, d->Cin));
+    if (wino_use_fwd(d)) return align4(wino_wt_floats(d));
     return align4((long)d->Cout * d->Cin * d->KH * d->KW);
 }
 
@@ -819,7 +835,7 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
         if (wino_use_fwd(d)) {
             conv_log("fwd", "wino", d);
             if (!wt_ready)
-                if (int rc = wino_weight_launch(w, wt, d->Cout, d->Cin, 0, st)) return rc;
+                if (int rc = wino_weight_launch(d, w, wt, 0, st)) return rc;
             return wino_conv_launch(d, x, wt, bias, y, ws, st, nullptr, stat_part);
         }
         conv_log("fwd", "direct", d);
@@ -850,7 +866,7 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
 extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     fd_conv_desc g;
-    if (wino_dgrad_desc(d, g)) return align4(wino_wt_floats(g.Cout, g.Cin));
+    if (wino_dgrad_desc(d, g)) return align4(wino_wt_floats(&g));
     return (d->stride == 1 ? 1 : 4) * align4((long)d->Cin * d->Cout * d->KH * d->KW);
 }
 
@@ -916,7 +932,7 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
         conv_log("dgrad", wino_dgrad_desc(d, gd) ? "wino" : "direct", d);
         if (wino_dgrad_desc(d, gd)) {
             if (!wt_ready)
-                if (int rc = wino_weight_launch(w, wt_base, gd.Cout, gd.Cin, 1, st)) return rc;
+                if (int rc = wino_weight_launch(&gd, w, wt_base, 1, st)) return rc;
             return wino_conv_launch(&gd, gy, wt_base, nullptr, gx, ws, st, gx_add);
         }
     }
@@ -1103,13 +1119,13 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
     };
     if (kind == 0) {
         if (!fast_fwd_ok(d)) return 0;
-        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? 3 : 0);
+        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? (wino_fwd_2d(d) ? 5 : 3) : 0);
         return 1;
     }
     const int KH = d->KH, KW = d->KW;
     {
         fd_conv_desc gd;
-        if (wino_dgrad_desc(d, gd)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, 4); return 1; }
+        if (wino_dgrad_desc(d, gd)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, wino_fwd_2d(&gd) ? 6 : 4); return 1; }
     }
     const int mode = fast_dgrad_ok(d) ? 1 : 2;
     if (d->stride == 1) {

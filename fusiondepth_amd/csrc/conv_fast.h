@@ -61,9 +61,10 @@ int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, l
 
 // conv_wino.hip: 3x3 stride-1 convolutions through the 1-D Winograd F(2,3) transform
 bool wino_fwd_ok(const fd_conv_desc* d);
-long wino_wt_floats(int M, int C);
+long wino_wt_floats(const fd_conv_desc* d);
+bool wino_fwd_2d(const fd_conv_desc* d);
 long wino_ws_floats(const fd_conv_desc* d);
-int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStream_t st);
+int wino_weight_launch(const fd_conv_desc* d, const float* w, float* U, int flip, hipStream_t st);
 int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st,
                      const float* add = nullptr, float* stat_part = nullptr);
 int wino_stat_slots(const fd_conv_desc* d);

@@ -80,6 +80,31 @@ __global__ void k_wino_weight(const float* __restrict__ w, float* __restrict__ U
     }
 }
 
+// TWOD (k_conv_wino<.., true>): U2[t][m][ri][c], the vertical transform (g_0, (g_0+g_1+g_2)/2, (g_0-g_1+g_2)/2, g_2)[ri] of the three
+// kernel rows applied first, then the horizontal one: the 16 components of F(2x2, 3x3), four per row component.
+__global__ void k_wino_weight2d(const float* __restrict__ w, float* __restrict__ U, int M, int C, int flip) {
+    const long n = (long)M * 4 * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int ri = (int)((i / C) % 4);
+        const int m = (int)(i / (4L * C));
+        float g[3][3];
+        const float* p = flip ? w + ((long)c * M + m) * 9 : w + ((long)m * C + c) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = flip ? p[(2 - a) * 3 + (2 - b)] : p[a * 3 + b];
+        float v[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            v[b] = ri == 0 ? g[0][b] : (ri == 3 ? g[2][b] : (ri == 1 ? 0.5f * (g[0][b] + g[1][b] + g[2][b]) : 0.5f * (g[0][b] - g[1][b] + g[2][b])));
+        U[i] = v[0];
+        U[n + i] = 0.5f * (v[0] + v[1] + v[2]);
+        U[2 * n + i] = 0.5f * (v[0] - v[1] + v[2]);
+        U[3 * n + i] = v[2];
+    }
+}
+
 struct WinoArgs {
     const float* U; const float* X; float* Y; const float* bias; float* slabs;
     const float* add;    // optional, laid out like Y: Y = act(conv + bias) + add
@@ -100,23 +125,39 @@ struct WinoArgs {
 // test: with `if (g.stat_part)` around writes into the accumulator array the compiler kept BOTH versions of every remaining
 // accumulator alive and emitted two v_accvgpr_read + a v_cndmask per accumulator and ROW - 700 of the 1 430 vector instructions of
 // the epilogue, 15 % of the kernel's time on the layer1 shape (profiles/round3_experiments.md).
-template <bool VDMA, bool STATS>
-__global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))) k_conv_wino(WinoArgs g) {
+// TWOD: F(2x2, 3x3) for the deep layers, where split-K slabs are written anyway.  The GEMM-N unit becomes a 2x2 output tile (tile
+// row ty = output rows 2 ty, 2 ty + 1), and blockIdx.z carries a row COMPONENT ri = z & 3 (z >> 2: split of the input channels)
+// instead of a share of the (kernel row, channel) chunks: the workgroup convolves the row combination
+//   (x_r0 - x_r2,  x_r1 + x_r2,  x_r2 - x_r1,  x_r1 - x_r3)[ri]      (input rows 2 ty - 1 .. 2 ty + 2, padded like the columns)
+// - formed by the loader from two row loads, register-staged - with U2[.][.][ri][.] over the input channels only (a third of the
+// 1-D kernel's K for four instead of one or two z), and writes the horizontally transformed products S_ri [N][M][H/2][W] to slab z.
+// k_wino2d_finish applies the vertical output transform  y[2 ty] = S0 + S1 + S2,  y[2 ty + 1] = S1 - S2 - S3  (+ bias, activation,
+// residual) while it sums the slabs: 16 products per 2x2 tile instead of 24, for the slab traffic of a 2-way split.
+template <bool VDMA, bool STATS, bool TWOD>
+__device__ __forceinline__ void conv_wino_body(const WinoArgs& g) {
+    static_assert(!TWOD || (!VDMA && !STATS), "the 2-D variant is register-staged and always writes slabs");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int W2 = g.W >> 1;
-    const int plane2 = g.H * W2;                                         // pairs per image; Nb * plane2 < 2^29 (size guard)
+    const int HT = TWOD ? g.H >> 1 : g.H;                                // rows of GEMM-N units (pairs / 2x2 tiles) per image
+    const int plane2 = HT * W2;                                          // units per image; Nb * plane2 < 2^29 (size guard)
     const int Np = g.Nb * plane2;
     const unsigned hw = (unsigned)(g.H * g.W);
     const int m0 = blockIdx.y * WBM;
     int bx = blockIdx.x;
     if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
     const int p0 = bx * WBN;
-    const int cpt = g.C / WBKC, nchunk_all = 3 * cpt;
-    const int nsplit = (int)gridDim.z, zs = (int)blockIdx.z;
+    const int cpt = g.C / WBKC, nchunk_all = TWOD ? cpt : 3 * cpt;
+    const int zs = (int)blockIdx.z;
+    const int ri = TWOD ? zs & 3 : 0;                                    // row component of this workgroup
+    const int nsplit = TWOD ? (int)gridDim.z >> 2 : (int)gridDim.z;
+    const int ks = TWOD ? zs >> 2 : zs;
+    constexpr unsigned UR = TWOD ? 4u : 3u;                              // weight rows per output channel
+    const int xr_a = ri == 0 ? 0 : (ri == 2 ? 2 : 1), xr_b = ri == 3 ? 3 : (ri == 2 ? 1 : 2);
+    const float x_sgn = ri == 1 ? 1.f : -1.f;
     const int per_split = (nchunk_all + nsplit - 1) / nsplit;
-    const int ch_lo = zs * per_split;
+    const int ch_lo = ks * per_split;
     const int ch_hi = ch_lo + per_split < nchunk_all ? ch_lo + per_split : nchunk_all;
 
     // ---- activation loader: this thread always fetches pair jn of the tile, channel rows kr + 4 i
@@ -142,7 +183,7 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int a4 = tid & 3, ar = tid >> 2;
     int mrow = m0 + ar;
     mrow = mrow < g.M ? mrow : g.M - 1;                                  // rows >= M are never stored
-    const unsigned u_comp = 4u * (unsigned)g.M * 3u * (unsigned)g.C;     // bytes between components
+    const unsigned u_comp = 4u * (unsigned)g.M * UR * (unsigned)g.C;     // bytes between components
     const __amdgpu_buffer_rsrc_t rsU = fd_make_rsrc(g.U), rsX = fd_make_rsrc(g.X);
 
     // ---- VDMA: the raw buffer is ONE linear stream of 16 rows x 34 sixteen-byte pieces (pixels -4 .. 131 of the tile's flat pixel
@@ -166,26 +207,35 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))
         }
     }
     float4 ru[4];
-    f32x2 rmid[4];
-    float rh[4];
-    unsigned u_off = FD_OOB, mid_off = FD_OOB, h_off = FD_OOB;
+    f32x2 rmid[4], rmid2[TWOD ? 4 : 1];
+    float rh[4], rh2[TWOD ? 4 : 1];
+    unsigned u_off = FD_OOB, mid_off = FD_OOB, h_off = FD_OOB, mid_off2 = FD_OOB, h_off2 = FD_OOB;
     unsigned d_soff = 0u;
     const unsigned c_step = 4u * 4u * hw;                                // 4 channel rows further
     int pc_ky, pc_c0;
     { pc_ky = ch_lo / cpt; pc_c0 = (ch_lo - pc_ky * cpt) * WBKC; }
     // Offsets of the next chunk to fetch, in two branch-free halves (each small enough to hide behind one MFMA, see the k-loop)
-    unsigned prep_base = 0u;
-    bool prep_ok = false;
+    unsigned prep_base = 0u, prep_base2 = 0u;
+    bool prep_ok = false, prep_ok2 = false;
     const int H2m2 = 2 * g.H - 2;
     auto prep_a = [&](bool live) __attribute__((always_inline)) {
-        u_off = live ? 4u * (((unsigned)mrow * 3u + (unsigned)pc_ky) * (unsigned)g.C + (unsigned)pc_c0 + 4u * a4) : FD_OOB;
-        const int r = y0 + pc_ky - 1;
+        u_off = live ? 4u * (((unsigned)mrow * UR + (unsigned)(TWOD ? ri : pc_ky)) * (unsigned)g.C + (unsigned)pc_c0 + 4u * a4) : FD_OOB;
+        const int r = TWOD ? 2 * y0 - 1 + xr_a : y0 + pc_ky - 1;
         const bool inb = (unsigned)r < (unsigned)g.H;
         int rr_ = r < 0 ? -r : r;
         rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
         const int ruse = refl ? rr_ : r;
         prep_ok = pvalid & live & (refl | inb);
         prep_base = 4u * (nbase + (unsigned)(pc_c0 + kr) * hw + (unsigned)(ruse * g.W + 2 * j0));
+        if constexpr (TWOD) {
+            const int r2 = 2 * y0 - 1 + xr_b;
+            const bool inb2 = (unsigned)r2 < (unsigned)g.H;
+            int rr2 = r2 < 0 ? -r2 : r2;
+            rr2 = rr2 >= g.H ? H2m2 - rr2 : rr2;
+            const int ruse2 = refl ? rr2 : r2;
+            prep_ok2 = pvalid & live & (refl | inb2);
+            prep_base2 = 4u * (nbase + (unsigned)(pc_c0 + kr) * hw + (unsigned)(ruse2 * g.W + 2 * j0));
+        }
         if (VDMA) {
             d_soff = 4u * (unsigned)pc_c0 * hw;                          // wave-uniform: first channel of the chunk
 #pragma unroll
@@ -202,6 +252,10 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))
     auto prep_b = [&]() __attribute__((always_inline)) {
         mid_off = prep_ok ? prep_base : FD_OOB;
         h_off = (prep_ok & halo_l) ? prep_base - 4u : ((prep_ok & halo_r) ? prep_base + 8u : FD_OOB);
+        if constexpr (TWOD) {
+            mid_off2 = prep_ok2 ? prep_base2 : FD_OOB;
+            h_off2 = (prep_ok2 & halo_l) ? prep_base2 - 4u : ((prep_ok2 & halo_r) ? prep_base2 + 8u : FD_OOB);
+        }
         if (FD_WINO_ABLATE & 16) { u_off = mid_off = h_off = FD_OOB; d_off[0] = d_off[1] = d_off[2] = FD_OOB; }   // loads issue, no memory traffic
         pc_c0 += WBKC;
         const bool wrap = pc_c0 >= g.C;
@@ -210,8 +264,14 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))
     };
     auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off + (unsigned)t * u_comp); };   // FD_OOB + (< 2^31) stays out of range
     // an FD_OOB base + (offset < 2^31) is still >= 2^31: reads 0 - vertical zero padding and pairs past the end need no select
-    auto load_mid = [&](int i) __attribute__((always_inline)) { rmid[i] = fd_ldg64(rsX, mid_off + (unsigned)i * c_step); };
-    auto load_h = [&](int i) __attribute__((always_inline)) { rh[i] = fd_ldg32(rsX, h_off + (unsigned)i * c_step); };
+    auto load_mid = [&](int i) __attribute__((always_inline)) {
+        rmid[i] = fd_ldg64(rsX, mid_off + (unsigned)i * c_step);
+        if constexpr (TWOD) rmid2[i] = fd_ldg64(rsX, mid_off2 + (unsigned)i * c_step);
+    };
+    auto load_h = [&](int i) __attribute__((always_inline)) {
+        rh[i] = fd_ldg32(rsX, h_off + (unsigned)i * c_step);
+        if constexpr (TWOD) rh2[i] = fd_ldg32(rsX, h_off2 + (unsigned)i * c_step);
+    };
     auto store_u = [&](int buf, int t) __attribute__((always_inline)) {
         float* q = smem + buf * W_BUF_FLOATS + t * WBKC * LDU + (4 * a4) * LDU + ar;
         q[0] = ru[t].x; q[LDU] = ru[t].y; q[2 * LDU] = ru[t].z; q[3 * LDU] = ru[t].w;
@@ -220,6 +280,10 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int h_col = jn == 0 ? 3 : 2 * WBN + 4;                         // where a halo lane puts its pixel
     auto store_v = [&](int buf, int i) __attribute__((always_inline)) {
         float* q = smem + buf * W_BUF_FLOATS + v_row + 4 * i * LDR;
+        if constexpr (TWOD) {                                            // the row combination (exact products: a +- b)
+            rmid[i].x = fmaf(x_sgn, rmid2[i].x, rmid[i].x); rmid[i].y = fmaf(x_sgn, rmid2[i].y, rmid[i].y);
+            rh[i] = fmaf(x_sgn, rh2[i], rh[i]);
+        }
         *reinterpret_cast<f32x2*>(q + 4 + 2 * jn) = rmid[i];
         if (jn == 0 || jn == WBN - 1) q[h_col] = rh[i];
     };
@@ -369,13 +433,14 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))
     //      row (channel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (FD_WINO_ABLATE & 4) { if (acc[0][0] == 123.456f) g.Y[tid] = acc[1][3] + acc[2][2] + acc[3][1]; return; }
     const int po = p0 + 32 * wn + acol;                                   // this lane's output pair
-    const bool final_pass = nsplit == 1;
+    const bool final_pass = !TWOD && nsplit == 1;
+    const unsigned hwo = TWOD ? (unsigned)(HT * g.W) : hw;                // plane of the tensor written: S_ri has H / 2 rows
     unsigned out_base = FD_OOB;
     if (po < Np) {
         const int n = po / plane2;
         const int rem = po - n * plane2;
         const int yy = rem / W2, jj = rem - yy * W2;
-        out_base = 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(yy * g.W + 2 * jj));
+        out_base = 4u * ((unsigned)n * (unsigned)g.M * hwo + (unsigned)(yy * g.W + 2 * jj));
     }
     const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(final_pass ? g.Y : g.slabs + (size_t)zs * g.slab_stride);
     const __amdgpu_buffer_rsrc_t rsAdd = fd_make_rsrc(g.add ? g.add : g.Y);
@@ -399,7 +464,7 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mbase + (r & 3) + 8 * (r >> 2);
-            const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hw : FD_OOB;       // out of range: the store is dropped
+            const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hwo : FD_OOB;      // out of range: the store is dropped
             f32x2 o;
             o.x = (acc[0][r] + acc[1][r]) + acc[2][r];
             o.y = (acc[1][r] - acc[2][r]) - acc[3][r];
@@ -454,6 +519,44 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))
             f32x2 v; v.x = s1[0]; v.y = s2[0];
             *reinterpret_cast<f32x2*>(g.stat_part + (((size_t)n * g.M + m) * g.stat_slots + 2 * tile + wn) * 2) = v;
         }
+    }
+}
+
+template <bool VDMA, bool STATS>
+__global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))) k_conv_wino(WinoArgs g) { conv_wino_body<VDMA, STATS, false>(g); }
+__global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(3, 3))) k_conv_wino2d(WinoArgs g) { conv_wino_body<false, false, true>(g); }
+
+// y[n][m][2 ty + (0, 1)][x] = act(bias[m] + (S0 + S1 + S2,  S1 - S2 - S3)) + add, S_ri = sum over the channel splits of slab 4 ks + ri
+// (fixed order => deterministic); one thread per pair of columns of a tile row.
+__global__ void __launch_bounds__(256) k_wino2d_finish(const float* __restrict__ slabs, float* __restrict__ Y, const float* __restrict__ bias,
+                                                       const float* __restrict__ add, unsigned total2, long slab_stride, int ksplit,
+                                                       int HT, int W, int M, int act) {
+    const unsigned W2 = (unsigned)W >> 1, hw2 = (unsigned)HT * W2;       // total2 = N * M * HT * W / 2 < 2^30
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total2; i += gridDim.x * 256u) {
+        f32x2 s[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[r].x = 0.f; s[r].y = 0.f; }
+        for (int k = 0; k < ksplit; ++k) {
+            f32x2 a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = *reinterpret_cast<const f32x2*>(slabs + (size_t)(4 * k + r) * slab_stride + 2 * (size_t)i);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r].x += a[r].x; s[r].y += a[r].y; }
+        }
+        const unsigned plane = i / hw2, rem = i - plane * hw2;
+        const unsigned ty = rem / W2, j = rem - ty * W2;
+        const float b = bias ? bias[plane % (unsigned)M] : 0.f;
+        f32x2 o0, o1;
+        o0.x = (s[0].x + s[1].x) + s[2].x + b; o0.y = (s[0].y + s[1].y) + s[2].y + b;
+        o1.x = (s[1].x - s[2].x) - s[3].x + b; o1.y = (s[1].y - s[2].y) - s[3].y + b;
+        if (act != 0) { o0.x = wino_act(o0.x, act); o0.y = wino_act(o0.y, act); o1.x = wino_act(o1.x, act); o1.y = wino_act(o1.y, act); }
+        const size_t o = ((size_t)plane * (2u * HT) + 2u * ty) * (unsigned)W + 2u * j;
+        if (add) {
+            const f32x2 a0 = *reinterpret_cast<const f32x2*>(add + o), a1 = *reinterpret_cast<const f32x2*>(add + o + W);
+            o0.x += a0.x; o0.y += a0.y; o1.x += a1.x; o1.y += a1.y;
+        }
+        *reinterpret_cast<f32x2*>(Y + o) = o0;
+        *reinterpret_cast<f32x2*>(Y + o + W) = o1;
     }
 }
 
@@ -741,14 +844,41 @@ bool wino_fwd_ok(const fd_conv_desc* d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 16 == 0 && d->W % 2 == 0 && !d->in_norm &&
            (long)d->Cout * 3 * d->Cin * 4 * 4 < 2147483648L;
 }
-long wino_wt_floats(int M, int C) { return 4L * M * 3 * C; }
+// F(2x2, 3x3) (k_conv_wino2d) for the layers whose matrix work dwarfs their output: Cin * Cout >= 256 * 256 (FD_WINO_FWD_2D_MIN) and
+// whole 2x2 tiles.  A function of the descriptor (+ environment, re-read per call: the tests run both kernels in one process), so
+// that the weight-layout size, the workspace size, the re-layout job and the launch agree.
+bool wino_fwd_2d(const fd_conv_desc* d) {
+    const char* e = getenv("FD_WINO_FWD_2D");
+    if (e && atoi(e) == 0) return false;
+    const char* m = getenv("FD_WINO_FWD_2D_MIN");
+    const long min_cc = m ? atol(m) : 65536;
+    return wino_fwd_ok(d) && d->H % 2 == 0 && (long)d->Cin * d->Cout >= min_cc && (long)d->Cout * 4 * d->Cin * 4 * 4 < 2147483648L;
+}
+// channel splits of the 2-D kernel on top of its four row components
+inline int wino2d_ksplits(const fd_conv_desc* d) {
+    const long tiles = 4L * fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN) * fd_cdiv(d->Cout, WBM);
+    static long target = 0;
+    if (!target) { const char* e = getenv("FD_WINO_TARGET"); target = e ? atol(e) : 384; }
+    long ks = tiles < target ? target / tiles : 1;
+    const long cap = d->Cin / WBKC / 4 > 0 ? d->Cin / WBKC / 4 : 1;          // at least 4 chunks per split
+    if (ks > cap) ks = cap;
+    if (ks > 4) ks = 4;
+    return ks < 1 ? 1 : (int)ks;
+}
+long wino_wt_floats(const fd_conv_desc* d) { return 4L * d->Cout * (wino_fwd_2d(d) ? 4 : 3) * d->Cin; }
 long wino_ws_floats(const fd_conv_desc* d) {
+    if (wino_fwd_2d(d)) return 4L * wino2d_ksplits(d) * d->N * d->Cout * (d->H / 2) * d->W;
     const int sp = wino_splits(d, d->Cout, d->Cin);
     return sp > 1 ? (long)sp * d->N * d->Cout * d->H * d->W : 0;
 }
-int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStream_t st) {
-    const long n = (long)M * 3 * C;
-    hipLaunchKernelGGL(k_wino_weight, dim3(fd_cdiv(n, 256) > 4096 ? 4096 : fd_cdiv(n, 256)), dim3(256), 0, st, w, U, M, C, flip);
+// U for the convolution `d` computes (for a data gradient: Cin / Cout already swapped, flip = 1; w is always [Cout][Cin][3][3] of the layer)
+int wino_weight_launch(const fd_conv_desc* d, const float* w, float* U, int flip, hipStream_t st) {
+    const int M = d->Cout, C = d->Cin;
+    const bool twod = wino_fwd_2d(d);
+    const long n = (long)M * (twod ? 4 : 3) * C;
+    const dim3 grid(fd_cdiv(n, 256) > 4096 ? 4096 : fd_cdiv(n, 256));
+    if (twod) hipLaunchKernelGGL(k_wino_weight2d, grid, dim3(256), 0, st, w, U, M, C, flip);
+    else hipLaunchKernelGGL(k_wino_weight, grid, dim3(256), 0, st, w, U, M, C, flip);
     FD_LAUNCH_CHECK("wino weight transform");
     return 0;
 }
@@ -756,7 +886,7 @@ int wino_weight_launch(const float* w, float* U, int M, int C, int flip, hipStre
 // slots of BatchNorm partial sums per (image, channel) the kernel can emit for `d`, 0 if not (split-K, tiles across images)
 int wino_stat_slots(const fd_conv_desc* d) {
     const long plane2 = (long)d->H * (d->W / 2);
-    if (!wino_fwd_ok(d) || plane2 % WBN != 0 || wino_splits(d, d->Cout, d->Cin) != 1 || d->act != 0) return 0;
+    if (!wino_fwd_ok(d) || wino_fwd_2d(d) || plane2 % WBN != 0 || wino_splits(d, d->Cout, d->Cin) != 1 || d->act != 0) return 0;
     return (int)(2 * plane2 / WBN);
 }
 
@@ -770,15 +900,32 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
     g.pad_mode = d->pad_mode; g.act = d->act;
     const long out_total = (long)d->N * d->Cout * d->H * d->W;
     g.slab_stride = out_total;
-    const int sp = wino_splits(d, d->Cout, d->Cin);
+    const bool twod = wino_fwd_2d(d);
+    const int sp = twod ? 4 * wino2d_ksplits(d) : wino_splits(d, d->Cout, d->Cin);
     if (sp > 1 && !ws) { fd_set_error("wino conv: split-K workspace missing"); return -1; }
     static bool attr_set = false;
     if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2d), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+    }
+    if (twod) {
+        if (stat_part) { fd_set_error("wino conv: no statistics epilogue for this shape"); return -1; }
+        const int HT = d->H / 2;
+        const int gx2 = fd_cdiv((long)d->N * HT * (d->W / 2), WBN);
+        g.slab_stride = out_total / 2;                                     // S_ri: [N][M][H/2][W]
+        g.xcd_swizzle = (gx2 % 8 == 0 && gx2 >= 16) ? 1 : 0;
+        hipLaunchKernelGGL(k_conv_wino2d, dim3(gx2, fd_cdiv(d->Cout, WBM), sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+        FD_LAUNCH_CHECK("k_conv_wino2d");
+        const unsigned total2 = (unsigned)(out_total / 4);               // one thread per (tile row, column pair)
+        const unsigned blocks = (total2 + 255u) / 256u;
+        hipLaunchKernelGGL(k_wino2d_finish, dim3(blocks > 4096u ? 4096u : blocks), dim3(256), 0, st, ws, y, bias, add, total2,
+                           g.slab_stride, sp / 4, HT, d->W, d->Cout, d->act);
+        FD_LAUNCH_CHECK("k_wino2d_finish");
+        return 0;
     }
     const int gx = fd_cdiv((long)d->N * d->H * (d->W / 2), WBN), gy = fd_cdiv(d->Cout, WBM);
     g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
@@ -795,7 +942,7 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
 }
 
 // ---- probe entry points (scripts/wino_probe.py, tests): the Winograd path on its own
-extern "C" long fd_conv3x3_wino_wt_floats(const fd_conv_desc* d) { return (d && wino_fwd_ok(d)) ? wino_wt_floats(d->Cout, d->Cin) : 0; }
+extern "C" long fd_conv3x3_wino_wt_floats(const fd_conv_desc* d) { return (d && wino_fwd_ok(d)) ? wino_wt_floats(d) : 0; }
 extern "C" long fd_conv3x3_wino_ws_floats(const fd_conv_desc* d) { return (d && wino_fwd_ok(d)) ? wino_ws_floats(d) : 0; }
 extern "C" int fd_conv3x3_wino_fwd(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, float* wt,
                                    int wt_ready, float* ws, void* stream) {
@@ -803,7 +950,7 @@ extern "C" int fd_conv3x3_wino_fwd(const fd_conv_desc* d, const float* x, const 
     FD_REQUIRE(wino_fwd_ok(d), "fd_conv3x3_wino_fwd: needs a 3x3 stride-1 pad-1 convolution with Cin %% 16 == 0 and an even width");
     hipStream_t st = (hipStream_t)stream;
     if (!wt_ready)
-        if (int rc = wino_weight_launch(w, wt, d->Cout, d->Cin, 0, st)) return rc;
+        if (int rc = wino_weight_launch(d, w, wt, 0, st)) return rc;
     return wino_conv_launch(d, x, wt, bias, y, ws, st);
 }
 

@@ -767,10 +767,11 @@ class _ConvPlan:
 
 
 def _conv_plan(x, w, stride, pad, pad_mode, act, in_norm):
-    # FD_CONV_FORCE and FD_WINO_WGRAD_2D are the tuning variables the library re-reads on every call (scripts/conv_cfg_sweep.py and
-    # the tests flip them within a process) and they change the split-K / slab workspace sizes: part of the key
+    # FD_CONV_FORCE and the FD_WINO_*_2D switches are the tuning variables the library re-reads on every call
+    # (scripts/conv_cfg_sweep.py and the tests flip them within a process) and they change the split-K / slab workspace and
+    # weight-layout sizes: part of the key
     key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, os.environ.get("FD_CONV_FORCE"),
-           os.environ.get("FD_WINO_WGRAD_2D"))
+           os.environ.get("FD_WINO_WGRAD_2D"), os.environ.get("FD_WINO_FWD_2D"), os.environ.get("FD_WINO_FWD_2D_MIN"))
     plan = _CONV_PLANS.get(key)
     if plan is None:
         plan = _CONV_PLANS[key] = _ConvPlan(x, w, stride, pad, pad_mode, act, in_norm)

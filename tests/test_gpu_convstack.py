@@ -630,33 +630,43 @@ def _wino_conv(x, w, bias, reflect, act=0):
     N, C, H, W = x.shape
     d = _lib.ConvDesc(N, C, H, W, w.shape[0], 3, 3, 1, 1, 1 if reflect else 0, act, 0)
     nwt = _lib.query("fd_conv3x3_wino_wt_floats", ctypes.byref(d))
-    assert nwt == 4 * w.shape[0] * 3 * C
+    assert nwt in (4 * w.shape[0] * 3 * C, 4 * w.shape[0] * 4 * C)          # F(2, 3) per kernel row / F(2x2, 3x3)
     y = torch.empty(N, w.shape[0], H, W, device="cuda")
     wt = torch.empty(nwt, device="cuda")
     ws = torch.empty(max(_lib.query("fd_conv3x3_wino_ws_floats", ctypes.byref(d)), 1), device="cuda")
     _lib.call("fd_conv3x3_wino_fwd", ctypes.byref(d), x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
               y.data_ptr(), wt.data_ptr(), 0, ws.data_ptr(), _lib.stream())
-    return y
+    return y, nwt
 
 
+@pytest.mark.parametrize("two_d", [1, 0])
 @pytest.mark.parametrize("N,Ci,Co,H,W,reflect,act", [
     (2, 64, 64, 48, 160, False, 0),      # layer1 shape, no split
     (1, 256, 256, 12, 40, False, 1),     # few tiles: split-K slabs + finish (bias + ReLU applied there)
     (2, 96, 80, 7, 10, False, 0),        # 80 output channels (partial channel tile), odd height, pairs < one tile
+    (2, 96, 80, 8, 10, False, 0),        # ... the same with whole 2x2 tiles
     (1, 128, 64, 24, 80, True, 2),       # reflect padding (decoder ConvBlock), ELU
     (3, 16, 64, 5, 6, True, 0),          # 16 input channels = a single chunk per kernel row
+    (3, 16, 64, 6, 6, True, 3),          # ... every 2x2 tile at one or two borders, sigmoid
+    (2, 64, 64, 2, 4, True, 0),          # one tile row: both vertical mirrors in the same tile
+    (2, 64, 64, 2, 4, False, 0),
+    (3, 512, 512, 6, 20, False, 1),      # layer4: the 2-D kernel also splits the input channels
 ])
-def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act):
+def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d, monkeypatch):
     """conv_wino.hip through its own entry point against torch float64 conv2d: error within a few fp32 ulps of the output scale,
-    i.e. no worse than the direct implicit GEMM (transform coefficients are +-1 and 1/2)."""
+    i.e. no worse than the direct implicit GEMM (transform coefficients are +-1 and 1/2).  two_d = 1: F(2x2, 3x3) (k_conv_wino2d +
+    k_wino2d_finish) forced onto every shape with an even height; 0: F(2, 3) per kernel row everywhere."""
+    monkeypatch.setenv("FD_WINO_FWD_2D", str(two_d))
+    monkeypatch.setenv("FD_WINO_FWD_2D_MIN", "1")
     torch.manual_seed(N * 1000 + Ci)
     x = torch.randn(N, Ci, H, W, device="cuda")
     w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
     b = torch.randn(Co, device="cuda")
     xp = F.pad(x.double(), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
     ref = F.conv2d(xp, w.double(), b.double())
-    ref = {0: ref, 1: F.relu(ref), 2: F.elu(ref)}[act]
-    got = _wino_conv(x, w, b, reflect, act)
+    ref = {0: ref, 1: F.relu(ref), 2: F.elu(ref), 3: torch.sigmoid(ref)}[act]
+    got, nwt = _wino_conv(x, w, b, reflect, act)
+    assert nwt == 4 * Co * (4 if two_d and H % 2 == 0 else 3) * Ci
     relclose(cpu(got), cpu(ref.float()), "winograd conv", rtol=1e-5, arel=3e-6)
 
 
@@ -674,13 +684,17 @@ def test_winograd_refuses_ineligible_shapes():
                   _lib.stream())
 
 
-def test_winograd_routing_forward_and_data_gradient_match_torch():
+@pytest.mark.parametrize("Ci,Co,two_d_min", [(64, 128, None), (64, 128, 1), (256, 256, None)])
+def test_winograd_routing_forward_and_data_gradient_match_torch(Ci, Co, two_d_min, monkeypatch):
     """FD.conv2d routes eligible 3x3 convs to the Winograd kernel (forward and zero-pad data gradient); values and both
-    gradients against torch autograd in float64, and the batched weight re-layout (modes 3 / 4) against the per-call transform."""
+    gradients against torch autograd in float64, and the batched weight re-layout (modes 3 / 4; 5 / 6 for the F(2x2, 3x3) layouts:
+    forced onto the small shape, by default on the 256-channel one) against the per-call transform."""
     import fusiondepth_amd.functional as FD
+    if two_d_min is not None:
+        monkeypatch.setenv("FD_WINO_FWD_2D_MIN", str(two_d_min))
     torch.manual_seed(5)
-    x = torch.randn(2, 64, 12, 40, device="cuda", requires_grad=True)
-    w = torch.nn.Parameter(torch.randn(128, 64, 3, 3, device="cuda") * 0.05)
+    x = torch.randn(2, Ci, 12, 40, device="cuda", requires_grad=True)
+    w = torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05)
     FD.enable_weight_cache([w])
     y = FD.conv2d(x, w, None, 1, 1)
     gy = torch.randn_like(y)
