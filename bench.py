@@ -306,7 +306,9 @@ def main():
     torch.cuda.set_device(local_rank % n_dev)
     opt = MonodepthOptions().parse(["--num_layers", str(args.num_layers), "--weights_init", "scratch", "--batch_size",
                                     str(args.batch_size), "--height", str(args.height), "--width", str(args.width)])
-    tr = Trainer(opt, rank=rank, world_size=world, verbose=(rank == 0))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):         # the trainer's banner: stdout carries the ONE JSON line and nothing else
+        tr = Trainer(opt, rank=rank, world_size=world, verbose=(rank == 0))
     tr.stack_microbatches = not args.no_stack
     # A pool of distinct step batches, resident in HBM.  The reference's loader yields the step's 12 images as 2 micro-batches of 6;
     # the stacked step consumes them as one batch: concatenate once, outside the timed region.

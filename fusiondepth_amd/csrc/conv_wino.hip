@@ -111,7 +111,9 @@ struct WinoArgs {
     long slab_stride;
     int M, C, Nb, H, W;
     int pad_mode, act;
-    int xcd_swizzle;     // consecutive pixel tiles (vertical neighbours share input rows) go to the same XCD / L2
+    int xcd_swizzle;     // 1: consecutive pixel tiles (vertical neighbours share input rows) go to the same XCD / L2
+                         // 2 (k_conv_wino2d): 1-D grid, all pixel tiles of a (channel tile, row component, split) on one XCD
+    int gx, gy, gz;      // the logical grid of xcd_swizzle == 2
     // optional: per-channel statistics of the output for the BatchNorm that follows (fd_conv2d_fwd_stats): [Nb][M][stat_slots][2] =
     // (sum, sum of squares) over the 64 pixels of each (pixel tile, 32-pair half); needs tiles that do not straddle images
     float* stat_part;
@@ -144,14 +146,23 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& g) {
     const int plane2 = HT * W2;                                          // units per image; Nb * plane2 < 2^29 (size guard)
     const int Np = g.Nb * plane2;
     const unsigned hw = (unsigned)(g.H * g.W);
-    const int m0 = blockIdx.y * WBM;
-    int bx = blockIdx.x;
-    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nz = gridDim.z;
+    if (TWOD && g.xcd_swizzle == 2) {
+        // Workgroup id L runs on XCD L % 8.  The deep layers are weight-heavy (layer4: 16.8 MB of U2 against 6 MB of activations at
+        // batch 24): with the pixel tile as the fastest grid index every XCD pulled every U2 slice through its own L2 - 154 MB of
+        // fetches per launch (profiles/round3_pmc_conv_wino2d_layer4.md).  Here the pixel tiles of one (channel tile, row
+        // component, split) slice get ids 8 apart: one XCD, back to back, the slice's 512 KB of U2 read from HBM once.
+        const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
+        bx = k % g.gx;
+        const int sl = (k / g.gx) * 8 + xcd;
+        by = sl % g.gy; bz = sl / g.gy; nz = g.gz;
+    } else if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    const int m0 = by * WBM;
     const int p0 = bx * WBN;
     const int cpt = g.C / WBKC, nchunk_all = TWOD ? cpt : 3 * cpt;
-    const int zs = (int)blockIdx.z;
+    const int zs = bz;
     const int ri = TWOD ? zs & 3 : 0;                                    // row component of this workgroup
-    const int nsplit = TWOD ? (int)gridDim.z >> 2 : (int)gridDim.z;
+    const int nsplit = TWOD ? nz >> 2 : nz;
     const int ks = TWOD ? zs >> 2 : zs;
     constexpr unsigned UR = TWOD ? 4u : 3u;                              // weight rows per output channel
     const int xr_a = ri == 0 ? 0 : (ri == 2 ? 2 : 1), xr_b = ri == 3 ? 3 : (ri == 2 ? 1 : 2);
@@ -917,8 +928,13 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         const int HT = d->H / 2;
         const int gx2 = fd_cdiv((long)d->N * HT * (d->W / 2), WBN);
         g.slab_stride = out_total / 2;                                     // S_ri: [N][M][H/2][W]
+        const int gy2 = fd_cdiv(d->Cout, WBM);
+        static int xmap = -1;
+        if (xmap < 0) { const char* e = getenv("FD_WINO_2D_MAP"); xmap = e ? atoi(e) : 1; }
         g.xcd_swizzle = (gx2 % 8 == 0 && gx2 >= 16) ? 1 : 0;
-        hipLaunchKernelGGL(k_conv_wino2d, dim3(gx2, fd_cdiv(d->Cout, WBM), sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+        dim3 grid(gx2, gy2, sp);
+        if (xmap && (gy2 * sp) % 8 == 0) { g.xcd_swizzle = 2; g.gx = gx2; g.gy = gy2; g.gz = sp; grid = dim3((unsigned)(gx2 * gy2 * sp)); }
+        hipLaunchKernelGGL(k_conv_wino2d, grid, dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
         FD_LAUNCH_CHECK("k_conv_wino2d");
         const unsigned total2 = (unsigned)(out_total / 4);               // one thread per (tile row, column pair)
         const unsigned blocks = (total2 + 255u) / 256u;

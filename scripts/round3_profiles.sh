@@ -18,3 +18,5 @@ bash scripts/pmc_kernel.sh round3_wgrad_wino_l3 k_wgrad_wino 2 -- python $R/scri
 bash scripts/pmc_kernel.sh round3_conv_wino_l1 k_conv_wino 2 -- python $R/scripts/probe_layer1.py 12 > /dev/null 2>&1
 bash scripts/pmc_kernel.sh round3_conv_fast_s2 k_conv_fast 4 -- python $R/scripts/conv_one.py 64 48 160 128 3 2 1 24 8 > /dev/null 2>&1
 ls -la $O | grep round3
+bash scripts/pmc_kernel.sh round3_conv_wino2d_l4 k_conv_wino2d 2 -- python $R/scripts/conv_one.py 512 6 20 512 3 1 1 24 8 > /dev/null 2>&1
+ls -la $O | grep round3
