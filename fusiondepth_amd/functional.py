@@ -579,8 +579,52 @@ _NEXT_CACHE_ID = [1]
 
 def _drop_plan():
     if _WT_PLAN[0] is not None:
-        _WT_RETIRED.append(_WT_PLAN[0][0])
+        _WT_RETIRED.extend(part[0] for part in _WT_PLAN[0] if part is not None)
         _WT_PLAN[0] = None
+    _sync_late_layouts(host=True)
+
+
+# The re-layout launch that follows the Adam kernel is pure HBM traffic (~0.5 GB: every 3x3 weight in its forward and its
+# data-gradient layout, the F(2x2, 3x3) ones at 16 floats per tap) with nothing to overlap it on the stream that just finished the
+# step.  Only the small forward layouts of the first layers are needed at once; everything else ("late": data-gradient layouts,
+# forward layouts from 1 MB up = ResNet layer3 / layer4 and the decoder's deep blocks) is refreshed on a side stream while the next
+# step's stems and first blocks run, and a stream that is about to USE a late layout waits for that launch first
+# (``_weight_layout``), as does the next optimiser step before it changes the weights again.  FD_LATE_RELAYOUT=0: one launch.
+_LATE_MIN_FLOATS = 1 << 18
+_LATE = {"event": None, "waited": set(), "stream": None}
+
+
+def _late_relayout_on():
+    return os.environ.get("FD_LATE_RELAYOUT", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+
+
+def _wait_late_layouts():
+    """Order the current stream behind the pending side-stream re-layout (once per stream and optimiser step)."""
+    ev = _LATE["event"]
+    if ev is None:
+        return
+    sid = stream()
+    if sid not in _LATE["waited"]:
+        torch.cuda.current_stream().wait_event(ev)
+        _LATE["waited"].add(sid)
+
+
+def sync_late_layouts():
+    """Order the current stream behind a pending side-stream re-layout and forget it (call before capturing a hipGraph, before
+    touching the cached layouts from outside)."""
+    _sync_late_layouts()
+
+
+def _sync_late_layouts(host=False):
+    """Forget the pending late re-layout after ordering the current stream behind it.  ``host``: wait on the host instead - for
+    callers in the middle of a step (a new layout shape dropped the plan), where other streams may be about to use a late layout
+    without passing through the current stream first."""
+    if _LATE["event"] is not None:
+        if host and not torch.cuda.is_current_stream_capturing():
+            _LATE["event"].synchronize()
+        torch.cuda.current_stream().wait_event(_LATE["event"])
+        _LATE["event"] = None
+        _LATE["waited"] = set()
 
 
 def evict_dead_weight_layouts():
@@ -680,6 +724,8 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
     stamp = (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
     ent = _WT_CACHE.get(key)
     if ent is not None and ent[1].numel() == nfloats:
+        if _LATE["event"] is not None and len(ent) > 4 and ent[4]:
+            _wait_late_layouts()
         if ent[0] == stamp:
             return ent[1], 1
         ent[0] = stamp
@@ -687,7 +733,7 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
     if ent is not None:
         _WT_RETIRED.append(ent[1])      # size changed (another input shape routed this weight to another kernel family)
     buf = torch.empty((nfloats,), device=w.device, dtype=torch.float32)
-    _WT_CACHE[key] = [stamp, buf, desc, weakref.ref(w)]
+    _WT_CACHE[key] = [stamp, buf, desc, weakref.ref(w), False]
     _drop_plan()                        # a layout the plan does not know: fall back to per-call re-layout until rebuilt
     return buf, 0
 
@@ -705,20 +751,32 @@ def build_weight_plan():
     if not ents:
         _drop_plan()
         return 0
-    jobs = (RelayoutJob * (4 * len(ents)))()
-    n = 0
-    for (cid, kind), e in ents:
-        n += query("fd_conv2d_relayout_jobs", ctypes.addressof(e[2]), 0 if kind == "f" else 1, ptr(e[3]()), ptr(e[1]),
-                   ctypes.addressof(jobs) + n * ctypes.sizeof(RelayoutJob))
-    if n == 0:
-        _drop_plan()
-        return 0
-    blocks = query("fd_relayout_plan", ctypes.addressof(jobs), n)
-    raw = bytes(memoryview(jobs))[: n * ctypes.sizeof(RelayoutJob)]
-    dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(ents[0][1][1].device)
+    def table(part):
+        if not part:
+            return None, 0
+        jobs = (RelayoutJob * (4 * len(part)))()
+        n = 0
+        for (cid, kind), e in part:
+            n += query("fd_conv2d_relayout_jobs", ctypes.addressof(e[2]), 0 if kind == "f" else 1, ptr(e[3]()), ptr(e[1]),
+                       ctypes.addressof(jobs) + n * ctypes.sizeof(RelayoutJob))
+        if n == 0:
+            return None, 0
+        blocks = query("fd_relayout_plan", ctypes.addressof(jobs), n)
+        raw = bytes(memoryview(jobs))[: n * ctypes.sizeof(RelayoutJob)]
+        dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(part[0][1][1].device)
+        return (dev, n, blocks, [k for k, _ in part]), n
+    is_late = lambda k, e: k[1] != "f" or e[1].numel() >= _LATE_MIN_FLOATS
+    for k, e in ents:
+        while len(e) < 5:
+            e.append(False)
+        e[4] = bool(is_late(k, e))
+    early, n_early = table([(k, e) for k, e in ents if not e[4]])
+    late, n_late = table([(k, e) for k, e in ents if e[4]])
     _drop_plan()
-    _WT_PLAN[0] = (dev, n, blocks, [k for k, _ in ents])
-    return n
+    if n_early + n_late == 0:
+        return 0
+    _WT_PLAN[0] = (early, late)
+    return n_early + n_late
 
 
 def refresh_weight_layouts():
@@ -726,13 +784,30 @@ def refresh_weight_layouts():
     plan = _WT_PLAN[0]
     if plan is None:
         return False
-    dev, n, blocks, keys = plan
-    call("fd_relayout_batch", ptr(dev), n, blocks, stream())
-    for k in keys:
-        e = _WT_CACHE[k]
-        w = e[3]()
-        if w is not None:
-            e[0] = (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
+    early, late = plan
+    _sync_late_layouts()                       # (a refresh without an optimiser step in between: never two in flight)
+    for part in (early, late):
+        if part is None:
+            continue
+        dev, n, blocks, keys = part
+        if part is late and _late_relayout_on():
+            cur = torch.cuda.current_stream()
+            if _LATE["stream"] is None:
+                _LATE["stream"] = torch.cuda.Stream()
+            side = _LATE["stream"]
+            side.wait_stream(cur)              # behind the Adam kernel (and everything that read the old layouts)
+            with torch.cuda.stream(side):
+                call("fd_relayout_batch", ptr(dev), n, blocks, stream())
+                ev = torch.cuda.Event()
+                ev.record(side)
+            _LATE["event"], _LATE["waited"] = ev, set()
+        else:
+            call("fd_relayout_batch", ptr(dev), n, blocks, stream())
+        for k in keys:
+            e = _WT_CACHE[k]
+            w = e[3]()
+            if w is not None:
+                e[0] = (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
     return True
 
 
@@ -1260,6 +1335,7 @@ def depth_errors(gt, pred):
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
     """One torch.optim.Adam update of a flat fp32 tensor, in place."""
     bc1, bc2 = 1.0 - betas[0] ** step, 1.0 - betas[1] ** step
+    _sync_late_layouts()
     bump_weights_epoch()
     call("fd_adam_step", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr), betas[0],
          betas[1], float(eps), bc1, bc2, float(grad_scale), stream())
@@ -1268,6 +1344,7 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), ep
 
 def adam_step_dev(param, grad, exp_avg, exp_avg_sq, state, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
     """Adam update whose step counter / lr live in ``state`` (device, [step, lr]) — hipGraph-replay safe."""
+    _sync_late_layouts()
     bump_weights_epoch()
     call("fd_adam_step_dev", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), ptr(state), betas[0],
          betas[1], float(eps), float(grad_scale), stream())

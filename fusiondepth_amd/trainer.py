@@ -445,6 +445,7 @@ class Trainer:
                 self._ensure_weight_plan()     # layouts valid now; inside the graph Adam is followed by the batched refresh
             if FD._WT_PLAN[0] is None:
                 FD.bump_weights_epoch()        # no plan: the captured step must re-derive every weight layout at first use
+            FD.sync_late_layouts()             # no event from outside the capture may be waited on inside it
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self._side):

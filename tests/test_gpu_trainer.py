@@ -498,6 +498,43 @@ def test_gradients_are_run_to_run_identical_under_gpu_contention(interleave):
             assert torch.equal(g, ref), "repetition %d: %d gradient entries differ" % (rep, int((g != ref).sum()))
 
 
+def test_late_weight_relayout_is_ordered_before_its_readers(monkeypatch):
+    """functional.refresh_weight_layouts sends the big half of the post-Adam re-layout (data-gradient layouts, forward layouts from
+    1 MB up) to a side stream and lets every stream that is about to use such a layout wait for it first.  Five optimiser steps with
+    that side stream held back by ~50 ms of queued matrix products must leave the parameters bit-identical to the one-launch
+    refresh (FD_LATE_RELAYOUT=0): a reader that did not wait would have convolved with the previous step's weights."""
+    from fusiondepth_amd import functional as FD
+    from fusiondepth_amd.trainer import Trainer
+    B, H, W = 2, 64, 96
+    batches = []
+    for i in range(5):
+        inp, noise = _batch(B, H, W, 1200 + i)
+        g = {k: v.cuda() for k, v in inp.items()}
+        g["_noise"] = [n.cuda() for n in noise]
+        batches.append(g)
+    junk = torch.randn(4096, 4096, device="cuda")
+    params, used = {}, 0
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FD_LATE_RELAYOUT", mode)
+        torch.manual_seed(4321)                                  # the same initial weights for both trainers
+        tr = Trainer(_opts(batch_size=B), verbose=False)
+        assert tr.accumulate_step == 1
+        for g in batches:
+            if mode == "1" and FD._LATE["stream"] is not None:
+                with torch.cuda.stream(FD._LATE["stream"]):      # queued in front of this step's re-layout launch
+                    for _ in range(40):
+                        junk @ junk
+            tr.train_step([g])
+            used += int(mode == "1" and FD._LATE["event"] is not None)
+        torch.cuda.synchronize()
+        params[mode] = tr.flat.flat_param.clone()
+        FD.sync_late_layouts()
+        del tr
+    assert used >= 3, "the side-stream re-layout never ran"
+    assert torch.isfinite(params["0"]).all()
+    assert torch.equal(params["0"], params["1"]), "%d parameters differ" % int((params["0"] != params["1"]).sum())
+
+
 def test_decoder_weight_gradients_on_the_side_stream_are_bit_identical(monkeypatch):
     """functional.enable_side_wgrad (default for the depth decoder): its weight gradients, slab reductions and bias sums run on a side
     stream beside the data gradients of the following layers.  Same kernels, same accumulation targets: the gradient buffer after a
