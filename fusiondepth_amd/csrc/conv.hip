@@ -788,6 +788,7 @@ void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
 
 extern "C" long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d) {
     if (!d || !fast_fwd_ok(d)) return 0;
+    if (n16_shape_ok(d, d->Cout, d->Cin)) return 0;              // reads the weights as they are
     if (wino_use_fwd(d)) return align4(wino_wt_floats(d));
     return align4((long)d->Cout * d->Cin * d->KH * d->KW);
 }
@@ -796,6 +797,7 @@ extern "C" long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s) || !fast_fwd_ok(d)) return 0;
+    if (n16_shape_ok(d, d->Cout, d->Cin)) return 0;
     if (wino_use_fwd(d)) return wino_ws_floats(d);
     FastGemmArgs f;
     fill_fwd_args(d, s, f);
@@ -830,6 +832,11 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
     FD_REQUIRE((long)d->N * d->Cin * d->H * d->W < (1L << 29) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 29),
                "fd_conv2d_fwd: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
+    if (fast_fwd_ok(d) && n16_shape_ok(d, d->Cout, d->Cin)) {
+        FD_REQUIRE(!stat_part, "fd_conv2d_fwd_stats: no statistics epilogue for this shape");
+        conv_log("fwd", "n16", d);
+        return n16_launch(d, d->Cout, d->Cin, x, w, bias, y, 0, d->pad_mode, d->act, st);
+    }
     if (fast_fwd_ok(d)) {
         FD_REQUIRE(wt, "fd_conv2d_fwd: weight-layout buffer required (fd_conv2d_fwd_wt_floats)");
         if (wino_use_fwd(d)) {
@@ -993,7 +1000,12 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
             g.Y = gx; g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin;
             add_in_kernel = false;       // a second gradient of the tensor (not used by the decoder) is added after the fold, so
                                          // that the sum keeps the order (interior + ring) + other of the fold path, bit for bit
-            if (int rc = run(KH, KW, KH - 1, -1, KW - 1, -1, true)) return rc;
+            if (n16_shape_ok(d, d->Cin, d->Cout)) {      // the zero-padded data gradient of a 16 / 32-channel block: conv_n16.hip on dY
+                conv_log("dgrad", "n16 + ring", d);
+                if (!wt_ready)                           // the ring below still runs on the implicit-GEMM kernel and its layout
+                    if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, KH, KW, KH, KW, KH - 1, -1, KW - 1, -1, 1, st)) return rc;
+                if (int rc = n16_launch(d, d->Cin, d->Cout, gy, w, nullptr, gx, 1, 0, 0, st)) return rc;
+            } else if (int rc = run(KH, KW, KH - 1, -1, KW - 1, -1, true)) return rc;
             const int Hp = d->H, Wp2 = d->W + 2;
             const long ring_plane = 2L * Wp2 + 2L * Hp;
             float* ring = gpad;                                   // [N][Cin][top W+2 | bottom W+2 | left H | right H]
@@ -1118,7 +1130,7 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
         j.n = (long)d->Cout * d->Cin * TA * TB;
     };
     if (kind == 0) {
-        if (!fast_fwd_ok(d)) return 0;
+        if (!fast_fwd_ok(d) || n16_shape_ok(d, d->Cout, d->Cin)) return 0;
         fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? (wino_fwd_2d(d) ? 5 : 3) : 0);
         return 1;
     }

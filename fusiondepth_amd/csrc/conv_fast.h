@@ -68,6 +68,10 @@ int wino_weight_launch(const fd_conv_desc* d, const float* w, float* U, int flip
 int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st,
                      const float* add = nullptr, float* stat_part = nullptr);
 int wino_stat_slots(const fd_conv_desc* d);
+// conv_n16.hip: 3x3 stride-1 convolutions with 16 / 32 channels on either side (the decoder's full-resolution blocks)
+bool n16_shape_ok(const fd_conv_desc* d, int M, int C);
+int n16_launch(const fd_conv_desc* d, int M, int C, const float* x, const float* w, const float* bias, float* y, int flip,
+               int pad_mode, int act, hipStream_t st);
 bool wino_wgrad_ok(const fd_conv_desc* d);
 long wino_wgrad_ws_floats(const fd_conv_desc* d);
 int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st);

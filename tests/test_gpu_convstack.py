@@ -77,6 +77,44 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("n16", [1, 0])
+@pytest.mark.parametrize("N,Cin,Cout,H,W,mode,act", [
+    (1, 16, 16, 64, 96, "reflect", "elu"),       # upconv(0,1) at a small input: one-and-a-half column tiles
+    (2, 16, 16, 37, 130, "reflect", "elu"),      # ragged: the first padding column is an interior lane of the last tile, 5 row tiles
+    (2, 32, 16, 37, 130, "reflect", "elu"),      # upconv(0,0): 8 channel groups, 4-row tiles
+    (2, 16, 32, 21, 67, "reflect", "none"),      # 32 output channels (the data gradient's shape of upconv(0,0))
+    (2, 16, 16, 21, 67, "zero", "relu"),         # zero padding
+    (3, 16, 16, 2, 2, "reflect", "sigmoid"),     # both mirrors inside one tile
+    (12, 16, 16, 192, 640, "reflect", "elu"),    # the real thing: 2 880 workgroups
+])
+def test_conv3x3_n16_kernel(FD, N, Cin, Cout, H, W, mode, act, n16, monkeypatch):
+    """conv_n16.hip (16 / 32-channel 3x3 blocks on the 16x16x4 MFMA, weights in registers, the patch staged once): forward, data
+    gradient (kernel on dY with flipped weights + the ring of the reflect adjoint) and weight gradient against torch on the CPU;
+    n16 = 0 runs the same cases on the implicit-GEMM kernel these layers used before."""
+    import ctypes
+    from fusiondepth_amd import _lib
+    monkeypatch.setenv("FD_CONV_N16", str(n16))
+    monkeypatch.setenv("FD_CONV_N16_MIN", "1")
+    monkeypatch.setenv("FD_REFLECT_RING", "2")             # the interior + ring data gradient on every plane size
+    d = _lib.ConvDesc(N, Cin, H, W, Cout, 3, 3, 1, 1, 1 if mode == "reflect" else 0, {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}[act], 0)
+    assert (_lib.query("fd_conv2d_fwd_wt_floats", ctypes.byref(d)) == 0) == bool(n16)      # the n16 kernel reads the weights as they are
+    rng = np.random.RandomState(N * 100 + Cin + H)
+    x = torch.from_numpy(rng.randn(N, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rng.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32))
+    b = torch.from_numpy((0.1 * rng.randn(Cout)).astype(np.float32))
+    xo, wo, bo = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = ACTS[act](F.conv2d(F.pad(xo, (1,) * 4, mode="reflect"), wo, bo) if mode == "reflect" else F.conv2d(xo, wo, bo, 1, 1))
+    cot = torch.from_numpy(rng.randn(*yo.shape).astype(np.float32))
+    want = torch.autograd.grad((yo * cot).sum(), [xo, wo, bo])
+    xg, wg, bg = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    yg = FD.conv2d(xg, wg, bg, 1, 1, mode, act)
+    got = torch.autograd.grad((yg * dev(cot)).sum(), [xg, wg, bg])
+    relclose(cpu(yg), cpu(yo), "conv fwd")
+    relclose(cpu(got[0]), cpu(want[0]), "conv dgrad")
+    relclose(cpu(got[1]), cpu(want[1]), "conv wgrad")
+    relclose(cpu(got[2]), cpu(want[2]), "conv bias grad")
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
 def test_conv2d_fwd_bwd(FD, case):
     N, Cin, H, W, Cout, K, stride, pad, mode, act, has_bias, in_norm = case
