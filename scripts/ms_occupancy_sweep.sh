@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in "3 0" "6 0" "12 0" "24 0" "12 40" "12 48" "12 64" "12 96" "12 16"; do
   set -- $cfg
   rm -rf /tmp/prof_occ
-  timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_occ -- python -u $R/scripts/time_ms_kernel.py $1 $2 1 > /tmp/occ.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_occ -- python -u $R/scripts/time_ms_kernel.py $1 $2 1 > /tmp/occ.log 2>&1
   DB=$(find /tmp/prof_occ -name "*_results.db" | head -1)
   python - "$DB" "$1" "$2" <<'PY'
 import sqlite3, sys

@@ -10,7 +10,7 @@ for grp in "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_GUI_ACTIVE WRITE_SIZE" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" \
            "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1)); rm -rf /tmp/pk_${TAG}_$i
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pk_${TAG}_$i --output-format csv -- "$@" > /tmp/pk_${TAG}_$i.log 2>&1
+  timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pk_${TAG}_$i --output-format csv -- "$@" > /tmp/pk_${TAG}_$i.log 2>&1
   echo "pass $i rc=$? ($grp)"
 done
 python - "$TAG" "$MATCH" "$SKIP" "$*" > $R/gpurun_out/${TAG}_pmc.md <<'PY'

@@ -7,7 +7,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_L
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/pl_$i
-  timeout 200 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pl_$i --output-format csv -- $R/scripts/ubench/limb_gemm > /tmp/pl_$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pl_$i --output-format csv -- $R/scripts/ubench/limb_gemm > /tmp/pl_$i.log 2>&1
   echo "pass $i rc=$? ($grp)"
   CSV=$(find /tmp/pl_$i -name "*counter_collection.csv" | head -1)
   python - "$CSV" <<'PY'

@@ -9,7 +9,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS" \
            "GRBM_GUI_ACTIVE FETCH_SIZE" "GRBM_GUI_ACTIVE WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
-  PROBE_TIMING=0 timeout 300 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc_$i --output-format csv -- python -u $R/scripts/probe_loss_ms.py $B $ROWS 6 > /tmp/pmc_$i.log 2>&1
+  PROBE_TIMING=0 timeout -k 10 300 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pmc_$i --output-format csv -- python -u $R/scripts/probe_loss_ms.py $B $ROWS 6 > /tmp/pmc_$i.log 2>&1
   echo "pass $i rc=$? ($grp)" >> $OUT
   CSV=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   python - "$CSV" >> $OUT <<'PY'

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1)); rm -rf /tmp/pp_$i
-  timeout 200 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pp_$i --output-format csv -- python -u $R/scripts/probe_layer1.py 12 > /tmp/pp_$i.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $grp --kernel-trace -d /tmp/pp_$i --output-format csv -- python -u $R/scripts/probe_layer1.py 12 > /tmp/pp_$i.log 2>&1
   echo "pass $i rc=$? ($grp)"
 done
 python - <<PY

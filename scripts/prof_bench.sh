@@ -3,7 +3,7 @@
 TAG=${1:-r2}; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/profb_$TAG
-timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/profb_$TAG -- python -u $R/bench.py --eager --steps 4 --warmup 2 --no_cpu_baseline --no_roofline "$@" > $R/gpurun_out/profb_$TAG.log 2>&1
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/profb_$TAG -- python -u $R/bench.py --eager --steps 4 --warmup 2 --no_cpu_baseline --no_roofline "$@" > $R/gpurun_out/profb_$TAG.log 2>&1
 echo "rocprof rc=$?"; tail -2 $R/gpurun_out/profb_$TAG.log | cut -c1-300
 DB=$(find /tmp/profb_$TAG -name "*_results.db" | head -1)
 # 2 steady-state + 2 warm-up + 4 timed = 8 optimiser steps traced

@@ -4,7 +4,7 @@
 TAG=${1:-r2}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/profp_$TAG
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/profp_$TAG -- python -u $R/bench.py --probe_only > $R/gpurun_out/profp_$TAG.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/profp_$TAG -- python -u $R/bench.py --probe_only > $R/gpurun_out/profp_$TAG.log 2>&1
 echo "rocprof rc=$?"; tail -1 $R/gpurun_out/profp_$TAG.log | cut -c1-700
 DB=$(find /tmp/profp_$TAG -name "*_results.db" | head -1)
 python $R/scripts/rocprof_summary.py $DB 1 30 > $R/gpurun_out/${TAG}_probe_kernel_stats.md
