@@ -773,6 +773,25 @@ inline bool wino_dgrad_desc(const fd_conv_desc* d, fd_conv_desc& g) {
     return wino_fwd_ok(&g) && g.Cout >= 64;
 }
 
+// The interior of a REFLECT-padded 3x3 data gradient (the padded grid's cells that are real pixels) is the zero-padded data
+// gradient: a plain 3x3 convolution over dY with the transposed, flipped kernel - Winograd-eligible like the trunk's.  With the
+// padded grid's one-pixel ring as four thin problems on the implicit-GEMM kernel + k_reflect_ring_fold (round 3), the decoder's
+// wide blocks (upconv(2..4, *): 64 .. 512 channels) leave the direct kernel's padded-grid pass (46 - 60 TFLOP/s on these shapes)
+// and its full fold pass.  `g`: the convolution the interior computes.  FD_REFLECT_WINO=0 switches it off; needs FD_REFLECT_RING != 0.
+bool refl_wino_interior(const fd_conv_desc* d, fd_conv_desc& g) {
+    if (!(wino_fwd_enabled() && d->pad_mode == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H >= 2 && d->W >= 2)) return false;
+    const char* e = getenv("FD_REFLECT_WINO");
+    if (e && atoi(e) == 0) return false;
+    const char* r = getenv("FD_REFLECT_RING");
+    if (r && atoi(r) == 0) return false;
+    const char* m = getenv("FD_REFLECT_WINO_MIN");
+    if ((long)d->H * d->W < (m ? atol(m) : 1)) return false;
+    if (!fast_dgrad_ok(d)) return false;                     // the ring runs on the implicit-GEMM kernel
+    g = *d;
+    g.Cin = d->Cout; g.Cout = d->Cin; g.pad_mode = 0; g.act = 0; g.in_norm = 0;
+    return wino_fwd_ok(&g) && g.Cout >= 64;
+}
+
 void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
     f = FastGemmArgs{};
     f.M = d->Cout; f.C = d->Cin; f.T = d->KH * d->KW; f.TB = d->KW; f.K = f.T * f.C;
@@ -874,6 +893,8 @@ extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     fd_conv_desc g;
     if (wino_dgrad_desc(d, g)) return align4(wino_wt_floats(&g));
+    if (refl_wino_interior(d, g))                            // [layout of the ring's implicit GEMM | U of the interior's Winograd kernel]
+        return align4((long)d->Cin * d->Cout * d->KH * d->KW) + align4(wino_wt_floats(&g));
     return (d->stride == 1 ? 1 : 4) * align4((long)d->Cin * d->Cout * d->KH * d->KW);
 }
 
@@ -900,6 +921,8 @@ extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
             f.out_total = (long)d->N * d->Cin * f.NY * f.NX;
             const long s2 = fast_splitk_slab_floats(f, nullptr);
             slabs = s2 > slabs ? s2 : slabs;
+            fd_conv_desc gz;
+            if (refl_wino_interior(d, gz)) { const long s3 = wino_ws_floats(&gz); slabs = s3 > slabs ? s3 : slabs; }
         }
     }
     return wt + padded + slabs;
@@ -990,8 +1013,10 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
         g.osy = 1; g.ooy = 0; g.osx = 1; g.oox = 0;
         int ring_on = 1;                       // read per call (reflect-padded layers only: 20 calls per step), so that tests can switch it
         if (d->pad_mode == 1) { const char* e = getenv("FD_REFLECT_RING"); ring_on = e ? atoi(e) : 1; }
+        fd_conv_desc gz;
+        const bool wino_interior = refl_wino_interior(d, gz);
         if (d->pad_mode == 1 && fast && ring_on && KH == 3 && KW == 3 && d->pad == 1 && d->H >= 2 && d->W >= 2 &&
-            (long)d->H * d->W >= (ring_on > 1 ? ring_on : 16384)) {      // smaller planes (measured up to 48 x 160): four thin launches + their fold cost more than the fold pass
+            (wino_interior || (long)d->H * d->W >= (ring_on > 1 ? ring_on : 16384))) {      // smaller planes (measured up to 48 x 160): four thin launches + their fold cost more than the fold pass
             // Reflect padding, 3x3: (1) the interior of the padded grid = the zero-padded data gradient, straight into gx (with the
             // second gradient of the tensor, if any, in the epilogue); (2) the ring's four strips as ONE grouped launch of thin
             // problems into a small buffer; (3) k_reflect_ring_fold.  The padded-grid gradient + k_reflect_fold of rounds 1-2 wrote
@@ -1000,7 +1025,15 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
             g.Y = gx; g.out_w = d->W; g.out_cs = (long)d->H * d->W; g.out_ns = g.out_cs * d->Cin;
             add_in_kernel = false;       // a second gradient of the tensor (not used by the decoder) is added after the fold, so
                                          // that the sum keeps the order (interior + ring) + other of the fold path, bit for bit
-            if (n16_shape_ok(d, d->Cin, d->Cout)) {      // the zero-padded data gradient of a 16 / 32-channel block: conv_n16.hip on dY
+            if (wino_interior) {                         // the decoder's wide blocks: the interior on the Winograd kernels
+                conv_log("dgrad", "wino + ring", d);
+                float* wt_wino = wt + wt_n;
+                if (!wt_ready) {
+                    if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, KH, KW, KH, KW, KH - 1, -1, KW - 1, -1, 1, st)) return rc;
+                    if (int rc = wino_weight_launch(&gz, w, wt_wino, 1, st)) return rc;
+                }
+                if (int rc = wino_conv_launch(&gz, gy, wt_wino, nullptr, gx, slabs, st, nullptr)) return rc;
+            } else if (n16_shape_ok(d, d->Cin, d->Cout)) {      // the zero-padded data gradient of a 16 / 32-channel block: conv_n16.hip on dY
                 conv_log("dgrad", "n16 + ring", d);
                 if (!wt_ready)                           // the ring below still runs on the implicit-GEMM kernel and its layout
                     if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, KH, KW, KH, KW, KH - 1, -1, KW - 1, -1, 1, st)) return rc;
@@ -1142,6 +1175,11 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
     const int mode = fast_dgrad_ok(d) ? 1 : 2;
     if (d->stride == 1) {
         fill(jobs[0], wt, KH, KW, KH - 1, -1, KW - 1, -1, mode);
+        fd_conv_desc gz;
+        if (refl_wino_interior(d, gz)) {                 // second layout behind the first: U of the interior's Winograd kernel
+            fill(jobs[1], wt + align4((long)d->Cin * d->Cout * KH * KW), KH, KW, 0, 1, 0, 1, wino_fwd_2d(&gz) ? 6 : 4);
+            return 2;
+        }
         return 1;
     }
     const long wt_n = align4((long)d->Cin * d->Cout * KH * KW);

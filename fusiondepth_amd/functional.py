@@ -847,7 +847,8 @@ def _conv_plan(x, w, stride, pad, pad_mode, act, in_norm):
     # weight-layout sizes: part of the key
     key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, os.environ.get("FD_CONV_FORCE"),
            os.environ.get("FD_WINO_WGRAD_2D"), os.environ.get("FD_WINO_FWD_2D"), os.environ.get("FD_WINO_FWD_2D_MIN"),
-           os.environ.get("FD_CONV_N16"), os.environ.get("FD_CONV_N16_MIN"))
+           os.environ.get("FD_CONV_N16"), os.environ.get("FD_CONV_N16_MIN"), os.environ.get("FD_REFLECT_RING"),
+           os.environ.get("FD_REFLECT_WINO"), os.environ.get("FD_REFLECT_WINO_MIN"))
     plan = _CONV_PLANS.get(key)
     if plan is None:
         plan = _CONV_PLANS[key] = _ConvPlan(x, w, stride, pad, pad_mode, act, in_norm)

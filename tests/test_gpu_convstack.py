@@ -620,13 +620,18 @@ def test_batchnorm_statistics_of_a_near_constant_map(FD):
 
 @pytest.mark.parametrize("N,Ci,Co,H,W", [(2, 64, 32, 3, 6), (1, 128, 64, 2, 4), (2, 96, 32, 5, 8), (1, 16, 16, 4, 10), (2, 64, 64, 12, 40),
                                          (1, 32, 48, 3, 3), (1, 512, 256, 6, 20), (2, 32, 16, 7, 5),
-                                         (2, 96, 32, 96, 320), (1, 16, 16, 192, 640), (1, 288, 32, 96, 320)])      # >= 16 384 pixels: the ring path by default
-def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W, monkeypatch):
+                                         (2, 96, 32, 96, 320), (1, 16, 16, 192, 640), (1, 288, 32, 96, 320),      # >= 16 384 pixels: the ring path by default
+                                         (2, 512, 256, 12, 40), (2, 128, 64, 48, 160), (3, 64, 32, 5, 6)])       # upconv(4,1), upconv(2,1); odd height
+@pytest.mark.parametrize("wino", [1, 0])
+def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W, wino, monkeypatch):
     """conv3x3(ReflectionPad2d(1)(x)) - every DepthDecoder convolution (networks/depth_decoder.py, layers.py Conv3x3): its data
     gradient = the zero-padded data gradient written straight to gx + the padded grid's one-pixel ring (four strips, one grouped
     launch) folded back onto rows 1 / H-2 and columns 1 / W-2 (k_reflect_ring_fold), including images so small that the two target
     rows / columns coincide (H = 3) or are the border itself (H = 2), odd sizes, and a second gradient joining at the input
-    (conv2d_tap).  Against torch's float64 autograd of F.pad(mode="reflect") + conv2d."""
+    (conv2d_tap).  wino = 1 (default): where the input has >= 64 channels and the width is even the interior runs on the Winograd
+    kernels (F(2, 3) per kernel row, F(2x2, 3x3) from 256 x 256 channels on) with its own weight layout behind the ring's; 0: the
+    interior on the implicit-GEMM kernel everywhere.  Against torch's float64 autograd of F.pad(mode="reflect") + conv2d."""
+    monkeypatch.setenv("FD_REFLECT_WINO", str(wino))
     monkeypatch.setenv("FD_REFLECT_RING", "2")        # planes from 2 pixels on (default: from 16 384 - smaller ones keep the fold pass)
     g = torch.Generator().manual_seed(N * 131 + H)
     x = torch.randn(N, Ci, H, W, generator=g)
