@@ -841,14 +841,26 @@ class _ConvPlan:
         return self.bwd_weight_ws
 
 
+# The tuning variables the library re-reads on every call (scripts/conv_cfg_sweep.py and the tests flip them within a process): they
+# change the split-K / slab workspace and weight-layout sizes, so they are part of the plan key.  Read from the environment's raw
+# byte dictionary: nine os.environ.get() calls per convolution were 0.8 ms of host time per training step.
+_PLAN_ENV = ("FD_CONV_FORCE", "FD_WINO_WGRAD_2D", "FD_WINO_FWD_2D", "FD_WINO_FWD_2D_MIN", "FD_CONV_N16", "FD_CONV_N16_MIN",
+             "FD_REFLECT_RING", "FD_REFLECT_WINO", "FD_REFLECT_WINO_MIN")
+_PLAN_ENV_B = tuple(k.encode() for k in _PLAN_ENV)
+_ENV_DATA = getattr(os.environ, "_data", None)
+if not isinstance(_ENV_DATA, dict) or (len(_ENV_DATA) and not isinstance(next(iter(_ENV_DATA)), bytes)):
+    _ENV_DATA = None                                   # not CPython-on-POSIX's byte dictionary: fall back to os.environ.get
+
+
+def _plan_env_key():
+    if _ENV_DATA is not None:
+        g = _ENV_DATA.get
+        return tuple([g(k) for k in _PLAN_ENV_B])
+    return tuple([os.environ.get(k) for k in _PLAN_ENV])
+
+
 def _conv_plan(x, w, stride, pad, pad_mode, act, in_norm):
-    # FD_CONV_FORCE and the FD_WINO_*_2D switches are the tuning variables the library re-reads on every call
-    # (scripts/conv_cfg_sweep.py and the tests flip them within a process) and they change the split-K / slab workspace and
-    # weight-layout sizes: part of the key
-    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, os.environ.get("FD_CONV_FORCE"),
-           os.environ.get("FD_WINO_WGRAD_2D"), os.environ.get("FD_WINO_FWD_2D"), os.environ.get("FD_WINO_FWD_2D_MIN"),
-           os.environ.get("FD_CONV_N16"), os.environ.get("FD_CONV_N16_MIN"), os.environ.get("FD_REFLECT_RING"),
-           os.environ.get("FD_REFLECT_WINO"), os.environ.get("FD_REFLECT_WINO_MIN"))
+    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, _plan_env_key())
     plan = _CONV_PLANS.get(key)
     if plan is None:
         plan = _CONV_PLANS[key] = _ConvPlan(x, w, stride, pad, pad_mode, act, in_norm)

@@ -1,9 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-( timeout -k 10 600 python -m pytest tests/test_gpu_convstack.py -q -m gpu -k "reflect or conv2d_fwd_bwd or n16 or tap or routing" ) > gpurun_out/r3_t20.log 2>&1; grep -n "passed\|failed\|FAILED\|Error" gpurun_out/r3_t20.log | tail -12
-run() { echo "$1"; env $1 timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no_cpu_baseline --no_roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print('   ', round(d['value'],1), round(d['ms_per_step'],3), d['final_loss'])"; }
-for i in 1 2; do
-run FD_REFLECT_WINO=1
-run FD_REFLECT_WINO=0
-run FD_REFLECT_WINO_MIN=1000
-done
+timeout -k 10 300 python scripts/host_profile.py 12 2>&1 | grep "un-profiled"
+( timeout -k 10 600 python -m pytest tests/test_gpu_convstack.py -q -m gpu -k "winograd or n16 or reflect" ) > gpurun_out/r3_t21.log 2>&1; grep -n "passed\|failed\|FAILED\|Error" gpurun_out/r3_t21.log | tail -5
+timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no_cpu_baseline --no_roofline 2>&1 | grep "timed\|value" | cut -c1-200

@@ -1,28 +1,38 @@
-"""Where does the HOST spend the issue time of a step?  cProfile over 5 eager optimiser steps of the bench configuration
-(the GPU runs behind; one synchronize at the end).   (run on the GPU box)"""
-import os, sys, cProfile, pstats, time
+"""Where the host time of an eager training step goes: cProfile over 20 steady-state steps, functions by own time.
+usage: host_profile.py [n_rows]"""
+import cProfile, io, os, pstats, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from fusiondepth_amd import synthetic
 from fusiondepth_amd.options import MonodepthOptions
 from fusiondepth_amd.trainer import Trainer
-
-opt = MonodepthOptions().parse(["--batch_size", "12", "--height", "192", "--width", "640", "--weights_init", "scratch"])
+opt = MonodepthOptions().parse(["--num_layers", "18", "--weights_init", "scratch", "--batch_size", "12", "--height", "192", "--width", "640"])
 tr = Trainer(opt, verbose=False)
-mbs = [synthetic.make_batch(tr.batch_size, 192, 640, seed=1234 + i) for i in range(tr.accumulate_step)]
-inp = tr.stack_micro_batches(mbs)
-for _ in range(4):
-    tr.train_step(inp)
+pool = []
+for i in range(6):
+    mbs = [synthetic.make_scene_batch(tr.batch_size, 192, 640, seed=1234 + 17 * i + j, clutter=0.5) for j in range(tr.accumulate_step)]
+    for mb in mbs:
+        mb.pop("depth_gt", None)
+        for f in (-1, 1):
+            mb.pop(("T_gt", f), None)
+    pool.append(tr.stack_micro_batches(mbs))
+for i in range(8):
+    tr.train_step(pool[i % 6])
 torch.cuda.synchronize()
+import time
 t0 = time.perf_counter()
-for _ in range(5):
-    tr.train_step(inp)
-t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-print("unprofiled: host issue %.2f ms/step, wall %.2f ms/step" % ((t1 - t0) * 200, (t2 - t0) * 200))
+for i in range(20):
+    tr.train_step(pool[i % 6])
+t_issue = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print("un-profiled: issue %.2f ms / step, wall %.2f ms / step" % (t_issue * 50, t_all * 50))
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(5):
-    tr.train_step(inp)
-pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45)
-st.sort_stats("cumulative").print_stats(35)
+for i in range(20):
+    tr.train_step(pool[i % 6])
+pr.disable()
+torch.cuda.synchronize()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(int(sys.argv[1]) if len(sys.argv) > 1 else 45)
+print(s.getvalue())
