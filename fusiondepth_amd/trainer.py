@@ -13,6 +13,7 @@ What differs, by design:
 Reference lines are cited per method.
 """
 import json
+import contextlib
 import os
 import time
 
@@ -272,6 +273,7 @@ class Trainer:
         evaluated per micro-batch, and the other loss terms are means, so loss = sum_g loss_g / accumulate_step and its
         gradient equal the reference's accumulated values while every kernel sees twice the work per launch.
         Returns the loss dict (device tensors; nothing is synchronised here)."""
+        self._pose_on_main = False             # (train_step_graphed keeps the pose decoder on the capture stream)
         prestacked = isinstance(micro_batches, dict)       # a loader that already delivers the step's images as one batch
         assert prestacked or len(micro_batches) == self.accumulate_step
         if self.stack_microbatches:
@@ -417,6 +419,7 @@ class Trainer:
         (allocator warm-up), the second captures, later calls copy the new batch into the captured input buffers
         and replay.  With several ranks the forward/backward micro-steps are replayed and the gradient all-reduce +
         Adam run after the graph."""
+        self._pose_on_main = True              # the captured step keeps the pose decoder on the capture stream (see predict_poses)
         if self._graph is None:
             if self.stack_microbatches:
                 self._static_in = self.stack_micro_batches(micro_batches)
@@ -673,42 +676,59 @@ class Trainer:
         fids = self._pose_fids()
         if self.num_pose_frames == 2:
             stacked = None
+            pose_stream = None
             if precomputed is not None:
                 pf, st, bf, st2 = precomputed["stacked"]
-                self._join(st, pf)
-                if bf is not None:
-                    self._join(st2, bf)
-                    aa_all, tr_all = self.models["pose"]([pf], beam_inputs=[bf])       # batch = len(fids) * B
+                # The pose decoder (a dozen small launches forward, ~60 backward incl. autograd's slicing glue) stays on the pose
+                # encoder's stream: autograd replays a node on its forward stream, so the decoder's backward - created last, hence
+                # replayed first - no longer sits on the main stream in front of the depth decoder's backward (FD_POSE_STREAM=0: main).
+                if (os.environ.get("FD_POSE_STREAM", "1") != "0" and self.parallel_streams and not getattr(self, "_pose_on_main", False)
+                        and not torch.cuda.is_current_stream_capturing()):
+                    pose_stream = st
+                    if bf is not None:
+                        st.wait_stream(st2)
+                        for t in bf:
+                            t.record_stream(st)
                 else:
-                    aa_all, tr_all = self.models["pose"]([pf])
-                stacked = (aa_all, tr_all)
-            for k, f_i in enumerate(fids):
-                order = (f_i, 0) if f_i < 0 else (0, f_i)                     # temporal order (trainer.py:338-346)
-                if stacked is not None:
-                    nf, G = len(fids), self._groups
-                    Bq = stacked[0].shape[0] // (nf * G)                 # rows are ordered (micro-batch g, frame k, sample)
-                    if G == 1:
-                        axisangle, translation = stacked[0][k * Bq:(k + 1) * Bq], stacked[1][k * Bq:(k + 1) * Bq]
+                    self._join(st, pf)
+                    if bf is not None:
+                        self._join(st2, bf)
+            with torch.cuda.stream(pose_stream) if pose_stream is not None else contextlib.nullcontext():
+                if precomputed is not None:
+                    if bf is not None:
+                        aa_all, tr_all = self.models["pose"]([pf], beam_inputs=[bf])       # batch = len(fids) * B
                     else:
-                        sl = [slice((g * nf + k) * Bq, (g * nf + k + 1) * Bq) for g in range(G)]
-                        axisangle = torch.cat([stacked[0][q] for q in sl], 0)
-                        translation = torch.cat([stacked[1][q] for q in sl], 0)
-                elif shared:
-                    axisangle, translation = self.models["pose"]([features[i] for i in order])
-                else:
-                    pose_inputs = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
-                    if self.opt.pose_model_type == "separate_resnet":
-                        pose_inputs = [self.models["pose_encoder"](pose_inputs)]
-                    if self.opt.beam_encoder and self.opt.pose_model_type == "separate_resnet":
-                        beam = torch.cat([inputs["2channel", i, 0] for i in order], 1)
-                        beam_inputs = [self.models["beam_encoder_pose"](beam)]
-                        axisangle, translation = self.models["pose"](pose_inputs, beam_inputs=beam_inputs)
+                        aa_all, tr_all = self.models["pose"]([pf])
+                    stacked = (aa_all, tr_all)
+                for k, f_i in enumerate(fids):
+                    order = (f_i, 0) if f_i < 0 else (0, f_i)                     # temporal order (trainer.py:338-346)
+                    if stacked is not None:
+                        nf, G = len(fids), self._groups
+                        Bq = stacked[0].shape[0] // (nf * G)                 # rows are ordered (micro-batch g, frame k, sample)
+                        if G == 1:
+                            axisangle, translation = stacked[0][k * Bq:(k + 1) * Bq], stacked[1][k * Bq:(k + 1) * Bq]
+                        else:
+                            sl = [slice((g * nf + k) * Bq, (g * nf + k + 1) * Bq) for g in range(G)]
+                            axisangle = torch.cat([stacked[0][q] for q in sl], 0)
+                            translation = torch.cat([stacked[1][q] for q in sl], 0)
+                    elif shared:
+                        axisangle, translation = self.models["pose"]([features[i] for i in order])
                     else:
-                        axisangle, translation = self.models["pose"](pose_inputs)
-                outputs[("axisangle", 0, f_i)] = axisangle
-                outputs[("translation", 0, f_i)] = translation
-                outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0],
-                                                                                invert=(f_i < 0))
+                        pose_inputs = torch.cat([inputs["color_aug", i, 0] for i in order], 1)
+                        if self.opt.pose_model_type == "separate_resnet":
+                            pose_inputs = [self.models["pose_encoder"](pose_inputs)]
+                        if self.opt.beam_encoder and self.opt.pose_model_type == "separate_resnet":
+                            beam = torch.cat([inputs["2channel", i, 0] for i in order], 1)
+                            beam_inputs = [self.models["beam_encoder_pose"](beam)]
+                            axisangle, translation = self.models["pose"](pose_inputs, beam_inputs=beam_inputs)
+                        else:
+                            axisangle, translation = self.models["pose"](pose_inputs)
+                    outputs[("axisangle", 0, f_i)] = axisangle
+                    outputs[("translation", 0, f_i)] = translation
+                    outputs[("cam_T_cam", 0, f_i)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0],
+                                                                                    invert=(f_i < 0))
+            if pose_stream is not None:
+                self._join(pose_stream, list(outputs.values()))
         else:
             if shared:
                 pose_inputs = [features[i] for i in self.opt.frame_ids if i != "s"]
