@@ -610,6 +610,13 @@ class Trainer:
         if val:
             self.generate_images_pred(inputs, outputs, [0])
         else:
+            if par and os.environ.get("FD_SMOOTH_STREAM", "1") != "0" and not getattr(self, "_pose_on_main", False):
+                # the smoothness terms (3 small launches per scale, forward and backward) beside the photometric kernel instead of
+                # behind it on the main stream; the beam encoder's stream is idle between its forward and its backward
+                st = self._fork(0)
+                with torch.cuda.stream(st):
+                    outputs["_smooth"] = ([FD.normalized_smooth_loss(outputs[("disp", sc)], inputs[("color", 0, sc)])
+                                           for sc in self.opt.scales], st)
             self.generate_images_pred(inputs, outputs, self.opt.frame_ids)
             losses = self.compute_losses(inputs, outputs)
         return outputs, losses
@@ -876,10 +883,14 @@ class Trainer:
         scales = list(self.opt.scales)
         lidar_name = self._lidar_term()[2]
         photo, si, smooth = [], [], []
-        for scale in scales:
+        pre = outputs.pop("_smooth", None)
+        if pre is not None:
+            self._join(pre[1], pre[0])
+        for i, scale in enumerate(scales):
             p, s_ = outputs[("photo", scale)]
             photo.append(p); si.append(s_)
-            smooth.append(FD.normalized_smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)]))
+            smooth.append(pre[0][i] if pre is not None else
+                          FD.normalized_smooth_loss(outputs[("disp", scale)], inputs[("color", 0, scale)]))
         if scales == list(range(len(scales))) and len(scales) == self.num_scales and len(scales) <= 4:
             per_scale, total = FD.combine_losses(photo, smooth, si, self.opt.disparity_smoothness)     # one kernel each way
             for scale in scales:

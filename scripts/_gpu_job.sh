@@ -1,7 +1,3 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-run() { echo "$1"; env $1 timeout -k 10 200 python bench.py --steps 30 --warmup 8 --no_cpu_baseline --no_roofline 2>gpurun_out/err.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print('   ', round(d['value'],1), round(d['ms_per_step'],3), d['param_checksum'])"; }
-for i in 1 2 3; do
-run FD_ENC_ORDER=depth_first
-run FD_ENC_ORDER=pose_first
-done
+( time timeout -k 10 900 python -m pytest tests -q -m gpu ) > gpurun_out/r3_tests24.log 2>&1; grep -n "passed\|failed\|FAILED" gpurun_out/r3_tests24.log | tail -8; grep -n "AbsRel after" gpurun_out/r3_tests24.log | head -4
