@@ -806,7 +806,7 @@ void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
 }  // namespace
 
 extern "C" long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d) {
-    if (!d || !fast_fwd_ok(d)) return 0;
+    if (!d || c1_shape_ok(d) || !fast_fwd_ok(d)) return 0;
     if (n16_shape_ok(d, d->Cout, d->Cin)) return 0;              // reads the weights as they are
     if (wino_use_fwd(d)) return align4(wino_wt_floats(d));
     return align4((long)d->Cout * d->Cin * d->KH * d->KW);
@@ -815,7 +815,7 @@ extern "C" long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d) {
 extern "C" long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
-    if (!conv_out_shape(d, s) || !fast_fwd_ok(d)) return 0;
+    if (!conv_out_shape(d, s) || c1_shape_ok(d) || !fast_fwd_ok(d)) return 0;
     if (n16_shape_ok(d, d->Cout, d->Cin)) return 0;
     if (wino_use_fwd(d)) return wino_ws_floats(d);
     FastGemmArgs f;
@@ -851,6 +851,11 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
     FD_REQUIRE((long)d->N * d->Cin * d->H * d->W < (1L << 29) && (long)d->N * d->Cout * s.Ho * s.Wo < (1L << 29),
                "fd_conv2d_fwd: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
+    if (c1_shape_ok(d)) {
+        FD_REQUIRE(!stat_part, "fd_conv2d_fwd_stats: no statistics epilogue for this shape");
+        conv_log("fwd", "c1 stencil", d);
+        return c1_fwd_launch(d, x, w, bias, y, st);
+    }
     if (fast_fwd_ok(d) && n16_shape_ok(d, d->Cout, d->Cin)) {
         FD_REQUIRE(!stat_part, "fd_conv2d_fwd_stats: no statistics epilogue for this shape");
         conv_log("fwd", "n16", d);
@@ -890,7 +895,7 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
 }  // namespace
 
 extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
-    if (!d) return 0;
+    if (!d || c1_shape_ok(d)) return 0;
     fd_conv_desc g;
     if (wino_dgrad_desc(d, g)) return align4(wino_wt_floats(&g));
     if (refl_wino_interior(d, g))                            // [layout of the ring's implicit GEMM | U of the interior's Winograd kernel]
@@ -901,7 +906,7 @@ extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
 extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
-    if (!conv_out_shape(d, s)) return 0;
+    if (!conv_out_shape(d, s) || c1_shape_ok(d)) return 0;
     {
         fd_conv_desc g;
         if (wino_dgrad_desc(d, g)) return wino_ws_floats(&g);
@@ -950,6 +955,12 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
     // GEMM, reflect padding with its fold pass, parity classes without taps) add it with one element-wise launch afterwards
     const long gx_n = (long)d->N * d->Cin * d->H * d->W;
     auto add_after = [&]() -> int { return gx_add ? fd_axpby(gx, gx_add, gx, gx_n, 1.0f, 1.0f, stream) : 0; };
+    if (c1_shape_ok(d)) {                                // dispconv: a stencil with the reflect adjoint folded in (conv_c1.hip)
+        FD_REQUIRE(gy && w && gx, "fd_conv2d_bwd_data: NULL tensor");
+        conv_log("dgrad", "c1 stencil", d);
+        if (int rc = c1_dgrad_launch(d, gy, w, gx, (hipStream_t)stream)) return rc;
+        return add_after();
+    }
     FD_REQUIRE(gy && w && gx && wt_base, "fd_conv2d_bwd_data: NULL tensor");
     ConvShape s;
     FD_REQUIRE(conv_out_shape(d, s), "fd_conv2d_bwd_data: empty output");
@@ -1162,6 +1173,7 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
         j.TA = TA; j.TB = TB; j.kh0 = kh0; j.dkh = dkh; j.kw0 = kw0; j.dkw = dkw; j.mode = mode;
         j.n = (long)d->Cout * d->Cin * TA * TB;
     };
+    if (c1_shape_ok(d)) return 0;                        // stencil kernels: no layouts
     if (kind == 0) {
         if (!fast_fwd_ok(d) || n16_shape_ok(d, d->Cout, d->Cin)) return 0;
         fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? (wino_fwd_2d(d) ? 5 : 3) : 0);

@@ -1,0 +1,125 @@
+// 3x3 stride-1 pad-1 convolutions with ONE output channel: the decoder's dispconv(s) (depth_decoder.py:59-61: Conv3x3(num_ch_dec[s], 1)
+// + sigmoid at four scales; refiner / completor heads) - forward and data gradient as stencils.
+//
+// As a GEMM these layers have M = 1: the implicit-GEMM kernel pads them to a 32-row MFMA tile (204 us for 16 -> 1 at 192x640, batch 12:
+// 1/32 of the matrix work is real), the data gradient (Cout = 1 is no multiple of 16) went through the generic gather GEMM on the
+// padded grid plus a full fold pass (56 + 54 us).  Both are pure streaming problems - C x 9 multiply-adds per pixel against 4 C bytes
+// read (forward) or written (data gradient):
+//   forward        y[p]    = act(b + sum_c sum_t W[c][t] x[c][pad(p + t - 1)])           one thread per pixel, rows coalesced, the
+//                                                                                       neighbours come from L1;
+//   data gradient  gx[c][p] = sum_t W[c][t] S_t[p],   S_t[p] = sum over the pre-images pp of p under the padding of gy[pp - (t - 1)]
+//                  - with reflect padding pixel row 1 is also the image of row -1, row H-2 of row H (columns alike), so the adjoint of
+//                  ReflectionPad2d(1) is folded into the nine tap sums (no padded-grid tensor, no fold pass); S_t is shared by all C
+//                  channels: 9 multiply-adds and one coalesced store per channel.
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+#include "conv_fast.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __forceinline__ float c1_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return v > 0.f ? v : expm1f(v);
+    if (act == 3) return 1.0f / (1.0f + expf(-v));
+    if (act == 4) return tanhf(v);
+    return v;
+}
+
+// grid: x = pixel blocks of 256 along a plane, y = image
+__global__ void __launch_bounds__(256) k_conv3x3_c1_fwd(const float* __restrict__ X, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                        float* __restrict__ Y, int C, int H, int W, int pad_mode, int act) {
+    extern __shared__ float sw[];                         // W[c][t]: 9 C floats
+    for (int i = threadIdx.x; i < 9 * C; i += 256) sw[i] = Wt[i];
+    __syncthreads();
+    const int hw = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const int y = p / W, x = p - y * W;
+    const bool refl = pad_mode == 1;
+    // the nine source offsets inside a plane (or -1: zero padding)
+    int off[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        bool ok = true;
+        if (yy < 0) { ok = refl; yy = 1; } else if (yy >= H) { ok = refl; yy = H - 2; }
+        if (xx < 0) { ok = ok && refl; xx = 1; } else if (xx >= W) { ok = ok && refl; xx = W - 2; }
+        off[t] = ok ? yy * W + xx : -1;
+    }
+    const float* xp = X + (size_t)blockIdx.y * C * hw;
+    float acc = bias ? bias[0] : 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float* q = xp + (size_t)c * hw;
+        const float* w = sw + 9 * c;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc = fmaf(w[t], off[t] >= 0 ? q[off[t]] : 0.f, acc);
+    }
+    Y[(size_t)blockIdx.y * hw + p] = c1_act(acc, act);
+}
+
+// gx[n][c][p] (+= nothing: plain store) from gy[n][0][.]; Wt = the layer's W[0][c][ky][kx]
+__global__ void __launch_bounds__(256) k_conv3x3_c1_dgrad(const float* __restrict__ GY, const float* __restrict__ Wt, float* __restrict__ GX,
+                                                          int C, int H, int W, int pad_mode) {
+    extern __shared__ float sw[];
+    for (int i = threadIdx.x; i < 9 * C; i += 256) sw[i] = Wt[i];
+    __syncthreads();
+    const int hw = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hw) return;
+    const int y = p / W, x = p - y * W;
+    const bool refl = pad_mode == 1;
+    // pre-images of (y, x) on the padded grid: itself, and the padding cells that mirror onto it (row -1 -> 1, row H -> H - 2;
+    // with H == 3 row 1 has all three)
+    int py[3], px[3], ny = 0, nx = 0;
+    py[ny++] = y; px[nx++] = x;
+    if (refl) {
+        if (y == 1) py[ny++] = -1;
+        if (y == H - 2) py[ny++] = H;
+        if (x == 1) px[nx++] = -1;
+        if (x == W - 2) px[nx++] = W;
+    }
+    const float* g = GY + (size_t)blockIdx.y * hw;
+    float S[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) S[t] = 0.f;
+    auto add = [&](int yy0, int xx0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = yy0 - (t / 3 - 1), xx = xx0 - (t % 3 - 1);        // the output pixel whose tap t reads padded cell (yy0, xx0)
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) S[t] += g[yy * W + xx];
+        }
+    };
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) add(py[a], px[b]);
+    float* o = GX + (size_t)blockIdx.y * C * hw + p;
+    for (int c = 0; c < C; ++c) {
+        const float* w = sw + 9 * c;
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v = fmaf(w[t], S[t], v);
+        o[(size_t)c * hw] = v;
+    }
+}
+}  // namespace
+
+bool c1_shape_ok(const fd_conv_desc* d) {
+    const char* e = getenv("FD_CONV_C1");                  // 0: Cout = 1 layers stay on the GEMM kernels (A/B timing, tests)
+    if (e && atoi(e) == 0) return false;
+    return d->Cout == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->in_norm && d->H >= 2 && d->W >= 2 &&
+           d->Cin <= 1024 && (long)d->N * d->Cin * d->H * d->W < (1L << 29);
+}
+
+int c1_fwd_launch(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+    const dim3 grid((unsigned)fd_cdiv((long)d->H * d->W, 256), (unsigned)d->N);
+    hipLaunchKernelGGL(k_conv3x3_c1_fwd, grid, dim3(256), sizeof(float) * 9 * d->Cin, st, x, w, bias, y, d->Cin, d->H, d->W, d->pad_mode, d->act);
+    FD_LAUNCH_CHECK("k_conv3x3_c1_fwd");
+    return 0;
+}
+
+int c1_dgrad_launch(const fd_conv_desc* d, const float* gy, const float* w, float* gx, hipStream_t st) {
+    const dim3 grid((unsigned)fd_cdiv((long)d->H * d->W, 256), (unsigned)d->N);
+    hipLaunchKernelGGL(k_conv3x3_c1_dgrad, grid, dim3(256), sizeof(float) * 9 * d->Cin, st, gy, w, gx, d->Cin, d->H, d->W, d->pad_mode);
+    FD_LAUNCH_CHECK("k_conv3x3_c1_dgrad");
+    return 0;
+}

@@ -72,6 +72,10 @@ int wino_stat_slots(const fd_conv_desc* d);
 bool n16_shape_ok(const fd_conv_desc* d, int M, int C);
 int n16_launch(const fd_conv_desc* d, int M, int C, const float* x, const float* w, const float* bias, float* y, int flip,
                int pad_mode, int act, hipStream_t st);
+// conv_c1.hip: 3x3 stride-1 convolutions with one output channel (dispconv) as stencils
+bool c1_shape_ok(const fd_conv_desc* d);
+int c1_fwd_launch(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
+int c1_dgrad_launch(const fd_conv_desc* d, const float* gy, const float* w, float* gx, hipStream_t st);
 bool wino_wgrad_ok(const fd_conv_desc* d);
 long wino_wgrad_ws_floats(const fd_conv_desc* d);
 int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st);

@@ -77,6 +77,45 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("N,Cin,H,W,mode,act", [
+    (2, 16, 33, 50, "reflect", "sigmoid"),       # dispconv(0) class, ragged
+    (1, 128, 6, 20, "reflect", "sigmoid"),       # dispconv(3)
+    (2, 8, 2, 2, "reflect", "none"),             # every pixel is a corner: rows -1 and 2 mirror onto rows 1 and 0
+    (1, 4, 3, 3, "reflect", "tanh"),             # H = W = 3: the centre has three pre-images per direction
+    (2, 16, 3, 7, "reflect", "sigmoid"),
+    (2, 5, 4, 6, "zero", "none"),                # Conv3x3(use_refl=False), odd channel count
+    (12, 16, 192, 640, "reflect", "sigmoid"),    # full size
+])
+def test_conv3x3_single_output_channel_stencils(FD, N, Cin, H, W, mode, act, monkeypatch):
+    """conv_c1.hip: Cout = 1 (dispconv) forward and data gradient as stencils - the data gradient with the adjoint of the reflection
+    padding folded into its tap sums - against torch on the CPU, and against the GEMM kernels these layers used before."""
+    import ctypes
+    from fusiondepth_amd import _lib
+    d = _lib.ConvDesc(N, Cin, H, W, 1, 3, 3, 1, 1, 1 if mode == "reflect" else 0, {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3, "tanh": 4}[act], 0)
+    assert _lib.query("fd_conv2d_bwd_data_wt_floats", ctypes.byref(d)) == 0
+    rng = np.random.RandomState(N * 100 + Cin + H)
+    x = torch.from_numpy(rng.randn(N, Cin, H, W).astype(np.float32))
+    w = torch.from_numpy((rng.randn(1, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32))
+    b = torch.from_numpy((0.1 * rng.randn(1)).astype(np.float32))
+    xo, wo, bo = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = ACTS[act](F.conv2d(F.pad(xo, (1,) * 4, mode="reflect"), wo, bo) if mode == "reflect" else F.conv2d(xo, wo, bo, 1, 1))
+    cot = torch.from_numpy(rng.randn(*yo.shape).astype(np.float32))
+    want = torch.autograd.grad((yo * cot).sum(), [xo, wo, bo])
+    res = {}
+    for c1 in ("1", "0"):
+        monkeypatch.setenv("FD_CONV_C1", c1)
+        xg, wg, bg = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+        yg = FD.conv2d(xg, wg, bg, 1, 1, mode, act)
+        got = torch.autograd.grad((yg * dev(cot)).sum(), [xg, wg, bg])
+        relclose(cpu(yg), cpu(yo), "conv fwd (FD_CONV_C1=%s)" % c1)
+        relclose(cpu(got[0]), cpu(want[0]), "conv dgrad (FD_CONV_C1=%s)" % c1)
+        relclose(cpu(got[1]), cpu(want[1]), "conv wgrad")
+        relclose(cpu(got[2]), cpu(want[2]), "conv bias grad")
+        res[c1] = (yg.detach(), got[0])
+    relclose(cpu(res["1"][0]), cpu(res["0"][0]), "stencil vs GEMM forward", arel=2e-6)
+    relclose(cpu(res["1"][1]), cpu(res["0"][1]), "stencil vs GEMM data gradient", arel=2e-6)
+
+
 @pytest.mark.parametrize("n16", [1, 0])
 @pytest.mark.parametrize("N,Cin,Cout,H,W,mode,act", [
     (1, 16, 16, 64, 96, "reflect", "elu"),       # upconv(0,1) at a small input: one-and-a-half column tiles
