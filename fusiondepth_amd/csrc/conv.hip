@@ -575,6 +575,16 @@ __global__ void __launch_bounds__(256) k_reflect_ring_fold(const float* __restri
     }
 }
 
+// planes of [H][W] -> planes of [H+2][W+2] with a border of zeros (the padded-grid data gradient on the Winograd kernel, below)
+__global__ void __launch_bounds__(256) k_zero_border_copy(const float* __restrict__ src, float* __restrict__ dst, long planes, int H, int W) {
+    const int Wp = W + 2, np = (H + 2) * Wp;
+    for (long pl = blockIdx.y; pl < planes; pl += gridDim.y)
+        for (int r = blockIdx.x * 256 + threadIdx.x; r < np; r += gridDim.x * 256) {
+            const int y = r / Wp - 1, x = r - (y + 1) * Wp - 1;
+            dst[pl * np + r] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? src[pl * (long)H * W + y * W + x] : 0.f;
+        }
+}
+
 // Adjoint of ReflectionPad2d(1): fold the gradient on the padded grid [H+2][W+2] back onto [H][W].
 __global__ void k_reflect_fold(const float* __restrict__ gp, float* __restrict__ gx, long planes, int H, int W) {
     const int Wp = W + 2;
@@ -792,6 +802,23 @@ bool refl_wino_interior(const fd_conv_desc* d, fd_conv_desc& g) {
     return wino_fwd_ok(&g) && g.Cout >= 64;
 }
 
+// ... and on SMALL planes (below the ring path's 16 384 pixels: upconv(1..4, *) at 6x20 .. 48x160) the ring's four thin problems -
+// few pixels against up to 512 output channels, 32 - 96 workgroups with 72 chunks each and no split-K - cost more than the interior
+// (189 us against 60 us for upconv(4,1)).  There the whole padded-grid gradient is ONE Winograd convolution over dY embedded in a
+// border of zeros ((H+2) x (W+2): 6 - 47 % more pixels), followed by the fold pass.  `gp`: that convolution.
+bool refl_wino_padded(const fd_conv_desc* d, fd_conv_desc& gp) {
+    fd_conv_desc gz;
+    if (!refl_wino_interior(d, gz)) return false;
+    const char* e = getenv("FD_REFLECT_WINO_PADDED");
+    if (e && atoi(e) == 0) return false;
+    const char* r = getenv("FD_REFLECT_RING");
+    const long thr = (r && atol(r) > 1) ? atol(r) : 16384;
+    if ((long)d->H * d->W >= thr) return false;              // large planes: interior + ring
+    gp = gz;
+    gp.H = d->H + 2; gp.W = d->W + 2;
+    return wino_fwd_ok(&gp);
+}
+
 void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
     f = FastGemmArgs{};
     f.M = d->Cout; f.C = d->Cin; f.T = d->KH * d->KW; f.TB = d->KW; f.K = f.T * f.C;
@@ -898,6 +925,7 @@ extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
     if (!d || c1_shape_ok(d)) return 0;
     fd_conv_desc g;
     if (wino_dgrad_desc(d, g)) return align4(wino_wt_floats(&g));
+    if (refl_wino_padded(d, g)) return align4(wino_wt_floats(&g));
     if (refl_wino_interior(d, g))                            // [layout of the ring's implicit GEMM | U of the interior's Winograd kernel]
         return align4((long)d->Cin * d->Cout * d->KH * d->KW) + align4(wino_wt_floats(&g));
     return (d->stride == 1 ? 1 : 4) * align4((long)d->Cin * d->Cout * d->KH * d->KW);
@@ -927,6 +955,8 @@ extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
             const long s2 = fast_splitk_slab_floats(f, nullptr);
             slabs = s2 > slabs ? s2 : slabs;
             fd_conv_desc gz;
+            if (refl_wino_padded(d, gz))                     // [padded-grid gradient | slabs | dY in its border of zeros]
+                return padded + wino_ws_floats(&gz) + align4((long)d->N * d->Cout * (d->H + 2) * (d->W + 2));
             if (refl_wino_interior(d, gz)) { const long s3 = wino_ws_floats(&gz); slabs = s3 > slabs ? s3 : slabs; }
         }
     }
@@ -1025,6 +1055,25 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
         int ring_on = 1;                       // read per call (reflect-padded layers only: 20 calls per step), so that tests can switch it
         if (d->pad_mode == 1) { const char* e = getenv("FD_REFLECT_RING"); ring_on = e ? atoi(e) : 1; }
         fd_conv_desc gz;
+        if (d->pad_mode == 1 && refl_wino_padded(d, gz)) {
+            conv_log("dgrad", "wino on the padded grid + fold", d);
+            const long planes_in = (long)d->N * d->Cout, planes_out = (long)d->N * d->Cin;
+            const long np = (long)(d->H + 2) * (d->W + 2);
+            float* wslabs = ws + pad_n;
+            float* gyp = wslabs + wino_ws_floats(&gz);
+            if (!wt_ready)
+                if (int rc = wino_weight_launch(&gz, w, wt, 1, st)) return rc;
+            const long bx = (np + 255) / 256;
+            hipLaunchKernelGGL(k_zero_border_copy, dim3((unsigned)(bx > 64 ? 64 : bx), (unsigned)(planes_in > 32768 ? 32768 : planes_in)), dim3(256), 0, st,
+                               gy, gyp, planes_in, d->H, d->W);
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(zero border)");
+            if (int rc = wino_conv_launch(&gz, gyp, wt, nullptr, gpad, wslabs, st, nullptr)) return rc;
+            const long fold_bx = ((long)d->H * d->W + 255) / 256;
+            hipLaunchKernelGGL(k_reflect_fold, dim3((unsigned)(fold_bx > 64 ? 64 : fold_bx), (unsigned)(planes_out > 32768 ? 32768 : planes_out)),
+                               dim3(256), 0, st, gpad, gx, planes_out, d->H, d->W);
+            FD_LAUNCH_CHECK("fd_conv2d_bwd_data(fold)");
+            return add_after();
+        }
         const bool wino_interior = refl_wino_interior(d, gz);
         if (d->pad_mode == 1 && fast && ring_on && KH == 3 && KW == 3 && d->pad == 1 && d->H >= 2 && d->W >= 2 &&
             (wino_interior || (long)d->H * d->W >= (ring_on > 1 ? ring_on : 16384))) {      // smaller planes (measured up to 48 x 160): four thin launches + their fold cost more than the fold pass
@@ -1186,8 +1235,9 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
     }
     const int mode = fast_dgrad_ok(d) ? 1 : 2;
     if (d->stride == 1) {
-        fill(jobs[0], wt, KH, KW, KH - 1, -1, KW - 1, -1, mode);
         fd_conv_desc gz;
+        if (refl_wino_padded(d, gz)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, wino_fwd_2d(&gz) ? 6 : 4); return 1; }
+        fill(jobs[0], wt, KH, KW, KH - 1, -1, KW - 1, -1, mode);
         if (refl_wino_interior(d, gz)) {                 // second layout behind the first: U of the interior's Winograd kernel
             fill(jobs[1], wt + align4((long)d->Cin * d->Cout * KH * KW), KH, KW, 0, 1, 0, 1, wino_fwd_2d(&gz) ? 6 : 4);
             return 2;

@@ -661,7 +661,7 @@ def test_batchnorm_statistics_of_a_near_constant_map(FD):
                                          (1, 32, 48, 3, 3), (1, 512, 256, 6, 20), (2, 32, 16, 7, 5),
                                          (2, 96, 32, 96, 320), (1, 16, 16, 192, 640), (1, 288, 32, 96, 320),      # >= 16 384 pixels: the ring path by default
                                          (2, 512, 256, 12, 40), (2, 128, 64, 48, 160), (3, 64, 32, 5, 6)])       # upconv(4,1), upconv(2,1); odd height
-@pytest.mark.parametrize("wino", [1, 0])
+@pytest.mark.parametrize("wino", [1, 0, "padded"])
 def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W, wino, monkeypatch):
     """conv3x3(ReflectionPad2d(1)(x)) - every DepthDecoder convolution (networks/depth_decoder.py, layers.py Conv3x3): its data
     gradient = the zero-padded data gradient written straight to gx + the padded grid's one-pixel ring (four strips, one grouped
@@ -669,9 +669,12 @@ def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W,
     rows / columns coincide (H = 3) or are the border itself (H = 2), odd sizes, and a second gradient joining at the input
     (conv2d_tap).  wino = 1 (default): where the input has >= 64 channels and the width is even the interior runs on the Winograd
     kernels (F(2, 3) per kernel row, F(2x2, 3x3) from 256 x 256 channels on) with its own weight layout behind the ring's; 0: the
-    interior on the implicit-GEMM kernel everywhere.  Against torch's float64 autograd of F.pad(mode="reflect") + conv2d."""
-    monkeypatch.setenv("FD_REFLECT_WINO", str(wino))
-    monkeypatch.setenv("FD_REFLECT_RING", "2")        # planes from 2 pixels on (default: from 16 384 - smaller ones keep the fold pass)
+    interior on the implicit-GEMM kernel everywhere; "padded": the default routing - planes below 16 384 pixels with >= 64 input
+    channels take the whole padded-grid gradient as one Winograd convolution over dY in a border of zeros + the fold pass.
+    Against torch's float64 autograd of F.pad(mode="reflect") + conv2d."""
+    monkeypatch.setenv("FD_REFLECT_WINO", "0" if wino == 0 else "1")
+    ring = lambda: monkeypatch.delenv("FD_REFLECT_RING", raising=False) if wino == "padded" else monkeypatch.setenv("FD_REFLECT_RING", "2")
+    ring()                                            # "2": planes from 2 pixels on (default: from 16 384 - smaller ones keep a fold pass)
     g = torch.Generator().manual_seed(N * 131 + H)
     x = torch.randn(N, Ci, H, W, generator=g)
     w = torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5
@@ -687,7 +690,7 @@ def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W,
     monkeypatch.setenv("FD_REFLECT_RING", "0")        # the fold path gives the same gradient up to the order of the ring's additions
     gx_fold = torch.autograd.grad((FD.conv2d(xg, dev(w), None, 1, 1, "reflect") * dev(cot)).sum(), xg)[0]
     relclose(cpu(gx), cpu(gx_fold), "ring path vs fold path", arel=1e-6)
-    monkeypatch.setenv("FD_REFLECT_RING", "2")
+    ring()
     xg2 = dev(x).requires_grad_(True)
     y2, xt = FD.conv2d_tap(xg2, dev(w), None, 1, 1, "reflect")
     gx2 = torch.autograd.grad((y2 * dev(cot)).sum() + (xt * xt).sum(), xg2)[0]
