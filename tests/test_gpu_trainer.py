@@ -498,6 +498,48 @@ def test_gradients_are_run_to_run_identical_under_gpu_contention(interleave):
             assert torch.equal(g, ref), "repetition %d: %d gradient entries differ" % (rep, int((g != ref).sum()))
 
 
+def test_pose_decoder_and_smoothness_on_side_streams_are_bit_identical(monkeypatch):
+    """Trainer.predict_poses runs the pose decoder (forward and, through autograd, backward) on the pose encoder's stream, and
+    Trainer._process_batch the smoothness terms on the beam encoder's stream, instead of on the main stream.  Same kernels, same
+    accumulation targets: the flat gradient buffer after a backward pass equals the all-on-the-main-stream result bit for bit, also
+    with a background stream keeping the GPU busy (a tensor handed between streams without ordering would show up here)."""
+    from fusiondepth_amd.trainer import Trainer
+    B, H, W = 2, 64, 96
+    inp, noise = _batch(B, H, W, 993)
+    ginp = {k: v.cuda() for k, v in inp.items()}
+    ginp["_noise"] = [n.cuda() for n in noise]
+    bg = torch.cuda.Stream()
+    junk = [torch.randn(s, s, device="cuda") for s in (512, 2048)]
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FD_POSE_STREAM", mode)
+        monkeypatch.setenv("FD_SMOOTH_STREAM", mode)
+        torch.manual_seed(4321)                                  # the same initial weights for both trainers
+        tr = Trainer(_opts(batch_size=B), verbose=False)
+        for rep in range(3):
+            tr.flat.zero_grad()
+            saved = {k: {n: b.clone() for n, b in m.named_buffers()} for k, m in tr.models.items()}
+            torch.cuda.synchronize()
+            with torch.cuda.stream(bg):
+                for i in range(8 + 7 * rep):
+                    junk[i % 2] @ junk[i % 2]
+            outputs, losses = tr.process_batch(ginp, groups=tr.accumulate_step)
+            losses["loss"].backward()
+            tr._join_side_streams()
+            torch.cuda.synchronize()
+            g = tr.flat.flat_grad.clone()
+            with torch.no_grad():
+                for k, m in tr.models.items():
+                    for n, b in m.named_buffers():
+                        b.copy_(saved[k][n])
+            if mode in grads:
+                assert torch.equal(g, grads[mode][0]), "mode %s, repetition %d" % (mode, rep)
+            grads[mode] = (g, float(losses["loss"]))
+    assert float(grads["0"][0].abs().max()) > 0
+    assert grads["0"][1] == grads["1"][1]
+    assert torch.equal(grads["0"][0], grads["1"][0]), "%d gradient entries differ" % int((grads["0"][0] != grads["1"][0]).sum())
+
+
 def test_late_weight_relayout_is_ordered_before_its_readers(monkeypatch):
     """functional.refresh_weight_layouts sends the big half of the post-Adam re-layout (data-gradient layouts, forward layouts from
     1 MB up) to a side stream and lets every stream that is about to use such a layout wait for it first.  Five optimiser steps with
