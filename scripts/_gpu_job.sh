@@ -1,10 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python -c "import torch; print('priority range', torch.cuda.Stream.priority_range())"
-run() { echo "$1"; env $1 timeout -k 10 200 python bench.py --eager --steps 30 --warmup 8 --no_cpu_baseline --no_roofline 2>gpurun_out/err.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print('   ', round(d['value'],1), round(d['ms_per_step'],3), d['param_checksum'][0])"; tail -1 gpurun_out/err.txt | grep -v timed; }
-for i in 1 2; do
+run() { echo "$1"; env $1 timeout -k 10 200 python bench.py --eager --steps 30 --warmup 8 --no_cpu_baseline --no_roofline 2>gpurun_out/err.txt | python -c "import sys,json; d=json.loads(sys.stdin.read().splitlines()[-1]); print('   ', round(d['value'],1), round(d['ms_per_step'],3), d['param_checksum'][0])"; }
+for i in 1 2 3; do
 run FD_NONE=1
-run FD_MAIN_PRIO=-1
-run FD_SIDE_PRIO=1
-run "FD_MAIN_PRIO=-1 FD_SIDE_PRIO=1"
+run FD_SIDE_PRIO=-1
 done
