@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The kernels of ONE steady-state optimiser step on the busiest HIP stream (the step's serial chain), in launch order, with their
-durations: rocprof_stream_chain.py results.db [delimiter=k_adam_dev]"""
+durations: rocprof_stream_chain.py results.db [delimiter=k_adam_dev] [rank of the stream by kernel time = 0]"""
 import collections, re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 delim = sys.argv[2] if len(sys.argv) > 2 else "k_adam_dev"
@@ -11,7 +11,8 @@ step = [(n, s, e, st) for n, s, e, st in rows if s >= lo and e <= hi]
 per = collections.Counter()
 for n, s, e, st in step:
     per[st] += e - s
-main = per.most_common(1)[0][0]
+rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+main = per.most_common(rank + 1)[rank][0]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)
     return re.sub(r"^void ", "", n)[:40]
@@ -38,3 +39,10 @@ gaps = sorted((g for _, _, _, g in acc), reverse=True)
 print("\nidle on this stream: %.2f ms in total; %d gaps > 20 us hold %.2f ms, the %d gaps <= 20 us %.2f ms (median %.1f us)" % (
     sum(gaps) / 1e3, sum(1 for g in gaps if g > 20), sum(g for g in gaps if g > 20) / 1e3, sum(1 for g in gaps if g <= 20),
     sum(g for g in gaps if g <= 20) / 1e3, gaps[len(gaps) // 2]))
+
+tot = collections.Counter(); cnt = collections.Counter()
+for n, d, t, gap in acc:
+    tot[n] += d; cnt[n] += 1
+print("\nby kernel on this stream:")
+for n, d in tot.most_common(40):
+    print("  %-42s x%-3d %8.1f us" % (n, cnt[n], d))
