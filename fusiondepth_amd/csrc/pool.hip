@@ -4,6 +4,7 @@
 // the Adam update (trainer.py:129,247).  All 1 thread per output element, coalesced along W.
 #include "../../include/fdhip.h"
 #include "fd_common.h"
+#include <stdint.h>
 
 namespace {
 
@@ -100,6 +101,51 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd(const float* __restrict__ a, c
             if (s2) v += s2[o];
         } else v = s3[((b * C3 + (c - Ca - Cs)) * H + y) * W + x];
         out[i] = v;
+    }
+}
+// Four output pixels per thread (w even, 16-byte aligned tensors): the up-sampled part reads two source pixels and writes one 16-byte
+// row piece, the skip part moves 16-byte pieces - the one-pixel kernels above ran at half the HBM rate on the decoder's serial chain
+// (upsample + concatenation 0.26 ms, channel split 0.10 ms, up-sample adjoint 0.05 ms per training step).
+__global__ void __launch_bounds__(NT) k_upcat_fwd4(const float* __restrict__ a, const float* __restrict__ s1, const float* __restrict__ s2,
+                                                   const float* __restrict__ s3, float* __restrict__ out, int N, int Ca, int Cs, int C3,
+                                                   int h, int w) {
+    const int H = 2 * h, W = 2 * w, W4 = W >> 2, Ct = Ca + Cs + C3;
+    PLANE_LOOP(pl, r, (long)N * Ct, H * W4) {
+        const int y = r / W4, x = (r - y * W4) * 4;
+        const long b = pl / Ct;
+        const int c = (int)(pl - b * Ct);
+        float4 v;
+        if (c < Ca) {
+            const float2 q = *reinterpret_cast<const float2*>(a + ((b * Ca + c) * h + (y >> 1)) * w + (x >> 1));
+            v = make_float4(q.x, q.x, q.y, q.y);
+        } else if (c < Ca + Cs) {
+            const long o = ((b * Cs + (c - Ca)) * H + y) * W + x;
+            v = *reinterpret_cast<const float4*>(s1 + o);
+            if (s2) { const float4 u = *reinterpret_cast<const float4*>(s2 + o); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        } else v = *reinterpret_cast<const float4*>(s3 + ((b * C3 + (c - Ca - Cs)) * H + y) * W + x);
+        *reinterpret_cast<float4*>(out + pl * H * W + (long)y * W + x) = v;
+    }
+}
+// two output pixels of ga per thread from two 16-byte pieces of gout
+__global__ void __launch_bounds__(NT) k_upcat_bwd_a2(const float* __restrict__ gout, float* __restrict__ ga, int N, int Ca, int Ct, int h, int w) {
+    const int H = 2 * h, W = 2 * w, w2 = w >> 1;
+    PLANE_LOOP(pl, r, (long)N * Ca, h * w2) {
+        const int y = r / w2, x = (r - y * w2) * 2;
+        const long b = pl / Ca;
+        const int c = (int)(pl - b * Ca);
+        const float* g = gout + ((b * Ct + c) * H + 2 * y) * W + 2 * x;
+        const float4 t = *reinterpret_cast<const float4*>(g), u = *reinterpret_cast<const float4*>(g + W);
+        float2 o;
+        o.x = (t.x + t.y) + (u.x + u.y); o.y = (t.z + t.w) + (u.z + u.w);
+        *reinterpret_cast<float2*>(ga + pl * h * w + (long)y * w + x) = o;
+    }
+}
+__global__ void __launch_bounds__(NT) k_slice_channels4(const float* __restrict__ src, float* __restrict__ dst, int N, int Ct, int c0, int Cn,
+                                                        long plane4) {
+    PLANE_LOOP(pl, r, (long)N * Cn, plane4) {
+        const long b = pl / Cn;
+        const int c = (int)(pl - b * Cn);
+        reinterpret_cast<float4*>(dst)[pl * plane4 + r] = reinterpret_cast<const float4*>(src)[(b * Ct + c0 + c) * plane4 + r];
     }
 }
 __global__ void __launch_bounds__(NT) k_upcat_bwd_a(const float* __restrict__ gout, float* __restrict__ ga, int N, int Ca,
@@ -259,6 +305,11 @@ extern "C" int fd_upcat_fwd(const float* a, const float* s1, const float* s2, co
     FD_REQUIRE(a && out && N > 0 && Ca > 0 && Cs >= 0 && C3 >= 0 && h > 0 && w > 0, "fd_upcat_fwd: bad args");
     FD_REQUIRE((Cs == 0 || s1) && (C3 == 0 || s3) && !(s2 && !s1), "fd_upcat_fwd: missing skip tensor");
     const long n = (long)N * (Ca + Cs + C3) * 4 * h * w;
+    const uintptr_t al = (uintptr_t)a | (uintptr_t)s1 | (uintptr_t)s2 | (uintptr_t)s3 | (uintptr_t)out;
+    if (w % 2 == 0 && (al & 15) == 0)            // planes of 4 h w and h w floats: multiples of 4 resp. 2 floats - every row piece stays aligned
+        hipLaunchKernelGGL(k_upcat_fwd4, plane_grid((long)N * (Ca + Cs + C3), (long)h * w), dim3(NT), 0, (hipStream_t)stream, a, s1, s2, s3, out,
+                           N, Ca, Cs, C3, h, w);
+    else
     hipLaunchKernelGGL(k_upcat_fwd, plane_grid((long)N * (Ca + Cs + C3), 4L * h * w), dim3(NT), 0, (hipStream_t)stream, a, s1, s2, s3, out, N, Ca, Cs,
                        C3, h, w);
     FD_LAUNCH_CHECK("fd_upcat_fwd");
@@ -270,18 +321,20 @@ extern "C" int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, 
     hipStream_t st = (hipStream_t)stream;
     const int Ct = Ca + Cs + C3;
     const long plane = 4L * h * w;
+    const bool vec = w % 2 == 0 && (((uintptr_t)gout | (uintptr_t)ga | (uintptr_t)gs | (uintptr_t)g3) & 15) == 0;
     if (ga) {
-        hipLaunchKernelGGL(k_upcat_bwd_a, plane_grid((long)N * Ca, (long)h * w), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w);
+        if (vec) hipLaunchKernelGGL(k_upcat_bwd_a2, plane_grid((long)N * Ca, (long)h * (w / 2)), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w);
+        else hipLaunchKernelGGL(k_upcat_bwd_a, plane_grid((long)N * Ca, (long)h * w), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w);
         FD_LAUNCH_CHECK("fd_upcat_bwd(a)");
     }
     if (gs && Cs > 0) {
-        hipLaunchKernelGGL(k_slice_channels, plane_grid((long)N * Cs, plane), dim3(NT), 0, st, gout, gs, N, Ct, Ca, Cs,
-                           plane);
+        if (vec) hipLaunchKernelGGL(k_slice_channels4, plane_grid((long)N * Cs, plane / 4), dim3(NT), 0, st, gout, gs, N, Ct, Ca, Cs, plane / 4);
+        else hipLaunchKernelGGL(k_slice_channels, plane_grid((long)N * Cs, plane), dim3(NT), 0, st, gout, gs, N, Ct, Ca, Cs, plane);
         FD_LAUNCH_CHECK("fd_upcat_bwd(s)");
     }
     if (g3 && C3 > 0) {
-        hipLaunchKernelGGL(k_slice_channels, plane_grid((long)N * C3, plane), dim3(NT), 0, st, gout, g3, N, Ct, Ca + Cs,
-                           C3, plane);
+        if (vec) hipLaunchKernelGGL(k_slice_channels4, plane_grid((long)N * C3, plane / 4), dim3(NT), 0, st, gout, g3, N, Ct, Ca + Cs, C3, plane / 4);
+        else hipLaunchKernelGGL(k_slice_channels, plane_grid((long)N * C3, plane), dim3(NT), 0, st, gout, g3, N, Ct, Ca + Cs, C3, plane);
         FD_LAUNCH_CHECK("fd_upcat_bwd(3)");
     }
     return 0;
