@@ -802,7 +802,7 @@ bool refl_wino_interior(const fd_conv_desc* d, fd_conv_desc& g) {
     return wino_fwd_ok(&g) && g.Cout >= 64;
 }
 
-// ... and on SMALL planes (below the ring path's 16 384 pixels: upconv(1..4, *) at 6x20 .. 48x160) the ring's four thin problems -
+// ... and on SMALL planes (below 4 096 pixels: upconv(2..4, *) at 6x20 .. 24x80) the ring's four thin problems -
 // few pixels against up to 512 output channels, 32 - 96 workgroups with 72 chunks each and no split-K - cost more than the interior
 // (189 us against 60 us for upconv(4,1)).  There the whole padded-grid gradient is ONE Winograd convolution over dY embedded in a
 // border of zeros ((H+2) x (W+2): 6 - 47 % more pixels), followed by the fold pass.  `gp`: that convolution.
@@ -812,8 +812,10 @@ bool refl_wino_padded(const fd_conv_desc* d, fd_conv_desc& gp) {
     const char* e = getenv("FD_REFLECT_WINO_PADDED");
     if (e && atoi(e) == 0) return false;
     const char* r = getenv("FD_REFLECT_RING");
-    const long thr = (r && atol(r) > 1) ? atol(r) : 16384;
-    if ((long)d->H * d->W >= thr) return false;              // large planes: interior + ring
+    const char* m = getenv("FD_REFLECT_WINO_PADDED_MAX");
+    long thr = m ? atol(m) : 4096;                           // measured in the step: 4 096 (planes up to 24x80) 20.35 - 20.43 ms, 16 384 20.44 - 20.51, 65 536 20.54 - 20.59
+    if (r && atol(r) > 1 && atol(r) < thr) thr = atol(r);    // (the tests' "ring from n pixels on")
+    if ((long)d->H * d->W >= thr) return false;              // larger planes: interior + ring
     gp = gz;
     gp.H = d->H + 2; gp.W = d->W + 2;
     return wino_fwd_ok(&gp);

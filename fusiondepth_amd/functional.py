@@ -845,7 +845,7 @@ class _ConvPlan:
 # change the split-K / slab workspace and weight-layout sizes, so they are part of the plan key.  Read from the environment's raw
 # byte dictionary: nine os.environ.get() calls per convolution were 0.8 ms of host time per training step.
 _PLAN_ENV = ("FD_CONV_C1", "FD_CONV_FORCE", "FD_WINO_WGRAD_2D", "FD_WINO_FWD_2D", "FD_WINO_FWD_2D_MIN", "FD_CONV_N16", "FD_CONV_N16_MIN",
-             "FD_REFLECT_RING", "FD_REFLECT_WINO", "FD_REFLECT_WINO_MIN", "FD_REFLECT_WINO_PADDED")
+             "FD_REFLECT_RING", "FD_REFLECT_WINO", "FD_REFLECT_WINO_MIN", "FD_REFLECT_WINO_PADDED", "FD_REFLECT_WINO_PADDED_MAX")
 _PLAN_ENV_B = tuple(k.encode() for k in _PLAN_ENV)
 _ENV_DATA = getattr(os.environ, "_data", None)
 if not isinstance(_ENV_DATA, dict) or (len(_ENV_DATA) and not isinstance(next(iter(_ENV_DATA)), bytes)):
