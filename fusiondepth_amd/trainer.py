@@ -652,10 +652,22 @@ class Trainer:
         orders = [(f, 0) if f < 0 else (0, f) for f in fids]
         G = self._groups
         Bg = inputs["color_aug", 0, 0].shape[0] // G
-        pairs = [torch.cat([inputs[key, i, 0] for i in o], 1) for o in orders]
-        if G == 1:
-            return torch.cat(pairs, 0)
-        return torch.cat([p[g * Bg:(g + 1) * Bg] for g in range(G) for p in pairs], 0)
+        if os.environ.get("FD_STACK_DIRECT", "1") == "0":
+            pairs = [torch.cat([inputs[key, i, 0] for i in o], 1) for o in orders]
+            if G == 1:
+                return torch.cat(pairs, 0)
+            return torch.cat([p[g * Bg:(g + 1) * Bg] for g in range(G) for p in pairs], 0)
+        # written straight into the stacked tensor (two concatenations in a row moved every image twice: 0.15 ms at the head of the
+        # pose encoder's stream)
+        first = inputs[key, orders[0][0], 0]
+        C = first.shape[1]
+        out = torch.empty((G * len(orders) * Bg, 2 * C) + tuple(first.shape[2:]), device=first.device, dtype=first.dtype)
+        for g in range(G):
+            for k, o in enumerate(orders):
+                dst = out[(g * len(orders) + k) * Bg:(g * len(orders) + k + 1) * Bg]
+                for j, i in enumerate(o):
+                    dst[:, j * C:(j + 1) * C].copy_(inputs[key, i, 0][g * Bg:(g + 1) * Bg])
+        return out
 
     def _encoders_interleaved(self, inputs, enc_in, groups):
         """All four encoder modules of the step, each on its own stream, issued block by block in turns
