@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FD_LIBFDHIP") or os.path.join(_HERE, "libfdhip.so")   # FD_LIBFDHIP: ablation builds (scripts/)
-ABI_VERSION = 1
+ABI_VERSION = 2
 PHOTO_OUT_FLOATS = 96        # FD_PHOTO_OUT_FLOATS
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
@@ -50,6 +50,10 @@ SIGNATURES = {
     "fd_abi_version": ("", "i"),
     "fd_supported_arch": ("", "s"),
     "fd_last_error": ("", "s"),
+    "fd_tuning_defaults": ("p", "v"),
+    "fd_set_tuning": ("p", "i"),
+    "fd_get_tuning": ("p", "v"),
+    "fd_tuning_generation": ("", "l"),
     "fd_disp_to_depth_fwd": ("ppplddp", "i"),
     "fd_disp_to_depth_bwd": ("pppplddp", "i"),
     "fd_pose_matrix_fwd": ("pppiip", "i"),
@@ -142,7 +146,7 @@ def load():
         for name, (args, res) in SIGNATURES.items():
             fn = getattr(lib, name)           # AttributeError if the symbol is not exported
             fn.argtypes = [_KIND[k] for k in args]
-            fn.restype = ctypes.c_char_p if res == "s" else _KIND[res]
+            fn.restype = ctypes.c_char_p if res == "s" else (None if res == "v" else _KIND[res])
         if lib.fd_abi_version() != ABI_VERSION:
             raise RuntimeError("libfdhip ABI %d != expected %d; rebuild" % (lib.fd_abi_version(), ABI_VERSION))
         _lib = lib
@@ -153,18 +157,19 @@ def last_error():
     return load().fd_last_error().decode()
 
 
-# FD_HOST_DELAY_US=x: busy-wait x microseconds before every entry-point call - the experiment behind DESIGN.md's "the step is
-# GPU-bound": up to 16 us per call (about +11 ms of host work per step) leaves ms_per_step unchanged (profiles/README.md, round 3)
-_HOST_DELAY_US = float(os.environ.get("FD_HOST_DELAY_US", "0"))
+# tuning.host.host_delay_us = x: busy-wait x microseconds before every entry-point call - the experiment behind DESIGN.md's "the
+# step is GPU-bound": up to 16 us per call (about +11 ms of host work per step) leaves ms_per_step unchanged (profiles/README.md,
+# round 3).  Set by fusiondepth_amd/tuning.py.
+HOST_DELAY_US = 0.0
 
 
 def call(name, *args):
     """Invoke an ``int``-returning entry point and raise RuntimeError on a non-zero status."""
     lib = load()
-    if _HOST_DELAY_US:
+    if HOST_DELAY_US:
         import time
         t0 = time.perf_counter()
-        while (time.perf_counter() - t0) * 1e6 < _HOST_DELAY_US:
+        while (time.perf_counter() - t0) * 1e6 < HOST_DELAY_US:
             pass
     rc = getattr(lib, name)(*args)
     if rc != 0:

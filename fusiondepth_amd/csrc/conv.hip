@@ -745,35 +745,17 @@ inline bool fast_fwd_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->
 inline bool fast_dgrad_ok(const fd_conv_desc* d) { return d->Cout % 16 == 0; }
 inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && d->Cin >= 64 && !d->in_norm; }   // narrow layers: a (tap, channel) tile would be mostly padding
 
-// FD_CONV_LOG=1: one stderr line per convolution call (which kernel family it was routed to) - a tuning aid
+// fd_tuning.log: one stderr line per convolution call (which kernel family it was routed to) - a tuning aid
 void conv_log(const char* what, const char* path, const fd_conv_desc* d) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("FD_CONV_LOG"); on = e ? atoi(e) : 0; }
-    if (on) fprintf(stderr, "FDCONV %s %s N=%d Cin=%d H=%d W=%d Cout=%d K=%d s=%d pad_mode=%d\n", what, path, d->N, d->Cin, d->H, d->W, d->Cout, d->KH,
-                    d->stride, d->pad_mode);
+    if (fd_tun().log) fprintf(stderr, "FDCONV %s %s N=%d Cin=%d H=%d W=%d Cout=%d K=%d s=%d pad_mode=%d\n", what, path, d->N, d->Cin, d->H, d->W, d->Cout, d->KH,
+                              d->stride, d->pad_mode);
 }
 // 1-D Winograd F(2,3) path (conv_wino.hip): 3x3 stride-1 pad-1 convs with >= 64 output channels (its tile is 64 channels tall).
-// FD_WINO=0 keeps everything on the direct implicit GEMM (A/B runs).
-bool wino_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("FD_WINO"); on = e ? atoi(e) : 1; }
-    return on != 0;
-}
-inline bool wino_use_wgrad(const fd_conv_desc* d) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("FD_WINO_WGRAD"); on = e ? atoi(e) : 1; }
-    // layer1's 64x64 weight (3 tiles x 256 pixel-splits) is 10 % slower than the direct kernel when run alone and still the
-    // better choice inside the step (449.6 vs 442 images/s): what the step is short of is MFMA cycles, not launch latency
-    static long min_cc = -1;
-    if (min_cc < 0) { const char* e = getenv("FD_WINO_WGRAD_MIN"); min_cc = e ? atol(e) : 0; }
-    return on != 0 && wino_enabled() && wino_wgrad_ok(d) && (long)d->Cin * d->Cout >= min_cc;
-}
-// FD_WINO_FWD=0: forward and data gradient stay on the direct kernels, the weight gradient keeps its Winograd kernel (A/B runs)
-bool wino_fwd_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("FD_WINO_FWD"); on = e ? atoi(e) : 1; }
-    return on != 0 && wino_enabled();
-}
+// layer1's 64x64 weight gradient (3 tiles x 256 pixel-splits) is 10 % slower than the direct kernel when run alone and still the
+// better choice inside the step (449.6 vs 442 images/s): what the step is short of is MFMA cycles, not launch latency
+inline bool wino_use_wgrad(const fd_conv_desc* d) { return fd_tun().wino_wgrad != 0 && wino_wgrad_ok(d); }
+// fd_tuning.wino_fwd = 0: forward and data gradient stay on the direct kernels (A/B runs)
+bool wino_fwd_enabled() { return fd_tun().wino_fwd != 0; }
 inline bool wino_use_fwd(const fd_conv_desc* d) { return wino_fwd_enabled() && wino_fwd_ok(d) && d->Cout >= 64; }
 // the data gradient of a zero-padded 3x3 stride-1 conv is the same kind of conv over dY (channels swapped, kernel flipped)
 inline bool wino_dgrad_desc(const fd_conv_desc* d, fd_conv_desc& g) {
@@ -787,15 +769,12 @@ inline bool wino_dgrad_desc(const fd_conv_desc* d, fd_conv_desc& g) {
 // gradient: a plain 3x3 convolution over dY with the transposed, flipped kernel - Winograd-eligible like the trunk's.  With the
 // padded grid's one-pixel ring as four thin problems on the implicit-GEMM kernel + k_reflect_ring_fold (round 3), the decoder's
 // wide blocks (upconv(2..4, *): 64 .. 512 channels) leave the direct kernel's padded-grid pass (46 - 60 TFLOP/s on these shapes)
-// and its full fold pass.  `g`: the convolution the interior computes.  FD_REFLECT_WINO=0 switches it off; needs FD_REFLECT_RING != 0.
+// and its full fold pass.  `g`: the convolution the interior computes.  fd_tuning.reflect_wino = 0 switches it off; needs reflect_ring != 0.
 bool refl_wino_interior(const fd_conv_desc* d, fd_conv_desc& g) {
     if (!(wino_fwd_enabled() && d->pad_mode == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H >= 2 && d->W >= 2)) return false;
-    const char* e = getenv("FD_REFLECT_WINO");
-    if (e && atoi(e) == 0) return false;
-    const char* r = getenv("FD_REFLECT_RING");
-    if (r && atoi(r) == 0) return false;
-    const char* m = getenv("FD_REFLECT_WINO_MIN");
-    if ((long)d->H * d->W < (m ? atol(m) : 1)) return false;
+    const fd_tuning& t = fd_tun();
+    if (!t.reflect_wino || !t.reflect_ring) return false;
+    if ((long)d->H * d->W < (long)t.reflect_wino_min_pixels) return false;
     if (!fast_dgrad_ok(d)) return false;                     // the ring runs on the implicit-GEMM kernel
     g = *d;
     g.Cin = d->Cout; g.Cout = d->Cin; g.pad_mode = 0; g.act = 0; g.in_norm = 0;
@@ -809,12 +788,9 @@ bool refl_wino_interior(const fd_conv_desc* d, fd_conv_desc& g) {
 bool refl_wino_padded(const fd_conv_desc* d, fd_conv_desc& gp) {
     fd_conv_desc gz;
     if (!refl_wino_interior(d, gz)) return false;
-    const char* e = getenv("FD_REFLECT_WINO_PADDED");
-    if (e && atoi(e) == 0) return false;
-    const char* r = getenv("FD_REFLECT_RING");
-    const char* m = getenv("FD_REFLECT_WINO_PADDED_MAX");
-    long thr = m ? atol(m) : 4096;                           // measured in the step: 4 096 (planes up to 24x80) 20.35 - 20.43 ms, 16 384 20.44 - 20.51, 65 536 20.54 - 20.59
-    if (r && atol(r) > 1 && atol(r) < thr) thr = atol(r);    // (the tests' "ring from n pixels on")
+    const fd_tuning& t = fd_tun();
+    long thr = t.reflect_wino_padded_max;                    // measured in the step: 4 096 (planes up to 24x80) 20.35 - 20.43 ms, 16 384 20.44 - 20.51, 65 536 20.54 - 20.59; 0: never
+    if (t.reflect_ring > 1 && t.reflect_ring < thr) thr = t.reflect_ring;    // (the tests' "ring from n pixels on")
     if ((long)d->H * d->W >= thr) return false;              // larger planes: interior + ring
     gp = gz;
     gp.H = d->H + 2; gp.W = d->W + 2;
@@ -1054,8 +1030,7 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
     if (d->stride == 1) {
         g.sy = 1; g.da = 1; g.sx = 1; g.db = 1;
         g.osy = 1; g.ooy = 0; g.osx = 1; g.oox = 0;
-        int ring_on = 1;                       // read per call (reflect-padded layers only: 20 calls per step), so that tests can switch it
-        if (d->pad_mode == 1) { const char* e = getenv("FD_REFLECT_RING"); ring_on = e ? atoi(e) : 1; }
+        const int ring_on = fd_tun().reflect_ring;
         fd_conv_desc gz;
         if (d->pad_mode == 1 && refl_wino_padded(d, gz)) {
             conv_log("dgrad", "wino on the padded grid + fold", d);

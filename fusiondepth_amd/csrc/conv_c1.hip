@@ -195,8 +195,7 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_dgrad(const float* __restric
 }  // namespace
 
 bool c1_shape_ok(const fd_conv_desc* d) {
-    const char* e = getenv("FD_CONV_C1");                  // 0: Cout = 1 layers stay on the GEMM kernels (A/B timing, tests)
-    if (e && atoi(e) == 0) return false;
+    if (!fd_tun().conv_c1) return false;                   // 0: Cout = 1 layers stay on the GEMM kernels (A/B timing, tests)
     return d->Cout == 1 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->in_norm && d->H >= 2 && d->W >= 2 &&
            d->Cin <= 1024 && (long)d->N * d->Cin * d->H * d->W < (1L << 29);
 }

@@ -582,13 +582,11 @@ namespace {
 // (measured: 360 blocks of 128x128 leave 30 % of the chip idle, 720 blocks of 64x128 do not).
 struct FastChoice { int cfg; int splits; };   // cfg 0: 128x128 (FD_CONV_FORCE only), 1: 64x128, 2: 32x256
 FastChoice choose_config(const FastGemmArgs& a) {
-    if (const char* f = getenv("FD_CONV_FORCE")) {        // tuning aid (scripts/conv_cfg_sweep.py): "cfg,splits", read per call
-        int c = -1, sp = 1;
-        if (sscanf(f, "%d,%d", &c, &sp) == 2 && c >= 0 && c <= 2 && sp >= 1) {
-            const bool ok_c = (c == 0 && a.M > 64) || (c == 1 && a.M > 32) || c == 2;
-            const bool can = a.osy == 1 && a.osx == 1 && a.slab_stride > 0;
-            if (ok_c) return {c, can ? sp : 1};
-        }
+    if (fd_tun().force_cfg >= 0) {                        // tuning aid (scripts/conv_cfg_sweep.py): fd_tuning.force_cfg / force_splits
+        const int c = fd_tun().force_cfg, sp = fd_tun().force_splits;
+        const bool ok_c = (c == 0 && a.M > 64) || (c == 1 && a.M > 32) || c == 2;
+        const bool can = a.osy == 1 && a.osx == 1 && a.slab_stride > 0;
+        if (ok_c) return {c, can ? sp : 1};
     }
     const long Np = (long)a.Nb * a.NY * a.NX;
     const int bkc = (a.C % 32 == 0) ? 32 : 16;
@@ -600,8 +598,7 @@ FastChoice choose_config(const FastGemmArgs& a) {
     // workgroups the chip holds (3 per CU) wins or ties everywhere: 720 = 720x1 = 360x2 = 180x4, 768 = 96x8 = 48x16.
     const int c = a.M > 32 ? 1 : 2;
     const long tiles = (long)fd_cdiv(Np, bn[c]) * fd_cdiv(a.M, bm[c]);
-    static long fill = 0;
-    if (!fill) { const char* e = getenv("FD_CONV_TARGET"); fill = e ? atol(e) : 768; }
+    const long fill = fd_tun().conv_target;
     int sp = 1;
     if (can_split && tiles < fill) {
         sp = (int)(fill / tiles);
@@ -724,8 +721,7 @@ int fast_wgrad_splits(int M, int C, int T, long Np) {
     // Workgroups co-resident on a CU share its matrix pipes, so a launch finishes when the fullest CU does: 513 workgroups
     // on 256 CUs (one CU with 3) take 1.5x the time of 512.  Aim at 3 per CU (what the 50 KB LDS tiles allow) and never
     // exceed it; measured in the training step against 256 / 512 / 1024 and against a rounds-based cost model.
-    static long target = 0;
-    if (!target) { const char* e = getenv("FD_WGRAD_TARGET"); target = e ? atol(e) : 768; }
+    const long target = fd_tun().wgrad_target;
     const int bn = C >= 128 ? 128 : 64;
     const long tiles = (long)T * fd_cdiv(C, bn) * fd_cdiv(M, M > 32 ? 64 : 32);
     long sp = target / tiles;

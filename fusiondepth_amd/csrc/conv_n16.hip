@@ -216,10 +216,8 @@ int n16_go(const N16Args& a, hipStream_t st) {
 
 // M output / C input channels of the convolution being computed (for a data gradient: the layer's Cin / Cout)
 bool n16_shape_ok(const fd_conv_desc* d, int M, int C) {
-    const char* e = getenv("FD_CONV_N16");                   // 0: these layers stay on the implicit-GEMM kernel (A/B timing, tests)
-    if (e && atoi(e) == 0) return false;
-    const char* mn = getenv("FD_CONV_N16_MIN");
-    const long min_px = mn ? atol(mn) : 16384;               // planes below 128 x 128: the patch halo and the tile quantisation eat the gain
+    const long min_px = fd_tun().conv_n16_min_pixels;        // default 16384 - planes below 128 x 128: the patch halo and the tile quantisation eat the gain
+    if (min_px < 0) return false;                            // these layers stay on the implicit-GEMM kernel (A/B timing, tests)
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->in_norm && d->H >= 2 && d->W >= 2 &&
            (long)d->H * d->W >= min_px && ((M == 16 && (C == 16 || C == 32)) || (M == 32 && C == 16)) &&
            (long)d->N * (M > C ? M : C) * d->H * d->W < (1L << 29);

@@ -838,8 +838,7 @@ inline int wino_splits(const fd_conv_desc* d, int M, int C) {
     const long tiles = (long)fd_cdiv((long)d->N * d->H * (d->W / 2), WBN) * fd_cdiv(M, WBM);
     const int nchunk = 3 * (C / WBKC);
     int sp = 1;
-    static long target = 0;
-    if (!target) { const char* e = getenv("FD_WINO_TARGET"); target = e ? atol(e) : 384; }     // alone on the GPU 768 is best; inside the step 256-384 (less slab traffic)
+    const long target = fd_tun().wino_target;              // alone on the GPU 768 is best; inside the step 256-384 (less slab traffic)
     if (tiles < target) {
         sp = (int)(target / tiles);
         const int cap = nchunk / 3 > 0 ? (nchunk / 3 < 16 ? nchunk / 3 : 16) : 1;
@@ -856,20 +855,17 @@ bool wino_fwd_ok(const fd_conv_desc* d) {
            (long)d->Cout * 3 * d->Cin * 4 * 4 < 2147483648L;
 }
 // F(2x2, 3x3) (k_conv_wino2d) for the layers whose matrix work dwarfs their output: Cin * Cout >= 256 * 256 (FD_WINO_FWD_2D_MIN) and
-// whole 2x2 tiles.  A function of the descriptor (+ environment, re-read per call: the tests run both kernels in one process), so
-// that the weight-layout size, the workspace size, the re-layout job and the launch agree.
+// whole 2x2 tiles.  A function of the descriptor and of fd_tuning, so that the weight-layout size, the workspace size, the
+// re-layout job and the launch agree.
 bool wino_fwd_2d(const fd_conv_desc* d) {
-    const char* e = getenv("FD_WINO_FWD_2D");
-    if (e && atoi(e) == 0) return false;
-    const char* m = getenv("FD_WINO_FWD_2D_MIN");
-    const long min_cc = m ? atol(m) : 65536;
+    const long min_cc = fd_tun().wino_fwd_2d_min;
+    if (min_cc <= 0) return false;
     return wino_fwd_ok(d) && d->H % 2 == 0 && (long)d->Cin * d->Cout >= min_cc && (long)d->Cout * 4 * d->Cin * 4 * 4 < 2147483648L;
 }
 // channel splits of the 2-D kernel on top of its four row components
 inline int wino2d_ksplits(const fd_conv_desc* d) {
     const long tiles = 4L * fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN) * fd_cdiv(d->Cout, WBM);
-    static long target = 0;
-    if (!target) { const char* e = getenv("FD_WINO_TARGET"); target = e ? atol(e) : 384; }
+    const long target = fd_tun().wino_target;
     long ks = tiles < target ? target / tiles : 1;
     const long cap = d->Cin / WBKC / 4 > 0 ? d->Cin / WBKC / 4 : 1;          // at least 4 chunks per split
     if (ks > cap) ks = cap;
@@ -929,8 +925,7 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         const int gx2 = fd_cdiv((long)d->N * HT * (d->W / 2), WBN);
         g.slab_stride = out_total / 2;                                     // S_ri: [N][M][H/2][W]
         const int gy2 = fd_cdiv(d->Cout, WBM);
-        static int xmap = -1;
-        if (xmap < 0) { const char* e = getenv("FD_WINO_2D_MAP"); xmap = e ? atoi(e) : 1; }
+        const int xmap = 1;        // XCD-aware 1-D grid (plain 3-D grid: layer4 162 instead of 79 MB of HBM traffic per launch, -0.35 % in the step)
         g.xcd_swizzle = (gx2 % 8 == 0 && gx2 >= 16) ? 1 : 0;
         dim3 grid(gx2, gy2, sp);
         if (xmap && (gy2 * sp) % 8 == 0) { g.xcd_swizzle = 2; g.gx = gx2; g.gy = gy2; g.gz = sp; grid = dim3((unsigned)(gx2 * gy2 * sp)); }
@@ -945,10 +940,9 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
     }
     const int gx = fd_cdiv((long)d->N * d->H * (d->W / 2), WBN), gy = fd_cdiv(d->Cout, WBM);
     g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
-    static int dma_on = -1;
-    if (dma_on < 0) { const char* e = getenv("FD_WINO_DMA"); dma_on = e ? atoi(e) : 1; }
-    // direct-to-LDS activations need 16-byte pieces that stay inside one image row and a 16-byte aligned tensor
-    const bool vdma = dma_on && d->W % 4 == 0 && ((uintptr_t)x & 15) == 0;
+    // direct-to-LDS activations need 16-byte pieces that stay inside one image row and a 16-byte aligned tensor (otherwise the
+    // register-staged loader: same results bit for bit, +0.12 ... +0.20 ms per step when forced)
+    const bool vdma = d->W % 4 == 0 && ((uintptr_t)x & 15) == 0;
     const bool stats = g.stat_part != nullptr;
     auto kern = vdma ? (stats ? k_conv_wino<true, true> : k_conv_wino<true, false>) : (stats ? k_conv_wino<false, true> : k_conv_wino<false, false>);
     hipLaunchKernelGGL(kern, dim3(gx, gy, sp), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
@@ -975,18 +969,15 @@ bool wino_wgrad_ok(const fd_conv_desc* d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 16 == 0 && d->Cin >= 64 && d->Cout >= 64 &&
            d->W % 2 == 0 && !d->in_norm;
 }
-// The 2-D algorithm needs whole 2x2 tiles of dY (FD_WINO_WGRAD_2D=0: the 1-D kernel everywhere, for A/B timing)
+// The 2-D algorithm needs whole 2x2 tiles of dY (fd_tuning.wino_wgrad_2d = 0: the 1-D kernel everywhere, for A/B timing)
 bool wino_wgrad_2d(const fd_conv_desc* d) {
-    const char* e = getenv("FD_WINO_WGRAD_2D");            // read per call: the tests run both kernels in one process
-    const int on = e ? atoi(e) : 1;
-    return on != 0 && d->H % 2 == 0 && d->Cin % 32 == 0;      // (k_wgrad_finish9<12> works on blocks of 32 input channels)
+    return fd_tun().wino_wgrad_2d != 0 && d->H % 2 == 0 && d->Cin % 32 == 0;      // (k_wgrad_finish9<12> works on blocks of 32 input channels)
 }
 int wino_wgrad_splits(const fd_conv_desc* d) {
     const bool twod = wino_wgrad_2d(d);
     const long tiles = (twod ? 4L : 3L) * fd_cdiv(d->Cin, WBN) * fd_cdiv(d->Cout, WBM);
     const long Np = (long)d->N * (twod ? d->H / 2 : d->H) * (d->W / 2);
-    static long target = 0;
-    if (!target) { const char* e = getenv("FD_WINO_WGRAD_TARGET"); target = e ? atol(e) : 384; }     // in-step optimum (768: -1 %)
+    const long target = fd_tun().wino_wgrad_target;          // in-step optimum 384 (768: -1 %)
     long sp = target / tiles;
     const long maxs = (Np + 4 * WGP - 1) / (4 * WGP);          // at least 4 chunks per split
     if (sp > maxs) sp = maxs;
@@ -1022,8 +1013,7 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static int slice_major = -1;
-    if (slice_major < 0) { const char* e = getenv("FD_WINO_WGRAD_MAP"); slice_major = e ? atoi(e) : 2; }     // 2 (XCD-aware 1-D grid): layer1 HBM traffic 157 -> 76 MB per launch, step -0.5 %; 1 measured slower than 0
+    const int slice_major = 2;        // XCD-aware 1-D grid: layer1 HBM traffic 157 -> 76 MB per launch, step -0.5 %; (1: slice-major 3-D grid measured slower than 0)
     g.slice_major = slice_major;
     const int nt = (twod ? 4 : 3) * fd_cdiv(d->Cin, WBN);
     const int mt = fd_cdiv(d->Cout, WBM);

@@ -6,6 +6,10 @@
 
 #define FD_WAVE 64
 
+// ---- tuning (include/fdhip.h: fd_tuning; csrc/tuning.hip) - the library never reads the environment
+struct fd_tuning;
+const fd_tuning& fd_tun();
+
 // ---- error plumbing (C ABI never throws; see include/fdhip.h) ------------------------------------
 void fd_set_error(const char* fmt, ...);
 

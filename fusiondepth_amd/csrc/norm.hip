@@ -497,7 +497,7 @@ inline bool bn_small(int Ng, long HW, int groups, bool vec) {
 #ifdef FD_ABLATE_NO_BN_SMALL     // timing experiment only: small planes cost nothing (the launches are skipped by the callers)
     (void)Ng; (void)HW; (void)groups; (void)vec;
 #endif
-    return vec && groups <= 16 && (long)Ng * (HW >> 2) <= (long)NT * SMALL_K && getenv("FD_BN_SMALL_OFF") == nullptr;
+    return vec && groups <= 16 && (long)Ng * (HW >> 2) <= (long)NT * SMALL_K;
 }
 
 inline int plane_blocks(long HW) {

@@ -52,6 +52,8 @@ class FlatParameters:
                 p.grad = self.flat_grad[o:o + n].view(p.shape)
 
     def zero_grad(self):
+        from . import functional as FD
+        FD.join_wgrad_streams()          # side-stream weight gradients still accumulating into the buffer come first
         self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):     # autograd may have replaced .grad; re-attach the views
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:
@@ -78,7 +80,10 @@ class GradientSynchronizer:
         self.handles = []
         self.buckets = []           # [start, end, n_params]
         self.param_bucket = []
-        self.overlap = (os.environ.get("FD_DP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        if overlap is None:
+            from . import tuning
+            overlap = tuning.host.dp_overlap
+        self.overlap = bool(overlap)
         self.skip_comm = False      # bench only: measure a step without the exchange
         per = max(bucket_bytes // 4, 1)
         ends = set()                # parameter indices after which a bucket must close

@@ -5,13 +5,12 @@ forward/backward pairing.  All arithmetic happens in the HIP kernels; nothing he
 torch ops on the data path.
 """
 import ctypes
-
-import os
 import weakref
 
 import torch
 
 from . import _lib
+from . import tuning
 from ._lib import call, f32, ptr, query, stream
 
 PROJECT_EPS = 1e-7
@@ -589,13 +588,13 @@ def _drop_plan():
 # step.  Only the small forward layouts of the first layers are needed at once; everything else ("late": data-gradient layouts,
 # forward layouts from 1 MB up = ResNet layer3 / layer4 and the decoder's deep blocks) is refreshed on a side stream while the next
 # step's stems and first blocks run, and a stream that is about to USE a late layout waits for that launch first
-# (``_weight_layout``), as does the next optimiser step before it changes the weights again.  FD_LATE_RELAYOUT=0: one launch.
+# (``_weight_layout``), as does the next optimiser step before it changes the weights again.  tuning.host.late_relayout = False: one launch.
 _LATE_MIN_FLOATS = 1 << 18
 _LATE = {"event": None, "waited": set(), "stream": None}
 
 
 def _late_relayout_on():
-    return os.environ.get("FD_LATE_RELAYOUT", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+    return tuning.host.late_relayout and not torch.cuda.is_current_stream_capturing()
 
 
 def _wait_late_layouts():
@@ -687,8 +686,12 @@ def _live_grad_ready():
 
 
 def begin_forward_pass():
-    """Start counting parameter uses afresh: the backward pass of this forward runs one gradient kernel per use."""
+    """Start counting parameter uses afresh: the backward pass of this forward runs one gradient kernel per use.  Side-stream
+    weight gradients of a previous backward pass that nobody joined (a caller driving process_batch + backward itself, without
+    Trainer._join_side_streams) are joined here, so that the tensors they keep alive are released at the latest one pass later."""
     _PARAM_USES.clear()
+    if _WGRAD_KEEPALIVE:
+        join_wgrad_streams()
 
 
 def param_uses(p):
@@ -841,26 +844,10 @@ class _ConvPlan:
         return self.bwd_weight_ws
 
 
-# The tuning variables the library re-reads on every call (scripts/conv_cfg_sweep.py and the tests flip them within a process): they
-# change the split-K / slab workspace and weight-layout sizes, so they are part of the plan key.  Read from the environment's raw
-# byte dictionary: nine os.environ.get() calls per convolution were 0.8 ms of host time per training step.
-_PLAN_ENV = ("FD_CONV_C1", "FD_CONV_FORCE", "FD_WINO_WGRAD_2D", "FD_WINO_FWD_2D", "FD_WINO_FWD_2D_MIN", "FD_CONV_N16", "FD_CONV_N16_MIN",
-             "FD_REFLECT_RING", "FD_REFLECT_WINO", "FD_REFLECT_WINO_MIN", "FD_REFLECT_WINO_PADDED", "FD_REFLECT_WINO_PADDED_MAX")
-_PLAN_ENV_B = tuple(k.encode() for k in _PLAN_ENV)
-_ENV_DATA = getattr(os.environ, "_data", None)
-if not isinstance(_ENV_DATA, dict) or (len(_ENV_DATA) and not isinstance(next(iter(_ENV_DATA)), bytes)):
-    _ENV_DATA = None                                   # not CPython-on-POSIX's byte dictionary: fall back to os.environ.get
-
-
-def _plan_env_key():
-    if _ENV_DATA is not None:
-        g = _ENV_DATA.get
-        return tuple([g(k) for k in _PLAN_ENV_B])
-    return tuple([os.environ.get(k) for k in _PLAN_ENV])
-
-
+# The library's kernel-selection thresholds (fd_tuning) change the split-K / slab workspace and weight-layout sizes, so the number of
+# fd_set_tuning calls so far is part of the plan key (one integer compare; the tests and sweeps flip thresholds within a process).
 def _conv_plan(x, w, stride, pad, pad_mode, act, in_norm):
-    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, _plan_env_key())
+    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, tuning.generation())
     plan = _CONV_PLANS.get(key)
     if plan is None:
         plan = _CONV_PLANS[key] = _ConvPlan(x, w, stride, pad, pad_mode, act, in_norm)

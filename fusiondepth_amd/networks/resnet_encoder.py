@@ -7,13 +7,12 @@ module tree (so ``state_dict()`` keys/shapes are identical: ``encoder.conv1.weig
 ``nn.BatchNorm2d`` used purely as parameter/buffer holders.  Every forward op is a libfdhip kernel:
 MFMA implicit-GEMM convs, BatchNorm fused with the residual add + ReLU, 3x3/s2 max-pool.
 """
-import os
-
 import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import functional as FD
+from .. import tuning
 
 _SPEC = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]),
          101: ("bottleneck", [3, 4, 23, 3]), 152: ("bottleneck", [3, 8, 36, 3])}
@@ -23,16 +22,12 @@ def _conv(x, conv, in_norm=False):
     return FD.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0], in_norm=in_norm)
 
 
-_CONV_STATS = os.environ.get("FD_CONV_STATS", "1") != "0"
-
-
 def _conv_bn(x, conv, bn, residual=None, relu=False, tap=False):
     """bn(conv(x)) [+ residual] [ReLU].  In training mode the convolution's epilogue gathers the BatchNorm's partial sums where its
     kernel can (FD.conv2d_stats), so the BatchNorm is ONE launch over the output instead of a statistics pass + an apply pass.
     ``tap``: also return ``x`` routed through the convolution's autograd node (see ``_conv_tap``)."""
-    if bn.training and _CONV_STATS and torch.is_grad_enabled():
-        res = FD.conv2d_stats(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0],
-                              tap=tap and os.environ.get("FD_CONV_TAP", "1") != "0")
+    if bn.training and tuning.host.conv_stats and torch.is_grad_enabled():
+        res = FD.conv2d_stats(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0], tap=tap)
         y, stats = res[0], res[1]
         out = FD.batch_norm(y, bn, residual=residual, relu=relu, conv_stats=stats)
         return (out, res[2]) if tap else out
@@ -46,8 +41,6 @@ def _conv_tap(x, conv):
     """(conv(x), x): the block input is needed twice - by the first convolution and by the residual branch.  Taking the second
     use from the tap makes the residual gradient join the first convolution's data gradient inside that kernel
     (functional._Conv2dTap) instead of being summed by a separate element-wise launch."""
-    if os.environ.get("FD_CONV_TAP", "1") == "0":
-        return _conv(x, conv), x
     return FD.conv2d_tap(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0])
 
 

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from . import dp
 from . import functional as FD
+from . import tuning
 from . import networks
 from .layers import disp_to_depth
 from .trainer import Outputs, Trainer, derived_hparams
@@ -96,7 +97,7 @@ class Refiner(Trainer):
         self.lr = self.learning_rate
         self.adam_state = torch.tensor([0.0, self.lr], device=self.device)
         self._graph, self._streams = None, []
-        self.parallel_streams = os.environ.get("FD_REFINER_STREAMS", "1") != "0"
+        self.parallel_streams = tuning.host.refiner_streams
         self.stack_microbatches = False
         self._groups = 1
         self.grad_sync = dp.GradientSynchronizer(self.flat, world_size)

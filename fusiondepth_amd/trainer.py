@@ -23,6 +23,7 @@ import torch
 from . import dp
 from . import functional as FD
 from . import networks
+from . import tuning
 from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transformation_from_parameters
 
 MODEL_ORDER = ["encoder", "beam_encoder", "beam_encoder_pose", "depth", "pose_encoder", "pose", "predictive_mask"]
@@ -97,6 +98,8 @@ def derived_hparams(opt, vram_gib):
 
 
 class Trainer:
+    _pose_on_main = False      # True only inside train_step_graphed: the captured step keeps every fork on the capture stream
+
     def __init__(self, options, device=None, rank=0, world_size=1, materialize_outputs=False, verbose=True):
         self.opt = options
         if self.opt.no_cuda or not torch.cuda.is_available():
@@ -176,7 +179,7 @@ class Trainer:
         FD.enable_weight_cache(self.parameters_to_train)
         FD.enable_direct_grad(self.parameters_to_train)
         # the depth decoder is the serial section of the step: its weight gradients leave the main stream (functional.enable_side_wgrad)
-        for k in os.environ.get("FD_SIDE_WGRAD", "depth").split(","):
+        for k in tuning.host.side_wgrad:
             if k in self.models:
                 FD.enable_side_wgrad(self.models[k].parameters())
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
@@ -191,10 +194,10 @@ class Trainer:
         # the flag variants without a separate pose encoder per frame pair run them one after the other like the reference
         self.stack_microbatches = (self.use_pose_net and self.opt.pose_model_type == "separate_resnet"
                                    and self.num_pose_frames == 2)
-        # opt-in (FD_INTERLEAVE=1): the four encoders issued block by block in turns instead of one after the other
+        # opt-in (tuning.host.interleave): the four encoders issued block by block in turns instead of one after the other
         # (networks.interleaved_forward).  Throughput-neutral on this host (the GPU is saturated either way), so the
         # longer-tested sequential issue order stays the default.
-        self.interleave_encoders = os.environ.get("FD_INTERLEAVE", "0") != "0"
+        self.interleave_encoders = bool(tuning.host.interleave)
         unused = [p for m in self.models.values() for n, p in m.named_parameters() if n.startswith("encoder.fc.")]
         self.grad_sync = dp.GradientSynchronizer(self.flat, world_size, never_used=unused,
                                                  segments=[len(list(m.parameters())) for m in self.models.values()])
@@ -273,7 +276,6 @@ class Trainer:
         evaluated per micro-batch, and the other loss terms are means, so loss = sum_g loss_g / accumulate_step and its
         gradient equal the reference's accumulated values while every kernel sees twice the work per launch.
         Returns the loss dict (device tensors; nothing is synchronised here)."""
-        self._pose_on_main = False             # (train_step_graphed keeps the pose decoder on the capture stream)
         prestacked = isinstance(micro_batches, dict)       # a loader that already delivers the step's images as one batch
         assert prestacked or len(micro_batches) == self.accumulate_step
         if self.stack_microbatches:
@@ -420,6 +422,12 @@ class Trainer:
         and replay.  With several ranks the forward/backward micro-steps are replayed and the gradient all-reduce +
         Adam run after the graph."""
         self._pose_on_main = True              # the captured step keeps the pose decoder on the capture stream (see predict_poses)
+        try:
+            return self._train_step_graphed(micro_batches)
+        finally:
+            self._pose_on_main = False         # direct process_batch / train_step calls afterwards fork their side streams again
+
+    def _train_step_graphed(self, micro_batches):
         if self._graph is None:
             if self.stack_microbatches:
                 self._static_in = self.stack_micro_batches(micro_batches)
@@ -454,6 +462,10 @@ class Trainer:
             with torch.cuda.graph(g, stream=self._side):
                 self._static_losses = self._graph_body(self._static_in)
             self._graph = g
+        # A refresh of the cached weight layouts issued eagerly since the last replay - the optimiser step that follows the graph when
+        # world_size > 1, load_model() - puts the large layouts on a side stream behind an event (functional.refresh_weight_layouts).
+        # The captured kernels were recorded with "layout ready" and never look at that event: the replay stream waits for it here.
+        FD.sync_late_layouts()
         self._graph.replay()
         if self.world_size > 1:
             self._sync_and_step()
@@ -511,7 +523,7 @@ class Trainer:
 
     def _fork(self, idx):
         """Side stream #idx, ordered after everything already queued on the current stream."""
-        idx = idx % int(os.environ.get("FD_NSTREAMS", "8"))
+        idx = idx % max(int(tuning.host.n_streams), 1)
         while len(self._streams) <= idx:
             self._streams.append(torch.cuda.Stream())
         st = self._streams[idx]
@@ -610,7 +622,7 @@ class Trainer:
         if val:
             self.generate_images_pred(inputs, outputs, [0])
         else:
-            if par and os.environ.get("FD_SMOOTH_STREAM", "1") != "0" and not getattr(self, "_pose_on_main", False):
+            if par and tuning.host.smooth_stream and not self._pose_on_main and not torch.cuda.is_current_stream_capturing():
                 # the smoothness terms (3 small launches per scale, forward and backward) beside the photometric kernel instead of
                 # behind it on the main stream; the beam encoder's stream is idle between its forward and its backward
                 st = self._fork(0)
@@ -652,13 +664,8 @@ class Trainer:
         orders = [(f, 0) if f < 0 else (0, f) for f in fids]
         G = self._groups
         Bg = inputs["color_aug", 0, 0].shape[0] // G
-        if os.environ.get("FD_STACK_DIRECT", "1") == "0":
-            pairs = [torch.cat([inputs[key, i, 0] for i in o], 1) for o in orders]
-            if G == 1:
-                return torch.cat(pairs, 0)
-            return torch.cat([p[g * Bg:(g + 1) * Bg] for g in range(G) for p in pairs], 0)
         # written straight into the stacked tensor (two concatenations in a row moved every image twice: 0.15 ms at the head of the
-        # pose encoder's stream)
+        # pose encoder's stream, -0.5 % images/s)
         first = inputs[key, orders[0][0], 0]
         C = first.shape[1]
         out = torch.empty((G * len(orders) * Bg, 2 * C) + tuple(first.shape[2:]), device=first.device, dtype=first.dtype)
@@ -700,8 +707,8 @@ class Trainer:
                 pf, st, bf, st2 = precomputed["stacked"]
                 # The pose decoder (a dozen small launches forward, ~60 backward incl. autograd's slicing glue) stays on the pose
                 # encoder's stream: autograd replays a node on its forward stream, so the decoder's backward - created last, hence
-                # replayed first - no longer sits on the main stream in front of the depth decoder's backward (FD_POSE_STREAM=0: main).
-                if (os.environ.get("FD_POSE_STREAM", "1") != "0" and self.parallel_streams and not getattr(self, "_pose_on_main", False)
+                # replayed first - no longer sits on the main stream in front of the depth decoder's backward (tuning.host.pose_stream).
+                if (tuning.host.pose_stream and self.parallel_streams and not self._pose_on_main
                         and not torch.cuda.is_current_stream_capturing()):
                     pose_stream = st
                     if bf is not None:
@@ -875,7 +882,7 @@ class Trainer:
     def _multiscale_loss_ok(self, fids):
         """The fused all-scales kernel covers the default loss configuration (two source frames, SSIM, per-frame minimum, one
         pose per frame shared by the scales, no materialised warps); every flag variant keeps the per-scale kernels."""
-        if os.environ.get("FD_PHOTO_MS", "1") == "0":
+        if not tuning.host.photo_ms:
             return False
         o = self.opt
         return (FD.photo_ms_supported(self.photo_options, len(fids), self.materialize_outputs) and not o.v1_multiscale

@@ -24,11 +24,47 @@
 extern "C" {
 #endif
 
-#define FD_ABI_VERSION 1
+/* 2: fd_tuning / fd_set_tuning added (the library no longer reads the process environment); fd_conv2d_fwd_stats and
+ *    fd_bn_train_fwd_parts added, the fd_conv2d_*_pair entry points removed, fd_bn_ws_floats grew by one shift value per
+ *    (group, channel) - a client that sized the BatchNorm workspace itself must re-query it. */
+#define FD_ABI_VERSION 2
 
 int fd_abi_version(void);
 const char* fd_supported_arch(void); /* "gfx950" */
 const char* fd_last_error(void);
+
+/* ------------------------------------------------------------------ tuning ----------------------
+ * Kernel-selection thresholds, process-wide.  The library NEVER reads the process environment: its behaviour - which kernel
+ * family a convolution is routed to, and therefore what fd_*_wt_floats / fd_*_ws_floats return - is a function of the arguments
+ * and of this struct alone.  The defaults are the measured best on MI355X and are in force from load on; the other values exist
+ * for A/B timing and for tests that pin a kernel family.  fd_set_tuning copies the struct (fields beyond `size` bytes keep their
+ * defaults); it must not race with calls in flight on other threads, and size queries made before the change do not apply after
+ * it (a caller that changes the tuning re-queries its workspaces; fd_tuning_generation() counts the changes). */
+typedef struct fd_tuning {
+    int size;                     /* sizeof(fd_tuning) as the caller compiled it */
+    int wino_fwd;                 /* 1   3x3 stride-1 forward / data gradient on the Winograd kernels (0: direct implicit GEMM) */
+    int wino_wgrad;               /* 1   their weight gradient on the transposed Winograd kernel */
+    int wino_fwd_2d_min;          /* 65536   F(2x2,3x3) forward / data gradient from Cin*Cout on (0: F(2,3) along x everywhere) */
+    int wino_wgrad_2d;            /* 1   weight gradient as transposed F(2x2,3x3) where the height is even and Cin % 32 == 0 */
+    int wino_target;              /* 384 workgroups a Winograd forward launch is split-K'd up to */
+    int wino_wgrad_target;        /* 384 ... a Winograd weight-gradient launch is pixel-sliced up to */
+    int conv_target;              /* 768 ... a direct forward / data-gradient launch */
+    int wgrad_target;             /* 768 ... a direct weight-gradient launch */
+    int conv_c1;                  /* 1   Cout == 1 layers (dispconv) as stencils (conv_c1.hip) */
+    int conv_n16_min_pixels;      /* 16384   16 / 32-channel 3x3 blocks on k_conv3x3_n16 from this plane size on (< 0: never) */
+    int reflect_ring;             /* 1   reflect-padded data gradients as interior + ring from 16384 pixels on (n > 1: from n pixels
+                                         on; 0: always through the padded-grid tensor + fold pass) */
+    int reflect_wino;             /* 1   the interior of such a gradient on the Winograd kernels (>= 64 input channels) */
+    int reflect_wino_min_pixels;  /* 1   ... on planes of at least this many pixels */
+    int reflect_wino_padded_max;  /* 4096   below this plane size: ONE Winograd convolution over the zero-bordered dY + fold (0: never) */
+    int force_cfg, force_splits;  /* -1, 1   force the direct kernel's tile configuration (0..2) and split-K (sweeps) */
+    int stem7;                    /* 1   7x7 stride-2 stems (Cin 2..6) on the dedicated patch kernels (conv_stem.hip) */
+    int log;                      /* 0   1: one stderr line per convolution call with the kernel family it was routed to */
+} fd_tuning;
+void fd_tuning_defaults(fd_tuning* t);
+int fd_set_tuning(const fd_tuning* t);
+void fd_get_tuning(fd_tuning* t);
+long fd_tuning_generation(void);
 
 /* ------------------------------------------------------------------ geometry (layers.py) ------- */
 

@@ -3,7 +3,7 @@ usage (GPU box): python scripts/conv_cfg_sweep.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from fusiondepth_amd import functional as FD
+from fusiondepth_amd import functional as FD, tuning
 
 SHAPES = [("layer1", 64, 64, 48, 160), ("layer2", 128, 128, 24, 80), ("layer3", 256, 256, 12, 40), ("layer4", 512, 512, 6, 20),
           ("dec4", 512, 256, 6, 20), ("dec3", 256, 128, 12, 40), ("dec2", 128, 64, 24, 80)]
@@ -26,7 +26,7 @@ for B in (12, 24):
         x = torch.randn(B, ci, h, w, device="cuda")
         wt = torch.randn(co, ci, 3, 3, device="cuda") * 0.05
         flops = 2.0 * B * h * w * co * ci * 9
-        os.environ.pop("FD_CONV_FORCE", None)
+        tuning.set_lib(force_cfg=-1, force_splits=1)
         with torch.no_grad():
             t0 = timeit(lambda: FD.conv2d(x, wt, None, 1, 1))
         res = []
@@ -34,11 +34,11 @@ for B in (12, 24):
             if (cfg == 0 and co <= 64) or (cfg == 2 and co > 64):
                 continue
             for sp in (1, 2, 3, 4, 6, 8, 12):
-                os.environ["FD_CONV_FORCE"] = "%d,%d" % (cfg, sp)
+                tuning.set_lib(force_cfg=cfg, force_splits=sp)
                 with torch.no_grad():
                     t = timeit(lambda: FD.conv2d(x, wt, None, 1, 1))
                 res.append((t, cfg, sp))
-        os.environ.pop("FD_CONV_FORCE", None)
+        tuning.set_lib(force_cfg=-1, force_splits=1)
         res.sort()
         print("B=%2d %-7s model %6.1f us %5.1f TF | best %s | top3 %s" % (
             B, name, t0, flops / t0 / 1e6, "cfg%d x%d %6.1f us %5.1f TF" % (res[0][1], res[0][2], res[0][0], flops / res[0][0] / 1e6),

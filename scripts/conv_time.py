@@ -3,14 +3,13 @@ and 24, cached weight layout: conv_time.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from fusiondepth_amd import functional as FD
+from fusiondepth_amd import functional as FD, tuning
 shapes = [(64, 48, 160), (128, 24, 80), (256, 12, 40), (512, 6, 20)]
 for B in (12, 24):
     for c, h, w in shapes:
         ts = []
         for two_d in ("1", "0"):
-            os.environ["FD_WINO_FWD_2D"] = two_d
-            os.environ["FD_WINO_FWD_2D_MIN"] = "1"
+            tuning.set_lib(wino_fwd_2d_min=1 if two_d == "1" else 0)
             x = torch.randn(B, c, h, w, device="cuda")
             wt = torch.randn(c, c, 3, 3, device="cuda") * 0.05
             wt._fd_cache_id = -2 - c - 10000 * int(two_d)

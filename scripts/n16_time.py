@@ -3,12 +3,12 @@ kernel: n16_time.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from fusiondepth_amd import functional as FD
+from fusiondepth_amd import functional as FD, tuning
 for cin, cout, h, w in [(16, 16, 192, 640), (32, 16, 96, 320)]:
     for what in ("fwd", "fwd+dgrad"):
         ts = []
         for n16 in ("1", "0"):
-            os.environ["FD_CONV_N16"] = n16
+            tuning.set_lib(conv_n16_min_pixels=16384 if n16 == "1" else -1)
             x = torch.randn(12, cin, h, w, device="cuda", requires_grad=True)
             wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
             wt._fd_cache_id = -500 - cin - 100 * int(n16)

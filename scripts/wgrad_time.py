@@ -3,13 +3,13 @@
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from fusiondepth_amd import _lib
+from fusiondepth_amd import _lib, tuning
 shapes = [(64, 64, 48, 160), (128, 128, 24, 80), (256, 256, 12, 40), (512, 512, 6, 20)]
 for B in (12, 24):
     for ci, co, h, w in shapes:
         row = []
         for two_d in ("1", "0"):
-            os.environ["FD_WINO_WGRAD_2D"] = two_d
+            tuning.set_lib(wino_wgrad_2d=int(two_d))
             x = torch.randn(B, ci, h, w, device="cuda"); gy = torch.randn(B, co, h, w, device="cuda"); gw = torch.zeros(co, ci, 3, 3, device="cuda")
             d = _lib.ConvDesc(B, ci, h, w, co, 3, 3, 1, 1, 0, 0, 0)
             ws = torch.empty(max(_lib.query("fd_conv2d_bwd_weight_ws_floats", ctypes.byref(d)), 1), device="cuda")

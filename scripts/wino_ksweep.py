@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from fusiondepth_amd import _lib
+from fusiondepth_amd import _lib, tuning
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 CO = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -26,7 +26,7 @@ def timeit(fn, n=40):
     return s.elapsed_time(e) / n * 1e3
 
 
-os.environ["FD_WINO_TARGET"] = "1"          # no split-K: the tile grid stays 720 x (Cout / 64)
+tuning.set_lib(wino_target=1)              # no split-K: the tile grid stays 720 x (Cout / 64)
 rows = []
 for C in (16, 32, 64, 128, 256, 512):
     x = torch.randn(B, C, H, W, device="cuda")

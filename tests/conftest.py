@@ -114,3 +114,35 @@ def assert_mostly_close(actual, expected, rtol, atol, what="", max_bad_frac=1e-2
         raise AssertionError("%s: %.4f%% of elements out of tolerance (allowed %.4f%%), aggregate rel-L1 %.3g "
                              "(allowed %.3g); worst at %s: got %.9g want %.9g"
                              % (what, 100 * frac, 100 * max_bad_frac, agg, agg_rtol, i, a[i], e[i]))
+
+
+class _FdTune:
+    """Handed to tests by the ``fdtune`` fixture: library thresholds (fd_set_tuning) and host-side issue switches for the duration of
+    one test.  Replaces the FD_* environment variables of rounds 1-3 - the library no longer reads the environment."""
+
+    def __init__(self):
+        from fusiondepth_amd import tuning
+        self._tuning = tuning
+        self._lib0 = tuning.get_lib()
+        self._host0 = {k: getattr(tuning.host, k) for k in dir(tuning.host) if not k.startswith("_")}
+
+    def lib(self, **fields):
+        self._tuning.set_lib(**fields)
+
+    def host(self, **fields):
+        for k, v in fields.items():
+            if k not in self._host0:
+                raise KeyError("tuning.host has no switch %r" % k)
+            setattr(self._tuning.host, k, v)
+
+    def restore(self):
+        self._tuning.set_lib(**self._lib0)
+        for k, v in self._host0.items():
+            setattr(self._tuning.host, k, v)
+
+
+@pytest.fixture
+def fdtune():
+    t = _FdTune()
+    yield t
+    t.restore()

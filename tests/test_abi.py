@@ -55,3 +55,41 @@ def test_ops_fail_loudly_without_gpu_tensors(lib_path):
         FD.ssim(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
     with pytest.raises(RuntimeError, match="GPU"):
         FD.scatter_2channel(torch.zeros(1, 1, 192, 640))
+
+
+def test_library_behaviour_does_not_depend_on_the_environment(lib_path, monkeypatch):
+    """kernel routing - and with it every fd_*_wt_floats / fd_*_ws_floats answer - is a function of the
+    arguments and of fd_tuning alone.  The library does not import getenv at all; flipping the variables rounds 1-3 read changes
+    nothing, fd_set_tuning does, and restoring the struct restores the answers."""
+    import subprocess
+    from fusiondepth_amd import _lib, tuning
+    und = subprocess.run(["nm", "-D", "--undefined-only", lib_path], stdout=subprocess.PIPE, text=True).stdout
+    assert "getenv" not in und
+    srcs = os.path.join(ROOT, "fusiondepth_amd", "csrc")
+    for f in os.listdir(srcs):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(srcs, f)).read(), f
+    d = _lib.ConvDesc(12, 256, 12, 40, 256, 3, 3, 1, 1, 0, 0, 0)
+    names = ("fd_conv2d_fwd_ws_floats", "fd_conv2d_fwd_wt_floats", "fd_conv2d_bwd_data_ws_floats", "fd_conv2d_bwd_data_wt_floats",
+             "fd_conv2d_bwd_weight_ws_floats")
+    sizes = lambda: tuple(_lib.query(n, ctypes.byref(d)) for n in names)
+    base = sizes()
+    for var in ("FD_WINO", "FD_WINO_FWD_2D", "FD_WINO_WGRAD_2D", "FD_WINO_FWD", "FD_WINO_WGRAD"):
+        monkeypatch.setenv(var, "0")
+    monkeypatch.setenv("FD_WINO_TARGET", "4096")
+    assert sizes() == base
+    gen = tuning.generation()
+    with tuning.override(wino_fwd_2d_min=0, wino_wgrad_2d=0):
+        assert tuning.generation() > gen
+        changed = sizes()
+        assert changed != base
+    assert sizes() == base
+    t = tuning.lib_defaults()
+    assert t.size == ctypes.sizeof(tuning.Tuning) and tuning.get_lib() == {n: getattr(t, n) for n in tuning.LIB_FIELDS}
+    with pytest.raises(KeyError):
+        tuning.set_lib(no_such_field=1)
+    bad = tuning.Tuning()
+    _lib.load().fd_get_tuning(ctypes.byref(bad))
+    bad.wino_target = 0
+    assert _lib.load().fd_set_tuning(ctypes.byref(bad)) != 0 and "targets" in _lib.last_error()
+    assert sizes() == base

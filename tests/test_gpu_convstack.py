@@ -86,7 +86,7 @@ CONV_CASES = [
     (2, 5, 4, 6, "zero", "none"),                # Conv3x3(use_refl=False), odd channel count
     (12, 16, 192, 640, "reflect", "sigmoid"),    # full size
 ])
-def test_conv3x3_single_output_channel_stencils(FD, N, Cin, H, W, mode, act, monkeypatch):
+def test_conv3x3_single_output_channel_stencils(FD, N, Cin, H, W, mode, act, fdtune):
     """conv_c1.hip: Cout = 1 (dispconv) forward and data gradient as stencils - the data gradient with the adjoint of the reflection
     padding folded into its tap sums - against torch on the CPU, and against the GEMM kernels these layers used before."""
     import ctypes
@@ -103,12 +103,12 @@ def test_conv3x3_single_output_channel_stencils(FD, N, Cin, H, W, mode, act, mon
     want = torch.autograd.grad((yo * cot).sum(), [xo, wo, bo])
     res = {}
     for c1 in ("1", "0"):
-        monkeypatch.setenv("FD_CONV_C1", c1)
+        fdtune.lib(conv_c1=int(c1))
         xg, wg, bg = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
         yg = FD.conv2d(xg, wg, bg, 1, 1, mode, act)
         got = torch.autograd.grad((yg * dev(cot)).sum(), [xg, wg, bg])
-        relclose(cpu(yg), cpu(yo), "conv fwd (FD_CONV_C1=%s)" % c1)
-        relclose(cpu(got[0]), cpu(want[0]), "conv dgrad (FD_CONV_C1=%s)" % c1)
+        relclose(cpu(yg), cpu(yo), "conv fwd (conv_c1=%s)" % c1)
+        relclose(cpu(got[0]), cpu(want[0]), "conv dgrad (conv_c1=%s)" % c1)
         relclose(cpu(got[1]), cpu(want[1]), "conv wgrad")
         relclose(cpu(got[2]), cpu(want[2]), "conv bias grad")
         res[c1] = (yg.detach(), got[0])
@@ -126,15 +126,13 @@ def test_conv3x3_single_output_channel_stencils(FD, N, Cin, H, W, mode, act, mon
     (3, 16, 16, 2, 2, "reflect", "sigmoid"),     # both mirrors inside one tile
     (12, 16, 16, 192, 640, "reflect", "elu"),    # the real thing: 2 880 workgroups
 ])
-def test_conv3x3_n16_kernel(FD, N, Cin, Cout, H, W, mode, act, n16, monkeypatch):
+def test_conv3x3_n16_kernel(FD, N, Cin, Cout, H, W, mode, act, n16, fdtune):
     """conv_n16.hip (16 / 32-channel 3x3 blocks on the 16x16x4 MFMA, weights in registers, the patch staged once): forward, data
     gradient (kernel on dY with flipped weights + the ring of the reflect adjoint) and weight gradient against torch on the CPU;
     n16 = 0 runs the same cases on the implicit-GEMM kernel these layers used before."""
     import ctypes
     from fusiondepth_amd import _lib
-    monkeypatch.setenv("FD_CONV_N16", str(n16))
-    monkeypatch.setenv("FD_CONV_N16_MIN", "1")
-    monkeypatch.setenv("FD_REFLECT_RING", "2")             # the interior + ring data gradient on every plane size
+    fdtune.lib(conv_n16_min_pixels=1 if n16 else -1, reflect_ring=2)      # reflect_ring=2: the interior + ring data gradient on every plane size
     d = _lib.ConvDesc(N, Cin, H, W, Cout, 3, 3, 1, 1, 1 if mode == "reflect" else 0, {"none": 0, "relu": 1, "elu": 2, "sigmoid": 3}[act], 0)
     assert (_lib.query("fd_conv2d_fwd_wt_floats", ctypes.byref(d)) == 0) == bool(n16)      # the n16 kernel reads the weights as they are
     rng = np.random.RandomState(N * 100 + Cin + H)
@@ -662,7 +660,7 @@ def test_batchnorm_statistics_of_a_near_constant_map(FD):
                                          (2, 96, 32, 96, 320), (1, 16, 16, 192, 640), (1, 288, 32, 96, 320),      # >= 16 384 pixels: the ring path by default
                                          (2, 512, 256, 12, 40), (2, 128, 64, 48, 160), (3, 64, 32, 5, 6)])       # upconv(4,1), upconv(2,1); odd height
 @pytest.mark.parametrize("wino", [1, 0, "padded"])
-def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W, wino, monkeypatch):
+def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W, wino, fdtune):
     """conv3x3(ReflectionPad2d(1)(x)) - every DepthDecoder convolution (networks/depth_decoder.py, layers.py Conv3x3): its data
     gradient = the zero-padded data gradient written straight to gx + the padded grid's one-pixel ring (four strips, one grouped
     launch) folded back onto rows 1 / H-2 and columns 1 / W-2 (k_reflect_ring_fold), including images so small that the two target
@@ -672,9 +670,9 @@ def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W,
     interior on the implicit-GEMM kernel everywhere; "padded": the default routing - planes below 16 384 pixels with >= 64 input
     channels take the whole padded-grid gradient as one Winograd convolution over dY in a border of zeros + the fold pass.
     Against torch's float64 autograd of F.pad(mode="reflect") + conv2d."""
-    monkeypatch.setenv("FD_REFLECT_WINO", "0" if wino == 0 else "1")
-    ring = lambda: monkeypatch.delenv("FD_REFLECT_RING", raising=False) if wino == "padded" else monkeypatch.setenv("FD_REFLECT_RING", "2")
-    ring()                                            # "2": planes from 2 pixels on (default: from 16 384 - smaller ones keep a fold pass)
+    fdtune.lib(reflect_wino=0 if wino == 0 else 1)
+    ring = lambda: fdtune.lib(reflect_ring=1 if wino == "padded" else 2)
+    ring()                                            # 2: planes from 2 pixels on (default 1: from 16 384 - smaller ones keep a fold pass)
     g = torch.Generator().manual_seed(N * 131 + H)
     x = torch.randn(N, Ci, H, W, generator=g)
     w = torch.randn(Co, Ci, 3, 3, generator=g) * (2.0 / (9 * Ci)) ** 0.5
@@ -687,7 +685,7 @@ def test_reflect_padded_data_gradient_by_interior_plus_ring(FD, N, Ci, Co, H, W,
     relclose(cpu(y), y64.detach().numpy(), "forward", arel=2e-6)
     gx = torch.autograd.grad((y * dev(cot)).sum(), xg)[0]
     relclose(cpu(gx), gx64, "data gradient", arel=3e-6)
-    monkeypatch.setenv("FD_REFLECT_RING", "0")        # the fold path gives the same gradient up to the order of the ring's additions
+    fdtune.lib(reflect_ring=0)                        # the fold path gives the same gradient up to the order of the ring's additions
     gx_fold = torch.autograd.grad((FD.conv2d(xg, dev(w), None, 1, 1, "reflect") * dev(cot)).sum(), xg)[0]
     relclose(cpu(gx), cpu(gx_fold), "ring path vs fold path", arel=1e-6)
     ring()
@@ -737,12 +735,11 @@ def _wino_conv(x, w, bias, reflect, act=0):
     (2, 64, 64, 2, 4, False, 0),
     (3, 512, 512, 6, 20, False, 1),      # layer4: the 2-D kernel also splits the input channels
 ])
-def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d, monkeypatch):
+def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d, fdtune):
     """conv_wino.hip through its own entry point against torch float64 conv2d: error within a few fp32 ulps of the output scale,
     i.e. no worse than the direct implicit GEMM (transform coefficients are +-1 and 1/2).  two_d = 1: F(2x2, 3x3) (k_conv_wino2d +
     k_wino2d_finish) forced onto every shape with an even height; 0: F(2, 3) per kernel row everywhere."""
-    monkeypatch.setenv("FD_WINO_FWD_2D", str(two_d))
-    monkeypatch.setenv("FD_WINO_FWD_2D_MIN", "1")
+    fdtune.lib(wino_fwd_2d_min=1 if two_d else 0)
     torch.manual_seed(N * 1000 + Ci)
     x = torch.randn(N, Ci, H, W, device="cuda")
     w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
@@ -770,13 +767,13 @@ def test_winograd_refuses_ineligible_shapes():
 
 
 @pytest.mark.parametrize("Ci,Co,two_d_min", [(64, 128, None), (64, 128, 1), (256, 256, None)])
-def test_winograd_routing_forward_and_data_gradient_match_torch(Ci, Co, two_d_min, monkeypatch):
+def test_winograd_routing_forward_and_data_gradient_match_torch(Ci, Co, two_d_min, fdtune):
     """FD.conv2d routes eligible 3x3 convs to the Winograd kernel (forward and zero-pad data gradient); values and both
     gradients against torch autograd in float64, and the batched weight re-layout (modes 3 / 4; 5 / 6 for the F(2x2, 3x3) layouts:
     forced onto the small shape, by default on the 256-channel one) against the per-call transform."""
     import fusiondepth_amd.functional as FD
     if two_d_min is not None:
-        monkeypatch.setenv("FD_WINO_FWD_2D_MIN", str(two_d_min))
+        fdtune.lib(wino_fwd_2d_min=two_d_min)
     torch.manual_seed(5)
     x = torch.randn(2, Ci, 12, 40, device="cuda", requires_grad=True)
     w = torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05)
@@ -815,13 +812,13 @@ def test_winograd_routing_forward_and_data_gradient_match_torch(Ci, Co, two_d_mi
     (5, 64, 64, 48, 160, "zero"),       # layer1 plane: 128 slices, chunks that cross image borders (48 * 80 / 2 tiles per image)
     (3, 512, 512, 6, 20, "zero"),       # layer4: one slice, 8 output channels per finishing workgroup
 ])
-def test_winograd_weight_gradient_vs_float64_reference(N, Ci, Co, H, W, mode, two_d, monkeypatch):
+def test_winograd_weight_gradient_vs_float64_reference(N, Ci, Co, H, W, mode, two_d, fdtune):
     """k_wgrad_wino through FD.conv2d's backward, against torch float64 autograd: the transposed F(2x2, 3x3) algorithm (16
     products per 2x2 tile of dY; two_d = 1, the default wherever the height is even) and the transposed F(2, 3) algorithm per
-    kernel row (4 products per pixel pair and row; FD_WINO_WGRAD_2D=0, and odd heights); also accumulation into an existing
+    kernel row (4 products per pixel pair and row; fd_tuning.wino_wgrad_2d = 0, and odd heights); also accumulation into an existing
     gradient (the trainer's direct-gradient mode)."""
     import fusiondepth_amd.functional as FD
-    monkeypatch.setenv("FD_WINO_WGRAD_2D", str(two_d))
+    fdtune.lib(wino_wgrad_2d=two_d)
     torch.manual_seed(Ci + Co)
     x = torch.randn(N, Ci, H, W, device="cuda")
     w = torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05)

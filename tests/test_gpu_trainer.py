@@ -498,7 +498,7 @@ def test_gradients_are_run_to_run_identical_under_gpu_contention(interleave):
             assert torch.equal(g, ref), "repetition %d: %d gradient entries differ" % (rep, int((g != ref).sum()))
 
 
-def test_pose_decoder_and_smoothness_on_side_streams_are_bit_identical(monkeypatch):
+def test_pose_decoder_and_smoothness_on_side_streams_are_bit_identical(fdtune):
     """Trainer.predict_poses runs the pose decoder (forward and, through autograd, backward) on the pose encoder's stream, and
     Trainer._process_batch the smoothness terms on the beam encoder's stream, instead of on the main stream.  Same kernels, same
     accumulation targets: the flat gradient buffer after a backward pass equals the all-on-the-main-stream result bit for bit, also
@@ -512,8 +512,7 @@ def test_pose_decoder_and_smoothness_on_side_streams_are_bit_identical(monkeypat
     junk = [torch.randn(s, s, device="cuda") for s in (512, 2048)]
     grads = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("FD_POSE_STREAM", mode)
-        monkeypatch.setenv("FD_SMOOTH_STREAM", mode)
+        fdtune.host(pose_stream=mode == "1", smooth_stream=mode == "1")
         torch.manual_seed(4321)                                  # the same initial weights for both trainers
         tr = Trainer(_opts(batch_size=B), verbose=False)
         for rep in range(3):
@@ -540,11 +539,11 @@ def test_pose_decoder_and_smoothness_on_side_streams_are_bit_identical(monkeypat
     assert torch.equal(grads["0"][0], grads["1"][0]), "%d gradient entries differ" % int((grads["0"][0] != grads["1"][0]).sum())
 
 
-def test_late_weight_relayout_is_ordered_before_its_readers(monkeypatch):
+def test_late_weight_relayout_is_ordered_before_its_readers(fdtune):
     """functional.refresh_weight_layouts sends the big half of the post-Adam re-layout (data-gradient layouts, forward layouts from
     1 MB up) to a side stream and lets every stream that is about to use such a layout wait for it first.  Five optimiser steps with
     that side stream held back by ~50 ms of queued matrix products must leave the parameters bit-identical to the one-launch
-    refresh (FD_LATE_RELAYOUT=0): a reader that did not wait would have convolved with the previous step's weights."""
+    refresh (tuning.host.late_relayout = False): a reader that did not wait would have convolved with the previous step's weights."""
     from fusiondepth_amd import functional as FD
     from fusiondepth_amd.trainer import Trainer
     B, H, W = 2, 64, 96
@@ -557,7 +556,7 @@ def test_late_weight_relayout_is_ordered_before_its_readers(monkeypatch):
     junk = torch.randn(4096, 4096, device="cuda")
     params, used = {}, 0
     for mode in ("0", "1"):
-        monkeypatch.setenv("FD_LATE_RELAYOUT", mode)
+        fdtune.host(late_relayout=mode == "1")
         torch.manual_seed(4321)                                  # the same initial weights for both trainers
         tr = Trainer(_opts(batch_size=B), verbose=False)
         assert tr.accumulate_step == 1
@@ -577,7 +576,7 @@ def test_late_weight_relayout_is_ordered_before_its_readers(monkeypatch):
     assert torch.equal(params["0"], params["1"]), "%d parameters differ" % int((params["0"] != params["1"]).sum())
 
 
-def test_decoder_weight_gradients_on_the_side_stream_are_bit_identical(monkeypatch):
+def test_decoder_weight_gradients_on_the_side_stream_are_bit_identical(fdtune):
     """functional.enable_side_wgrad (default for the depth decoder): its weight gradients, slab reductions and bias sums run on a side
     stream beside the data gradients of the following layers.  Same kernels, same accumulation targets: the gradient buffer after a
     backward pass must equal the all-on-one-stream result bit for bit, also under background GPU load (a tensor freed or reused on
@@ -592,7 +591,7 @@ def test_decoder_weight_gradients_on_the_side_stream_are_bit_identical(monkeypat
     bg = torch.cuda.Stream()
     junk = [torch.randn(s, s, device="cuda") for s in (512, 2048)]
     for mode in ("none", "depth"):
-        monkeypatch.setenv("FD_SIDE_WGRAD", mode)
+        fdtune.host(side_wgrad=() if mode == "none" else (mode,))
         torch.manual_seed(4321)                                  # the same initial weights for both trainers
         tr = Trainer(_opts(batch_size=B), verbose=False)
         marked = [p for p in tr.models["depth"].parameters() if getattr(p, "_fd_side_wgrad", False)]
