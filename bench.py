@@ -62,7 +62,7 @@ def parse():
                     "synchronize); value / ms_per_step are the MEDIAN window's, min / max are reported beside them")
     ap.add_argument("--no_other_configs", action="store_true", help="skip the short runs of the other BASELINE configurations "
                     "(ResNet-50 batch 8, 1024x320 batch 8, Refiner, Completor) that the 1-GPU line carries as `other_configs`")
-    ap.add_argument("--other_steps", type=int, default=5, help="timed steps of each `other_configs` entry (3 untimed steps before them)")
+    ap.add_argument("--other_steps", type=int, default=5, help="timed steps of each `other_configs` entry (5 untimed steps before them)")
     ap.add_argument("--probe_only", action="store_true", help="run only the roofline probes (no training steps) and print their "
                     "JSON: the command profiled for profiles/*probe_kernel_stats*.md, so that rocprofv3's per-kernel average "
                     "covers the probe launches alone")
@@ -229,12 +229,14 @@ def cpu_baseline(args, budget_s=60.0, warm=3, timed_steps=10, threads=None):
         sweep = {}
     timed = run(threads, warm, timed_steps, budget_s)
     step = float(np.median(timed))
-    # ... and on ONE thread (the scalar-port figure of the contract): one step, no extra warm-up - the trainer, its buffers and
-    # torch's kernels are warm from the run above; a single-thread step of this configuration takes ~10 s
-    one = run(1, 0, 1, 1.0)
+    # ... and on ONE thread (the scalar-port figure of the contract): the trainer, its buffers and torch's kernels are warm from the
+    # run above; a single-thread step of this configuration takes ~2.6 s on the GPU boxes' hosts
+    one = run(1, 1, 3, 15.0)
     torch.set_num_threads(threads)
-    one_thread = {"value": B / float(one[0]), "unit": "images/s", "cores": 1, "kind": "port",
-                  "sample": "1 optimiser step of the same oracle trainer on 1 thread, after the %d-thread run above (%.2f s)" % (threads, one[0])}
+    one_s = float(np.median(one))
+    one_thread = {"value": B / one_s, "unit": "images/s", "cores": 1, "kind": "port",
+                  "sample": "%d timed optimiser steps (1 warm-up) of the same oracle trainer on 1 thread, after the %d-thread run above; median "
+                            "%.2f s/step" % (len(one), threads, one_s)}
     return one_thread, {"value": B / step, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": "%d timed optimiser steps after %d warm-up steps of the oracle trainer (ResNet-%d, %dx%d, batch %d, fp32, "
                       "torch CPU) on %d threads of a %d-thread host - the fastest of the sweep %s (s/step); median %.2f s/step, "
@@ -242,7 +244,7 @@ def cpu_baseline(args, budget_s=60.0, warm=3, timed_steps=10, threads=None):
                                               {k: round(v, 2) for k, v in sweep.items()}, step, min(timed), max(timed))}
 
 
-def _short_run(step, n, warm=3):
+def _short_run(step, n, warm=5):
     """(seconds per step over n steps after `warm` untimed ones, last return value), synchronize on both sides."""
     for _ in range(warm):
         step()
@@ -294,7 +296,7 @@ def other_configs(args):
             return tr.train_step(pool[k[0] % len(pool)])
         dt, losses = _short_run(step, n)
         loss = float(losses["loss"].detach())
-        r = {"value": opt.batch_size / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "steps": n, "warmup": 3,
+        r = {"value": opt.batch_size / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "steps": n, "warmup": 5,
              "final_loss": loss if loss == loss else None,
              "final_loss_photometric": float(sum(losses["loss/%d" % s_].detach() for s_ in range(4)) / 4.0),
              "params_finite": bool(torch.isfinite(tr.flat.flat_param).all()),
@@ -321,7 +323,7 @@ def other_configs(args):
         inp["inf_gdc"] = torch.empty(B, 1, 192, 640, device="cuda").uniform_(0.05, 1.5, generator=gen)
         dt, losses = _short_run(lambda: rf.train_step(inp), n)
         loss = float(losses["loss"])
-        return {"value": B / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "steps": n, "warmup": 3, "final_loss": loss if loss == loss else None,
+        return {"value": B / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "steps": n, "warmup": 5, "final_loss": loss if loss == loss else None,
                 "step_mfma_frac": None,
                 "workload": "Refiner.train_step (refiner.py:272-278), 640x192, --batch_size 12 = one optimiser step per batch of %d, stage-1 "
                             "networks (ResNet-18) frozen, refine2d decoder trained" % B}
@@ -337,7 +339,7 @@ def other_configs(args):
         dt, losses = _short_run(lambda: cp.train_step(inp), n)
         loss = float(losses["loss"])
         imgs = cp.batch_size * cp.accumulate_step
-        return {"value": imgs / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "steps": n, "warmup": 3, "final_loss": loss if loss == loss else None,
+        return {"value": imgs / dt, "unit": "images/s", "ms_per_step": 1e3 * dt, "steps": n, "warmup": 5, "final_loss": loss if loss == loss else None,
                 "step_mfma_frac": None,
                 "workload": "Completor.train_step (completor.py), %dx%d, --batch_size 12 = %d micro-batch(es) of %d, --completion_num_layers 18 "
                             "(the configuration of rounds 2-3's scripts/bench_config5.py)" % (W, H, cp.accumulate_step, cp.batch_size)}
