@@ -866,6 +866,11 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
         conv_log("fwd", "n16", d);
         return n16_launch(d, d->Cout, d->Cin, x, w, bias, y, 0, d->pad_mode, d->act, st);
     }
+    if (!bias && stem7_fwd_ok(d)) {
+        FD_REQUIRE(!stat_part, "fd_conv2d_fwd_stats: no statistics epilogue for this shape");
+        conv_log("fwd", "stem7", d);
+        return stem7_fwd_launch(d, x, w, bias, y, st);
+    }
     if (fast_fwd_ok(d)) {
         FD_REQUIRE(wt, "fd_conv2d_fwd: weight-layout buffer required (fd_conv2d_fwd_wt_floats)");
         if (wino_use_fwd(d)) {

@@ -76,6 +76,9 @@ int n16_launch(const fd_conv_desc* d, int M, int C, const float* x, const float*
 bool c1_shape_ok(const fd_conv_desc* d);
 int c1_fwd_launch(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
 int c1_dgrad_launch(const fd_conv_desc* d, const float* gy, const float* w, float* gx, hipStream_t st);
+// conv_stem.hip: the 7x7 stride-2 encoder stems (2..6 input channels) on a patch-staged MFMA kernel
+bool stem7_fwd_ok(const fd_conv_desc* d);
+int stem7_fwd_launch(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
 bool wino_wgrad_ok(const fd_conv_desc* d);
 long wino_wgrad_ws_floats(const fd_conv_desc* d);
 int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st);

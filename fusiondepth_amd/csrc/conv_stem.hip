@@ -1,0 +1,169 @@
+// 7x7 stride-2 pad-3 stem convolution of the ResNet encoders, forward (networks/resnet_encoder.py:95 `self.encoder.conv1` with
+// 2 / 3 / 4 / 6 input channels: LiDAR 2-channel map, RGB, and their frame pairs for the pose encoders; 64 output channels, no bias).
+//
+// Until round 3 this ran on the generic gather GEMM (k_gather_gemm<7, 7, ...>): every one of the 49 C taps of every output pixel
+// was an address computation + a global load in the K loop, 64 - 68 TFLOP/s (0.41 - 0.43 of the fp32 MFMA peak) for 3 % of the
+// step's flops and 2.9 % of its kernel time.  Here the operands of a whole output tile are staged ONCE:
+//   * a workgroup (8 waves) owns 8 output rows x 64 output columns of one image, all 64 output channels; wave w = output row w;
+//   * the (2 * 8 + 5) x (2 * 64 + 5) x C input patch goes to LDS once, split into its even and odd columns, so that tap kx of
+//     output column px is element px + (kx >> 1) of plane (kx & 1): unit stride across the lanes, no bank conflicts despite the
+//     stride-2 convolution; padding is resolved by the loader (zeros), the tap loop has no bounds logic at all;
+//   * all 49 C x 64 weights go to LDS once ([k][m], row stride 65: the coalesced read of the OIHW array scatters into 16 banks);
+//   * GEMM-K pairs two input CHANNELS (k-step = (channel pair, ky, kx), MFMA k index = channel parity), so the two half-waves of
+//     an MFMA operand differ by one constant LDS offset and every operand read is `base + compile-time immediate`:
+//     v_mfma_f32_32x32x2_f32, 64 channels x 64 pixels per wave = 2 x 2 tiles, 4 LDS reads per 4 MFMAs, nothing else in the loop.
+//     An odd channel count (RGB) is padded to the next pair with zero weights (+33 % MFMA work on the smallest of the four stems).
+// Algorithmic work 2 * 64 * 49 * C flop per output pixel; LDS: 49 * 2 CP * 65 * 4 (weights) + 2 CP * 21 * 2 * 68 * 4 (patch)
+// = 76 + 69 KB for C = 6: one workgroup of 8 waves per CU.
+#include "../../include/fdhip.h"
+#include "fd_common.h"
+#include "conv_fast.h"
+
+namespace {
+
+constexpr int ST_TR = 8, ST_TC = 64, ST_NT = 512;
+constexpr int ST_PR = 2 * ST_TR + 5;            // patch rows
+constexpr int ST_PW = 2 * ST_TC + 5;            // patch columns (133)
+constexpr int ST_PC2 = 68;                      // row stride of a parity plane (67 even / 66 odd columns)
+constexpr int ST_LDW = 65;                      // weight row stride
+
+struct StemArgs {
+    const float* X; const float* Wt; float* Y;
+    int Nb, C, H, W, Ho, Wo;
+    int tiles_x, tiles_y;
+};
+
+template <int CP>
+__global__ void __launch_bounds__(ST_NT) k_conv7s2_stem(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;                                           // [CP * 49][2][ST_LDW]
+    float* patch = smem + CP * 49 * 2 * ST_LDW;                 // [2 CP][ST_PR][2][ST_PC2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int blk = blockIdx.x;
+    const int bx = blk % a.tiles_x; blk /= a.tiles_x;
+    const int by = blk % a.tiles_y;
+    const int n = blk / a.tiles_y;
+    const int oy0 = by * ST_TR, ox0 = bx * ST_TC;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+    const int C = a.C;
+
+    // ---- weights: flat OIHW read (coalesced), scattered to [k = (cp, t)][parity][m]
+    {
+        const int total = 64 * C * 49;
+        for (int f = tid; f < total; f += ST_NT) {
+            const int m = f / (C * 49);
+            const int r = f - m * (C * 49);
+            const int c = r / 49, t = r - c * 49;
+            Wl[(((c >> 1) * 49 + t) * 2 + (c & 1)) * ST_LDW + m] = a.Wt[f];
+        }
+        if (C & 1) {                                            // the padding channel of the last pair
+            for (int f = tid; f < 49 * 64; f += ST_NT) {
+                const int t = f >> 6, m = f & 63;
+                Wl[(((CP - 1) * 49 + t) * 2 + 1) * ST_LDW + m] = 0.f;
+            }
+        }
+    }
+    // ---- input patch, de-interleaved by column parity; out-of-image elements and the padding channel are zeros
+    {
+        const float* xn = a.X + (size_t)n * C * a.H * a.W;
+        const int per_c = ST_PR * ST_PW, total = 2 * CP * per_c;
+        for (int e = tid; e < total; e += ST_NT) {
+            const int c = e / per_c;
+            const int r2 = e - c * per_c;
+            const int r = r2 / ST_PW, j = r2 - r * ST_PW;
+            const int iy = iy0 + r, ix = ix0 + j;
+            float v = 0.f;
+            if (c < C && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = xn[((size_t)c * a.H + iy) * a.W + ix];
+            patch[((c * ST_PR + r) * 2 + (j & 1)) * ST_PC2 + (j >> 1)] = v;
+        }
+    }
+    __syncthreads();
+
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc[2][2];                                           // [channel block][column block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int arow = lane >> 5, l31 = lane & 31;
+    const float* pa = Wl + arow * ST_LDW + l31;                                              // + k-step * 2 LDW (+ 32: channels 32..63)
+    const float* pb = patch + ((arow * ST_PR + 2 * wave) * 2) * ST_PC2 + l31;               // + tap offset (+ 32: columns 32..63)
+#pragma unroll 1
+    for (int cp = 0; cp < CP; ++cp) {
+        const float* qa = pa + cp * 49 * 2 * ST_LDW;
+        const float* qb = pb + cp * 2 * ST_PR * 2 * ST_PC2;
+        float a0 = qa[0], a1 = qa[32], b0 = qb[0], b1 = qb[32];
+#pragma unroll
+        for (int t = 0; t < 49; ++t) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (t + 1 < 49) {
+                const int t1 = t + 1, ky = t1 / 7, kx = t1 - 7 * ky;
+                const int ob = (ky * 2 + (kx & 1)) * ST_PC2 + (kx >> 1);
+                na0 = qa[t1 * 2 * ST_LDW]; na1 = qa[t1 * 2 * ST_LDW + 32];
+                nb0 = qb[ob]; nb1 = qb[ob + 32];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+    }
+
+    // ---- epilogue (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+    const int oy = oy0 + wave;
+    if (oy >= a.Ho) return;
+    float* yn = a.Y + (size_t)n * 64 * a.Ho * a.Wo + (size_t)oy * a.Wo;
+    const size_t cs = (size_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ox = ox0 + 32 * j + l31;
+            if (ox < a.Wo) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                    yn[m * cs + ox] = acc[i][j][r];
+                }
+            }
+        }
+}
+
+template <int CP>
+int stem_go(const StemArgs& a, hipStream_t st) {
+    const size_t lds = sizeof(float) * ((size_t)CP * 49 * 2 * ST_LDW + (size_t)2 * CP * ST_PR * 2 * ST_PC2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv7s2_stem<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv7s2_stem<CP>, dim3((unsigned)(a.Nb * a.tiles_y * a.tiles_x)), dim3(ST_NT), lds, st, a);
+    FD_LAUNCH_CHECK("k_conv7s2_stem");
+    return 0;
+}
+
+}  // namespace
+
+// The encoder stems: 7x7, stride 2, padding 3 (zeros), 2..6 input channels, 64 output channels, no activation, plain input
+bool stem7_fwd_ok(const fd_conv_desc* d) {
+    return fd_tun().stem7 != 0 && d->KH == 7 && d->KW == 7 && d->stride == 2 && d->pad == 3 && d->pad_mode == 0 && d->Cout == 64 &&
+           d->Cin >= 1 && d->Cin <= 6 && d->act == 0 && !d->in_norm && d->H >= 8 && d->W >= 8 &&
+           (long)d->N * 64 * ((d->H - 1) / 2 + 1) * ((d->W - 1) / 2 + 1) < (1L << 31);
+}
+
+int stem7_fwd_launch(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
+    if (bias) { fd_set_error("stem7: bias not supported (the ResNet stems have none)"); return -1; }
+    StemArgs a;
+    a.X = x; a.Wt = w; a.Y = y;
+    a.Nb = d->N; a.C = d->Cin; a.H = d->H; a.W = d->W;
+    a.Ho = (d->H + 2 * 3 - 7) / 2 + 1; a.Wo = (d->W + 2 * 3 - 7) / 2 + 1;
+    a.tiles_x = fd_cdiv(a.Wo, ST_TC); a.tiles_y = fd_cdiv(a.Ho, ST_TR);
+    const int cp = (d->Cin + 1) / 2;
+    if (cp == 1) return stem_go<1>(a, st);
+    if (cp == 2) return stem_go<2>(a, st);
+    return stem_go<3>(a, st);
+}

@@ -571,6 +571,310 @@ __global__ void __launch_bounds__(256) k_wino2d_finish(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ F(2x2, 3x3) in ONE workgroup
+// k_conv_wino2p (round 4): the 16 components of F(2x2, 3x3) for the layers where slabs cost more than the matrix work they save
+// (ResNet layer1 / layer2, the decoder's wide blocks: few channels, many pixels - the 1-D kernel's territory until now).  A
+// workgroup keeps its 64 (channels) x 64 (2x2 tiles) output tile for the WHOLE computation and runs the four row components one
+// after the other through the same four horizontal accumulators: GEMM-K = (ri, input channel), a flat sequence of 4 C / 16 chunks
+// fed by one uninterrupted register-staged pipeline (the 2-D loader of k_conv_wino2d with ri advancing per chunk).  At the end of
+// a row component the horizontal output transform h = (M0 + M1 + M2, M1 - M2 - M3) is folded into two more accumulator pairs - the
+// vertical output transform y[2 ty] = S0 + S1 + S2, y[2 ty + 1] = S1 - S2 - S3 is linear - and the epilogue writes FINAL outputs
+// (bias, activation, residual, BatchNorm partial sums): no slabs, no finishing launch, 16 instead of 24 products per 2x2 tile,
+// K loops a third longer than the 1-D kernel's (4 C / 16 against 3 C / 16 chunks per tile of twice the pixels), and the four row
+// combinations of a tile's input rows are formed by ONE workgroup out of L1 / L2 instead of four.  128 accumulator registers per
+// lane: two waves per SIMD.
+template <bool STATS>
+__global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_wino2p(WinoArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W2 = g.W >> 1, HT = g.H >> 1;
+    const int plane2 = HT * W2;                                          // 2x2 tiles per image; Nb * plane2 < 2^29 (size guard)
+    const int Np = g.Nb * plane2;
+    const unsigned hw = (unsigned)(g.H * g.W);
+    int bx = blockIdx.x;
+    const int by = blockIdx.y;
+    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }     // vertical neighbours share input rows: same XCD
+    const int m0 = by * WBM, p0 = bx * WBN;
+    const int cpt = g.C / WBKC, nchunk = 4 * cpt;
+    auto ri_of = [&](int f) __attribute__((always_inline)) { return (f >= cpt ? 1 : 0) + (f >= 2 * cpt ? 1 : 0) + (f >= 3 * cpt ? 1 : 0); };
+
+    // ---- activation loader: this thread always fetches tile jn of the workgroup's 64, channel rows kr + 4 i
+    const int jn = lane, kr = wave;
+    const int pg = p0 + jn;
+    const bool pvalid = pg < Np;
+    int y0, j0;
+    unsigned nbase;
+    {
+        const int pp = pvalid ? pg : 0;
+        const int n = pp / plane2;
+        const int rem = pp - n * plane2;
+        y0 = rem / W2; j0 = rem - y0 * W2;
+        nbase = (unsigned)n * (unsigned)g.C * hw;
+    }
+    const bool refl = g.pad_mode == 1;
+    const bool left_edge = j0 == 0, right_edge = 2 * j0 + 2 >= g.W;
+    const bool halo_l = jn == 0 && !left_edge, halo_r = jn == WBN - 1 && !right_edge;
+    const int a4 = tid & 3, ar = tid >> 2;
+    int mrow = m0 + ar;
+    mrow = mrow < g.M ? mrow : g.M - 1;
+    const unsigned u_comp = 4u * (unsigned)g.M * 4u * (unsigned)g.C;     // bytes between components of U2[t][m][ri][c]
+    const __amdgpu_buffer_rsrc_t rsU = fd_make_rsrc(g.U), rsX = fd_make_rsrc(g.X);
+    float4 ru[4];
+    f32x2 rmid[4], rmid2[4];
+    float rh[4], rh2[4];
+    unsigned u_off = FD_OOB, mid_off = FD_OOB, h_off = FD_OOB, mid_off2 = FD_OOB, h_off2 = FD_OOB;
+    const unsigned c_step = 4u * 4u * hw;
+    int pc_f = 0;                                                        // flat chunk index being prepared
+    int pc_ri = 0, pc_c0 = 0;
+    unsigned prep_base = 0u, prep_base2 = 0u;
+    bool prep_ok = false, prep_ok2 = false;
+    const int H2m2 = 2 * g.H - 2;
+    auto prep_a = [&]() __attribute__((always_inline)) {
+        const bool live = pc_f < nchunk;
+        const int ri = pc_ri;
+        const int xr_a = ri == 0 ? 0 : (ri == 2 ? 2 : 1), xr_b = ri == 3 ? 3 : (ri == 2 ? 1 : 2);
+        u_off = live ? 4u * (((unsigned)mrow * 4u + (unsigned)ri) * (unsigned)g.C + (unsigned)pc_c0 + 4u * a4) : FD_OOB;
+        auto row = [&](int r, bool& ok, unsigned& base) __attribute__((always_inline)) {
+            const bool inb = (unsigned)r < (unsigned)g.H;
+            int rr_ = r < 0 ? -r : r;
+            rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
+            const int ruse = refl ? rr_ : r;
+            ok = pvalid & live & (refl | inb);
+            base = 4u * (nbase + (unsigned)(pc_c0 + kr) * hw + (unsigned)(ruse * g.W + 2 * j0));
+        };
+        row(2 * y0 - 1 + xr_a, prep_ok, prep_base);
+        row(2 * y0 - 1 + xr_b, prep_ok2, prep_base2);
+    };
+    auto prep_b = [&]() __attribute__((always_inline)) {
+        mid_off = prep_ok ? prep_base : FD_OOB;
+        h_off = (prep_ok & halo_l) ? prep_base - 4u : ((prep_ok & halo_r) ? prep_base + 8u : FD_OOB);
+        mid_off2 = prep_ok2 ? prep_base2 : FD_OOB;
+        h_off2 = (prep_ok2 & halo_l) ? prep_base2 - 4u : ((prep_ok2 & halo_r) ? prep_base2 + 8u : FD_OOB);
+        ++pc_f;
+        pc_c0 += WBKC;
+        const bool wrap = pc_c0 >= g.C;
+        pc_c0 = wrap ? 0 : pc_c0;
+        pc_ri += wrap ? 1 : 0;
+    };
+    auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off + (unsigned)t * u_comp); };
+    auto load_mid = [&](int i) __attribute__((always_inline)) {
+        rmid[i] = fd_ldg64(rsX, mid_off + (unsigned)i * c_step);
+        rmid2[i] = fd_ldg64(rsX, mid_off2 + (unsigned)i * c_step);
+    };
+    auto load_h = [&](int i) __attribute__((always_inline)) {
+        rh[i] = fd_ldg32(rsX, h_off + (unsigned)i * c_step);
+        rh2[i] = fd_ldg32(rsX, h_off2 + (unsigned)i * c_step);
+    };
+    auto store_u = [&](int buf, int t) __attribute__((always_inline)) {
+        float* q = smem + buf * W_BUF_FLOATS + t * WBKC * LDU + (4 * a4) * LDU + ar;
+        q[0] = ru[t].x; q[LDU] = ru[t].y; q[2 * LDU] = ru[t].z; q[3 * LDU] = ru[t].w;
+    };
+    const int v_row = 4 * WBKC * LDU + kr * LDR;
+    const int h_col = jn == 0 ? 3 : 2 * WBN + 4;
+    // `sgn`: sign of the second row in the row combination of the chunk whose data sit in the staging registers (+1 for ri = 1)
+    auto store_v = [&](int buf, int i, float sgn) __attribute__((always_inline)) {
+        float* q = smem + buf * W_BUF_FLOATS + v_row + 4 * i * LDR;
+        rmid[i].x = fmaf(sgn, rmid2[i].x, rmid[i].x); rmid[i].y = fmaf(sgn, rmid2[i].y, rmid[i].y);
+        rh[i] = fmaf(sgn, rh2[i], rh[i]);
+        *reinterpret_cast<f32x2*>(q + 4 + 2 * jn) = rmid[i];
+        if (jn == 0 || jn == WBN - 1) q[h_col] = rh[i];
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    int o12, o0, o3;
+    float ml, mr;
+    {
+        const int jp = 32 * wn + (lane & 31);
+        const int pp = p0 + jp < Np ? p0 + jp : 0;
+        const int rem = pp % plane2;
+        const int jj = rem % W2;
+        const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
+        o12 = 4 + 2 * jp;
+        o0 = (le && refl) ? o12 + 1 : o12 - 1;
+        o3 = (re && refl) ? o12 : o12 + 2;
+        ml = (le && !refl) ? 0.f : 1.f;
+        mr = (re && !refl) ? 0.f : 1.f;
+    }
+    f32x16 acc[4], ya[2], yb[2];                 // working components; output rows 2 ty (ya) / 2 ty + 1 (yb), columns 2 j / 2 j + 1
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][r] = 0.f;
+        ya[0][r] = ya[1][r] = yb[0][r] = yb[1][r] = 0.f;
+    }
+
+    constexpr int NK = WBKC / 2, LS = NK / 2;
+    const int arow = lane >> 5, acol = lane & 31;
+    {
+        prep_a(); prep_b();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) load_u(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load_mid(i); load_h(i); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store_u(0, t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_v(0, i, -1.f);             // chunk 0 is ri = 0: x_r0 - x_r2
+        prep_a(); prep_b();                                          // chunk 1: loaded now, written to LDS during chunk 0
+#pragma unroll
+        for (int t = 0; t < 4; ++t) load_u(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { load_mid(i); load_h(i); }
+        prep_a(); prep_b();                                          // offsets of chunk 2, re-loaded during chunk 0
+        __syncthreads();
+        int next_fold = cpt - 1;                                     // last chunk of the current row component
+        int ri_cur = 0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int cur = ch & 1;
+            const float sgn_regs = ri_of(ch + 1) == 1 ? 1.f : -1.f;  // the registers hold chunk ch + 1
+            const float* pa = smem + cur * W_BUF_FLOATS + arow * LDU + 32 * wm + acol;
+            const float* pr = smem + cur * W_BUF_FLOATS + 4 * WBKC * LDU + arow * LDR;
+            float av[2][4], bv[2][4];
+            auto read_a = [&](int nb, int k2, int t) __attribute__((always_inline)) { av[nb][t] = pa[t * WBKC * LDU + k2 * LDU]; };
+            f32x2 d12;
+            float d0, d3;
+            auto read_b = [&](int k2) __attribute__((always_inline)) {
+                d12 = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o12);
+                d0 = pr[k2 * LDR + o0]; d3 = pr[k2 * LDR + o3];
+            };
+            auto xform_b = [&](int nb) __attribute__((always_inline)) {
+                bv[nb][0] = fmaf(d0, ml, -d12.y); bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = fmaf(-d3, mr, d12.x);
+            };
+#pragma unroll
+            for (int t = 0; t < 4; ++t) read_a(0, 0, t);
+            read_b(0); xform_b(0);
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) { read_b(2 * (kk + 1)); read_a(nb, 2 * (kk + 1), 0); read_a(nb, 2 * (kk + 1), 1); }
+                if (kk < LS) store_u(cur ^ 1, kk);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) { read_a(nb, 2 * (kk + 1), 2); read_a(nb, 2 * (kk + 1), 3); }
+                if (kk < LS) load_u(kk);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < LS) store_v(cur ^ 1, kk, sgn_regs);
+                if (kk + 1 < NK) xform_b(nb);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < LS) { load_mid(kk); load_h(kk); }
+                if (kk == NK - 2) prep_a();                          // chunk ch + 3; every load of chunk ch + 2 has been issued by now
+                if (kk == NK - 1) prep_b();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch == next_fold) {
+                // end of row component ri_cur: fold the horizontally transformed products into the two output rows and start afresh
+                const float sa = ri_cur <= 2 ? 1.f : 0.f;             // y[2 ty]     = S0 + S1 + S2
+                const float sb = ri_cur == 0 ? 0.f : (ri_cur == 1 ? 1.f : -1.f);   // y[2 ty + 1] = S1 - S2 - S3
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float h0 = (acc[0][r] + acc[1][r]) + acc[2][r];
+                    const float h1 = (acc[1][r] - acc[2][r]) - acc[3][r];
+                    ya[0][r] = fmaf(sa, h0, ya[0][r]); ya[1][r] = fmaf(sa, h1, ya[1][r]);
+                    yb[0][r] = fmaf(sb, h0, yb[0][r]); yb[1][r] = fmaf(sb, h1, yb[1][r]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t][r] = 0.f;
+                }
+                next_fold += cpt;
+                ++ri_cur;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: final outputs of the tile's two rows (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+    const int po = p0 + 32 * wn + acol;
+    unsigned out_base = FD_OOB;
+    if (po < Np) {
+        const int n = po / plane2;
+        const int rem = po - n * plane2;
+        const int yy = rem / W2, jj = rem - yy * W2;
+        out_base = 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(2 * yy * g.W + 2 * jj));
+    }
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.Y);
+    const __amdgpu_buffer_rsrc_t rsAdd = fd_make_rsrc(g.add ? g.add : g.Y);
+    const bool has_add = g.add != nullptr;
+    const int mbase = m0 + 32 * wm + 4 * arow;
+    const unsigned row_b = 4u * (unsigned)g.W;
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
+    if (g.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            bias_r[r] = g.bias[m < g.M ? m : g.M - 1];
+        }
+    }
+    float s1[16], s2[16];                       // STATS: (sum, M2) of each row's four pixels
+    auto rows = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hw : FD_OOB;
+            f32x2 oa, ob;
+            oa.x = ya[0][r] + bias_r[r]; oa.y = ya[1][r] + bias_r[r];
+            ob.x = yb[0][r] + bias_r[r]; ob.y = yb[1][r] + bias_r[r];
+            if (ACT != 0) { oa.x = wino_act(oa.x, g.act); oa.y = wino_act(oa.y, g.act); ob.x = wino_act(ob.x, g.act); ob.y = wino_act(ob.y, g.act); }
+            if (has_add) {
+                const f32x2 a2 = fd_ldg64(rsAdd, off), b2 = fd_ldg64(rsAdd, off + row_b);
+                oa.x += a2.x; oa.y += a2.y; ob.x += b2.x; ob.y += b2.y;
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oa), rsY, (int)off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsY, (int)(off + row_b), 0, 0);
+            if (STATS) {
+                const float da = oa.x - oa.y, db = ob.x - ob.y;
+                const float ta = oa.x + oa.y, tb = ob.x + ob.y, dab = ta - tb;
+                s1[r] = ta + tb;
+                s2[r] = fmaf(dab * dab, 0.25f, 0.5f * da * da + 0.5f * db * db);      // two pairs of two: (sa - sb)^2 / (2 * 2)
+            }
+        }
+    };
+    if (g.act == 0) rows(std::integral_constant<int, 0>{});
+    else rows(std::integral_constant<int, -1>{});
+    if (STATS) {
+        // the butterfly of k_conv_wino with four pixels per lane and row to start from: slots of 32 tiles = 128 pixels
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int width = 8 >> step;
+            const int xm = 16 >> step;
+            const bool hi = (lane & xm) != 0;
+            const float inv2n = 0.125f / (float)(1 << step);                // each side holds n = 4 << step pixels
+#pragma unroll
+            for (int j = 0; j < width; ++j) {
+                const float k1 = hi ? s1[j + width] : s1[j], g1 = hi ? s1[j] : s1[j + width];
+                const float k2 = hi ? s2[j + width] : s2[j], g2 = hi ? s2[j] : s2[j + width];
+                const float o1 = __shfl_xor(g1, xm, 64), o2 = __shfl_xor(g2, xm, 64);
+                const float df = k1 - o1;
+                s1[j] = k1 + o1;
+                s2[j] = fmaf(df * df, inv2n, k2 + o2);
+            }
+        }
+        {
+            const float o1 = __shfl_xor(s1[0], 1, 64), o2 = __shfl_xor(s2[0], 1, 64);
+            const float df = s1[0] - o1;
+            s2[0] = fmaf(df * df, 1.0f / 128.0f, s2[0] + o2);               // n = 64 per side
+            s1[0] += o1;
+        }
+        const int rr = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int m = mbase + (rr & 3) + 8 * (rr >> 2);
+        if (!(lane & 1) && m < g.M) {
+            const int n = p0 / plane2, tile = (p0 - n * plane2) / WBN;     // the whole tile lies in image n (launcher's guarantee)
+            f32x2 v; v.x = s1[0]; v.y = s2[0];
+            *reinterpret_cast<f32x2*>(g.stat_part + (((size_t)n * g.M + m) * g.stat_slots + 2 * tile + wn) * 2) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dW[m][c][ky][kx] = sum over pixels dY[m][y][x] * X[c][y+ky-1][x+kx-1].  Per pixel pair (dy0, dy1) and the same four inputs
 // d0..d3 as the forward, the transposed F(2,3) algorithm needs 4 products instead of 6:
@@ -857,11 +1161,18 @@ bool wino_fwd_ok(const fd_conv_desc* d) {
 // F(2x2, 3x3) (k_conv_wino2d) for the layers whose matrix work dwarfs their output: Cin * Cout >= 256 * 256 (FD_WINO_FWD_2D_MIN) and
 // whole 2x2 tiles.  A function of the descriptor and of fd_tuning, so that the weight-layout size, the workspace size, the
 // re-layout job and the launch agree.
-bool wino_fwd_2d(const fd_conv_desc* d) {
-    const long min_cc = fd_tun().wino_fwd_2d_min;
-    if (min_cc <= 0) return false;
-    return wino_fwd_ok(d) && d->H % 2 == 0 && (long)d->Cin * d->Cout >= min_cc && (long)d->Cout * 4 * d->Cin * 4 * 4 < 2147483648L;
+// -> 0: F(2, 3) along x (k_conv_wino), 1: F(2x2, 3x3) with the row components as slabs (k_conv_wino2d + k_wino2d_finish),
+//    2: F(2x2, 3x3) with all 16 components in one workgroup (k_conv_wino2p): the layers with enough 2x2 tiles to fill the chip
+//    without splitting anything - ResNet layer1 / layer2 at the step's batch sizes, the decoder's wide full-resolution blocks
+int wino_fwd_mode(const fd_conv_desc* d) {
+    if (!wino_fwd_ok(d) || d->H % 2 != 0 || (long)d->Cout * 4 * d->Cin * 4 * 4 >= 2147483648L) return 0;
+    const fd_tuning& t = fd_tun();
+    if (t.wino_fwd_2d_min > 0 && (long)d->Cin * d->Cout >= (long)t.wino_fwd_2d_min) return 1;
+    const long wgs = (long)fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN) * fd_cdiv(d->Cout, WBM);
+    if (t.wino_fwd_2dp_min_wgs > 0 && wgs >= (long)t.wino_fwd_2dp_min_wgs) return 2;
+    return 0;
 }
+bool wino_fwd_2d(const fd_conv_desc* d) { return wino_fwd_mode(d) != 0; }      // the weights are U2[t][m][ri][c] for both 2-D kernels
 // channel splits of the 2-D kernel on top of its four row components
 inline int wino2d_ksplits(const fd_conv_desc* d) {
     const long tiles = 4L * fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN) * fd_cdiv(d->Cout, WBM);
@@ -874,7 +1185,9 @@ inline int wino2d_ksplits(const fd_conv_desc* d) {
 }
 long wino_wt_floats(const fd_conv_desc* d) { return 4L * d->Cout * (wino_fwd_2d(d) ? 4 : 3) * d->Cin; }
 long wino_ws_floats(const fd_conv_desc* d) {
-    if (wino_fwd_2d(d)) return 4L * wino2d_ksplits(d) * d->N * d->Cout * (d->H / 2) * d->W;
+    const int mode = wino_fwd_mode(d);
+    if (mode == 2) return 0;
+    if (mode == 1) return 4L * wino2d_ksplits(d) * d->N * d->Cout * (d->H / 2) * d->W;
     const int sp = wino_splits(d, d->Cout, d->Cin);
     return sp > 1 ? (long)sp * d->N * d->Cout * d->H * d->W : 0;
 }
@@ -892,8 +1205,15 @@ int wino_weight_launch(const fd_conv_desc* d, const float* w, float* U, int flip
 // y = act(conv3x3(x; U) + bias); d describes the convolution being computed (for a data gradient: Cin / Cout already swapped).
 // slots of BatchNorm partial sums per (image, channel) the kernel can emit for `d`, 0 if not (split-K, tiles across images)
 int wino_stat_slots(const fd_conv_desc* d) {
+    if (!wino_fwd_ok(d) || d->act != 0) return 0;
+    const int mode = wino_fwd_mode(d);
+    if (mode == 1) return 0;
+    if (mode == 2) {                                                       // slots of 32 tiles x 4 pixels
+        const long tiles = (long)(d->H / 2) * (d->W / 2);
+        return tiles % WBN == 0 ? (int)(2 * tiles / WBN) : 0;
+    }
     const long plane2 = (long)d->H * (d->W / 2);
-    if (!wino_fwd_ok(d) || wino_fwd_2d(d) || plane2 % WBN != 0 || wino_splits(d, d->Cout, d->Cin) != 1 || d->act != 0) return 0;
+    if (plane2 % WBN != 0 || wino_splits(d, d->Cout, d->Cin) != 1) return 0;
     return (int)(2 * plane2 / WBN);
 }
 
@@ -907,8 +1227,9 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
     g.pad_mode = d->pad_mode; g.act = d->act;
     const long out_total = (long)d->N * d->Cout * d->H * d->W;
     g.slab_stride = out_total;
-    const bool twod = wino_fwd_2d(d);
-    const int sp = twod ? 4 * wino2d_ksplits(d) : wino_splits(d, d->Cout, d->Cin);
+    const int mode = wino_fwd_mode(d);
+    const bool twod = mode == 1;
+    const int sp = twod ? 4 * wino2d_ksplits(d) : (mode == 2 ? 1 : wino_splits(d, d->Cout, d->Cin));
     if (sp > 1 && !ws) { fd_set_error("wino conv: split-K workspace missing"); return -1; }
     static bool attr_set = false;
     if (!attr_set) {
@@ -917,7 +1238,17 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
+    }
+    if (mode == 2) {
+        const int gx2 = fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN), gy2 = fd_cdiv(d->Cout, WBM);
+        g.xcd_swizzle = (gx2 % 8 == 0 && gx2 >= 16) ? 1 : 0;
+        if (stat_part) hipLaunchKernelGGL(k_conv_wino2p<true>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+        else hipLaunchKernelGGL(k_conv_wino2p<false>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+        FD_LAUNCH_CHECK("k_conv_wino2p");
+        return 0;
     }
     if (twod) {
         if (stat_part) { fd_set_error("wino conv: no statistics epilogue for this shape"); return -1; }

@@ -182,6 +182,24 @@ def test_conv2d_fwd_bwd(FD, case):
         relclose(cpu(got[2]), cpu(want[2]), "conv bias grad")
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 3, 192, 640), (2, 6, 192, 640), (3, 2, 96, 320), (2, 4, 70, 150), (1, 5, 8, 8), (1, 1, 33, 9)])
+def test_stem_convolution_on_the_patch_kernel(FD, N, C, H, W, fdtune):
+    """conv_stem.hip (7x7 stride-2 pad-3 stems, networks/resnet_encoder.py:95) against torch float64 conv2d, and against the generic
+    gather-GEMM route it replaces (fd_tuning.stem7 = 0): full-size planes, ragged tiles in both directions, odd channel counts
+    (padded to a channel pair inside the kernel), planes smaller than one tile."""
+    rng = np.random.RandomState(N * 100 + C)
+    x = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32))
+    w = torch.from_numpy((rng.randn(64, C, 7, 7) * np.sqrt(2.0 / (49 * C))).astype(np.float32))
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3).float()
+    out = {}
+    for on in (1, 0):
+        fdtune.lib(stem7=on)
+        with torch.no_grad():
+            out[on] = FD.conv2d(dev(x), dev(w), None, 2, 3)
+        relclose(cpu(out[on]), cpu(ref), "stem forward (stem7=%d)" % on, rtol=1e-5, arel=3e-6)
+    relclose(cpu(out[1]), cpu(out[0]), "patch kernel vs gather GEMM", rtol=1e-5, arel=2e-6)
+
+
 @pytest.mark.parametrize("case", [
     (2, 64, 16, 24, 64, 3, 1, 1, "zero"),        # Winograd data gradient, split-K finish
     (12, 64, 48, 160, 64, 3, 1, 1, "zero"),      # Winograd data gradient, direct epilogue (layer1 at the bench batch)
@@ -545,16 +563,21 @@ def test_grouped_batchnorm_equals_separate_passes(FD, N, C, H, W, G, res):
     assert int(bn_g.num_batches_tracked) == int(bn_o.num_batches_tracked) == G
 
 
+@pytest.mark.parametrize("kern", ["1d", "2p"])
 @pytest.mark.parametrize("N,Cin,Cout,H,W,G,res", [
     (6, 64, 64, 48, 160, 2, True),      # the step's layer1 plane: 60 tiles per image, grouped, residual + ReLU
     (12, 128, 128, 24, 80, 3, False),   # layer2: 15 tiles per image, 2 channel tiles, three groups
     (8, 128, 64, 48, 160, 1, True),     # one group
 ])
-def test_conv_epilogue_statistics_feed_batchnorm(FD, N, Cin, Cout, H, W, G, res):
+def test_conv_epilogue_statistics_feed_batchnorm(FD, N, Cin, Cout, H, W, G, res, kern, fdtune):
     """fd_conv2d_fwd_stats + fd_bn_train_fwd_parts (BatchNorm statistics gathered in the convolution's epilogue, one BatchNorm
     launch) == fd_conv2d_fwd + fd_bn_train_fwd (statistics pass + apply pass), and both == torch's conv2d + BatchNorm2d in float64:
     outputs, running statistics after the grouped in-order updates, and every gradient.  Reference ops: torchvision BasicBlock
     (conv3x3 -> BatchNorm2d -> [+ identity] -> ReLU) as driven by networks/resnet_encoder.py:95-101."""
+    # kern: "1d" = k_conv_wino (slots of 64 pixels), "2p" = k_conv_wino2p (slots of 32 2x2 tiles = 128 pixels; planes whose tile
+    # count is not a multiple of 64 - the 24x80 case - have no statistics epilogue there: the BatchNorm makes its own pass)
+    fdtune.lib(wino_fwd_2dp_min_wgs=1 if kern == "2p" else 0)
+    slots = 2 * (H * W // 2) // 64 if kern == "1d" else (2 * (H * W // 4) // 64 if (H * W // 4) % 64 == 0 else None)
     rng = np.random.RandomState(N * 1000 + Cin)
     x = torch.from_numpy((rng.randn(N, Cin, H, W) + 0.5).astype(np.float32))
     w = torch.from_numpy((rng.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32))
@@ -572,7 +595,7 @@ def test_conv_epilogue_statistics_feed_batchnorm(FD, N, Cin, Cout, H, W, G, res)
         with FD.bn_groups(G):
             if use_stats:
                 y, stats = FD.conv2d_stats(xg, wg, None, 1, 1)
-                assert stats is not None and tuple(stats.shape) == (N, Cout, 2 * (H * W // 2) // 64, 2)
+                assert (stats is None) if slots is None else (stats is not None and tuple(stats.shape) == (N, Cout, slots, 2))
                 out = FD.batch_norm(y, bn, residual=rg, relu=True, conv_stats=stats)
             else:
                 out = FD.batch_norm(FD.conv2d(xg, wg, None, 1, 1), bn, residual=rg, relu=True)
@@ -722,7 +745,7 @@ def _wino_conv(x, w, bias, reflect, act=0):
     return y, nwt
 
 
-@pytest.mark.parametrize("two_d", [1, 0])
+@pytest.mark.parametrize("two_d", [1, 0, 2])
 @pytest.mark.parametrize("N,Ci,Co,H,W,reflect,act", [
     (2, 64, 64, 48, 160, False, 0),      # layer1 shape, no split
     (1, 256, 256, 12, 40, False, 1),     # few tiles: split-K slabs + finish (bias + ReLU applied there)
@@ -738,8 +761,9 @@ def _wino_conv(x, w, bias, reflect, act=0):
 def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d, fdtune):
     """conv_wino.hip through its own entry point against torch float64 conv2d: error within a few fp32 ulps of the output scale,
     i.e. no worse than the direct implicit GEMM (transform coefficients are +-1 and 1/2).  two_d = 1: F(2x2, 3x3) (k_conv_wino2d +
-    k_wino2d_finish) forced onto every shape with an even height; 0: F(2, 3) per kernel row everywhere."""
-    fdtune.lib(wino_fwd_2d_min=1 if two_d else 0)
+    k_wino2d_finish) forced onto every shape with an even height; 2: F(2x2, 3x3) with the 16 components in one workgroup
+    (k_conv_wino2p, round 4) forced likewise; 0: F(2, 3) per kernel row everywhere."""
+    fdtune.lib(wino_fwd_2d_min=1 if two_d == 1 else 0, wino_fwd_2dp_min_wgs=1 if two_d == 2 else 0)
     torch.manual_seed(N * 1000 + Ci)
     x = torch.randn(N, Ci, H, W, device="cuda")
     w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
@@ -750,6 +774,29 @@ def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d
     got, nwt = _wino_conv(x, w, b, reflect, act)
     assert nwt == 4 * Co * (4 if two_d and H % 2 == 0 else 3) * Ci
     relclose(cpu(got), cpu(ref.float()), "winograd conv", rtol=1e-5, arel=3e-6)
+
+
+@pytest.mark.parametrize("mode", ["zero", "reflect"])
+def test_one_workgroup_winograd_forward_backward_with_residual_tap(mode, fdtune):
+    """k_conv_wino2p through FD.conv2d / FD.conv2d_tap: forward (bias + ReLU in its epilogue) and, for zero padding, the data
+    gradient with the second incoming gradient added in the epilogue (fd_conv2d_bwd_data_add: both rows of every 2x2 tile),
+    against torch float64 autograd; layer1-like plane with pixel tiles that cross image borders (3 x 12 x 20 = 720 tiles)."""
+    import fusiondepth_amd.functional as FD
+    fdtune.lib(wino_fwd_2dp_min_wgs=1)
+    torch.manual_seed(77)
+    x = torch.randn(3, 64, 24, 40, device="cuda", requires_grad=True)
+    w = torch.randn(64, 64, 3, 3, device="cuda") * 0.05
+    b = torch.randn(64, device="cuda") * 0.1
+    y, xt = FD.conv2d_tap(x, w, b, 1, 1, mode, "relu")
+    cot = torch.randn_like(y)
+    gx = torch.autograd.grad((y * cot).sum() + (xt * xt).sum(), x)[0]
+    xd = x.detach().double().requires_grad_(True)
+    xp = F.pad(xd, (1, 1, 1, 1), mode="reflect" if mode == "reflect" else "constant")
+    yd = F.relu(F.conv2d(xp, w.double(), b.double()))
+    gxd = torch.autograd.grad((yd * cot.double()).sum() + (xd * xd).sum(), xd)[0]
+    relclose(cpu(y), cpu(yd.float()), "y", rtol=1e-5, arel=3e-6)
+    from conftest import assert_mostly_close
+    assert_mostly_close(cpu(gx), cpu(gxd.float()), rtol=1e-4, atol=1e-4 * float(gxd.abs().max()), what="dx + tap", max_bad_frac=1e-3)
 
 
 def test_winograd_refuses_ineligible_shapes():
@@ -766,13 +813,15 @@ def test_winograd_refuses_ineligible_shapes():
                   _lib.stream())
 
 
-@pytest.mark.parametrize("Ci,Co,two_d_min", [(64, 128, None), (64, 128, 1), (256, 256, None)])
+@pytest.mark.parametrize("Ci,Co,two_d_min", [(64, 128, None), (64, 128, 1), (256, 256, None), (64, 128, "2p")])
 def test_winograd_routing_forward_and_data_gradient_match_torch(Ci, Co, two_d_min, fdtune):
     """FD.conv2d routes eligible 3x3 convs to the Winograd kernel (forward and zero-pad data gradient); values and both
     gradients against torch autograd in float64, and the batched weight re-layout (modes 3 / 4; 5 / 6 for the F(2x2, 3x3) layouts:
     forced onto the small shape, by default on the 256-channel one) against the per-call transform."""
     import fusiondepth_amd.functional as FD
-    if two_d_min is not None:
+    if two_d_min == "2p":                       # the one-workgroup F(2x2, 3x3) kernel (same U2 layouts, modes 5 / 6) forced onto the small shape
+        fdtune.lib(wino_fwd_2dp_min_wgs=1)
+    elif two_d_min is not None:
         fdtune.lib(wino_fwd_2d_min=two_d_min)
     torch.manual_seed(5)
     x = torch.randn(2, Ci, 12, 40, device="cuda", requires_grad=True)
