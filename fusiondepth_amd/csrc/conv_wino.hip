@@ -583,6 +583,103 @@ __global__ void __launch_bounds__(256) k_wino2d_finish(const float* __restrict__
 // K loops a third longer than the 1-D kernel's (4 C / 16 against 3 C / 16 chunks per tile of twice the pixels), and the four row
 // combinations of a tile's input rows are formed by ONE workgroup out of L1 / L2 instead of four.  128 accumulator registers per
 // lane: two waves per SIMD.
+#ifndef FD_W2P_ABLATE
+#define FD_W2P_ABLATE 0      // timing experiments only (wrong results): 1 no fold, 2 loop loads out of range, 4 no LDS stores in the loop, 8 no barrier, 16 no output stores
+#endif
+typedef float f32x16_w2p __attribute__((ext_vector_type(16)));
+// Final outputs of a k_conv_wino2p tile from the two folded accumulator pairs (shared by the register-staged and the direct-to-LDS
+// variant of the kernel)
+template <bool STATS>
+__device__ __forceinline__ void w2p_epilogue(const WinoArgs& g, const f32x16_w2p (&ya)[2], const f32x16_w2p (&yb)[2], int p0, int m0, int Np, int plane2,
+                                             int W2, unsigned hw, int lane, int wm, int wn) {
+    const int arow = lane >> 5, acol = lane & 31;
+    // ---- epilogue: final outputs of the tile's two rows (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
+    const int po = p0 + 32 * wn + acol;
+    unsigned out_base = FD_OOB;
+    if (po < Np) {
+        const int n = po / plane2;
+        const int rem = po - n * plane2;
+        const int yy = rem / W2, jj = rem - yy * W2;
+        out_base = 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(2 * yy * g.W + 2 * jj));
+    }
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.Y);
+    const __amdgpu_buffer_rsrc_t rsAdd = fd_make_rsrc(g.add ? g.add : g.Y);
+    const bool has_add = g.add != nullptr;
+    const int mbase = m0 + 32 * wm + 4 * arow;
+    const unsigned row_b = 4u * (unsigned)g.W;
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
+    if (g.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            bias_r[r] = g.bias[m < g.M ? m : g.M - 1];
+        }
+    }
+    float s1[16], s2[16];                       // STATS: (sum, M2) of each row's four pixels
+    auto rows = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hw : FD_OOB;
+            f32x2 oa, ob;
+            oa.x = ya[0][r] + bias_r[r]; oa.y = ya[1][r] + bias_r[r];
+            ob.x = yb[0][r] + bias_r[r]; ob.y = yb[1][r] + bias_r[r];
+            if (ACT != 0) { oa.x = wino_act(oa.x, g.act); oa.y = wino_act(oa.y, g.act); ob.x = wino_act(ob.x, g.act); ob.y = wino_act(ob.y, g.act); }
+            if (has_add) {
+                const f32x2 a2 = fd_ldg64(rsAdd, off), b2 = fd_ldg64(rsAdd, off + row_b);
+                oa.x += a2.x; oa.y += a2.y; ob.x += b2.x; ob.y += b2.y;
+            }
+            if (!(FD_W2P_ABLATE & 16) || oa.x == 123.456f) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oa), rsY, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsY, (int)(off + row_b), 0, 0);
+            }
+            if (STATS) {
+                const float da = oa.x - oa.y, db = ob.x - ob.y;
+                const float ta = oa.x + oa.y, tb = ob.x + ob.y, dab = ta - tb;
+                s1[r] = ta + tb;
+                s2[r] = fmaf(dab * dab, 0.25f, 0.5f * da * da + 0.5f * db * db);      // two pairs of two: (sa - sb)^2 / (2 * 2)
+            }
+        }
+    };
+    if (g.act == 0) rows(std::integral_constant<int, 0>{});
+    else rows(std::integral_constant<int, -1>{});
+    if (STATS) {
+        // the butterfly of k_conv_wino with four pixels per lane and row to start from: slots of 32 tiles = 128 pixels
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+            const int width = 8 >> step;
+            const int xm = 16 >> step;
+            const bool hi = (lane & xm) != 0;
+            const float inv2n = 0.125f / (float)(1 << step);                // each side holds n = 4 << step pixels
+#pragma unroll
+            for (int j = 0; j < width; ++j) {
+                const float k1 = hi ? s1[j + width] : s1[j], g1 = hi ? s1[j] : s1[j + width];
+                const float k2 = hi ? s2[j + width] : s2[j], g2 = hi ? s2[j] : s2[j + width];
+                const float o1 = __shfl_xor(g1, xm, 64), o2 = __shfl_xor(g2, xm, 64);
+                const float df = k1 - o1;
+                s1[j] = k1 + o1;
+                s2[j] = fmaf(df * df, inv2n, k2 + o2);
+            }
+        }
+        {
+            const float o1 = __shfl_xor(s1[0], 1, 64), o2 = __shfl_xor(s2[0], 1, 64);
+            const float df = s1[0] - o1;
+            s2[0] = fmaf(df * df, 1.0f / 128.0f, s2[0] + o2);               // n = 64 per side
+            s1[0] += o1;
+        }
+        const int rr = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        const int m = mbase + (rr & 3) + 8 * (rr >> 2);
+        if (!(lane & 1) && m < g.M) {
+            const int n = p0 / plane2, tile = (p0 - n * plane2) / WBN;     // the whole tile lies in image n (launcher's guarantee)
+            f32x2 v; v.x = s1[0]; v.y = s2[0];
+            *reinterpret_cast<f32x2*>(g.stat_part + (((size_t)n * g.M + m) * g.stat_slots + 2 * tile + wn) * 2) = v;
+        }
+    }
+}
+
 template <bool STATS>
 __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_wino2p(WinoArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -651,6 +748,7 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
         h_off = (prep_ok & halo_l) ? prep_base - 4u : ((prep_ok & halo_r) ? prep_base + 8u : FD_OOB);
         mid_off2 = prep_ok2 ? prep_base2 : FD_OOB;
         h_off2 = (prep_ok2 & halo_l) ? prep_base2 - 4u : ((prep_ok2 & halo_r) ? prep_base2 + 8u : FD_OOB);
+        if ((FD_W2P_ABLATE & 2) && pc_f > 1) { u_off = mid_off = h_off = mid_off2 = h_off2 = FD_OOB; }
         ++pc_f;
         pc_c0 += WBKC;
         const bool wrap = pc_c0 >= g.C;
@@ -751,7 +849,7 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk + 1 < NK) { read_b(2 * (kk + 1)); read_a(nb, 2 * (kk + 1), 0); read_a(nb, 2 * (kk + 1), 1); }
-                if (kk < LS) store_u(cur ^ 1, kk);
+                if (kk < LS && !(FD_W2P_ABLATE & 4)) store_u(cur ^ 1, kk);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -760,7 +858,7 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
                 __builtin_amdgcn_sched_barrier(0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < LS) store_v(cur ^ 1, kk, sgn_regs);
+                if (kk < LS && !(FD_W2P_ABLATE & 4)) store_v(cur ^ 1, kk, sgn_regs);
                 if (kk + 1 < NK) xform_b(nb);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
@@ -770,7 +868,7 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
                 if (kk == NK - 1) prep_b();
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (ch == next_fold) {
+            if (ch == next_fold && !(FD_W2P_ABLATE & 1)) {
                 // end of row component ri_cur: fold the horizontally transformed products into the two output rows and start afresh
                 const float sa = ri_cur <= 2 ? 1.f : 0.f;             // y[2 ty]     = S0 + S1 + S2
                 const float sb = ri_cur == 0 ? 0.f : (ri_cur == 1 ? 1.f : -1.f);   // y[2 ty + 1] = S1 - S2 - S3
@@ -786,93 +884,207 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
                 next_fold += cpt;
                 ++ri_cur;
             }
-            __syncthreads();
+            if (!(FD_W2P_ABLATE & 8)) __syncthreads();
         }
+    }
+    w2p_epilogue<STATS>(g, ya, yb, p0, m0, Np, plane2, W2, hw, lane, wm, wn);
+}
+
+// The same computation with the activations on the LDS-DMA path (needs W % 4 == 0, a 16-byte aligned tensor): BOTH input rows of the
+// chunk's row combination go from global memory straight into LDS as raw rows (`buffer_load_dwordx4 ... lds`, three 1-KB pieces per
+// wave and row set), and the vertical AND the horizontal input transform are applied when the B operands are read:
+//   d = rowA + sgn * rowB  (4 fused multiply-adds),  V = (d0 - d2, d1 + d2, d2 - d1, d1 - d3).
+// No staging registers, no s_waitcnt + ds_write for the activations in the MFMA stream (the VGPR -> LDS stores were the largest
+// removable term of the register-staged loop: profiles/round4_w2p_ablation.md); 70 KB of LDS: two workgroups per CU, which is what
+// the 128 accumulator registers allow anyway.  Flat pixel order of the DMA pieces: (image, tile row, x) - 64 consecutive 2x2 tiles are
+// 128 consecutive columns of one tile row (or wrap into the next), exactly the 1-D kernel's scheme with H / 2 rows.
+constexpr int W2D_BUF_FLOATS = 4 * WBKC * LDU + 2 * V_RAW_FLOATS;
+constexpr int W2D_LDS_FLOATS = 2 * W2D_BUF_FLOATS;
+template <bool STATS>
+__global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_wino2p_dma(WinoArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W2 = g.W >> 1, HT = g.H >> 1;
+    const int plane2 = HT * W2;
+    const int Np = g.Nb * plane2;
+    const unsigned hw = (unsigned)(g.H * g.W);
+    int bx = blockIdx.x;
+    const int by = blockIdx.y;
+    if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    const int m0 = by * WBM, p0 = bx * WBN;
+    const int cpt = g.C / WBKC, nchunk = 4 * cpt;
+    const bool refl = g.pad_mode == 1;
+    const int a4 = tid & 3, ar = tid >> 2;
+    int mrow = m0 + ar;
+    mrow = mrow < g.M ? mrow : g.M - 1;
+    const unsigned u_comp = 4u * (unsigned)g.M * 4u * (unsigned)g.C;
+    const __amdgpu_buffer_rsrc_t rsU = fd_make_rsrc(g.U);
+    const __amdgpu_buffer_rsrc_t rsXd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)(4u * (unsigned)g.Nb * (unsigned)g.C * hw), 0x00020000);
+    // per lane and DMA piece, fixed for the whole tile: tile row and byte offset (channel 0, image row 0) of its four pixels
+    unsigned d_base[3] = {FD_OOB, FD_OOB, FD_OOB};
+    int d_ty[3] = {0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int L = 64 * (wave + 4 * q) + lane;
+        const int row = L / 34, seg = L - row * 34;
+        const int F = 2 * p0 - 4 + 4 * seg;                              // flat pixel index over (image, tile row, x)
+        const bool ok = row < WBKC && F >= 0 && F < g.Nb * HT * g.W;
+        const int Fc = ok ? F : 0;
+        const int nrow = Fc / g.W, x = Fc - nrow * g.W;
+        const int n = nrow / HT;
+        d_ty[q] = nrow - n * HT;
+        d_base[q] = ok ? 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)row * hw + (unsigned)x) : FD_OOB;
+    }
+    unsigned d_off[2][3] = {{FD_OOB, FD_OOB, FD_OOB}, {FD_OOB, FD_OOB, FD_OOB}};
+    unsigned d_soff = 0u, u_off = FD_OOB;
+    float4 ru[4];
+    int pc_f = 0, pc_ri = 0, pc_c0 = 0;
+    const int H2m2 = 2 * g.H - 2;
+    auto prep = [&]() __attribute__((always_inline)) {                  // offsets of flat chunk pc_f, then advance
+        const bool live = pc_f < nchunk;
+        const int ri = pc_ri;
+        const int xr[2] = {ri == 0 ? 0 : (ri == 2 ? 2 : 1), ri == 3 ? 3 : (ri == 2 ? 1 : 2)};
+        u_off = live ? 4u * (((unsigned)mrow * 4u + (unsigned)ri) * (unsigned)g.C + (unsigned)pc_c0 + 4u * a4) : FD_OOB;
+        d_soff = 4u * (unsigned)pc_c0 * hw;                              // wave-uniform: first channel of the chunk
+        if (pc_c0 == 0) {                                                // the pieces' row offsets change with the row component only
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int r = 2 * d_ty[q] - 1 + xr[s_];
+                    const bool inb = (unsigned)r < (unsigned)g.H;
+                    int rr_ = r < 0 ? -r : r;
+                    rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
+                    const int ruse = refl ? rr_ : r;
+                    d_off[s_][q] = (live & (refl | inb)) ? d_base[q] + (unsigned)(ruse * g.W * 4) : FD_OOB;   // FD_OOB base + anything stays out of range
+                }
+        }
+        if ((FD_W2P_ABLATE & 2) && pc_f > 1) { u_off = FD_OOB; for (int s_ = 0; s_ < 2; ++s_) for (int q = 0; q < 3; ++q) d_off[s_][q] = FD_OOB; }
+        ++pc_f;
+        pc_c0 += WBKC;
+        const bool wrap = pc_c0 >= g.C;
+        pc_c0 = wrap ? 0 : pc_c0;
+        pc_ri += wrap ? 1 : 0;
+    };
+    auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off + (unsigned)t * u_comp); };
+    auto store_u = [&](int buf, int t) __attribute__((always_inline)) {
+        float* q = smem + buf * W2D_BUF_FLOATS + t * WBKC * LDU + (4 * a4) * LDU + ar;
+        q[0] = ru[t].x; q[LDU] = ru[t].y; q[2 * LDU] = ru[t].z; q[3 * LDU] = ru[t].w;
+    };
+    auto dma_v = [&](int buf, int s_, int q) __attribute__((always_inline)) {
+        float* dst = smem + buf * W2D_BUF_FLOATS + 4 * WBKC * LDU + s_ * V_RAW_FLOATS + (wave + 4 * q) * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsXd, (__attribute__((address_space(3))) void*)dst, 16, (int)d_off[s_][q], (int)d_soff, 0, 0);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    int o12, o0, o3;
+    float ml, mr;
+    {
+        const int jp = 32 * wn + (lane & 31);
+        const int pp = p0 + jp < Np ? p0 + jp : 0;
+        const int rem = pp % plane2;
+        const int jj = rem % W2;
+        const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
+        o12 = 4 + 2 * jp;
+        o0 = (le && refl) ? o12 + 1 : o12 - 1;
+        o3 = (re && refl) ? o12 : o12 + 2;
+        ml = (le && !refl) ? 0.f : 1.f;
+        mr = (re && !refl) ? 0.f : 1.f;
+    }
+    f32x16 acc[4], ya[2], yb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][r] = 0.f;
+        ya[0][r] = ya[1][r] = yb[0][r] = yb[1][r] = 0.f;
     }
 
-    // ---- epilogue: final outputs of the tile's two rows (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
-    const int po = p0 + 32 * wn + acol;
-    unsigned out_base = FD_OOB;
-    if (po < Np) {
-        const int n = po / plane2;
-        const int rem = po - n * plane2;
-        const int yy = rem / W2, jj = rem - yy * W2;
-        out_base = 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)(2 * yy * g.W + 2 * jj));
-    }
-    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.Y);
-    const __amdgpu_buffer_rsrc_t rsAdd = fd_make_rsrc(g.add ? g.add : g.Y);
-    const bool has_add = g.add != nullptr;
-    const int mbase = m0 + 32 * wm + 4 * arow;
-    const unsigned row_b = 4u * (unsigned)g.W;
-    float bias_r[16];
+    constexpr int NK = WBKC / 2, LS = NK / 2;
+    const int arow = lane >> 5, acol = lane & 31;
+    {
+        prep();                                                      // chunk 0
 #pragma unroll
-    for (int r = 0; r < 16; ++r) bias_r[r] = 0.f;
-    if (g.bias) {
+        for (int t = 0; t < 4; ++t) load_u(t);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbase + (r & 3) + 8 * (r >> 2);
-            bias_r[r] = g.bias[m < g.M ? m : g.M - 1];
+        for (int s_ = 0; s_ < 2; ++s_) {
+            dma_v(0, s_, 0); dma_v(0, s_, 1);
+            if (wave == 0) dma_v(0, s_, 2);
         }
-    }
-    float s1[16], s2[16];                       // STATS: (sum, M2) of each row's four pixels
-    auto rows = [&](auto act_tag) __attribute__((always_inline)) {
-        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mbase + (r & 3) + 8 * (r >> 2);
-            const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hw : FD_OOB;
-            f32x2 oa, ob;
-            oa.x = ya[0][r] + bias_r[r]; oa.y = ya[1][r] + bias_r[r];
-            ob.x = yb[0][r] + bias_r[r]; ob.y = yb[1][r] + bias_r[r];
-            if (ACT != 0) { oa.x = wino_act(oa.x, g.act); oa.y = wino_act(oa.y, g.act); ob.x = wino_act(ob.x, g.act); ob.y = wino_act(ob.y, g.act); }
-            if (has_add) {
-                const f32x2 a2 = fd_ldg64(rsAdd, off), b2 = fd_ldg64(rsAdd, off + row_b);
-                oa.x += a2.x; oa.y += a2.y; ob.x += b2.x; ob.y += b2.y;
+        for (int t = 0; t < 4; ++t) store_u(0, t);
+        prep();                                                      // offsets of chunk 1: fetched DURING chunk 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int next_fold = cpt - 1, ri_cur = 0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int cur = ch & 1;
+            float sgn = ri_cur == 1 ? 1.f : -1.f;                    // this chunk's row combination: rowA + sgn * rowB
+            asm volatile("" : "+v"(sgn));                            // in a VGPR: an SGPR operand halves the VALU rate on gfx950
+            const float* pa = smem + cur * W2D_BUF_FLOATS + arow * LDU + 32 * wm + acol;
+            const float* pr = smem + cur * W2D_BUF_FLOATS + 4 * WBKC * LDU + arow * LDR;
+            float av[2][4], bv[2][4];
+            auto read_a = [&](int nb, int k2, int t) __attribute__((always_inline)) { av[nb][t] = pa[t * WBKC * LDU + k2 * LDU]; };
+            f32x2 d12, e12;
+            float d0, d3, e0, e3;
+            auto read_b = [&](int k2) __attribute__((always_inline)) {
+                d12 = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o12);
+                e12 = *reinterpret_cast<const f32x2*>(pr + V_RAW_FLOATS + k2 * LDR + o12);
+                d0 = pr[k2 * LDR + o0]; d3 = pr[k2 * LDR + o3];
+                e0 = pr[V_RAW_FLOATS + k2 * LDR + o0]; e3 = pr[V_RAW_FLOATS + k2 * LDR + o3];
+            };
+            auto xform_b = [&](int nb) __attribute__((always_inline)) {
+                const float c0 = fmaf(sgn, e0, d0), c1 = fmaf(sgn, e12.x, d12.x), c2 = fmaf(sgn, e12.y, d12.y), c3 = fmaf(sgn, e3, d3);
+                bv[nb][0] = fmaf(c0, ml, -c2); bv[nb][1] = c1 + c2; bv[nb][2] = c2 - c1; bv[nb][3] = fmaf(-c3, mr, c1);
+            };
+#pragma unroll
+            for (int t = 0; t < 4; ++t) read_a(0, 0, t);
+            read_b(0); xform_b(0);
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) { read_b(2 * (kk + 1)); read_a(nb, 2 * (kk + 1), 0); read_a(nb, 2 * (kk + 1), 1); }
+                if (kk >= LS && !(FD_W2P_ABLATE & 4)) store_u(cur ^ 1, kk - LS);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) { read_a(nb, 2 * (kk + 1), 2); read_a(nb, 2 * (kk + 1), 3); }
+                if (kk < LS) load_u(kk);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < NK) xform_b(nb);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < 4) dma_v(cur ^ 1, kk >> 1, kk & 1);         // row set A: pieces 0, 1; row set B: pieces 0, 1
+                if (kk == 4 && wave == 0) { dma_v(cur ^ 1, 0, 2); dma_v(cur ^ 1, 1, 2); }
+                if (kk == NK - 2) prep();                            // chunk ch + 2; every fetch of chunk ch + 1 has been issued by now
             }
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, oa), rsY, (int)off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), rsY, (int)(off + row_b), 0, 0);
-            if (STATS) {
-                const float da = oa.x - oa.y, db = ob.x - ob.y;
-                const float ta = oa.x + oa.y, tb = ob.x + ob.y, dab = ta - tb;
-                s1[r] = ta + tb;
-                s2[r] = fmaf(dab * dab, 0.25f, 0.5f * da * da + 0.5f * db * db);      // two pairs of two: (sa - sb)^2 / (2 * 2)
-            }
-        }
-    };
-    if (g.act == 0) rows(std::integral_constant<int, 0>{});
-    else rows(std::integral_constant<int, -1>{});
-    if (STATS) {
-        // the butterfly of k_conv_wino with four pixels per lane and row to start from: slots of 32 tiles = 128 pixels
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch == next_fold && !(FD_W2P_ABLATE & 1)) {
+                const float sa = ri_cur <= 2 ? 1.f : 0.f;
+                const float sb = ri_cur == 0 ? 0.f : (ri_cur == 1 ? 1.f : -1.f);
 #pragma unroll
-        for (int step = 0; step < 4; ++step) {
-            const int width = 8 >> step;
-            const int xm = 16 >> step;
-            const bool hi = (lane & xm) != 0;
-            const float inv2n = 0.125f / (float)(1 << step);                // each side holds n = 4 << step pixels
+                for (int r = 0; r < 16; ++r) {
+                    const float h0 = (acc[0][r] + acc[1][r]) + acc[2][r];
+                    const float h1 = (acc[1][r] - acc[2][r]) - acc[3][r];
+                    ya[0][r] = fmaf(sa, h0, ya[0][r]); ya[1][r] = fmaf(sa, h1, ya[1][r]);
+                    yb[0][r] = fmaf(sb, h0, yb[0][r]); yb[1][r] = fmaf(sb, h1, yb[1][r]);
 #pragma unroll
-            for (int j = 0; j < width; ++j) {
-                const float k1 = hi ? s1[j + width] : s1[j], g1 = hi ? s1[j] : s1[j + width];
-                const float k2 = hi ? s2[j + width] : s2[j], g2 = hi ? s2[j] : s2[j + width];
-                const float o1 = __shfl_xor(g1, xm, 64), o2 = __shfl_xor(g2, xm, 64);
-                const float df = k1 - o1;
-                s1[j] = k1 + o1;
-                s2[j] = fmaf(df * df, inv2n, k2 + o2);
+                    for (int t = 0; t < 4; ++t) acc[t][r] = 0.f;
+                }
             }
-        }
-        {
-            const float o1 = __shfl_xor(s1[0], 1, 64), o2 = __shfl_xor(s2[0], 1, 64);
-            const float df = s1[0] - o1;
-            s2[0] = fmaf(df * df, 1.0f / 128.0f, s2[0] + o2);               // n = 64 per side
-            s1[0] += o1;
-        }
-        const int rr = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-        const int m = mbase + (rr & 3) + 8 * (rr >> 2);
-        if (!(lane & 1) && m < g.M) {
-            const int n = p0 / plane2, tile = (p0 - n * plane2) / WBN;     // the whole tile lies in image n (launcher's guarantee)
-            f32x2 v; v.x = s1[0]; v.y = s2[0];
-            *reinterpret_cast<f32x2*>(g.stat_part + (((size_t)n * g.M + m) * g.stat_slots + 2 * tile + wn) * 2) = v;
+            if (ch == next_fold) { next_fold += cpt; ++ri_cur; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this chunk's DMAs (into the other buffer) have landed
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(FD_W2P_ABLATE & 8)) __syncthreads();
         }
     }
+    w2p_epilogue<STATS>(g, ya, yb, p0, m0, Np, plane2, W2, hw, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1167,10 +1379,10 @@ bool wino_fwd_ok(const fd_conv_desc* d) {
 int wino_fwd_mode(const fd_conv_desc* d) {
     if (!wino_fwd_ok(d) || d->H % 2 != 0 || (long)d->Cout * 4 * d->Cin * 4 * 4 >= 2147483648L) return 0;
     const fd_tuning& t = fd_tun();
-    if (t.wino_fwd_2d_min > 0 && (long)d->Cin * d->Cout >= (long)t.wino_fwd_2d_min) return 1;
     const long wgs = (long)fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN) * fd_cdiv(d->Cout, WBM);
-    if (t.wino_fwd_2dp_min_wgs > 0 && wgs >= (long)t.wino_fwd_2dp_min_wgs) return 2;
-    return 0;
+    const bool deep = t.wino_fwd_2d_min > 0 && (long)d->Cin * d->Cout >= (long)t.wino_fwd_2d_min;
+    if (t.wino_fwd_2dp_min_wgs > 0 && wgs >= (long)t.wino_fwd_2dp_min_wgs && (!deep || t.wino_fwd_2dp_deep)) return 2;
+    return deep ? 1 : 0;
 }
 bool wino_fwd_2d(const fd_conv_desc* d) { return wino_fwd_mode(d) != 0; }      // the weights are U2[t][m][ri][c] for both 2-D kernels
 // channel splits of the 2-D kernel on top of its four row components
@@ -1240,12 +1452,19 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p_dma<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p_dma<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     if (mode == 2) {
         const int gx2 = fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN), gy2 = fd_cdiv(d->Cout, WBM);
         g.xcd_swizzle = (gx2 % 8 == 0 && gx2 >= 16) ? 1 : 0;
-        if (stat_part) hipLaunchKernelGGL(k_conv_wino2p<true>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+        // direct-to-LDS activations need 16-byte pieces that stay inside one image row and a 16-byte aligned tensor
+        const bool vdma = fd_tun().wino_fwd_2dp_dma != 0 && d->W % 4 == 0 && ((uintptr_t)x & 15) == 0;
+        if (vdma) {
+            if (stat_part) hipLaunchKernelGGL(k_conv_wino2p_dma<true>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
+            else hipLaunchKernelGGL(k_conv_wino2p_dma<false>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
+        } else if (stat_part) hipLaunchKernelGGL(k_conv_wino2p<true>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
         else hipLaunchKernelGGL(k_conv_wino2p<false>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
         FD_LAUNCH_CHECK("k_conv_wino2p");
         return 0;

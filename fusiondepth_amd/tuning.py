@@ -22,7 +22,7 @@ _I = ctypes.c_int
 class Tuning(ctypes.Structure):
     """Mirror of ``fd_tuning`` (include/fdhip.h)."""
     _fields_ = [(n, _I) for n in (
-        "size", "wino_fwd", "wino_wgrad", "wino_fwd_2d_min", "wino_fwd_2dp_min_wgs", "wino_wgrad_2d", "wino_target", "wino_wgrad_target", "conv_target",
+        "size", "wino_fwd", "wino_wgrad", "wino_fwd_2d_min", "wino_fwd_2dp_min_wgs", "wino_fwd_2dp_dma", "wino_fwd_2dp_deep", "wino_wgrad_2d", "wino_target", "wino_wgrad_target", "conv_target",
         "wgrad_target", "conv_c1", "conv_n16_min_pixels", "reflect_ring", "reflect_wino", "reflect_wino_min_pixels",
         "reflect_wino_padded_max", "force_cfg", "force_splits", "stem7", "log")]
 
@@ -99,7 +99,7 @@ host = _Host()
 # FD_* variable -> (kind, name, converter).  Read once, below.
 _ENV_LIB = {
     "FD_WINO_FWD": ("wino_fwd", int), "FD_WINO_WGRAD": ("wino_wgrad", int), "FD_WINO_FWD_2D_MIN": ("wino_fwd_2d_min", int),
-    "FD_WINO_WGRAD_2D": ("wino_wgrad_2d", int), "FD_WINO_FWD_2DP_MIN": ("wino_fwd_2dp_min_wgs", int), "FD_WINO_TARGET": ("wino_target", int),
+    "FD_WINO_WGRAD_2D": ("wino_wgrad_2d", int), "FD_WINO_FWD_2DP_MIN": ("wino_fwd_2dp_min_wgs", int), "FD_WINO_FWD_2DP_DMA": ("wino_fwd_2dp_dma", int), "FD_WINO_FWD_2DP_DEEP": ("wino_fwd_2dp_deep", int), "FD_WINO_TARGET": ("wino_target", int),
     "FD_WINO_WGRAD_TARGET": ("wino_wgrad_target", int), "FD_CONV_TARGET": ("conv_target", int), "FD_WGRAD_TARGET": ("wgrad_target", int),
     "FD_CONV_C1": ("conv_c1", int), "FD_CONV_N16_MIN": ("conv_n16_min_pixels", int), "FD_REFLECT_RING": ("reflect_ring", int),
     "FD_REFLECT_WINO": ("reflect_wino", int), "FD_REFLECT_WINO_MIN": ("reflect_wino_min_pixels", int),

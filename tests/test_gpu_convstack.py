@@ -745,7 +745,7 @@ def _wino_conv(x, w, bias, reflect, act=0):
     return y, nwt
 
 
-@pytest.mark.parametrize("two_d", [1, 0, 2])
+@pytest.mark.parametrize("two_d", [1, 0, 2, 3])
 @pytest.mark.parametrize("N,Ci,Co,H,W,reflect,act", [
     (2, 64, 64, 48, 160, False, 0),      # layer1 shape, no split
     (1, 256, 256, 12, 40, False, 1),     # few tiles: split-K slabs + finish (bias + ReLU applied there)
@@ -763,7 +763,8 @@ def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d
     i.e. no worse than the direct implicit GEMM (transform coefficients are +-1 and 1/2).  two_d = 1: F(2x2, 3x3) (k_conv_wino2d +
     k_wino2d_finish) forced onto every shape with an even height; 2: F(2x2, 3x3) with the 16 components in one workgroup
     (k_conv_wino2p, round 4) forced likewise; 0: F(2, 3) per kernel row everywhere."""
-    fdtune.lib(wino_fwd_2d_min=1 if two_d == 1 else 0, wino_fwd_2dp_min_wgs=1 if two_d == 2 else 0)
+    # (3: k_conv_wino2p with the register-staged loader - what widths that are not multiples of 4 take - instead of the direct-to-LDS one)
+    fdtune.lib(wino_fwd_2d_min=1 if two_d == 1 else 0, wino_fwd_2dp_min_wgs=1 if two_d >= 2 else 0, wino_fwd_2dp_dma=0 if two_d == 3 else 1)
     torch.manual_seed(N * 1000 + Ci)
     x = torch.randn(N, Ci, H, W, device="cuda")
     w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
