@@ -18,7 +18,12 @@ def w(fn, name):
     def f(*a, **k):
         r = fn(*a, **k); mark(name); return r
     return f
-tr.models["encoder"].forward = w(enc, "depth encoder issued+done (main stream)")
+def enc_w(*a, **k):
+    r = enc(*a, **k); mark("depth encoder issued+done (main stream)")
+    if torch.is_grad_enabled() and r[-1].requires_grad:
+        r[-1].register_hook(lambda g: mark("loss bwd + depth decoder bwd (main stream, until d features[-1])"))
+    return r
+tr.models["encoder"].forward = enc_w
 tr.models["depth"].forward = w(dep, "depth decoder fwd")
 tr.predict_poses = w(pp, "pose decoder fwd (joins pose encoders)")
 tr.compute_losses = w(cl, "warp + losses fwd")
@@ -27,7 +32,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 acc = {}
 for _ in range(n):
     marks.clear(); torch.cuda.synchronize(); mark("start")
-    tr.train_step(batch); mark("backward + Adam + re-layout")
+    tr.train_step(batch); mark("encoders bwd (4 streams) + Adam + re-layout")
     torch.cuda.synchronize()
     for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
         acc[n1] = acc.get(n1, 0.0) + e0.elapsed_time(e1)

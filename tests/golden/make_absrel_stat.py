@@ -7,8 +7,8 @@ tests/golden/make_absrel.py showed that from-scratch training is chaotic: one fl
 leaves another (same code, weights one ulp apart) by more than 0.001 in AbsRel after ~4 optimiser steps.  Trajectory-by-trajectory
 agreement is therefore not a property a correct implementation can have beyond the first steps; what CAN be tested over a long
 run is that the HIP trainer and the reference draw from the same DISTRIBUTION.  This fixture holds K = 6 independent runs of the CPU
-oracle trainer (ResNet-18, 96x320, --batch_size 2, the reference's default learning rate; run k has its own initial weights -
-``gin.fill_params`` seeds - and its own stream of scene batches), 60 optimiser steps each, AbsRel of two held-out scenes
+oracle trainer (ResNet-18, 96x320, --batch_size 2, the reference's default learning rate; the runs share the initial weights and
+have each their own stream of scene batches), 60 optimiser steps each, AbsRel of two held-out scenes
 (``fusiondepth_amd.synthetic.make_scene_batch``: consistent depth field, frames rendered through it, LiDAR from it, ``depth_gt`` at
 375x1242) after 0, 20, 40 and 60 steps.  (Where the untrained network's depths lie outside the 2 m window around every LiDAR
 return the SI-log term of that scale is NaN with finite gradients, as in the reference - trainer.py:577-589; the recorded loss is
@@ -56,10 +56,12 @@ def oracle_opt():
 
 
 def models(opt, k):
-    """Initial state of run k (the HIP trainer of the test copies it)."""
+    """Initial state of every run (the HIP trainer of the test copies it): the deterministic state of the other trainer tests.  The
+    runs differ by their stream of scene batches (``train_seed``): from-scratch training with two-image BatchNorm amplifies any
+    difference within a few steps (make_absrel.py), so different data order is all it takes to make them independent draws."""
     m = OT.build_models(opt, 3)
     for name, net in m.items():
-        gin.fill_params(net, 7000 + 97 * k + len(name))
+        gin.fill_params(net, 100 + len(name))
     return m
 
 

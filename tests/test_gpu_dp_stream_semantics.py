@@ -158,31 +158,36 @@ def test_graphed_step_with_an_eager_exchange_behind_it(monkeypatch, fdtune):
 
 
 def test_refiner_under_nccl_stream_semantics(monkeypatch, fdtune):
-    from fusiondepth_amd import synthetic
+    """The Refiner's optimiser step (frozen stage-1 networks, refine decoder trained, refiner.py:264-297) under the same stub; set up
+    like tests/test_gpu_refiner.py (seeded networks whose disparity heads stay away from saturation, 192x640)."""
+    import inputs as gin
+    from oracle import refiner as OR
+    from fusiondepth_amd.options import MonodepthOptions
     from fusiondepth_amd.refiner import Refiner
-    from fusiondepth_amd.trainer import Trainer
-    B, H, W = 2, 64, 96
+    B, H, W = 1, 192, 640
+    oopt = OR.default_opt(batch_size=B, height=H, width=W)
+    omodels = gin.refiner_models(OR.build_models(oopt, 0))
     folder = tempfile.mkdtemp(prefix="fd_stage1_")
-    torch.manual_seed(99)
-    tr = Trainer(_opts(B, H, W, ["--log_dir", folder, "--model_name", "stage1"]), verbose=False)
-    tr.save_model("stage1")
-    w = os.path.join(tr.log_path, "models", "weights_stage1")
-    del tr
+    for k, m in omodels.items():
+        sd = {n: v.detach().clone() for n, v in m.state_dict().items()}
+        if k == "encoder":
+            sd.update(height=H, width=W, use_stereo=False)
+        torch.save(sd, "%s/%s.pth" % (folder, k))
     fake = _FakeNccl()
     _patch(monkeypatch, fake)
     res = {}
     for tag, world, overlap in (("solo", 1, True), ("overlap", 2, True), ("whole", 2, False)):
         fdtune.host(dp_overlap=overlap)
-        torch.manual_seed(1234)
-        rf = Refiner(_opts(B, H, W, ["--refine_load_weights_folder", w]), rank=0, world_size=world, verbose=False)
-        gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+        o = MonodepthOptions().parse(["--num_layers", "18", "--weights_init", "scratch", "--batch_size", str(B), "--height", str(H), "--width", str(W),
+                                      "--refine_load_weights_folder", folder])
+        rf = Refiner(o, rank=0, world_size=world, verbose=False)
         for i in range(3):
-            inp = synthetic.make_batch(rf.batch_size, H, W, seed=300 + i)
-            inp["inf_gdc"] = torch.empty(rf.batch_size, 1, H, W, device="cuda").uniform_(0.05, 1.5, generator=gen)
-            inp["_noise"] = [torch.randn(rf.batch_size, 2, H, W, device="cuda", generator=gen) for _ in range(4)]
+            inp, noise = gin.refiner_inputs(820 + i, B, H, W)
+            ginp = {k: v.cuda() for k, v in inp.items()}
+            ginp["_noise"] = [n.cuda() for n in noise]
             if world > 1:
                 fake.hold_back()
-            rf.train_step(inp)
+            rf.train_step(ginp)
         torch.cuda.synchronize()
         res[tag] = rf.flat.flat_param.clone()
         del rf
