@@ -94,6 +94,7 @@ SIGNATURES = {
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),
     "fd_conv2d_bwd_data": ("ppppp" "i" "pp", "i"),
     "fd_conv2d_bwd_data_add": ("pppppp" "i" "pp", "i"),
+    "fd_conv2d_bwd_data_inact": ("pppp" "i" "pp" "i" "pp", "i"),
     "fd_conv3x3_wino_wt_floats": ("p", "l"),
     "fd_conv3x3_wino_ws_floats": ("p", "l"),
     "fd_conv3x3_wino_fwd": ("pppppp" "i" "pp", "i"),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "fd_maxpool3x3s2_bwd": ("pppiiiip", "i"),
     "fd_upcat_fwd": ("ppppp" "iiiiii" "p", "i"),
     "fd_upcat_bwd": ("pppp" "iiiiii" "p", "i"),
+    "fd_upcat_bwd_act": ("pp" "i" "ppp" "iiiiii" "p", "i"),
     "fd_upsample2x_fwd": ("ppliip", "i"),
     "fd_upsample2x_bwd": ("ppliip", "i"),
     "fd_axpby": ("ppplffp", "i"),

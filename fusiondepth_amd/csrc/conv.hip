@@ -960,6 +960,19 @@ extern "C" int fd_conv2d_bwd_data_add(const fd_conv_desc* d, const float* gy, co
     FD_REQUIRE(gx_add != gx, "fd_conv2d_bwd_data_add: gx_add must not alias gx");
     return bwd_data_impl(d, gy, w, gx, wt_base, wt_ready, ws, stream, gx_add);
 }
+extern "C" int fd_act_bwd(const float* y, const float* gy, float* gpre, long n, int act, void* stream);   // pool.hip
+extern "C" int fd_conv2d_bwd_data_inact(const fd_conv_desc* d, const float* gy, const float* w, const float* x_in, int in_act, float* gx,
+                                        float* wt_base, int wt_ready, float* ws, void* stream) {
+    if (int rc = check_desc(d, "fd_conv2d_bwd_data_inact")) return rc;
+    FD_REQUIRE(x_in && in_act >= 1 && in_act <= 4, "fd_conv2d_bwd_data_inact: needs the layer's input and an activation id 1..4");
+    if (c1_shape_ok(d)) {                                // dispconv: the factor act'(x_in) rides in the stencil's store
+        FD_REQUIRE(gy && w && gx, "fd_conv2d_bwd_data_inact: NULL tensor");
+        conv_log("dgrad", "c1 stencil * act'(input)", d);
+        return c1_dgrad_launch(d, gy, w, gx, (hipStream_t)stream, x_in, in_act);
+    }
+    if (int rc = bwd_data_impl(d, gy, w, gx, wt_base, wt_ready, ws, stream, nullptr)) return rc;
+    return fd_act_bwd(x_in, gx, gx, (long)d->N * d->Cin * d->H * d->W, in_act, stream);       // every other kernel family: one element-wise pass
+}
 namespace {
 int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float* gx, float* wt_base, int wt_ready, float* ws,
                   void* stream, const float* gx_add) {

@@ -150,8 +150,9 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_fwd4(const float* __restrict
 }
 
 // gx[n][c][p] (+= nothing: plain store) from gy[n][0][.]; Wt = the layer's W[0][c][ky][kx]
+// XIN != NULL: the layer's input is the OUTPUT of activation in_act and its producer expects the gradient w.r.t. the PRE-activation
 __global__ void __launch_bounds__(256) k_conv3x3_c1_dgrad(const float* __restrict__ GY, const float* __restrict__ Wt, float* __restrict__ GX,
-                                                          int C, int H, int W, int pad_mode) {
+                                                          int C, int H, int W, int pad_mode, const float* __restrict__ XIN, int in_act) {
     extern __shared__ float sw[];
     for (int i = threadIdx.x; i < 9 * C; i += 256) sw[i] = Wt[i];
     __syncthreads();
@@ -184,11 +185,16 @@ __global__ void __launch_bounds__(256) k_conv3x3_c1_dgrad(const float* __restric
     for (int a = 0; a < ny; ++a)
         for (int b = 0; b < nx; ++b) add(py[a], px[b]);
     float* o = GX + (size_t)blockIdx.y * C * hw + p;
+    const float* xi = XIN ? XIN + (size_t)blockIdx.y * C * hw + p : nullptr;
     for (int c = 0; c < C; ++c) {
         const float* w = sw + 9 * c;
         float v = 0.f;
 #pragma unroll
         for (int t = 0; t < 9; ++t) v = fmaf(w[t], S[t], v);
+        if (xi) {
+            const float a = xi[(size_t)c * hw];
+            v *= in_act == 1 ? (a > 0.f ? 1.f : 0.f) : in_act == 2 ? (a > 0.f ? 1.f : a + 1.f) : in_act == 3 ? a * (1.f - a) : 1.f - a * a;
+        }
         o[(size_t)c * hw] = v;
     }
 }
@@ -220,9 +226,9 @@ int c1_fwd_launch(const fd_conv_desc* d, const float* x, const float* w, const f
     return 0;
 }
 
-int c1_dgrad_launch(const fd_conv_desc* d, const float* gy, const float* w, float* gx, hipStream_t st) {
+int c1_dgrad_launch(const fd_conv_desc* d, const float* gy, const float* w, float* gx, hipStream_t st, const float* x_in, int in_act) {
     const dim3 grid((unsigned)fd_cdiv((long)d->H * d->W, 256), (unsigned)d->N);
-    hipLaunchKernelGGL(k_conv3x3_c1_dgrad, grid, dim3(256), sizeof(float) * 9 * d->Cin, st, gy, w, gx, d->Cin, d->H, d->W, d->pad_mode);
+    hipLaunchKernelGGL(k_conv3x3_c1_dgrad, grid, dim3(256), sizeof(float) * 9 * d->Cin, st, gy, w, gx, d->Cin, d->H, d->W, d->pad_mode, x_in, in_act);
     FD_LAUNCH_CHECK("k_conv3x3_c1_dgrad");
     return 0;
 }

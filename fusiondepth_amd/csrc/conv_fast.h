@@ -75,7 +75,7 @@ int n16_launch(const fd_conv_desc* d, int M, int C, const float* x, const float*
 // conv_c1.hip: 3x3 stride-1 convolutions with one output channel (dispconv) as stencils
 bool c1_shape_ok(const fd_conv_desc* d);
 int c1_fwd_launch(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st);
-int c1_dgrad_launch(const fd_conv_desc* d, const float* gy, const float* w, float* gx, hipStream_t st);
+int c1_dgrad_launch(const fd_conv_desc* d, const float* gy, const float* w, float* gx, hipStream_t st, const float* x_in = nullptr, int in_act = 0);
 // conv_stem.hip: the 7x7 stride-2 encoder stems (2..6 input channels) on a patch-staged MFMA kernel
 bool stem7_fwd_ok(const fd_conv_desc* d);
 int stem7_fwd_launch(const fd_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st);

@@ -118,6 +118,7 @@ struct WinoArgs {
     // (sum, sum of squares) over the 64 pixels of each (pixel tile, 32-pair half); needs tiles that do not straddle images
     float* stat_part;
     int stat_slots;
+    int img_tiles;       // k_conv_wino2p_dma: > 0 = tiles per image of the image-aligned tiling (statistics on planes of 32 k tiles)
 };
 
 // VDMA: the raw activation rows go from global memory straight into LDS (buffer_load_dwordx4 ... lds; needs W % 4 == 0 so that a
@@ -672,8 +673,8 @@ __device__ __forceinline__ void w2p_epilogue(const WinoArgs& g, const f32x16_w2p
         }
         const int rr = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
         const int m = mbase + (rr & 3) + 8 * (rr >> 2);
-        if (!(lane & 1) && m < g.M) {
-            const int n = p0 / plane2, tile = (p0 - n * plane2) / WBN;     // the whole tile lies in image n (launcher's guarantee)
+        const int n = p0 / plane2, tile = (p0 - n * plane2) / WBN;         // the whole tile lies in image n (launcher's guarantee)
+        if (!(lane & 1) && m < g.M && 2 * tile + wn < g.stat_slots) {      // (image-aligned tiling: the last tile's second half may be empty)
             f32x2 v; v.x = s1[0]; v.y = s2[0];
             *reinterpret_cast<f32x2*>(g.stat_part + (((size_t)n * g.M + m) * g.stat_slots + 2 * tile + wn) * 2) = v;
         }
@@ -912,7 +913,12 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
     int bx = blockIdx.x;
     const int by = blockIdx.y;
     if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
-    const int m0 = by * WBM, p0 = bx * WBN;
+    // g.img_tiles > 0: image-aligned tiling - workgroup bx is tile bx % img_tiles of image bx / img_tiles, so that no tile straddles
+    // two images (the BatchNorm partial sums are per image) although the image's tile count is not a multiple of 64; tiles past the
+    // image's last one (`lim`) are computed on whatever the loads return and never stored
+    const int m0 = by * WBM;
+    const int p0 = g.img_tiles > 0 ? (bx / g.img_tiles) * plane2 + (bx % g.img_tiles) * WBN : bx * WBN;
+    const int lim = g.img_tiles > 0 ? (bx / g.img_tiles + 1) * plane2 : Np;
     const int cpt = g.C / WBKC, nchunk = 4 * cpt;
     const bool refl = g.pad_mode == 1;
     const int a4 = tid & 3, ar = tid >> 2;
@@ -982,7 +988,7 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
     float ml, mr;
     {
         const int jp = 32 * wn + (lane & 31);
-        const int pp = p0 + jp < Np ? p0 + jp : 0;
+        const int pp = p0 + jp < lim ? p0 + jp : 0;
         const int rem = pp % plane2;
         const int jj = rem % W2;
         const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
@@ -1084,7 +1090,7 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (!(FD_W2P_ABLATE & 8)) __syncthreads();
         }
     }
-    w2p_epilogue<STATS>(g, ya, yb, p0, m0, Np, plane2, W2, hw, lane, wm, wn);
+    w2p_epilogue<STATS>(g, ya, yb, p0, m0, lim, plane2, W2, hw, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1380,7 +1386,12 @@ int wino_fwd_mode(const fd_conv_desc* d) {
     if (!wino_fwd_ok(d) || d->H % 2 != 0 || (long)d->Cout * 4 * d->Cin * 4 * 4 >= 2147483648L) return 0;
     const fd_tuning& t = fd_tun();
     const long wgs = (long)fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN) * fd_cdiv(d->Cout, WBM);
-    const bool deep = t.wino_fwd_2d_min > 0 && (long)d->Cin * d->Cout >= (long)t.wino_fwd_2d_min;
+    // (reflect padding = a ConvBlock of the depth decoder: these run ALONE on the main stream - decoder -> loss -> decoder is the step's
+    // serial section - where the stand-alone time decides, and there the slab kernel wins from 128 x 64 channels on:
+    // upconv(3,1) 77 against 113 us, upconv(2,1) 85 against 98 us, scripts/decoder_conv_time.py; the trunk's zero-padded layers run
+    // beside three other streams, where fewer matrix cycles per launch decide: k_conv_wino2p, -0.7 ms per step)
+    const long cc_min = d->pad_mode == 1 ? (t.wino_fwd_2d_min < 8192 ? t.wino_fwd_2d_min : 8192) : t.wino_fwd_2d_min;
+    const bool deep = t.wino_fwd_2d_min > 0 && (long)d->Cin * d->Cout >= cc_min;
     if (t.wino_fwd_2dp_min_wgs > 0 && wgs >= (long)t.wino_fwd_2dp_min_wgs && (!deep || t.wino_fwd_2dp_deep)) return 2;
     return deep ? 1 : 0;
 }
@@ -1422,7 +1433,9 @@ int wino_stat_slots(const fd_conv_desc* d) {
     if (mode == 1) return 0;
     if (mode == 2) {                                                       // slots of 32 tiles x 4 pixels
         const long tiles = (long)(d->H / 2) * (d->W / 2);
-        return tiles % WBN == 0 ? (int)(2 * tiles / WBN) : 0;
+        if (tiles % WBN == 0) return (int)(2 * tiles / WBN);
+        // half a tile left over per image (ResNet layer2 at 640x192: 480 tiles): the direct-to-LDS kernel tiles image by image
+        return (tiles % 32 == 0 && d->W % 4 == 0 && fd_tun().wino_fwd_2dp_dma != 0) ? (int)(tiles / 32) : 0;
     }
     const long plane2 = (long)d->H * (d->W / 2);
     if (plane2 % WBN != 0 || wino_splits(d, d->Cout, d->Cin) != 1) return 0;
@@ -1457,10 +1470,14 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         attr_set = true;
     }
     if (mode == 2) {
-        const int gx2 = fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN), gy2 = fd_cdiv(d->Cout, WBM);
+        const long img_tiles = (long)(d->H / 2) * (d->W / 2);
+        const bool aligned = stat_part && img_tiles % WBN != 0;             // statistics on a plane of 64 k + 32 tiles: tile image by image
+        const int gx2 = aligned ? d->N * fd_cdiv(img_tiles, WBN) : fd_cdiv((long)d->N * img_tiles, WBN), gy2 = fd_cdiv(d->Cout, WBM);
+        g.img_tiles = aligned ? fd_cdiv(img_tiles, WBN) : 0;
         g.xcd_swizzle = (gx2 % 8 == 0 && gx2 >= 16) ? 1 : 0;
         // direct-to-LDS activations need 16-byte pieces that stay inside one image row and a 16-byte aligned tensor
         const bool vdma = fd_tun().wino_fwd_2dp_dma != 0 && d->W % 4 == 0 && ((uintptr_t)x & 15) == 0;
+        if (aligned && !vdma) { fd_set_error("wino conv: the statistics epilogue of this shape needs a 16-byte aligned input"); return -1; }
         if (vdma) {
             if (stat_part) hipLaunchKernelGGL(k_conv_wino2p_dma<true>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
             else hipLaunchKernelGGL(k_conv_wino2p_dma<false>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);

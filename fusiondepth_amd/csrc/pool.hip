@@ -127,7 +127,16 @@ __global__ void __launch_bounds__(NT) k_upcat_fwd4(const float* __restrict__ a, 
     }
 }
 // two output pixels of ga per thread from two 16-byte pieces of gout
-__global__ void __launch_bounds__(NT) k_upcat_bwd_a2(const float* __restrict__ gout, float* __restrict__ ga, int N, int Ca, int Ct, int h, int w) {
+// derivative of the activation from its OUTPUT v (1 ReLU, 2 ELU(alpha=1), 3 sigmoid, 4 tanh), as k_act_bwd
+__device__ __forceinline__ float act_deriv(float v, int act) {
+    if (act == 1) return v > 0.f ? 1.f : 0.f;
+    if (act == 2) return v > 0.f ? 1.f : v + 1.f;
+    if (act == 3) return v * (1.f - v);
+    return 1.f - v * v;
+}
+// `a_out` != NULL: `a` is the OUTPUT of an activation whose producer expects the gradient w.r.t. its PRE-activation: ga *= act'(a)
+__global__ void __launch_bounds__(NT) k_upcat_bwd_a2(const float* __restrict__ gout, float* __restrict__ ga, int N, int Ca, int Ct, int h, int w,
+                                                     const float* __restrict__ a_out, int a_act) {
     const int H = 2 * h, W = 2 * w, w2 = w >> 1;
     PLANE_LOOP(pl, r, (long)N * Ca, h * w2) {
         const int y = r / w2, x = (r - y * w2) * 2;
@@ -137,6 +146,10 @@ __global__ void __launch_bounds__(NT) k_upcat_bwd_a2(const float* __restrict__ g
         const float4 t = *reinterpret_cast<const float4*>(g), u = *reinterpret_cast<const float4*>(g + W);
         float2 o;
         o.x = (t.x + t.y) + (u.x + u.y); o.y = (t.z + t.w) + (u.z + u.w);
+        if (a_out) {
+            const float2 av = *reinterpret_cast<const float2*>(a_out + pl * h * w + (long)y * w + x);
+            o.x *= act_deriv(av.x, a_act); o.y *= act_deriv(av.y, a_act);
+        }
         *reinterpret_cast<float2*>(ga + pl * h * w + (long)y * w + x) = o;
     }
 }
@@ -149,7 +162,7 @@ __global__ void __launch_bounds__(NT) k_slice_channels4(const float* __restrict_
     }
 }
 __global__ void __launch_bounds__(NT) k_upcat_bwd_a(const float* __restrict__ gout, float* __restrict__ ga, int N, int Ca,
-                                                    int Ct, int h, int w) {
+                                                    int Ct, int h, int w, const float* __restrict__ a_out, int a_act) {
     const int H = 2 * h, W = 2 * w;
     PLANE_LOOP(pl, r, (long)N * Ca, h * w) {
         const int y = r / w, x = r - y * w;
@@ -157,7 +170,9 @@ __global__ void __launch_bounds__(NT) k_upcat_bwd_a(const float* __restrict__ go
         const int c = (int)(pl - b * Ca);
         const long i = pl * h * w + r;
         const float* g = gout + ((b * Ct + c) * H + 2 * y) * W + 2 * x;
-        ga[i] = (g[0] + g[1]) + (g[W] + g[W + 1]);
+        float v = (g[0] + g[1]) + (g[W] + g[W + 1]);
+        if (a_out) v *= act_deriv(a_out[i], a_act);
+        ga[i] = v;
     }
 }
 __global__ void __launch_bounds__(NT) k_slice_channels(const float* __restrict__ src, float* __restrict__ dst, int N,
@@ -315,16 +330,17 @@ extern "C" int fd_upcat_fwd(const float* a, const float* s1, const float* s2, co
     FD_LAUNCH_CHECK("fd_upcat_fwd");
     return 0;
 }
-extern "C" int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, int N, int Ca, int Cs, int C3, int h,
-                            int w, void* stream) {
+static int upcat_bwd_impl(const float* gout, float* ga, float* gs, float* g3, int N, int Ca, int Cs, int C3, int h, int w, const float* a_out,
+                          int a_act, void* stream) {
     FD_REQUIRE(gout && N > 0 && Ca > 0 && h > 0 && w > 0, "fd_upcat_bwd: bad args");
     hipStream_t st = (hipStream_t)stream;
     const int Ct = Ca + Cs + C3;
     const long plane = 4L * h * w;
     const bool vec = w % 2 == 0 && (((uintptr_t)gout | (uintptr_t)ga | (uintptr_t)gs | (uintptr_t)g3) & 15) == 0;
     if (ga) {
-        if (vec) hipLaunchKernelGGL(k_upcat_bwd_a2, plane_grid((long)N * Ca, (long)h * (w / 2)), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w);
-        else hipLaunchKernelGGL(k_upcat_bwd_a, plane_grid((long)N * Ca, (long)h * w), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w);
+        const bool veca = vec && (!a_out || ((uintptr_t)a_out & 7) == 0);
+        if (veca) hipLaunchKernelGGL(k_upcat_bwd_a2, plane_grid((long)N * Ca, (long)h * (w / 2)), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w, a_out, a_act);
+        else hipLaunchKernelGGL(k_upcat_bwd_a, plane_grid((long)N * Ca, (long)h * w), dim3(NT), 0, st, gout, ga, N, Ca, Ct, h, w, a_out, a_act);
         FD_LAUNCH_CHECK("fd_upcat_bwd(a)");
     }
     if (gs && Cs > 0) {
@@ -338,6 +354,15 @@ extern "C" int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, 
         FD_LAUNCH_CHECK("fd_upcat_bwd(3)");
     }
     return 0;
+}
+extern "C" int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, int N, int Ca, int Cs, int C3, int h,
+                            int w, void* stream) {
+    return upcat_bwd_impl(gout, ga, gs, g3, N, Ca, Cs, C3, h, w, nullptr, 0, stream);
+}
+extern "C" int fd_upcat_bwd_act(const float* gout, const float* a_out, int a_act, float* ga, float* gs, float* g3, int N, int Ca, int Cs,
+                                int C3, int h, int w, void* stream) {
+    FD_REQUIRE(a_out && ga && a_act >= 1 && a_act <= 4, "fd_upcat_bwd_act: needs the activation output, ga and an activation id 1..4");
+    return upcat_bwd_impl(gout, ga, gs, g3, N, Ca, Cs, C3, h, w, a_out, a_act, stream);
 }
 extern "C" int fd_upsample2x_fwd(const float* x, float* y, long planes, int h, int w, void* stream) {
     FD_REQUIRE(x && y && planes > 0 && h > 0 && w > 0, "fd_upsample2x_fwd: bad args");

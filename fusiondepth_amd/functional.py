@@ -889,7 +889,7 @@ def _conv_backward(ctx, gy, gx_add=None):
     if gy is None:                   # only the tap was used downstream
         return (f32(gx_add) if gx_add is not None else None), None, None
     gy = f32(gy)
-    if d.act != 0:
+    if d.act != 0 and not getattr(ctx, "grad_preact", False):
         gpre = torch.empty_like(gy)
         call("fd_act_bwd", ptr(y), ptr(gy), ptr(gpre), gy.numel(), d.act, stream())
         gy = gpre
@@ -900,7 +900,11 @@ def _conv_backward(ctx, gy, gx_add=None):
         n_ws, n_wt = plan.data_sizes()
         ws = _empty((n_ws,), x)
         wt, ready = _weight_layout(w, ctx.cache_id, "d", n_wt, d)
-        if gx_add is not None and not d.in_norm:
+        in_act = getattr(ctx, "in_act", 0)
+        if in_act and gx_add is None and not d.in_norm:
+            # x is an activation output consumed by this layer alone: hand its producer the gradient w.r.t. the PRE-activation
+            call("fd_conv2d_bwd_data_inact", dp, ptr(gy), ptr(w), ptr(x), in_act, ptr(gx), ptr(wt), ready, ptr(ws), stream())
+        elif gx_add is not None and not d.in_norm:
             call("fd_conv2d_bwd_data_add", dp, ptr(gy), ptr(w), ptr(f32(gx_add)), ptr(gx), ptr(wt), ready, ptr(ws), stream())
         else:
             call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(w), ptr(gx), ptr(wt), ready, ptr(ws), stream())
@@ -971,12 +975,13 @@ def _wgrad_stream():
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm):
+    def forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm, grad_preact=False, in_act=0):
+        ctx.grad_preact, ctx.in_act = bool(grad_preact), int(in_act)
         return _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm)[1]
 
     @staticmethod
     def backward(ctx, gy):
-        return _conv_backward(ctx, gy) + (None, None, None, None, None)
+        return _conv_backward(ctx, gy) + (None, None, None, None, None, None, None)
 
 
 _NO_STATS = {}
@@ -1083,9 +1088,17 @@ def input_normalize(x, mean=0.45, std=0.225):
     return _InputNormalize.apply(x, mean, std)
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", in_norm=False):
+def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", in_norm=False, grad_preact=False, in_act="none"):
     """act(conv2d(pad(x)) + bias) on the MFMA implicit-GEMM kernels; ``in_norm`` folds the encoder's
-    (x-0.45)/0.225 into the tap loads (resnet_encoder.py:94)."""
+    (x-0.45)/0.225 into the tap loads (resnet_encoder.py:94).
+
+    A contract between a layer with an activation and the ONE consumer of its output, so that ``act'`` is applied where the
+    gradient is produced instead of in an element-wise pass of its own (the depth decoder sets both ends, networks/depth_decoder.py):
+    ``grad_preact``: the gradient this call receives already is the gradient w.r.t. its pre-activation (its consumer multiplied by
+    act'(y) - ``upsample_concat(..., a_act=)`` or a ``conv2d(..., in_act=)``); ``in_act``: ``x`` is the output of that activation
+    and feeds this call alone - the data gradient returned is multiplied by act'(x)."""
+    if (grad_preact or ACT[in_act]) and torch.is_grad_enabled():
+        return _Conv2d.apply(x, weight, bias, int(stride), int(pad), PAD_MODE[pad_mode], ACT[act], bool(in_norm), bool(grad_preact), ACT[in_act])
     return _Conv2d.apply(x, weight, bias, int(stride), int(pad), PAD_MODE[pad_mode], ACT[act], bool(in_norm))
 
 
@@ -1221,8 +1234,11 @@ def max_pool3x3s2(x):
 
 class _UpCat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, s1, s2, s3):
+    def forward(ctx, a, s1, s2, s3, a_act=0):
         a = f32(a)
+        ctx.a_act = int(a_act)
+        if ctx.a_act:
+            ctx.save_for_backward(a)
         _need_cuda(a)
         N, Ca, h, w = a.shape
         s1 = f32(s1) if s1 is not None else None
@@ -1244,16 +1260,23 @@ class _UpCat(torch.autograd.Function):
         ga = _empty((N, Ca, h, w), g) if ctx.needs_input_grad[0] else None
         gs = _empty((N, Cs, 2 * h, 2 * w), g) if need_s else None
         g3 = _empty((N, C3, 2 * h, 2 * w), g) if ctx.has[2] and ctx.needs_input_grad[3] else None
-        call("fd_upcat_bwd", ptr(g), ptr(ga), ptr(gs), ptr(g3), N, Ca, Cs, C3, h, w, stream())
+        if ctx.a_act and ga is not None:
+            (a_out,) = ctx.saved_tensors
+            call("fd_upcat_bwd_act", ptr(g), ptr(a_out), ctx.a_act, ptr(ga), ptr(gs), ptr(g3), N, Ca, Cs, C3, h, w, stream())
+        else:
+            call("fd_upcat_bwd", ptr(g), ptr(ga), ptr(gs), ptr(g3), N, Ca, Cs, C3, h, w, stream())
         # skip and skip_add come from encoders that run their backward on DIFFERENT streams.  Handing both the same tensor is
         # a race: autograd may accumulate a second incoming gradient into it in place on one stream while the other stream's
         # kernels still read it (seen as run-to-run different encoder gradients under GPU contention).  One owner each.
         both = ctx.has[0] and ctx.has[1] and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
-        return ga, gs if ctx.has[0] else None, (gs.clone() if both else gs) if ctx.has[1] else None, g3
+        return ga, gs if ctx.has[0] else None, (gs.clone() if both else gs) if ctx.has[1] else None, g3, None
 
 
-def upsample_concat(a, skip=None, skip_add=None, extra=None):
-    """cat([nearest_up2(a), skip (+ skip_add), extra], 1)  — depth_decoder.py:75-83 in one pass."""
+def upsample_concat(a, skip=None, skip_add=None, extra=None, a_act="none"):
+    """cat([nearest_up2(a), skip (+ skip_add), extra], 1)  — depth_decoder.py:75-83 in one pass.  ``a_act``: ``a`` is the output of
+    that activation, produced by a ``conv2d(..., grad_preact=True)`` and consumed here alone: its gradient is returned times act'(a)."""
+    if ACT[a_act] and torch.is_grad_enabled() and a.requires_grad:
+        return _UpCat.apply(a, skip, skip_add, extra, ACT[a_act])
     return _UpCat.apply(a, skip, skip_add, extra)
 
 

@@ -45,9 +45,11 @@ class ConvBlock(nn.Module):
         super().__init__()
         self.conv = Conv3x3(in_channels, out_channels)
 
-    def forward(self, x):
+    def forward(self, x, grad_preact=False):
+        """``grad_preact``: the caller guarantees that the ONE consumer of the result returns the gradient w.r.t. this block's
+        pre-activation (FD.conv2d: the ELU' pass then runs inside that consumer's backward kernel)."""
         c = self.conv.conv
-        return FD.conv2d(x, c.weight, c.bias, stride=1, pad=1, pad_mode="reflect", act="elu")
+        return FD.conv2d(x, c.weight, c.bias, stride=1, pad=1, pad_mode="reflect", act="elu", grad_preact=grad_preact)
 
 
 class BackprojectDepth(nn.Module):

@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as FD
+from .. import tuning
 from ..layers import Conv3x3, ConvBlock
 
 
@@ -61,9 +62,9 @@ class DepthDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     @staticmethod
-    def _disp(conv3x3, x, act):
+    def _disp(conv3x3, x, act, in_act="none"):
         c = conv3x3.conv
-        return FD.conv2d(x, c.weight, c.bias, stride=1, pad=1, pad_mode="reflect" if conv3x3.use_refl else "zero", act=act)
+        return FD.conv2d(x, c.weight, c.bias, stride=1, pad=1, pad_mode="reflect" if conv3x3.use_refl else "zero", act=act, in_act=in_act)
 
     def forward(self, input_features, two_channel=None, beam_features=None, depth_maps=None, tanh=False):
         self.outputs = {}
@@ -71,8 +72,14 @@ class DepthDecoder(nn.Module):
             x = FD.add(input_features[-1], beam_features[-1])
         else:
             x = input_features[-1]
+        # ELU' where the gradient is produced (FD.conv2d's grad_preact / in_act contract): upconv(i, 0) feeds the concatenation only,
+        # and the full-resolution upconv(0, 1) feeds dispconv(0) only - their element-wise ELU-backward passes (0.15 ms of the step's
+        # serial decoder -> loss -> decoder section) ride in fd_upcat_bwd_act / in the disparity head's data-gradient stencil
+        fuse = torch.is_grad_enabled() and tuning.host.decoder_fused_act
         for i in range(4, -1, -1):
-            x = self.convs[("upconv", i, 0)](x)
+            blk0 = self.convs[("upconv", i, 0)]
+            pre0 = fuse and isinstance(blk0, ConvBlock)
+            x = blk0(x, grad_preact=True) if pre0 else blk0(x)
             skip = skip_add = extra = None
             if self.use_skips and i > 0:
                 skip = input_features[i - 1]
@@ -80,9 +87,13 @@ class DepthDecoder(nn.Module):
                     skip_add = beam_features[i - 1]
             if depth_maps is not None and i in self.scales and self.use_skips:
                 extra = depth_maps[("disp", i)]
-            x = FD.upsample_concat(x, skip, skip_add, extra)
-            x = self.convs[("upconv", i, 1)](x)
-            if i in self.scales:
+            x = FD.upsample_concat(x, skip, skip_add, extra, a_act="elu" if pre0 else "none")
+            blk1 = self.convs[("upconv", i, 1)]
+            pre1 = fuse and i == 0 and i in self.scales and not self.cat2end and isinstance(blk1, ConvBlock)
+            x = blk1(x, grad_preact=True) if pre1 else blk1(x)
+            if pre1:
+                self.outputs[("disp", i)] = self._disp(self.convs[("dispconv", i)], x, "tanh" if tanh else "sigmoid", in_act="elu")
+            elif i in self.scales:
                 if i == 0 and self.cat2end:
                     self.outputs[("disp", i)] = self._disp(self.convs[("dispconv", i)], torch.cat((x, two_channel), 1),
                                                            "sigmoid")

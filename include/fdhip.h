@@ -307,6 +307,13 @@ int fd_conv2d_bwd_data(const fd_conv_desc* d, const float* gy, const float* w, f
  * data-gradient kernel instead of costing an element-wise pass over both tensors.  Bitwise the sum torch would form. */
 int fd_conv2d_bwd_data_add(const fd_conv_desc* d, const float* gy, const float* w, const float* gx_add, float* gx, float* wt,
                            int wt_ready, float* ws, void* stream);
+/* gx = (data gradient as above) * act'(x_in): for a layer whose INPUT x_in is the output of activation in_act (1 ReLU, 2 ELU, 3 sigmoid,
+ * 4 tanh) and is consumed by this layer alone, the result is the gradient w.r.t. the producer's PRE-activation - what fd_act_bwd
+ * would compute from gx in a separate pass over the tensor (layers.py:100-112 ConvBlock -> networks/depth_decoder.py:92 dispconv:
+ * the full-resolution ELU output feeds the disparity head only).  Fused into the store of the one-output-channel stencil; the other
+ * kernel families run the data gradient followed by the element-wise pass (same result). */
+int fd_conv2d_bwd_data_inact(const fd_conv_desc* d, const float* gy, const float* w, const float* x_in, int in_act, float* gx, float* wt,
+                             int wt_ready, float* ws, void* stream);
 /* gw [Cout,Cin,KH,KW], gbias [Cout] (NULL to skip).  accumulate != 0: gw += / gbias += (gradient accumulation straight
  * into the caller's buffers).  ws: fd_conv2d_bwd_weight_ws_floats(d) floats. */
 long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d);
@@ -349,6 +356,10 @@ int fd_upcat_fwd(const float* a, const float* s1, const float* s2, const float* 
 /* ga [N,Ca,h,w] (2x2 sums), gs [N,Cs,2h,2w] (shared by s1 and s2), g3 [N,C3,2h,2w]; each may be NULL. */
 int fd_upcat_bwd(const float* gout, float* ga, float* gs, float* g3, int N, int Ca, int Cs, int C3, int h, int w,
                  void* stream);
+/* The same with ga *= act'(a_out): `a` was the output of activation a_act (layers.py:100-112 ConvBlock, upconv(i, 0)) and feeds this
+ * concatenation only, so ga is the gradient w.r.t. that layer's PRE-activation (no separate fd_act_bwd pass). */
+int fd_upcat_bwd_act(const float* gout, const float* a_out, int a_act, float* ga, float* gs, float* g3, int N, int Ca, int Cs, int C3,
+                     int h, int w, void* stream);
 /* layers.py:229-232 upsample (nearest x2) alone */
 int fd_upsample2x_fwd(const float* x, float* y, long planes, int h, int w, void* stream);
 int fd_upsample2x_bwd(const float* gy, float* gx, long planes, int h, int w, void* stream);

@@ -574,10 +574,10 @@ def test_conv_epilogue_statistics_feed_batchnorm(FD, N, Cin, Cout, H, W, G, res,
     launch) == fd_conv2d_fwd + fd_bn_train_fwd (statistics pass + apply pass), and both == torch's conv2d + BatchNorm2d in float64:
     outputs, running statistics after the grouped in-order updates, and every gradient.  Reference ops: torchvision BasicBlock
     (conv3x3 -> BatchNorm2d -> [+ identity] -> ReLU) as driven by networks/resnet_encoder.py:95-101."""
-    # kern: "1d" = k_conv_wino (slots of 64 pixels), "2p" = k_conv_wino2p (slots of 32 2x2 tiles = 128 pixels; planes whose tile
-    # count is not a multiple of 64 - the 24x80 case - have no statistics epilogue there: the BatchNorm makes its own pass)
+    # kern: "1d" = k_conv_wino (slots of 64 pixels), "2p" = k_conv_wino2p (slots of 32 2x2 tiles = 128 pixels; a plane whose tile count
+    # is 64 k + 32 - the 24x80 case, ResNet layer2 at 640x192 - is tiled image by image, its last tile half empty)
     fdtune.lib(wino_fwd_2dp_min_wgs=1 if kern == "2p" else 0)
-    slots = 2 * (H * W // 2) // 64 if kern == "1d" else (2 * (H * W // 4) // 64 if (H * W // 4) % 64 == 0 else None)
+    slots = 2 * (H * W // 2) // 64 if kern == "1d" else ((H * W // 4) // 32 if (H * W // 4) % 32 == 0 else None)
     rng = np.random.RandomState(N * 1000 + Cin)
     x = torch.from_numpy((rng.randn(N, Cin, H, W) + 0.5).astype(np.float32))
     w = torch.from_numpy((rng.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32))
