@@ -99,10 +99,12 @@ def roofline_probes(args, tr, batch):
     from fusiondepth_amd import functional as FD
     out = {}
     B = tr.batch_size
-    # dominant kernel: the 3x3 stride-1 convolutions of the ResNet trunks (k_conv_wino, the 1-D Winograd F(2,3) MFMA kernel).
+    # dominant kernel: the 3x3 stride-1 convolutions of the ResNet trunks - since round 4 k_conv_wino2p_dma, F(2x2, 3x3) with all 16
+    # components in one workgroup (17 % of the step's kernel time, the largest single kernel; rounds 1-3: k_conv_wino, F(2, 3) along x).
     # Probe = layer1's 64->64 conv at H/4 x W/4, forward (the data-gradient launch is the same kernel with transformed flipped
     # weights).  `achieved` divides the ALGORITHMIC flops of the convolution (2*Cout*Cin*9 per output pixel) by the
-    # launch time; the kernel itself issues 2/3 of them as MFMA work (6 multiplies per output instead of 9), `mfma_flop_per_launch`.
+    # launch time; the kernel itself issues 4/9 of them as MFMA work (16 multiplies per 2x2 outputs instead of 36),
+    # `mfma_flop_per_launch` - so `frac` is a Winograd fraction, the matrix-pipe utilisation is `mfma_pipe_frac`.
     # In the training step four such streams run concurrently; the probe runs alone.
     h8, w8 = args.height // 4, args.width // 4
     Bc = B * (tr.accumulate_step if tr.stack_microbatches else 1)      # what the step launches: the stacked micro-batches
@@ -115,7 +117,10 @@ def roofline_probes(args, tr, batch):
     # HBM bytes per launch: rocprofv3 --pmc passes cannot run inside this process, so the number comes from the committed passes of
     # this exact kernel and shape (scripts/pmc_probe.sh) - and only while the kernel source is the one that was profiled.
     traffic, traffic_src = None, None
-    for name in ("round3_pmc_probe_wino.json", "round2_pmc_probe_wino.json"):
+    from fusiondepth_amd import tuning as _tuning
+    two_p = _tuning.get_lib()["wino_fwd_2dp_min_wgs"] > 0 and Bc * (h8 // 2) * (w8 // 2) // 64 >= _tuning.get_lib()["wino_fwd_2dp_min_wgs"] and h8 % 2 == 0
+    executed = 4.0 / 9.0 if two_p else 2.0 / 3.0
+    for name in ("round4_pmc_probe_wino.json", "round3_pmc_probe_wino.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -130,12 +135,14 @@ def roofline_probes(args, tr, batch):
             break
         traffic, traffic_src = pmc["traffic_bytes_per_launch"], name
         break
-    out["roofline"] = {"bound": "mfma", "kernel": "k_conv_wino (ResNet layer1 conv 3x3 64->64 @%dx%d, batch %d = the "
-                       "stacked micro-batches, alone on the GPU; Winograd F(2,3): algorithmic flops, 2/3 of them executed)" % (h8, w8, Bc),
+    out["roofline"] = {"bound": "mfma", "kernel": "%s (ResNet layer1 conv 3x3 64->64 @%dx%d, batch %d = the stacked micro-batches, alone on the "
+                       "GPU; Winograd %s: algorithmic flops, %s of them executed)"
+                       % ("k_conv_wino2p_dma" if two_p else "k_conv_wino", h8, w8, Bc, "F(2x2,3x3)" if two_p else "F(2,3)", "4/9" if two_p else "2/3"),
                        "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                        "frac": flops / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                        "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/%s)" % traffic_src,
-                       "us_per_launch": ms * 1e3, "flop_per_launch": flops, "mfma_flop_per_launch": flops * 2.0 / 3.0}
+                       "us_per_launch": ms * 1e3, "flop_per_launch": flops, "mfma_flop_per_launch": flops * executed,
+                       "mfma_pipe_frac": flops * executed / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
     # fused loss path: the multi-scale kernel (forward + gradients of the four scales in one launch) at the batch the step
     # launches (stacked micro-batches, SI-log statistics per micro-batch).  Reported against the HBM roofline as the north star
     # asks; the kernel is bound by VALU issue (profiles/round2_pmc_loss.md), not by HBM.
@@ -163,7 +170,7 @@ def roofline_probes(args, tr, batch):
     loss_traffic, loss_traffic_src = None, None
     sha = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fusiondepth_amd", "csrc",
                                            "photometric_ms.hip"), "rb").read()).hexdigest()
-    for name in ("round3_pmc_loss.json", "round2_pmc_loss.json"):
+    for name in ("round4_pmc_loss.json", "round3_pmc_loss.json", "round2_pmc_loss.json"):
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         if not os.path.exists(pmc_path):
             continue

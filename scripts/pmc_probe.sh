@@ -25,7 +25,9 @@ for i in (1, 2, 3, 4):
         rows = [r for r in csv.DictReader(open(f)) if "k_conv_wino" in r["Kernel_Name"]]
         dur += [(float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3 for r in rows][2:]
 m = {c: sum(v) / len(v) for c, v in acc.items()}
-out = {"kernel": "k_conv_wino<true> (activations through direct-to-LDS loads) layer1 3x3 64->64 @48x160 batch 12 (scripts/probe_layer1.py)",
+names = sorted({r["Kernel_Name"].split("(")[0] for i in (1, 2, 3, 4) for f in glob.glob("/tmp/pp_%d/**/*kernel_trace.csv" % i, recursive=True)
+                for r in csv.DictReader(open(f)) if "k_conv_wino" in r["Kernel_Name"]})
+out = {"kernel": "%s: layer1 3x3 64->64 @48x160 batch 12 (scripts/probe_layer1.py)" % ", ".join(names),
        "collected": "rocprofv3 --pmc <one group per pass> --kernel-trace (scripts/pmc_probe.sh), mean of %d launches after 2 warm-up launches" % len(acc.get("FETCH_SIZE", [])),
        "source_sha256": hashlib.sha256(open("$R/fusiondepth_amd/csrc/conv_wino.hip", "rb").read()).hexdigest(),
        "FETCH_SIZE_KB": m.get("FETCH_SIZE"), "WRITE_SIZE_KB": m.get("WRITE_SIZE"), "fetch_correction": 2.0,
