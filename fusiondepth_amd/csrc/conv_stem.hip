@@ -48,14 +48,29 @@ __global__ void __launch_bounds__(ST_NT) k_conv7s2_stem(StemArgs a) {
     const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
     const int C = a.C;
 
-    // ---- weights: flat OIHW read (coalesced), scattered to [k = (cp, t)][parity][m]
+    // ---- weights: flat OIHW read (coalesced), scattered to [k = (cp, t)][parity][m]; input patch, de-interleaved by column parity
+    //      (out-of-image elements and the padding channel are zeros).  Both in batches of 8 independent loads per thread (the loop
+    //      with one load -> one LDS store per trip serialised ~35 memory latencies per workgroup: 23 us of a 54 us workgroup)
     {
+        const __amdgpu_buffer_rsrc_t rsW = fd_make_rsrc(a.Wt);
         const int total = 64 * C * 49;
-        for (int f = tid; f < total; f += ST_NT) {
-            const int m = f / (C * 49);
-            const int r = f - m * (C * 49);
-            const int c = r / 49, t = r - c * 49;
-            Wl[(((c >> 1) * 49 + t) * 2 + (c & 1)) * ST_LDW + m] = a.Wt[f];
+        for (int f0 = tid; f0 < total; f0 += 8 * ST_NT) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = f0 + u * ST_NT;
+                v[u] = fd_ldg32(rsW, f < total ? 4u * (unsigned)f : FD_OOB);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int f = f0 + u * ST_NT;
+                if (f < total) {
+                    const int m = f / (C * 49);
+                    const int r = f - m * (C * 49);
+                    const int c = r / 49, t = r - c * 49;
+                    Wl[(((c >> 1) * 49 + t) * 2 + (c & 1)) * ST_LDW + m] = v[u];
+                }
+            }
         }
         if (C & 1) {                                            // the padding channel of the last pair
             for (int f = tid; f < 49 * 64; f += ST_NT) {
@@ -63,19 +78,25 @@ __global__ void __launch_bounds__(ST_NT) k_conv7s2_stem(StemArgs a) {
                 Wl[(((CP - 1) * 49 + t) * 2 + 1) * ST_LDW + m] = 0.f;
             }
         }
-    }
-    // ---- input patch, de-interleaved by column parity; out-of-image elements and the padding channel are zeros
-    {
-        const float* xn = a.X + (size_t)n * C * a.H * a.W;
-        const int per_c = ST_PR * ST_PW, total = 2 * CP * per_c;
-        for (int e = tid; e < total; e += ST_NT) {
-            const int c = e / per_c;
-            const int r2 = e - c * per_c;
-            const int r = r2 / ST_PW, j = r2 - r * ST_PW;
-            const int iy = iy0 + r, ix = ix0 + j;
-            float v = 0.f;
-            if (c < C && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = xn[((size_t)c * a.H + iy) * a.W + ix];
-            patch[((c * ST_PR + r) * 2 + (j & 1)) * ST_PC2 + (j >> 1)] = v;
+        const __amdgpu_buffer_rsrc_t rsX = fd_make_rsrc(a.X + (size_t)n * C * a.H * a.W);
+        const int per_c = ST_PR * ST_PW, totp = 2 * CP * per_c;
+        for (int e0 = tid; e0 < totp; e0 += 8 * ST_NT) {
+            float v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * ST_NT;
+                const int c = e / per_c;
+                const int r2 = e - c * per_c;
+                const int r = r2 / ST_PW, j = r2 - r * ST_PW;
+                const int iy = iy0 + r, ix = ix0 + j;
+                const bool in = e < totp && c < C && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                v[u] = fd_ldg32(rsX, in ? 4u * (unsigned)((c * a.H + iy) * a.W + ix) : FD_OOB);       // out of range reads 0
+                dst[u] = e < totp ? ((c * ST_PR + r) * 2 + (j & 1)) * ST_PC2 + (j >> 1) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (dst[u] >= 0) patch[dst[u]] = v[u];
         }
     }
     __syncthreads();
