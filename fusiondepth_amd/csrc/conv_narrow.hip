@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) k_wgrad_stem(NarrowWgradArgs g) {
     float* sY = smem + C * SXCS;               // [64][SYS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const __amdgpu_buffer_rsrc_t rsX = fd_make_rsrc(g.X), rsY = fd_make_rsrc(g.dY);
+    const __amdgpu_buffer_rsrc_t rsXs = fd_make_rsrc(g.X - (3 * g.W + 3)), rsY = fd_make_rsrc(g.dY);
     const int Ho = (g.H + 6 - 7) / 2 + 1, Wo = (g.W + 6 - 7) / 2 + 1;
     const int tiles_x = (Wo + STW - 1) / STW, tiles_y = (Ho + STH - 1) / STH;
     const int tiles_per_img = tiles_x * tiles_y;
@@ -199,51 +199,61 @@ __global__ void __launch_bounds__(256) k_wgrad_stem(NarrowWgradArgs g) {
     // B operand of column n = li: tap row parity li >> 3, tap column li & 7 (column 7 and row 7 are padding, never stored)
     const int boff = (li >> 3) * SXRS + (li & 7) + 2 * lk;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
+    // Software pipeline over the workgroup's tiles: the global loads of tile t + 1 (patch + all of dY: NXI + 32 registers) are issued
+    // in front of the MFMA loop of tile t and written to LDS behind it.  (Round 3 loaded, stored and computed one tile after the
+    // other and left the overlap to the second workgroup of the CU: 45 % of the matrix floor, the 2- and 3-channel stems bound by
+    // the load phase.)
+    // Thread -> element maps with ONE vector offset per operand and tile: dY element (row 2 it + hi, pixel tid & 127), patch element
+    // (channel c, row 2 k + hi, column tid & 127 < 69); everything that varies with it / (c, k) is a wave-uniform scalar offset of the
+    // buffer load resp. an immediate of the LDS store.  (With the flat index tid + 256 it decomposed per load, hipcc hoisted 53
+    // offsets + masks out of the tile loop: 365 registers for six channels.)
+    constexpr int NYI = 64 * STH * STW / 256, NXK = (SPR + 1) / 2;
+    float vx[C][NXK], vy[NYI];
+    const int hi = tid >> 7, q7 = tid & 127;
+    const int qy = q7 >> 5, qx = q7 & 31;
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        const bool live = tile < ntiles;
+        const int tl = live ? tile : 0;
+        const int n = tl / tiles_per_img, r = tl - n * tiles_per_img;
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const int y0 = ty * STH, x0 = tx * STW;                 // output coordinates
         const int iy0 = 2 * y0 - 3, ix0 = 2 * x0 - 3;           // input coordinates of the patch origin
-        __syncthreads();
-        constexpr int NXI = (C * SPR * SPC + 255) / 256, NYI = 64 * STH * STW / 256;
-        float vx[NXI];
+        const int xx = ix0 + q7;
+        const bool colok = live & (q7 < SPC) & ((unsigned)xx < (unsigned)g.W);
+        // rsXs starts 3 rows + 3 pixels in front of X, so the offset of (row iy0 + hi, column xx) is never negative (a wrapped
+        // offset would fail the range check for the rows 2 k below it that ARE inside the image)
+        const unsigned xb = 4u * ((unsigned)(n * C) * hw + (unsigned)((iy0 + hi + 3) * g.W + xx + 3));
 #pragma unroll
-        for (int it = 0; it < NXI; ++it) {
-            const int i = tid + it * 256;
-            const int c = i / (SPR * SPC), q = i - c * (SPR * SPC);
-            const int pr = q / SPC, pc = q - pr * SPC;
-            const int yy = iy0 + pr, xx = ix0 + pc;
-            const bool in = (i < C * SPR * SPC) & ((unsigned)yy < (unsigned)g.H) & ((unsigned)xx < (unsigned)g.W);
-            vx[it] = fd_ldg32(rsX, in ? 4u * (((unsigned)(n * C + c)) * hw + (unsigned)(yy * g.W + xx)) : FD_OOB);
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int k = 0; k < NXK; ++k) {
+                const int yy = iy0 + hi + 2 * k;
+                const bool in = colok & ((unsigned)yy < (unsigned)g.H) & (2 * k + hi < SPR);
+                vx[c][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsXs, (int)(in ? xb : FD_OOB), (int)(4u * ((unsigned)c * hw + (unsigned)(2 * k * g.W))), 0));
+            }
+        const bool ok = live & (y0 + qy < Ho) & (x0 + qx < Wo);
+        const unsigned yb = 4u * (((unsigned)(n * g.M + hi)) * howo + (unsigned)((y0 + qy) * Wo + x0 + qx));
+#pragma unroll
+        for (int it = 0; it < NYI; ++it)
+            vy[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, (int)((ok & (2 * it + hi < g.M)) ? yb : FD_OOB), (int)(4u * 2u * (unsigned)it * howo), 0));
+    };
+    auto stage = [&]() __attribute__((always_inline)) {
+        if (q7 < SPC) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int k = 0; k < NXK; ++k)
+                    if (2 * k + hi < SPR) sX[c * SXCS + (2 * k + hi) * SXRS + q7] = vx[c][k];
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                            // dY in two halves of 16 loads (bounds the registers)
-            float vy[NYI / 2];
-#pragma unroll
-            for (int it = 0; it < NYI / 2; ++it) {
-                const int i = tid + (h * (NYI / 2) + it) * 256;
-                const int m = i / (STH * STW), p = i - m * (STH * STW);
-                const int py = p / STW, px = p - py * STW;
-                const bool ok = (m < g.M) & (y0 + py < Ho) & (x0 + px < Wo);
-                vy[it] = fd_ldg32(rsY, ok ? 4u * (((unsigned)(n * g.M + m)) * howo + (unsigned)((y0 + py) * Wo + x0 + px)) : FD_OOB);
-            }
-            if (h == 0) {
-#pragma unroll
-                for (int it = 0; it < NXI; ++it) {
-                    const int i = tid + it * 256;
-                    const int c = i / (SPR * SPC), q = i - c * (SPR * SPC);
-                    const int pr = q / SPC, pc = q - pr * SPC;
-                    if (i < C * SPR * SPC) sX[c * SXCS + pr * SXRS + pc] = vx[it];
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < NYI / 2; ++it) {
-                const int i = tid + (h * (NYI / 2) + it) * 256;
-                const int m = i / (STH * STW), p = i - m * (STH * STW);
-                sY[m * SYS + p] = vy[it];
-            }
-        }
+        for (int it = 0; it < NYI; ++it) sY[(2 * it + hi) * SYS + q7] = vy[it];
+    };
+    fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                        // the previous tile's operand reads are done
+        stage();
         __syncthreads();
+        fetch(tile + gridDim.x);                                // in flight during the MFMA loop below
         const float* pa = sY + (wave * 16 + li) * SYS + lk;
 #pragma unroll 1
         for (int py = 0; py < STH; ++py) {

@@ -323,8 +323,8 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& g) {
         const int jj = rem % W2;
         const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
         o12 = 4 + 2 * jp;
-        o0 = (le && refl) ? o12 + 1 : o12 - 1;
-        o3 = (re && refl) ? o12 : o12 + 2;
+        o0 = (le && refl) ? o12 : o12 - 2;       // 8-byte cell whose .y is d0 (reflection: column -1 is column 1 = d12.y)
+        o3 = (re && refl) ? o12 : o12 + 2;       // 8-byte cell whose .x is d3 (reflection: column W is column W - 2 = d12.x)
         ml = (le && !refl) ? 0.f : 1.f;
         mr = (re && !refl) ? 0.f : 1.f;
     }
@@ -388,14 +388,14 @@ __device__ __forceinline__ void conv_wino_body(const WinoArgs& g) {
             const float* pr = smem + cur * W_BUF_FLOATS + 4 * WBKC * LDU + arow * LDR;
             float av[2][4], bv[2][4];
             auto read_a = [&](int nb, int k2, int t) __attribute__((always_inline)) { av[nb][t] = pa[t * WBKC * LDU + k2 * LDU]; };
-            f32x2 d12;
-            float d0, d3;
-            auto read_b = [&](int k2) __attribute__((always_inline)) {
+            f32x2 d12, dl, dr;                                           // three 8-byte reads (conflict-free at stride 8 over a half-wave;
+            auto read_b = [&](int k2) __attribute__((always_inline)) {   // the 4-byte reads of d0 / d3 at stride 8 were 2-way bank conflicts)
                 d12 = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o12);
-                d0 = pr[k2 * LDR + o0]; d3 = pr[k2 * LDR + o3];
+                dl = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o0); dr = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o3);
             };
             auto xform_b = [&](int nb) __attribute__((always_inline)) {   // (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-                bv[nb][0] = fmaf(d0, ml, -d12.y); bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = fmaf(-d3, mr, d12.x);
+                asm volatile("" : "+v"(dl), "+v"(dr));                   // both halves live: keeps the reads 8 bytes wide
+                bv[nb][0] = fmaf(dl.y, ml, -d12.y); bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = fmaf(-dr.x, mr, d12.x);
             };
 #pragma unroll
             for (int t = 0; t < 4; ++t) read_a(0, 0, t);
@@ -790,8 +790,8 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int jj = rem % W2;
         const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
         o12 = 4 + 2 * jp;
-        o0 = (le && refl) ? o12 + 1 : o12 - 1;
-        o3 = (re && refl) ? o12 : o12 + 2;
+        o0 = (le && refl) ? o12 : o12 - 2;       // 8-byte cell whose .y is d0 (reflection: column -1 is column 1 = d12.y)
+        o3 = (re && refl) ? o12 : o12 + 2;       // 8-byte cell whose .x is d3 (reflection: column W is column W - 2 = d12.x)
         ml = (le && !refl) ? 0.f : 1.f;
         mr = (re && !refl) ? 0.f : 1.f;
     }
@@ -831,14 +831,14 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
             const float* pr = smem + cur * W_BUF_FLOATS + 4 * WBKC * LDU + arow * LDR;
             float av[2][4], bv[2][4];
             auto read_a = [&](int nb, int k2, int t) __attribute__((always_inline)) { av[nb][t] = pa[t * WBKC * LDU + k2 * LDU]; };
-            f32x2 d12;
-            float d0, d3;
-            auto read_b = [&](int k2) __attribute__((always_inline)) {
+            f32x2 d12, dl, dr;                                           // three 8-byte reads (conflict-free at stride 8 over a half-wave;
+            auto read_b = [&](int k2) __attribute__((always_inline)) {   // the 4-byte reads of d0 / d3 at stride 8 were 2-way bank conflicts)
                 d12 = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o12);
-                d0 = pr[k2 * LDR + o0]; d3 = pr[k2 * LDR + o3];
+                dl = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o0); dr = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o3);
             };
             auto xform_b = [&](int nb) __attribute__((always_inline)) {
-                bv[nb][0] = fmaf(d0, ml, -d12.y); bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = fmaf(-d3, mr, d12.x);
+                asm volatile("" : "+v"(dl), "+v"(dr));                   // both halves live: keeps the reads 8 bytes wide
+                bv[nb][0] = fmaf(dl.y, ml, -d12.y); bv[nb][1] = d12.x + d12.y; bv[nb][2] = d12.y - d12.x; bv[nb][3] = fmaf(-dr.x, mr, d12.x);
             };
 #pragma unroll
             for (int t = 0; t < 4; ++t) read_a(0, 0, t);
@@ -993,8 +993,8 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int jj = rem % W2;
         const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
         o12 = 4 + 2 * jp;
-        o0 = (le && refl) ? o12 + 1 : o12 - 1;
-        o3 = (re && refl) ? o12 : o12 + 2;
+        o0 = (le && refl) ? o12 : o12 - 2;       // 8-byte cell whose .y is d0 (reflection: column -1 is column 1 = d12.y)
+        o3 = (re && refl) ? o12 : o12 + 2;       // 8-byte cell whose .x is d3 (reflection: column W is column W - 2 = d12.x)
         ml = (le && !refl) ? 0.f : 1.f;
         mr = (re && !refl) ? 0.f : 1.f;
     }
@@ -1029,18 +1029,22 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
             asm volatile("" : "+v"(sgn));                            // in a VGPR: an SGPR operand halves the VALU rate on gfx950
             const float* pa = smem + cur * W2D_BUF_FLOATS + arow * LDU + 32 * wm + acol;
             const float* pr = smem + cur * W2D_BUF_FLOATS + 4 * WBKC * LDU + arow * LDR;
+            typedef const __attribute__((address_space(3))) float* lds_cf;       // (stays an LDS pointer through the asm: a generic one
+            typedef const __attribute__((address_space(3))) f32x2* lds_cf2;      //  turns the reads into flat loads)
+            lds_cf pe = (lds_cf)(pr + V_RAW_FLOATS);                     // row set B through its own address register: with one base hipcc
+            asm volatile("" : "+v"(pe));                                 // pairs the reads into ds_read2st64_b64 (8 LDS cycles instead of 2 x 2)
             float av[2][4], bv[2][4];
             auto read_a = [&](int nb, int k2, int t) __attribute__((always_inline)) { av[nb][t] = pa[t * WBKC * LDU + k2 * LDU]; };
-            f32x2 d12, e12;
-            float d0, d3, e0, e3;
+            f32x2 d12, e12, dl, dr, el, er;                              // 8-byte reads only (d0 / d3 as 4-byte reads at stride 8: 2-way bank conflicts)
             auto read_b = [&](int k2) __attribute__((always_inline)) {
                 d12 = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o12);
-                e12 = *reinterpret_cast<const f32x2*>(pr + V_RAW_FLOATS + k2 * LDR + o12);
-                d0 = pr[k2 * LDR + o0]; d3 = pr[k2 * LDR + o3];
-                e0 = pr[V_RAW_FLOATS + k2 * LDR + o0]; e3 = pr[V_RAW_FLOATS + k2 * LDR + o3];
+                e12 = *(lds_cf2)(pe + k2 * LDR + o12);
+                dl = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o0); dr = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o3);
+                el = *(lds_cf2)(pe + k2 * LDR + o0); er = *(lds_cf2)(pe + k2 * LDR + o3);
             };
             auto xform_b = [&](int nb) __attribute__((always_inline)) {
-                const float c0 = fmaf(sgn, e0, d0), c1 = fmaf(sgn, e12.x, d12.x), c2 = fmaf(sgn, e12.y, d12.y), c3 = fmaf(sgn, e3, d3);
+                asm volatile("" : "+v"(dl), "+v"(dr), "+v"(el), "+v"(er));   // both halves live: keeps the reads 8 bytes wide
+                const float c0 = fmaf(sgn, el.y, dl.y), c1 = fmaf(sgn, e12.x, d12.x), c2 = fmaf(sgn, e12.y, d12.y), c3 = fmaf(sgn, er.x, dr.x);
                 bv[nb][0] = fmaf(c0, ml, -c2); bv[nb][1] = c1 + c2; bv[nb][2] = c2 - c1; bv[nb][3] = fmaf(-c3, mr, c1);
             };
 #pragma unroll

@@ -98,3 +98,7 @@ __device__ __forceinline__ float fd_ldg32(__amdgpu_buffer_rsrc_t r, unsigned byt
 __device__ __forceinline__ float4 fd_ldg128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+
+#ifdef FD_SKIP_ABLATION      // timing experiments only: scripts/ubench/fd_skip.h (not part of the product build)
+#include "fd_skip.h"
+#endif

@@ -27,6 +27,16 @@ t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
 print("un-profiled: issue %.2f ms / step, wall %.2f ms / step" % (t_issue * 50, t_all * 50))
+# issue time of ONE step into empty queues (no back-pressure from the GPU: the host's own cost)
+single = []
+for i in range(9):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train_step(pool[i % 6])
+    single.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+single.sort()
+print("one step into empty queues: issue median %.2f ms (min %.2f, max %.2f)" % (single[4] * 1e3, single[0] * 1e3, single[-1] * 1e3))
 pr = cProfile.Profile()
 pr.enable()
 for i in range(20):
