@@ -572,6 +572,242 @@ __global__ void __launch_bounds__(256) k_wino2d_finish(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------ F(2x2, 3x3) slabs, 128 x 64 tile
+// k_conv_wino2d_m128 (round 4): k_conv_wino2d for layers with Cout % 128 == 0 (ResNet layer2 .. layer4) with TWICE the output
+// channels per workgroup and wave: a wave owns 64 (channels) x 32 (2x2 tiles) = two 32 x 32 blocks per Winograd component that
+// share every B operand.  The B side is the expensive one (per k-step 6 LDS reads, the row combination and the horizontal input
+// transform: 8 vector instructions) and is now paid once per EIGHT matrix instructions instead of four; the activations of a pixel
+// tile are fetched from L2 / HBM by half as many workgroups.  Activations go global -> LDS raw (both input rows of the row
+// combination, k_conv_wino2p_dma's scheme with the row component fixed per workgroup, so the DMA offsets are computed once), weights
+// register-staged.  128 accumulator registers -> two waves per SIMD; chunks of 8 input channels keep two workgroups per CU in LDS
+// (2 x 26.1 KB each) at the same 32 matrix instructions per wave and barrier as the other Winograd kernels.  Same slabs, same
+// k_wino2d_finish.
+constexpr int M2_KC = 8, M2_BM = 128, M2_LDU = M2_BM + 1;
+constexpr int M2_VRAW = 5 * 256;                                 // one raw row set: 8 rows x 34 sixteen-byte pieces in 5 wave-wide DMAs
+constexpr int M2_BUF_FLOATS = 4 * M2_KC * M2_LDU + 2 * M2_VRAW;
+constexpr int M2_LDS_FLOATS = 2 * M2_BUF_FLOATS;
+__global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_wino2d_m128(WinoArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W2 = g.W >> 1, HT = g.H >> 1;
+    const int plane2 = HT * W2;
+    const int Np = g.Nb * plane2;
+    const unsigned hw = (unsigned)(g.H * g.W);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nz = gridDim.z;
+    if (g.xcd_swizzle == 2) {                                    // all pixel tiles of a (channel tile, row component, split) slice on one XCD
+        const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
+        bx = k % g.gx;
+        const int sl = (k / g.gx) * 8 + xcd;
+        by = sl % g.gy; bz = sl / g.gy; nz = g.gz;
+    } else if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    const int m0 = by * M2_BM;
+    const int p0 = bx * WBN;
+    const int ri = bz & 3, ks = bz >> 2, nsplit = nz >> 2;
+    const int cpt = g.C / M2_KC;
+    const int per_split = (cpt + nsplit - 1) / nsplit;
+    const int ch_lo = ks * per_split;
+    const int ch_hi = ch_lo + per_split < cpt ? ch_lo + per_split : cpt;
+    const int nchunk = ch_hi > ch_lo ? ch_hi - ch_lo : 0;
+    const bool refl = g.pad_mode == 1;
+    // ---- weight loader: float4 a4 (of the chunk's 8 channels) of row ar, for each horizontal component
+    const int a4 = tid & 1, ar = tid >> 1;
+    int mrow = m0 + ar;
+    mrow = mrow < g.M ? mrow : g.M - 1;
+    const unsigned u_comp = 4u * (unsigned)g.M * 4u * (unsigned)g.C;
+    const unsigned u_base = 4u * (((unsigned)mrow * 4u + (unsigned)ri) * (unsigned)g.C + (unsigned)(ch_lo * M2_KC) + 4u * a4);
+    const __amdgpu_buffer_rsrc_t rsU = fd_make_rsrc(g.U);
+    const __amdgpu_buffer_rsrc_t rsXd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)(4u * (unsigned)g.Nb * (unsigned)g.C * hw), 0x00020000);
+    // ---- activation DMAs: piece L = 64 (wave + 4 q) + lane of the linear raw stream (8 rows x 34 pieces: pixels -4 .. 131 of the tile's
+    //      flat pixel range over (image, tile row, x)); the two input rows of row component ri are fixed for the whole workgroup
+    const int xr[2] = {ri == 0 ? 0 : (ri == 2 ? 2 : 1), ri == 3 ? 3 : (ri == 2 ? 1 : 2)};
+    const int H2m2 = 2 * g.H - 2;
+    unsigned d_row[2][2];                                        // [row set][q]: byte offset of the piece at channel 0 of the chunk, or FD_OOB
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int L = 64 * (wave + 4 * q) + lane;
+        const int row = L / 34, seg = L - row * 34;
+        const int F = 2 * p0 - 4 + 4 * seg;
+        const bool ok = row < M2_KC && F >= 0 && F < g.Nb * HT * g.W;
+        const int Fc = ok ? F : 0;
+        const int nrow = Fc / g.W, x = Fc - nrow * g.W;
+        const int n = nrow / HT, ty = nrow - n * HT;
+        const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)row * hw + (unsigned)x);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const int r = 2 * ty - 1 + xr[s_];
+            const bool inb = (unsigned)r < (unsigned)g.H;
+            int rr_ = r < 0 ? -r : r;
+            rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
+            const int ruse = refl ? rr_ : r;
+            d_row[s_][q] = (ok & (refl | inb)) ? base + (unsigned)(ruse * g.W * 4) : FD_OOB;
+        }
+    }
+    unsigned d_off[2][2] = {{FD_OOB, FD_OOB}, {FD_OOB, FD_OOB}};
+    unsigned d_soff = 0u, u_off = FD_OOB;
+    int pc = 0;                                                  // chunk (relative to ch_lo) the offsets point at
+    auto prep = [&]() __attribute__((always_inline)) {           // offsets of chunk pc, then advance
+        const bool live = pc < nchunk;
+        u_off = live ? u_base + 4u * (unsigned)(pc * M2_KC) : FD_OOB;
+        d_soff = 4u * (unsigned)((ch_lo + pc) * M2_KC) * hw;     // wave-uniform: first channel of the chunk
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) d_off[s_][q] = live ? d_row[s_][q] : FD_OOB;
+        ++pc;
+    };
+    float4 ru[4];
+    auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off + (unsigned)t * u_comp); };
+    auto store_u = [&](int buf, int t) __attribute__((always_inline)) {
+        float* q = smem + buf * M2_BUF_FLOATS + t * M2_KC * M2_LDU + (4 * a4) * M2_LDU + ar;
+        q[0] = ru[t].x; q[M2_LDU] = ru[t].y; q[2 * M2_LDU] = ru[t].z; q[3 * M2_LDU] = ru[t].w;
+    };
+    auto dma_v = [&](int buf, int s_, int q) __attribute__((always_inline)) {
+        float* dst = smem + buf * M2_BUF_FLOATS + 4 * M2_KC * M2_LDU + s_ * M2_VRAW + (wave + 4 * q) * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsXd, (__attribute__((address_space(3))) void*)dst, 16, (int)d_off[s_][q], (int)d_soff, 0, 0);
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    int o12, o0, o3;
+    float ml, mr;
+    {
+        const int jp = 32 * wn + (lane & 31);
+        const int pp = p0 + jp < Np ? p0 + jp : 0;
+        const int rem = pp % plane2;
+        const int jj = rem % W2;
+        const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
+        o12 = 4 + 2 * jp;
+        o0 = (le && refl) ? o12 : o12 - 2;       // 8-byte cell whose .y is d0 (reflection: column -1 is column 1 = d12.y)
+        o3 = (re && refl) ? o12 : o12 + 2;       // 8-byte cell whose .x is d3 (reflection: column W is column W - 2 = d12.x)
+        ml = (le && !refl) ? 0.f : 1.f;
+        mr = (re && !refl) ? 0.f : 1.f;
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
+
+    constexpr int NK = M2_KC / 2;                                // 4 k-steps of 8 matrix instructions per chunk
+    const int arow = lane >> 5, acol = lane & 31;
+    float sgn = ri == 1 ? 1.f : -1.f;                            // the row combination: rowA + sgn * rowB
+    asm volatile("" : "+v"(sgn));                                // in a VGPR: an SGPR operand halves the VALU rate on gfx950
+    if (nchunk > 0) {
+        prep();                                                  // chunk 0
+#pragma unroll
+        for (int t = 0; t < 4; ++t) load_u(t);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            dma_v(0, s_, 0);
+            if (wave == 0) dma_v(0, s_, 1);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) store_u(0, t);
+        prep();                                                  // offsets of chunk 1: fetched DURING chunk 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int cur = ch & 1;
+            const float* pa = smem + cur * M2_BUF_FLOATS + arow * M2_LDU + 64 * wm + acol;
+            const float* pr = smem + cur * M2_BUF_FLOATS + 4 * M2_KC * M2_LDU + arow * LDR;
+            typedef const __attribute__((address_space(3))) float* lds_cf;       // (stays an LDS pointer through the asm: a generic one
+            typedef const __attribute__((address_space(3))) f32x2* lds_cf2;      //  turns the reads into flat loads)
+            lds_cf pe = (lds_cf)(pr + M2_VRAW);                      // row set B through its own address register: with one base hipcc
+            asm volatile("" : "+v"(pe));                             // pairs the reads into ds_read2st64_b64 (8 LDS cycles instead of 2 x 2)
+            float av[2][2][4], bv[2][4];
+            auto read_a = [&](int nb, int k2, int b, int t) __attribute__((always_inline)) { av[nb][b][t] = pa[t * M2_KC * M2_LDU + k2 * M2_LDU + 32 * b]; };
+            f32x2 d12, e12, dl, dr, el, er;
+            auto read_b = [&](int k2) __attribute__((always_inline)) {
+                d12 = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o12);
+                e12 = *(lds_cf2)(pe + k2 * LDR + o12);
+                dl = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o0); dr = *reinterpret_cast<const f32x2*>(pr + k2 * LDR + o3);
+                el = *(lds_cf2)(pe + k2 * LDR + o0); er = *(lds_cf2)(pe + k2 * LDR + o3);
+            };
+            auto xform_b = [&](int nb) __attribute__((always_inline)) {
+                asm volatile("" : "+v"(dl), "+v"(dr), "+v"(el), "+v"(er));   // both halves live: keeps the reads 8 bytes wide
+                const float c0 = fmaf(sgn, el.y, dl.y), c1 = fmaf(sgn, e12.x, d12.x), c2 = fmaf(sgn, e12.y, d12.y), c3 = fmaf(sgn, er.x, dr.x);
+                bv[nb][0] = fmaf(c0, ml, -c2); bv[nb][1] = c1 + c2; bv[nb][2] = c2 - c1; bv[nb][3] = fmaf(-c3, mr, c1);
+            };
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) read_a(0, 0, b, t);
+            read_b(0); xform_b(0);
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                const bool more = kk + 1 < NK;
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0][0], bv[cb][0], acc[0][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) read_b(2 * (kk + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0][1], bv[cb][1], acc[0][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { read_a(nb, 2 * (kk + 1), 0, 0); read_a(nb, 2 * (kk + 1), 0, 1); read_a(nb, 2 * (kk + 1), 0, 2); }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0][2], bv[cb][2], acc[0][2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { read_a(nb, 2 * (kk + 1), 0, 3); read_a(nb, 2 * (kk + 1), 1, 0); read_a(nb, 2 * (kk + 1), 1, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0][3], bv[cb][3], acc[0][3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) { read_a(nb, 2 * (kk + 1), 1, 2); read_a(nb, 2 * (kk + 1), 1, 3); }
+                if (kk < 2) load_u(2 * kk);
+                if (kk >= 2) store_u(cur ^ 1, 2 * (kk - 2));
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1][0], bv[cb][0], acc[1][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < 2) load_u(2 * kk + 1);
+                if (kk >= 2) store_u(cur ^ 1, 2 * (kk - 2) + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1][1], bv[cb][1], acc[1][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) xform_b(nb);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1][2], bv[cb][2], acc[1][2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk < 2) dma_v(cur ^ 1, kk, 0);                       // row set A, then row set B
+                if (kk == 2 && wave == 0) { dma_v(cur ^ 1, 0, 1); dma_v(cur ^ 1, 1, 1); }
+                if (kk == NK - 1) prep();                                // chunk ch + 2; every fetch of chunk ch + 1 has been issued by now
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1][3], bv[cb][3], acc[1][3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this chunk's DMAs (into the other buffer) have landed
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: the horizontally transformed products S_ri [N][M][H/2][W] of this (row component, channel split) to slab bz
+    const int po = p0 + 32 * wn + acol;
+    const unsigned hwo = (unsigned)(HT * g.W);
+    unsigned out_base = FD_OOB;
+    if (po < Np) {
+        const int n = po / plane2;
+        const int rem = po - n * plane2;
+        const int yy = rem / W2, jj = rem - yy * W2;
+        out_base = 4u * ((unsigned)n * (unsigned)g.M * hwo + (unsigned)(yy * g.W + 2 * jj));
+    }
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.slabs + (size_t)bz * g.slab_stride);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int mbase = m0 + 64 * wm + 32 * b + 4 * arow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mbase + (r & 3) + 8 * (r >> 2);
+            const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hwo : FD_OOB;      // out of range: the store is dropped
+            f32x2 o;
+            o.x = (acc[b][0][r] + acc[b][1][r]) + acc[b][2][r];
+            o.y = (acc[b][1][r] - acc[b][2][r]) - acc[b][3][r];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsY, (int)off, 0, 0);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ F(2x2, 3x3) in ONE workgroup
 // k_conv_wino2p (round 4): the 16 components of F(2x2, 3x3) for the layers where slabs cost more than the matrix work they save
 // (ResNet layer1 / layer2, the decoder's wide blocks: few channels, many pixels - the 1-D kernel's territory until now).  A
@@ -1401,8 +1637,9 @@ int wino_fwd_mode(const fd_conv_desc* d) {
 }
 bool wino_fwd_2d(const fd_conv_desc* d) { return wino_fwd_mode(d) != 0; }      // the weights are U2[t][m][ri][c] for both 2-D kernels
 // channel splits of the 2-D kernel on top of its four row components
-inline int wino2d_ksplits(const fd_conv_desc* d) {
-    const long tiles = 4L * fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN) * fd_cdiv(d->Cout, WBM);
+// channel splits of the 2-D slab kernels on top of their four row components, for workgroup tiles of `bm` output channels
+inline int wino2d_ksplits_bm(const fd_conv_desc* d, int bm) {
+    const long tiles = 4L * fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN) * fd_cdiv(d->Cout, bm);
     const long target = fd_tun().wino_target;
     long ks = tiles < target ? target / tiles : 1;
     const long cap = d->Cin / WBKC / 4 > 0 ? d->Cin / WBKC / 4 : 1;          // at least 4 chunks per split
@@ -1410,6 +1647,20 @@ inline int wino2d_ksplits(const fd_conv_desc* d) {
     if (ks > 4) ks = 4;
     return ks < 1 ? 1 : (int)ks;
 }
+// k_conv_wino2d_m128 (128 output channels per workgroup, two workgroups per CU) instead of k_conv_wino2d (64, three per CU): its
+// loop carries 40 % fewer vector instructions per matrix instruction, but it halves the workgroup count - it wins exactly where its
+// launch fills the chip's workgroup slots better (scripts/conv2d_m128_time.py: layer3 / layer4 at batch 12 and layer4 at batch 24
+// -4 ... -10 %; layer3 at batch 24, 720 -> 360 workgroups, +14 %).  The launcher additionally needs a 16-byte aligned x.
+inline bool wino2d_m128(const fd_conv_desc* d) {
+    if (fd_tun().wino_fwd_2d_m128 == 0 || d->Cout % M2_BM != 0 || d->W % 4 != 0 || d->Cin % M2_KC != 0) return false;
+    if (fd_tun().wino_fwd_2d_m128 > 1) return true;                         // 2: wherever it can run (tests, timing scripts)
+    const long px = fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN);
+    const long n64 = 4L * px * fd_cdiv(d->Cout, WBM) * wino2d_ksplits_bm(d, WBM), n128 = 4L * px * (d->Cout / M2_BM) * wino2d_ksplits_bm(d, M2_BM);
+    const long s64 = 3 * 256, s128 = 2 * 256;                               // workgroup slots of the chip
+    // fill = n / (rounds * slots), compared as cross products
+    return n128 * (fd_cdiv(n64, s64) * s64) > n64 * (fd_cdiv(n128, s128) * s128);
+}
+inline int wino2d_ksplits(const fd_conv_desc* d) { return wino2d_ksplits_bm(d, wino2d_m128(d) ? M2_BM : WBM); }
 long wino_wt_floats(const fd_conv_desc* d) { return 4L * d->Cout * (wino_fwd_2d(d) ? 4 : 3) * d->Cin; }
 long wino_ws_floats(const fd_conv_desc* d) {
     const int mode = wino_fwd_mode(d);
@@ -1495,12 +1746,14 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         const int HT = d->H / 2;
         const int gx2 = fd_cdiv((long)d->N * HT * (d->W / 2), WBN);
         g.slab_stride = out_total / 2;                                     // S_ri: [N][M][H/2][W]
-        const int gy2 = fd_cdiv(d->Cout, WBM);
+        const bool m128 = wino2d_m128(d) && ((uintptr_t)x & 15) == 0;      // (unaligned x: k_conv_wino2d with the same split count)
+        const int gy2 = fd_cdiv(d->Cout, m128 ? M2_BM : WBM);
         const int xmap = 1;        // XCD-aware 1-D grid (plain 3-D grid: layer4 162 instead of 79 MB of HBM traffic per launch, -0.35 % in the step)
         g.xcd_swizzle = (gx2 % 8 == 0 && gx2 >= 16) ? 1 : 0;
         dim3 grid(gx2, gy2, sp);
         if (xmap && (gy2 * sp) % 8 == 0) { g.xcd_swizzle = 2; g.gx = gx2; g.gy = gy2; g.gz = sp; grid = dim3((unsigned)(gx2 * gy2 * sp)); }
-        hipLaunchKernelGGL(k_conv_wino2d, grid, dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
+        if (m128) hipLaunchKernelGGL(k_conv_wino2d_m128, grid, dim3(WNT), sizeof(float) * M2_LDS_FLOATS, st, g);
+        else hipLaunchKernelGGL(k_conv_wino2d, grid, dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
         FD_LAUNCH_CHECK("k_conv_wino2d");
         const unsigned total2 = (unsigned)(out_total / 4);               // one thread per (tile row, column pair)
         const unsigned blocks = (total2 + 255u) / 256u;

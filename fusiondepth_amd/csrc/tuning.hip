@@ -19,6 +19,7 @@ fd_tuning make_defaults() {
     t.force_cfg = -1; t.force_splits = 1;
     t.stem7 = 1;
     t.log = 0;
+    t.wino_fwd_2d_m128 = 1;
     return t;
 }
 fd_tuning g_tuning = make_defaults();

@@ -64,6 +64,7 @@ typedef struct fd_tuning {
     int force_cfg, force_splits;  /* -1, 1   force the direct kernel's tile configuration (0..2) and split-K (sweeps) */
     int stem7;                    /* 1   7x7 stride-2 stems (Cin 2..6) on the dedicated patch kernels (conv_stem.hip) */
     int log;                      /* 0   1: one stderr line per convolution call with the kernel family it was routed to */
+    int wino_fwd_2d_m128;         /* 1   the slab variant with 128 output channels per workgroup (k_conv_wino2d_m128; Cout % 128 == 0, W % 4 == 0) where its launch fills the chip better; 2: wherever it can run; 0: never */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);

@@ -70,6 +70,7 @@ CONV_CASES = [
     (1, 6, 30, 44, 64, 7, 2, 3, "zero", "none", False, False),
     (2, 2, 37, 131, 64, 7, 2, 3, "zero", "none", False, False),    # ragged tiles, odd sizes
     (3, 4, 64, 160, 64, 7, 2, 3, "zero", "none", False, False),
+    (6, 6, 192, 640, 64, 7, 2, 3, "zero", "none", False, False),   # full size: 1 440 tiles on 512 persistent workgroups (the software-pipelined tile loop)
     (2, 32, 37, 130, 16, 3, 1, 1, "reflect", "elu", True, False),  # upconv(0,0): narrow wgrad kernel, 2 channel groups, ragged tiles
     (3, 32, 9, 70, 1, 3, 1, 1, "reflect", "sigmoid", True, False), # dispconv(1) shape class, Cout = 1
     (2, 16, 21, 67, 12, 3, 1, 1, "zero", "none", False, False),    # narrow kernel with zero padding
@@ -775,6 +776,33 @@ def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d
     got, nwt = _wino_conv(x, w, b, reflect, act)
     assert nwt == 4 * Co * (4 if two_d and H % 2 == 0 else 3) * Ci
     relclose(cpu(got), cpu(ref.float()), "winograd conv", rtol=1e-5, arel=3e-6)
+
+
+@pytest.mark.parametrize("m128", [2, 0])
+@pytest.mark.parametrize("N,Ci,Co,H,W,reflect,act", [
+    (1, 256, 256, 12, 40, False, 1),     # layer3: channel splits on top of the four row components
+    (3, 512, 512, 6, 20, False, 1),      # layer4
+    (2, 256, 128, 24, 80, True, 2),      # upconv(3, 1) of the depth decoder: reflect padding, ELU in the finish pass
+    (3, 80, 128, 12, 20, False, 0),      # 10 chunks of 8 channels (uneven splits), 180 tiles = 2.8 pixel tiles across image borders
+    (2, 128, 128, 6, 8, True, 3),        # every tile at a border, rows of two 16-byte pieces
+    (3, 64, 128, 2, 4, False, 0),        # one tile row per image
+    (2, 64, 384, 8, 12, False, 0),       # three channel tiles of 128
+])
+def test_winograd_slab_kernel_with_128_channel_tiles(N, Ci, Co, H, W, reflect, act, m128, fdtune):
+    """k_conv_wino2d_m128 (128 output channels per workgroup, activations direct-to-LDS, 8-channel chunks) against torch float64,
+    forced wherever it can run (fd_tuning.wino_fwd_2d_m128 = 2), next to k_conv_wino2d (0) on the same shapes: both must sit within a few fp32 ulps of the output
+    scale, and within that of each other."""
+    fdtune.lib(wino_fwd_2d_min=1, wino_fwd_2dp_min_wgs=0, wino_fwd_2d_m128=m128)
+    torch.manual_seed(N * 1000 + Ci + Co)
+    x = torch.randn(N, Ci, H, W, device="cuda")
+    w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
+    b = torch.randn(Co, device="cuda")
+    xp = F.pad(x.double(), (1, 1, 1, 1), mode="reflect" if reflect else "constant")
+    ref = F.conv2d(xp, w.double(), b.double())
+    ref = {0: ref, 1: F.relu(ref), 2: F.elu(ref), 3: torch.sigmoid(ref)}[act]
+    got, nwt = _wino_conv(x, w, b, reflect, act)
+    assert nwt == 4 * Co * 4 * Ci
+    relclose(cpu(got), cpu(ref.float()), "winograd slabs (m128=%d)" % m128, rtol=1e-5, arel=3e-6)
 
 
 @pytest.mark.parametrize("mode", ["zero", "reflect"])
