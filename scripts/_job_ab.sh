@@ -1,12 +1,11 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-L=gpurun_out/r4_ab_m128b.log
+L=gpurun_out/r4_stream_shift.log
 : > $L
-timeout 900 python -m pytest tests/test_gpu_convstack.py -x -q 2>&1 | tail -2 >> $L
-python scripts/conv2d_m128_time.py 2>&1 | grep batch >> $L
-python scripts/conv2d_m128_time.py 2>&1 | grep "256 -> 128" >> $L
-for i in 1 2; do
-  python scripts/step_time.py m128_rule >> $L 2>/dev/null
-  FD_WINO_FWD_2D_M128=0 python scripts/step_time.py m128_off >> $L 2>/dev/null
+for rep in 1 2; do
+for k in 0 1 2 3 4 5 6 7; do
+  FD_STREAM_SHIFT=$k python scripts/step_time.py shift_$k >> $L 2>/dev/null
 done
+done
+for q in 3 5 6; do GPU_MAX_HW_QUEUES=$q python scripts/step_time.py queues_$q >> $L 2>/dev/null; done
 cat $L

@@ -17,6 +17,7 @@ bash scripts/prof_probe.sh round4$SUF > /dev/null 2>&1
 bash scripts/pmc_kernel.sh round4_conv_wino2p_l1_b12 k_conv_wino2p 2 -- python $R/scripts/probe_w2p.py 12 1 > /dev/null 2>&1
 bash scripts/pmc_kernel.sh round4_conv_wino2p_l1_b24 k_conv_wino2p 2 -- python $R/scripts/probe_w2p.py 24 1 > /dev/null 2>&1
 bash scripts/pmc_kernel.sh round4_conv_wino2d_l4 k_conv_wino2d 2 -- python $R/scripts/conv_one.py 512 6 20 512 3 1 1 24 8 > /dev/null 2>&1
+FD_WINO_FWD_2D_M128=0 bash scripts/pmc_kernel.sh round4_conv_wino2d_l4_m64 k_conv_wino2d 2 -- python $R/scripts/conv_one.py 512 6 20 512 3 1 1 24 8 > /dev/null 2>&1
 bash scripts/pmc_kernel.sh round4_wgrad_wino_l3 k_wgrad_wino 2 -- python $R/scripts/wgrad_one.py 256 256 12 40 24 8 > /dev/null 2>&1
 bash scripts/pmc_kernel.sh round4_wgrad_wino_l1 k_wgrad_wino 2 -- python $R/scripts/wgrad_one.py 64 64 48 160 12 8 > /dev/null 2>&1
 bash scripts/pmc_kernel.sh round4_conv_stem k_conv7s2_stem 2 -- python $R/scripts/conv_one.py 6 192 640 64 7 2 3 24 8 > /dev/null 2>&1

@@ -8,6 +8,7 @@ from fusiondepth_amd import synthetic
 from fusiondepth_amd.options import MonodepthOptions
 from fusiondepth_amd.trainer import Trainer
 opt = MonodepthOptions().parse(["--num_layers", "18", "--weights_init", "scratch", "--batch_size", "12", "--height", "192", "--width", "640"])
+_shift = [torch.cuda.Stream() for _ in range(int(os.environ.get("FD_STREAM_SHIFT", "0")))]     # moves the step's streams along the runtime's stream -> hardware-queue round robin
 tr = Trainer(opt, verbose=False)
 pool = []
 for i in range(6):
