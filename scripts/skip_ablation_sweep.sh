@@ -1,4 +1,5 @@
 #!/bin/bash
+# The sweep behind profiles/round4_skip_ablation.log: the step with the launches of one kernel class dropped (run on the GPU box after scripts/build_skip_ablation.sh)
 cd $GRAFT_REPO_ROOT
 export FD_LIBFDHIP=$PWD/fusiondepth_amd/libfdhip_skip.so
 L=gpurun_out/r4_skip_ablation2.log
