@@ -787,6 +787,7 @@ def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d
     (2, 128, 128, 6, 8, True, 3),        # every tile at a border, rows of two 16-byte pieces
     (3, 64, 128, 2, 4, False, 0),        # one tile row per image
     (2, 64, 384, 8, 12, False, 0),       # three channel tiles of 128
+    (2, 64, 128, 32, 64, False, 1),      # 16 pixel tiles x 1 channel tile x 4 components: the 3-D grid with the XCD swizzle of the pixel tiles
 ])
 def test_winograd_slab_kernel_with_128_channel_tiles(N, Ci, Co, H, W, reflect, act, m128, fdtune):
     """k_conv_wino2d_m128 (128 output channels per workgroup, activations direct-to-LDS, 8-channel chunks) against torch float64,
