@@ -1102,55 +1102,124 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, pad_mode="zero", act="none", i
     return _Conv2d.apply(x, weight, bias, int(stride), int(pad), PAD_MODE[pad_mode], ACT[act], bool(in_norm))
 
 
+def _bn_forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, groups, conv_stats=None):
+    """Body of ``_BatchNorm.forward``; ``ctx`` is the Function's context or the BatchNorm half of a fused node (``_Part``)."""
+    ctx.params = (weight, bias)
+    _note_use(weight, bias)
+    ctx.groups = groups
+    x = f32(x)
+    _need_cuda(x)
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    res = f32(residual) if residual is not None else None
+    if training:
+        mean, invstd = _empty((groups * C,), x), _empty((groups * C,), x)
+        if conv_stats is not None and groups <= 16:
+            # statistics gathered by the producing convolution's epilogue: one launch, no statistics pass over x
+            assert conv_stats.shape[:2] == (N, C) and conv_stats.shape[3] == 2
+            call("fd_bn_train_fwd_parts", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
+                 ptr(mean), ptr(invstd), ptr(conv_stats), int(conv_stats.shape[2]), N, C, H, W, groups, float(eps),
+                 float(momentum), int(relu), stream())
+        else:
+            ws = _empty((query("fd_bn_ws_floats", N, C, H, W, groups),), x)
+            call("fd_bn_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
+                 ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, groups, float(eps), float(momentum), int(relu), stream())
+        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+    else:
+        call("fd_bn_eval_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
+             N, C, H, W, float(eps), int(relu), stream())
+    ctx.training, ctx.relu, ctx.has_res = bool(training), int(relu), residual is not None
+    return y
+
+
+def _bn_backward(ctx, gy, need_res):
+    """Body of ``_BatchNorm.backward`` -> (gx, gweight, gbias, gresidual)."""
+    if not ctx.training:
+        raise RuntimeError("BatchNorm backward is implemented for training mode only (frozen nets run under no_grad)")
+    x, y, weight, mean, invstd = ctx.saved_tensors
+    N, C, H, W = x.shape
+    gy = f32(gy)
+    gx = torch.empty_like(x)
+    tw, tb = _direct_grad_target(ctx.params[0]), _direct_grad_target(ctx.params[1])
+    direct = tw is not None and tb is not None
+    gw, gb = (tw, tb) if direct else (_empty((C,), x), _empty((C,), x))
+    gres = torch.empty_like(x) if ctx.has_res and need_res else None
+    ws = _empty((query("fd_bn_ws_floats", N, C, H, W, ctx.groups),), x)
+    call("fd_bn_train_bwd", ptr(x), ptr(y), ptr(gy), ptr(weight), ptr(mean), ptr(invstd), ptr(gx), ptr(gw), ptr(gb),
+         ptr(gres), ptr(ws), N, C, H, W, ctx.groups, ctx.relu, int(direct), stream())
+    if direct:
+        gw = gb = None
+        _grad_ready(ctx.params[0], ctx.params[1])
+    return gx, gw, gb, gres
+
+
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, groups, conv_stats=None):
-        ctx.params = (weight, bias)
-        _note_use(weight, bias)
-        ctx.groups = groups
-        x = f32(x)
-        _need_cuda(x)
-        N, C, H, W = x.shape
-        y = torch.empty_like(x)
-        res = f32(residual) if residual is not None else None
-        if training:
-            mean, invstd = _empty((groups * C,), x), _empty((groups * C,), x)
-            if conv_stats is not None and groups <= 16:
-                # statistics gathered by the producing convolution's epilogue: one launch, no statistics pass over x
-                assert conv_stats.shape[:2] == (N, C) and conv_stats.shape[3] == 2
-                call("fd_bn_train_fwd_parts", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
-                     ptr(mean), ptr(invstd), ptr(conv_stats), int(conv_stats.shape[2]), N, C, H, W, groups, float(eps),
-                     float(momentum), int(relu), stream())
-            else:
-                ws = _empty((query("fd_bn_ws_floats", N, C, H, W, groups),), x)
-                call("fd_bn_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
-                     ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, groups, float(eps), float(momentum), int(relu), stream())
-            ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
-        else:
-            call("fd_bn_eval_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
-                 N, C, H, W, float(eps), int(relu), stream())
-        ctx.training, ctx.relu, ctx.has_res = bool(training), int(relu), residual is not None
-        return y
+        return _bn_forward(ctx, x, weight, bias, residual, running_mean, running_var, training, momentum, eps, relu, groups, conv_stats)
 
     @staticmethod
     def backward(ctx, gy):
-        if not ctx.training:
-            raise RuntimeError("BatchNorm backward is implemented for training mode only (frozen nets run under no_grad)")
-        x, y, weight, mean, invstd = ctx.saved_tensors
-        N, C, H, W = x.shape
-        gy = f32(gy)
-        gx = torch.empty_like(x)
-        tw, tb = _direct_grad_target(ctx.params[0]), _direct_grad_target(ctx.params[1])
-        direct = tw is not None and tb is not None
-        gw, gb = (tw, tb) if direct else (_empty((C,), x), _empty((C,), x))
-        gres = torch.empty_like(x) if ctx.has_res and ctx.needs_input_grad[3] else None
-        ws = _empty((query("fd_bn_ws_floats", N, C, H, W, ctx.groups),), x)
-        call("fd_bn_train_bwd", ptr(x), ptr(y), ptr(gy), ptr(weight), ptr(mean), ptr(invstd), ptr(gx), ptr(gw), ptr(gb),
-             ptr(gres), ptr(ws), N, C, H, W, ctx.groups, ctx.relu, int(direct), stream())
-        if direct:
-            gw = gb = None
-            _grad_ready(ctx.params[0], ctx.params[1])
-        return gx, gw, gb, gres, None, None, None, None, None, None, None, None
+        return _bn_backward(ctx, gy, ctx.needs_input_grad[3]) + (None, None, None, None, None, None, None, None)
+
+
+class _Part:
+    """Context of one half of a fused autograd node: what ``_conv_forward`` / ``_bn_forward`` keep between the passes.  The tensors go
+    through the node's own ``save_for_backward`` (``_ConvBN``), so nothing here holds a reference to an output of the node."""
+    saved_tensors = ()
+    needs_input_grad = (True, True, True)
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _ConvBN(torch.autograd.Function):
+    """Training-mode ``bn(conv(x)) [+ residual] [ReLU]`` of a ResNet block as ONE autograd node (bias-free convolution, zero padding,
+    statistics from the convolution's epilogue where its kernel has one): the same C-ABI calls in the same order as ``_Conv2dStats``
+    / ``_Conv2dTapStats`` followed by ``_BatchNorm`` - half the ``Function.apply`` calls and backward nodes for the 80 conv + BatchNorm
+    pairs of the step (host time only; the launches are unchanged).  ``tap``: also return x for the block's second consumer, whose
+    gradient then joins the data gradient in the kernel's epilogue (see ``_Conv2dTap``)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bn_w, bn_b, residual, running_mean, running_var, stride, pad, momentum, eps, relu, groups, tap):
+        c, b = _Part(), _Part()
+        xf, y, part = _conv_forward(c, x, w, None, stride, pad, 0, 0, False, True)
+        out = _bn_forward(b, y, bn_w, bn_b, residual, running_mean, running_var, True, momentum, eps, relu, groups, part)
+        ctx.n_conv = len(c.saved_tensors)
+        ctx.save_for_backward(*(c.saved_tensors + b.saved_tensors))
+        c.saved_tensors = b.saved_tensors = ()
+        ctx.c, ctx.b = c, b
+        ctx.set_materialize_grads(False)
+        return (out, xf.view_as(xf)) if tap else out
+
+    @staticmethod
+    def backward(ctx, gout, g_tap=None):
+        c, b = ctx.c, ctx.b
+        saved = ctx.saved_tensors
+        c.saved_tensors, b.saved_tensors = saved[:ctx.n_conv], saved[ctx.n_conv:]
+        c.needs_input_grad = (ctx.needs_input_grad[0], ctx.needs_input_grad[1], False)
+        if gout is None:                              # only the tap was used downstream
+            return (f32(g_tap) if g_tap is not None else None,) + (None,) * 13
+        gy, gbw, gbb, gres = _bn_backward(b, gout, ctx.needs_input_grad[4])
+        gx, gw, _ = _conv_backward(c, gy, g_tap)
+        c.saved_tensors = b.saved_tensors = ()
+        return (gx, gw, gbw, gbb, gres) + (None,) * 9
+
+
+def conv_bn(x, conv_weight, bn, stride=1, pad=0, residual=None, relu=False, tap=False):
+    """``batch_norm(conv2d(x, w), bn, residual, relu)`` in training mode as one autograd node -> out, or (out, x_tap) with ``tap``."""
+    groups = _BN_GROUPS[0]
+    if bn.num_batches_tracked is not None:
+        if _BN_COUNTERS[0] is not None:
+            _BN_COUNTERS[0].append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked.add_(groups)
+    want_tap = bool(tap and x.requires_grad)
+    res = _ConvBN.apply(x, conv_weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, int(stride), int(pad),
+                        bn.momentum, bn.eps, bool(relu), groups, want_tap)
+    if tap:
+        return res if want_tap else (res, x)
+    return res
 
 
 _BN_GROUPS = [1]

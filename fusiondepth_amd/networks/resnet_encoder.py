@@ -27,6 +27,8 @@ def _conv_bn(x, conv, bn, residual=None, relu=False, tap=False):
     kernel can (FD.conv2d_stats), so the BatchNorm is ONE launch over the output instead of a statistics pass + an apply pass.
     ``tap``: also return ``x`` routed through the convolution's autograd node (see ``_conv_tap``)."""
     if bn.training and tuning.host.conv_stats and torch.is_grad_enabled():
+        if tuning.host.fused_conv_bn and conv.bias is None:
+            return FD.conv_bn(x, conv.weight, bn, stride=conv.stride[0], pad=conv.padding[0], residual=residual, relu=relu, tap=tap)
         res = FD.conv2d_stats(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0], tap=tap)
         y, stats = res[0], res[1]
         out = FD.batch_norm(y, bn, residual=residual, relu=relu, conv_stats=stats)

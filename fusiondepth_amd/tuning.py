@@ -89,6 +89,7 @@ class _Host:
     n_streams = 8               # HIP streams of the training step (4 are used; 1 = everything on one stream)
     interleave = False          # the four encoders issued block by block in turns
     conv_stats = True           # BatchNorm statistics from the convolution epilogue where the kernel has one
+    fused_conv_bn = True        # conv + BatchNorm of a ResNet block as ONE autograd node (host time only: same launches)
     refiner_streams = True      # the Refiner's frozen encoders on per-module streams
     decoder_fused_act = True    # ELU' of the decoder's single-consumer blocks applied where the gradient is produced (-0.15 ms when on)
     dp_overlap = True           # per-network gradient buckets all-reduced from inside the backward pass
@@ -111,7 +112,7 @@ _ENV_HOST = {
     "FD_SMOOTH_STREAM": ("smooth_stream", lambda v: v != "0"), "FD_PHOTO_MS": ("photo_ms", lambda v: v != "0"),
     "FD_SIDE_WGRAD": ("side_wgrad", lambda v: tuple(k for k in v.split(",") if k and k != "none")),
     "FD_NSTREAMS": ("n_streams", int), "FD_INTERLEAVE": ("interleave", lambda v: v != "0"),
-    "FD_CONV_STATS": ("conv_stats", lambda v: v != "0"), "FD_REFINER_STREAMS": ("refiner_streams", lambda v: v != "0"),
+    "FD_CONV_STATS": ("conv_stats", lambda v: v != "0"), "FD_FUSED_CONV_BN": ("fused_conv_bn", lambda v: v != "0"), "FD_REFINER_STREAMS": ("refiner_streams", lambda v: v != "0"),
     "FD_DP_OVERLAP": ("dp_overlap", lambda v: v != "0"), "FD_DECODER_FUSED_ACT": ("decoder_fused_act", lambda v: v != "0"), "FD_HOST_DELAY_US": ("host_delay_us", float),
 }
 

@@ -725,6 +725,44 @@ def test_late_weight_relayout_is_ordered_before_its_readers(fdtune):
     assert torch.equal(params["0"], params["1"]), "%d parameters differ" % int((params["0"] != params["1"]).sum())
 
 
+@pytest.mark.parametrize("layers", [18, 50])
+def test_fused_conv_batchnorm_node_is_bit_identical(layers, fdtune):
+    """functional._ConvBN (conv + BatchNorm of a ResNet block as ONE autograd node, tuning.host.fused_conv_bn) issues the same C-ABI
+    calls in the same order as the two nodes it replaces: parameters (and BatchNorm running statistics) after three optimiser steps
+    must be identical bit for bit, for the basic and the bottleneck block, and the fused node must really have been used."""
+    from fusiondepth_amd import functional as FD
+    from fusiondepth_amd.trainer import Trainer
+    B, H, W = 2, 64, 96
+    res = {}
+    for fused in (True, False):
+        fdtune.host(fused_conv_bn=fused)
+        n_apply = [0]
+        orig = FD._ConvBN.forward
+
+        def counting(ctx, *a, _orig=orig):
+            n_apply[0] += 1
+            return _orig(ctx, *a)
+        FD._ConvBN.forward = staticmethod(counting)
+        try:
+            torch.manual_seed(2468)
+            tr = Trainer(_opts(batch_size=B, num_layers=layers), verbose=False)
+            for i in range(3):
+                inp, noise = _batch(B, H, W, 700 + i)
+                ginp = {k: v.cuda() for k, v in inp.items()}
+                ginp["_noise"] = [n.cuda() for n in noise]
+                tr.train_step([ginp])
+            torch.cuda.synchronize()
+        finally:
+            FD._ConvBN.forward = staticmethod(orig)
+        assert (n_apply[0] > 0) == fused, n_apply
+        bufs = torch.cat([b.detach().float().flatten() for m in tr.models.values() for b in m.buffers()])
+        res[fused] = (tr.flat.flat_param.clone(), bufs)
+        del tr
+    assert torch.isfinite(res[True][0]).all()
+    assert torch.equal(res[True][0], res[False][0]), "%d parameters differ" % int((res[True][0] != res[False][0]).sum())
+    assert torch.equal(res[True][1], res[False][1])
+
+
 def test_decoder_weight_gradients_on_the_side_stream_are_bit_identical(fdtune):
     """functional.enable_side_wgrad (default for the depth decoder): its weight gradients, slab reductions and bias sums run on a side
     stream beside the data gradients of the following layers.  Same kernels, same accumulation targets: the gradient buffer after a
