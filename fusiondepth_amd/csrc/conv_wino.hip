@@ -1648,12 +1648,15 @@ inline int wino2d_ksplits_bm(const fd_conv_desc* d, int bm) {
     return ks < 1 ? 1 : (int)ks;
 }
 // k_conv_wino2d_m128 (128 output channels per workgroup, two workgroups per CU) instead of k_conv_wino2d (64, three per CU): its
-// loop carries 40 % fewer vector instructions per matrix instruction, but it halves the workgroup count - it wins exactly where its
-// launch fills the chip's workgroup slots better (scripts/conv2d_m128_time.py: layer3 / layer4 at batch 12 and layer4 at batch 24
-// -4 ... -10 %; layer3 at batch 24, 720 -> 360 workgroups, +14 %).  The launcher additionally needs a 16-byte aligned x.
+// loop carries 40 % fewer vector instructions per matrix instruction, but it halves the workgroup count.  Stand-alone it wins exactly
+// where its launch fills the chip's workgroup slots better (scripts/conv2d_m128_time.py: layer3 / layer4 at batch 12 and layer4 at
+// batch 24 -4 ... -10 %; layer3 at batch 24, 720 -> 360 workgroups, +14 %) - fd_tuning.wino_fwd_2d_m128 = 2 chooses by that rule.
+// INSIDE the training step the other streams fill a launch's empty slots, and the kernel with the leaner loop is the better one
+// everywhere it can run (19.07 / 19.07 / 19.17 / 19.14 ms against 19.15 - 19.34 for the rule or the 64-channel kernel): the default (1).
+// The launcher additionally needs a 16-byte aligned x.
 inline bool wino2d_m128(const fd_conv_desc* d) {
     if (fd_tun().wino_fwd_2d_m128 == 0 || d->Cout % M2_BM != 0 || d->W % 4 != 0 || d->Cin % M2_KC != 0) return false;
-    if (fd_tun().wino_fwd_2d_m128 > 1) return true;                         // 2: wherever it can run (tests, timing scripts)
+    if (fd_tun().wino_fwd_2d_m128 != 2) return true;
     const long px = fd_cdiv((long)d->N * (d->H / 2) * (d->W / 2), WBN);
     const long n64 = 4L * px * fd_cdiv(d->Cout, WBM) * wino2d_ksplits_bm(d, WBM), n128 = 4L * px * (d->Cout / M2_BM) * wino2d_ksplits_bm(d, M2_BM);
     const long s64 = 3 * 256, s128 = 2 * 256;                               // workgroup slots of the chip

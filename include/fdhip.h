@@ -50,7 +50,7 @@ typedef struct fd_tuning {
     int wino_fwd_2dp_dma;         /* 1   ... with its activations on the direct-to-LDS path where W % 4 == 0 (0: register-staged loader) */
     int wino_fwd_2dp_deep;        /* 0   1: the one-workgroup kernel also above wino_fwd_2d_min when the launch has enough tiles (A/B) */
     int wino_wgrad_2d;            /* 1   weight gradient as transposed F(2x2,3x3) where the height is even and Cin % 32 == 0 */
-    int wino_target;              /* 256 workgroups a Winograd forward launch is split-K'd up to */
+    int wino_target;              /* 384 workgroups a Winograd forward launch is split-K'd up to */
     int wino_wgrad_target;        /* 256 ... a Winograd weight-gradient launch is pixel-sliced up to */
     int conv_target;              /* 768 ... a direct forward / data-gradient launch */
     int wgrad_target;             /* 768 ... a direct weight-gradient launch */
@@ -64,7 +64,7 @@ typedef struct fd_tuning {
     int force_cfg, force_splits;  /* -1, 1   force the direct kernel's tile configuration (0..2) and split-K (sweeps) */
     int stem7;                    /* 1   7x7 stride-2 stems (Cin 2..6) on the dedicated patch kernels (conv_stem.hip) */
     int log;                      /* 0   1: one stderr line per convolution call with the kernel family it was routed to */
-    int wino_fwd_2d_m128;         /* 1   the slab variant with 128 output channels per workgroup (k_conv_wino2d_m128; Cout % 128 == 0, W % 4 == 0) where its launch fills the chip better; 2: wherever it can run; 0: never */
+    int wino_fwd_2d_m128;         /* 1   the slab variant with 128 output channels per workgroup (k_conv_wino2d_m128) wherever it can run (Cout % 128 == 0, W % 4 == 0); 2: only where its launch fills the chip better; 0: never */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);

@@ -778,7 +778,7 @@ def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d
     relclose(cpu(got), cpu(ref.float()), "winograd conv", rtol=1e-5, arel=3e-6)
 
 
-@pytest.mark.parametrize("m128", [2, 0])
+@pytest.mark.parametrize("m128", [1, 0])
 @pytest.mark.parametrize("N,Ci,Co,H,W,reflect,act", [
     (1, 256, 256, 12, 40, False, 1),     # layer3: channel splits on top of the four row components
     (3, 512, 512, 6, 20, False, 1),      # layer4
@@ -791,7 +791,7 @@ def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d
 ])
 def test_winograd_slab_kernel_with_128_channel_tiles(N, Ci, Co, H, W, reflect, act, m128, fdtune):
     """k_conv_wino2d_m128 (128 output channels per workgroup, activations direct-to-LDS, 8-channel chunks) against torch float64,
-    forced wherever it can run (fd_tuning.wino_fwd_2d_m128 = 2), next to k_conv_wino2d (0) on the same shapes: both must sit within a few fp32 ulps of the output
+    wherever it can run (fd_tuning.wino_fwd_2d_m128 = 1, the default), next to k_conv_wino2d (0) on the same shapes: both must sit within a few fp32 ulps of the output
     scale, and within that of each other."""
     fdtune.lib(wino_fwd_2d_min=1, wino_fwd_2dp_min_wgs=0, wino_fwd_2d_m128=m128)
     torch.manual_seed(N * 1000 + Ci + Co)
