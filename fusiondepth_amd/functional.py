@@ -571,7 +571,7 @@ def _conv_out_hw(d):
 # (``_WEIGHTS_EPOCH``, bumped by adam_step*), i.e. once per optimiser step instead of once per launch (the six ResNet
 # passes of the two micro-batches reuse the same weights).  Tensors that did not opt in are re-laid-out on every call.
 _WEIGHTS_EPOCH = [0]
-_WT_CACHE = {}            # (cache id, kind) -> [stamp, layout buffer, conv descriptor, weakref(parameter)]
+_WT_CACHE = {}            # (cache id, kind, layout floats) -> [stamp, layout buffer, conv descriptor, weakref(parameter)]
 _WT_RETIRED = []          # replaced layout buffers / job tables: a captured hipGraph may still hold their raw pointers
 _NEXT_CACHE_ID = [1]
 
@@ -723,18 +723,19 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
     """-> (buffer, ready flag) for weight ``w`` and layout ``kind`` ('f' forward, 'd' data-gradient)."""
     if cache_id is None:
         return torch.empty((nfloats,), device=w.device, dtype=torch.float32), 0
-    key = (cache_id, kind)
+    # nfloats is part of the key: the layout FORMAT of a weight depends on the kernel family its input shape is routed to (12 or 16
+    # floats per tap: conv_wino.hip::wino_fwd_mode looks at N*H*W), so a weight used at two batch sizes (the stacked training batch and
+    # a smaller validation batch) keeps both layouts resident instead of rebuilding one over the other on every switch (ADVICE round 4)
+    key = (cache_id, kind, nfloats)
     stamp = (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
     ent = _WT_CACHE.get(key)
-    if ent is not None and ent[1].numel() == nfloats:
+    if ent is not None:
         if _LATE["event"] is not None and len(ent) > 4 and ent[4]:
             _wait_late_layouts()
         if ent[0] == stamp:
             return ent[1], 1
         ent[0] = stamp
         return ent[1], 0
-    if ent is not None:
-        _WT_RETIRED.append(ent[1])      # size changed (another input shape routed this weight to another kernel family)
     buf = torch.empty((nfloats,), device=w.device, dtype=torch.float32)
     _WT_CACHE[key] = [stamp, buf, desc, weakref.ref(w), False]
     _drop_plan()                        # a layout the plan does not know: fall back to per-call re-layout until rebuilt
@@ -759,7 +760,7 @@ def build_weight_plan():
             return None, 0
         jobs = (RelayoutJob * (4 * len(part)))()
         n = 0
-        for (cid, kind), e in part:
+        for (cid, kind, _nf), e in part:
             n += query("fd_conv2d_relayout_jobs", ctypes.addressof(e[2]), 0 if kind == "f" else 1, ptr(e[3]()), ptr(e[1]),
                        ctypes.addressof(jobs) + n * ctypes.sizeof(RelayoutJob))
         if n == 0:
@@ -818,6 +819,7 @@ def refresh_weight_layouts():
 # the shapes and flags, so they are asked for once per distinct layer shape instead of on every launch (a step launches ~220
 # convolutions forward and as many backward; the size queries alone were ~1 300 library calls per step).
 _CONV_PLANS = {}
+_CONV_PLANS_GEN = [0]
 
 
 class _ConvPlan:
@@ -847,11 +849,25 @@ class _ConvPlan:
 # The library's kernel-selection thresholds (fd_tuning) change the split-K / slab workspace and weight-layout sizes, so the number of
 # fd_set_tuning calls so far is part of the plan key (one integer compare; the tests and sweeps flip thresholds within a process).
 def _conv_plan(x, w, stride, pad, pad_mode, act, in_norm):
-    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm, tuning.generation())
+    gen = tuning.generation()
+    if gen != _CONV_PLANS_GEN[0]:          # plans of an older fd_tuning can never be hit again: drop them (sweeps flip thresholds in loops)
+        _CONV_PLANS.clear()
+        _CONV_PLANS_GEN[0] = gen
+    key = (tuple(x.shape), tuple(w.shape), stride, pad, pad_mode, act, in_norm)
     plan = _CONV_PLANS.get(key)
     if plan is None:
         plan = _CONV_PLANS[key] = _ConvPlan(x, w, stride, pad, pad_mode, act, in_norm)
     return plan
+
+
+# direct-equivalent convolution flops issued since the tally was switched on (bench.py: the MFMA fraction of the configurations that
+# have no analytic table - Refiner / Completor steps); None = off, [0.0] = counting
+CONV_FLOP_TALLY = None
+
+
+def _tally(d, Ho, Wo, passes=1):
+    if CONV_FLOP_TALLY is not None:
+        CONV_FLOP_TALLY[0] += 2.0 * passes * d.N * d.Cout * Ho * Wo * d.Cin * d.KH * d.KW
 
 
 def _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm, want_stats=False):
@@ -867,6 +883,7 @@ def _conv_forward(ctx, x, w, bias, stride, pad, pad_mode, act, in_norm, want_sta
     plan = _conv_plan(x, w, stride, pad, pad_mode, act, bool(in_norm))
     d, Ho, Wo, nws, nwt = plan.d, plan.Ho, plan.Wo, plan.fwd_ws, plan.fwd_wt
     y = _empty((d.N, d.Cout, Ho, Wo), x)
+    _tally(d, Ho, Wo)
     ws = _empty((nws,), x) if nws > 0 else None
     wt, ready = _weight_layout(w, cache_id, "f", nwt, d) if nwt > 0 else (None, 0)
     part = None
@@ -895,13 +912,19 @@ def _conv_backward(ctx, gy, gx_add=None):
         gy = gpre
     plan = ctx.plan
     dp = plan.dp
+    in_act = getattr(ctx, "in_act", 0)
+    if in_act and ctx.needs_input_grad[0] and (gx_add is not None or d.in_norm):
+        # the producer of x was built with grad_preact=True and has skipped its own act' pass: this layer MUST multiply by act'(x)
+        # (the fallback branches below would drop it silently)
+        raise RuntimeError("conv2d(in_act=...): the fused act' data gradient cannot be taken here (second incoming gradient or "
+                           "normalised input) - build the producer without grad_preact")
     if ctx.needs_input_grad[0]:
+        _tally(d, plan.Ho, plan.Wo)
         gx = torch.empty_like(x)
         n_ws, n_wt = plan.data_sizes()
         ws = _empty((n_ws,), x)
         wt, ready = _weight_layout(w, ctx.cache_id, "d", n_wt, d)
-        in_act = getattr(ctx, "in_act", 0)
-        if in_act and gx_add is None and not d.in_norm:
+        if in_act:
             # x is an activation output consumed by this layer alone: hand its producer the gradient w.r.t. the PRE-activation
             call("fd_conv2d_bwd_data_inact", dp, ptr(gy), ptr(w), ptr(x), in_act, ptr(gx), ptr(wt), ready, ptr(ws), stream())
         elif gx_add is not None and not d.in_norm:
@@ -913,6 +936,7 @@ def _conv_backward(ctx, gy, gx_add=None):
             if gx_add is not None:
                 call("fd_axpby", ptr(gx), ptr(f32(gx_add)), ptr(gx), gx.numel(), 1.0, 1.0, stream())
     if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        _tally(d, plan.Ho, plan.Wo)
         tw = _direct_grad_target(ctx.params[0])
         tb = _direct_grad_target(ctx.params[1]) if ctx.has_bias else None
         direct = tw is not None and (not ctx.has_bias or tb is not None)

@@ -322,6 +322,8 @@ class Trainer:
     def lr_scheduler_step(self):
         """StepLR(step_size, 0.1).step()  (trainer.py:266): the learning rate drops by 10x every ``scheduler_step_size`` calls."""
         self.scheduler_epochs = getattr(self, "scheduler_epochs", 0) + 1
+        if self._graph is None:                 # no captured graph can hold a raw pointer into a retired layout buffer: free them
+            FD.release_retired_layouts()
         if self.scheduler_step_size > 0 and self.scheduler_epochs % self.scheduler_step_size == 0:
             self.lr *= 0.1
             self.adam_state[1] = self.lr

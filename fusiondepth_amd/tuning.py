@@ -43,11 +43,15 @@ def get_lib():
 
 
 def generation():
-    """Number of fd_set_tuning calls so far (cached size queries are keyed on it)."""
-    return _GEN[0]
+    """Number of fd_set_tuning calls so far (cached size queries are keyed on it).  Read from the library, so that a direct
+    ``fd_set_tuning`` call through ctypes invalidates the cached plan sizes as well."""
+    fn = _GEN_FN[0]
+    if fn is None:
+        fn = _GEN_FN[0] = _lib.load().fd_tuning_generation
+    return int(fn())
 
 
-_GEN = [0]
+_GEN_FN = [None]
 
 
 def set_lib(**fields):
@@ -65,7 +69,6 @@ def set_lib(**fields):
     rc = lib.fd_set_tuning(ctypes.byref(t))
     if rc != 0:
         raise RuntimeError("fd_set_tuning failed: %s" % lib.fd_last_error().decode())
-    _GEN[0] = int(lib.fd_tuning_generation())
     return prev
 
 
@@ -93,7 +96,14 @@ class _Host:
     refiner_streams = True      # the Refiner's frozen encoders on per-module streams
     decoder_fused_act = True    # ELU' of the decoder's single-consumer blocks applied where the gradient is produced (-0.15 ms when on)
     dp_overlap = True           # per-network gradient buckets all-reduced from inside the backward pass
-    host_delay_us = 0.0         # busy-wait before every entry-point call (the host-slack experiment, profiles/round3_experiments.md)
+
+    @property
+    def host_delay_us(self):    # busy-wait before every entry-point call (the host-slack experiment, profiles/round3_experiments.md)
+        return _lib.HOST_DELAY_US
+
+    @host_delay_us.setter
+    def host_delay_us(self, v):  # lives in _lib (read by _lib.call): assigning the attribute at run time takes effect at once
+        _lib.HOST_DELAY_US = float(v)
 
 
 host = _Host()
@@ -131,15 +141,18 @@ def _from_environment():
         lib_fields["conv_n16_min_pixels"] = -1
     if env.get("FD_REFLECT_WINO_PADDED") == "0":
         lib_fields["reflect_wino_padded_max"] = 0
-    if "FD_CONV_FORCE" in env:                        # "cfg,splits"
-        c, sp = env["FD_CONV_FORCE"].split(",")
-        lib_fields.update(force_cfg=int(c), force_splits=int(sp))
-    if lib_fields:
-        set_lib(**lib_fields)
+    try:
+        if "FD_CONV_FORCE" in env:                        # "cfg,splits"
+            c, sp = env["FD_CONV_FORCE"].split(",")
+            lib_fields.update(force_cfg=int(c), force_splits=int(sp))
+        if lib_fields:
+            set_lib(**lib_fields)
+    except (ValueError, RuntimeError, KeyError) as e:
+        raise RuntimeError("fusiondepth_amd.tuning: an FD_* variable of the A/B scripts has a value fd_set_tuning rejects (%s); "
+                           "unset it or fix it - FD_* variables are only read here, once, at import" % e) from e
     for var, (name, conv) in _ENV_HOST.items():
         if var in env:
             setattr(host, name, conv(env[var]))
-    _lib.HOST_DELAY_US = float(host.host_delay_us)
 
 
 _from_environment()

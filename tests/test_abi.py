@@ -93,3 +93,29 @@ def test_library_behaviour_does_not_depend_on_the_environment(lib_path, monkeypa
     bad.wino_target = 0
     assert _lib.load().fd_set_tuning(ctypes.byref(bad)) != 0 and "targets" in _lib.last_error()
     assert sizes() == base
+
+
+def integration_stub():
+    """The ctypes stub INTEGRATION.md shows a reference maintainer (section 2, first python block)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = text[text.index("## 2. C-ABI level"):]
+    return re.search(r"```python\n(.*?)```", sec, flags=re.S).group(1)
+
+
+def test_integration_stub_executes(lib_path, monkeypatch):
+    """the stub asserted ``fd_abi_version() == 1`` against a header that says 2 - and compared an ``int``
+    with ``b"gfx950"``.  It is executed here (the definitions and its two asserts; the GPU suite calls the functions it defines,
+    tests/test_gpu_losspath.py::test_integration_stub_functions), so it cannot rot again."""
+    from fusiondepth_amd import _lib
+    monkeypatch.chdir(ROOT)
+    code = integration_stub()
+    assert "fd_abi_version() == %d" % _lib.ABI_VERSION in code
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    lib = ns["lib"]
+    for name in set(re.findall(r"lib\.(fd_[a-z0-9_]+)", code)):
+        assert hasattr(lib, name), name
+        fn = getattr(lib, name)
+        if fn.argtypes is not None and name in _lib.SIGNATURES:
+            assert len(fn.argtypes) == len(_lib.SIGNATURES[name][0]), (name, len(fn.argtypes), _lib.SIGNATURES[name][0])
+    assert callable(ns["ssim"]) and callable(ns["get_4beam_2channel"]) and callable(ns["get_4beam"])

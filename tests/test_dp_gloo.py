@@ -167,3 +167,123 @@ def test_in_place_gradients_trigger_overlapped_buckets():
     assert torch.equal(g0, g1)
     n = out["ref"].numel()
     assert torch.allclose(g0[:n], out["ref"], rtol=1e-5, atol=1e-7) and float(g0[n:].abs().max()) == 0.0
+
+
+# ---- world size 8: the layout the driver's 8-GPU run will use ------------------------------------------
+class _Branch(torch.nn.Module):
+    """One 'network' of the trainer in miniature: two layers whose weight gradients are accumulated in place (like the HIP
+    kernels do), plus a head that is in parameters() but never used - the ResNet ``fc`` of every encoder."""
+
+    def __init__(self, d_in, width, with_fc):
+        super().__init__()
+        self.w1 = torch.nn.Parameter(torch.randn(width, d_in) * 0.3)
+        self.w2 = torch.nn.Parameter(torch.randn(d_in, width) * 0.3)
+        if with_fc:
+            self.fc_w = torch.nn.Parameter(torch.randn(10, width))
+            self.fc_b = torch.nn.Parameter(torch.randn(10))
+
+    def forward(self, x):
+        return torch.tanh(_InPlaceLinear.apply(torch.tanh(_InPlaceLinear.apply(x, self.w1)), self.w2))
+
+
+def _branches():
+    # four "encoders" (with an unused head) and two "decoders", different sizes so that bucket boundaries fall unevenly
+    return torch.nn.ModuleList([_Branch(8, 24, True), _Branch(8, 40, True), _Branch(8, 16, False), _Branch(8, 56, True),
+                                _Branch(8, 32, True), _Branch(8, 12, False)])
+
+
+def _worker8(rank, world, port, out):
+    from fusiondepth_amd import dp, functional as FD
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dp.init_from_env(backend="gloo")
+    torch.set_num_threads(1)
+    torch.manual_seed(300 + rank)                         # every rank starts elsewhere: the broadcast must make them rank 0's
+    nets = _branches()
+    dp.broadcast_module_state(nets)
+    params = [p for n in nets for p in n.parameters()]
+    unused = [p for n in nets for name, p in n.named_parameters() if name.startswith("fc_")]
+    flat = dp.FlatParameters(params)
+    sync = dp.GradientSynchronizer(flat, world, bucket_bytes=1500, segments=[len(list(n.parameters())) for n in nets], never_used=unused)
+    data = torch.randn(world, 3, 5, 8, generator=torch.Generator().manual_seed(11))      # [rank, step, sample, feature]
+    overl = []
+    for step in range(3):
+        FD.begin_forward_pass()
+        sync.arm()
+        loss = 0
+        for n in nets:
+            loss = loss + n(data[rank, step]).pow(2).mean()
+        loss.backward()
+        overl.append(sync.n_overlapped)
+        scale = sync.finish()
+        assert scale == 1.0 / world
+        with torch.no_grad():
+            flat.flat_param -= 0.05 * scale * flat.flat_grad
+        flat.zero_grad()
+    out[rank] = (flat.flat_param.clone(), overl, [list(b) for b in sync.buckets])
+    if rank == 0:
+        torch.manual_seed(300)
+        ref = _branches()
+        rp = [p for n in ref for p in n.parameters()]
+        for step in range(3):
+            for p in rp:
+                p.grad = torch.zeros_like(p)
+            tot = 0
+            for r in range(world):
+                for n in ref:
+                    tot = tot + n(data[r, step]).pow(2).mean()
+            (tot / world).backward()
+            with torch.no_grad():
+                for p in rp:
+                    p -= 0.05 * p.grad
+        out["ref"] = torch.cat([p.detach().reshape(-1) for p in rp])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_bucket_layout_unused_heads_and_broadcast():
+    """World size 8 over gloo: six per-network segments cut into several buckets each, unused ``fc`` heads inside the segments, a
+    different initial state per rank (the broadcast must repair it), different data per rank, three optimiser steps.  Every replica
+    must end bit-identical and on the single-process result over the 8 concatenated shards; every bucket that holds a used
+    parameter must have left DURING the backward pass."""
+    world = 8
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker8, args=(world, _free_port(), out), nprocs=world, join=True)
+    p0, overl0, buckets = out[0]
+    for r in range(1, world):
+        assert torch.equal(out[r][0], p0), "replica %d diverged" % r
+        assert out[r][1] == overl0 and out[r][2] == buckets
+    assert torch.allclose(p0, out["ref"], rtol=2e-5, atol=1e-6), float((p0 - out["ref"]).abs().max())
+    # layout: contiguous cover of the flat buffer, several buckets, none straddling a network; buckets made of unused heads only leave at finish()
+    assert buckets[0][0] == 0 and all(buckets[i][1] == buckets[i + 1][0] for i in range(len(buckets) - 1))
+    n_used_buckets = sum(1 for b in buckets if b[2] > 0)
+    assert len(buckets) >= 8 and overl0 == [n_used_buckets] * 3
+
+
+def test_trainer_bucket_layout_for_the_real_networks():
+    """The bucket partition of the REAL parameter list (the six ResNet-18 networks of BASELINE config 2 / 4, built on the CPU: no
+    kernels involved): ~25 MB buckets, none across a network boundary, the eight ``encoder.fc.*`` tensors not waited for, the whole
+    197 MB gradient covered exactly once."""
+    from fusiondepth_amd import dp, networks
+    m = [networks.ResnetEncoder(18, False), networks.ResnetEncoder(18, False, beam_encoder=True),
+         networks.ResnetEncoder(18, False, num_input_images=2, beam_encoder=True)]
+    m.append(networks.DepthDecoder(m[0].num_ch_enc, range(4)))
+    m.append(networks.ResnetEncoder(18, False, num_input_images=2))
+    m.append(networks.PoseDecoder(m[4].num_ch_enc, num_input_features=1, num_frames_to_predict_for=2))
+    params = [p for n in m for p in n.parameters()]
+    unused = [p for n in m for name, p in n.named_parameters() if name.startswith("encoder.fc.")]
+    assert len(unused) == 8
+    flat = dp.FlatParameters(params)
+    sync = dp.GradientSynchronizer(flat, 8, segments=[len(list(n.parameters())) for n in m], never_used=unused)
+    b = sync.buckets
+    assert b[0][0] == 0 and b[-1][1] == flat.numel() and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+    seg_ends, acc = [], 0
+    for n in m:
+        acc += sum(p.numel() for p in n.parameters())
+        seg_ends.append(acc)
+    ends = [x[1] for x in b]
+    assert all(e in ends for e in seg_ends), "a bucket straddles two networks (their backward passes run on different streams)"
+    assert sum(x[2] for x in b) == len(params) - 8
+    sizes = [4 * (x[1] - x[0]) for x in b]
+    assert max(sizes) < 2 * (25 << 20) + (10 << 20) and 6 <= len(b) <= 16, sizes
+    assert flat.numel() == 49182752 + 4 * (512 * 1000 + 1000)          # SURVEY 8e's 49 182 752 trained parameters + the four unused fc heads

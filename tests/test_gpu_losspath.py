@@ -649,3 +649,27 @@ def cpu_grid(H, W, B):
 def test_ops_refuse_cpu_tensors(FD):
     with pytest.raises(RuntimeError):
         FD.ssim(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
+
+
+def test_integration_stub_functions(FD, monkeypatch):
+    """The ctypes stub of INTEGRATION.md section 2 (what a reference maintainer would paste), executed as written: its ``ssim``,
+    ``get_4beam_2channel`` and ``get_4beam`` against the package's own wrappers (themselves checked against the oracle above)."""
+    import os
+    import test_abi
+    from fusiondepth_amd import functional as F_
+    monkeypatch.chdir(test_abi.ROOT)
+    ns = {}
+    exec(compile(test_abi.integration_stub(), "INTEGRATION.md", "exec"), ns)
+    rng = np.random.RandomState(5)
+    x, y = (torch.from_numpy(rng.rand(2, 3, 32, 64).astype(np.float32)).cuda() for _ in range(2))
+    assert torch.equal(ns["ssim"](x, y), F_.ssim(x, y))
+    beam = torch.zeros(2, 1, 192, 640)
+    beam[:, 0, 100:180:20, 4:636:3] = torch.from_numpy(rng.uniform(0.05, 0.65, (2, 4, 211)).astype(np.float32))
+    beam = beam.cuda()
+    assert torch.equal(ns["get_4beam_2channel"](beam), F_.scatter_2channel(beam))
+    velo, P = gin.lidar_scan(21, n_points=5000)
+    pts = torch.from_numpy(velo).cuda()
+    got = ns["get_4beam"](pts, torch.from_numpy(np.ascontiguousarray(P, dtype=np.float64)).cuda(), 375, 1242)
+    want = F_.velo_rasterize(pts, P, 375, 1242, (384, 1280))
+    torch.cuda.synchronize()
+    assert torch.equal(got.reshape(-1), want.reshape(-1)) and float(got.abs().sum()) > 0
