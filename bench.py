@@ -48,9 +48,9 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--batch_size", type=int, default=12, help="per-process --batch_size of the reference trainer")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
-    ap.add_argument("--graph", action="store_true", help="force hipGraph replay (default: whichever of the two launch paths "
-                    "measures faster during the untimed warm-up)")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python on the four module streams (the default since round 5)")
+    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of the step instead (slower on ROCm 7.2; rounds 1-4 chose between the two "
+                    "during the untimed warm-up; the replay never won)")
     ap.add_argument("--no_stack", action="store_true", help="run the accumulated micro-batches sequentially (reference order) "
                     "instead of as one stacked pass with grouped BatchNorm")
     ap.add_argument("--no_roofline", action="store_true")
@@ -559,30 +559,20 @@ def main():
 
     barrier(); barrier()          # the first collective builds the communicator (seconds): keep it out of every measurement
     abs_rel_before = float(tr.val_metrics([val_batch])["de/abs_rel"])
-    launch = "eager" if args.eager else ("graph" if args.graph else "auto")
-    if launch == "auto" and world > 1:
-        # Multi-process runs keep to the eager path: it measured faster than hipGraph replay on one GPU (profiles/README.md),
-        # and a capture that fails on one rank only would leave the others waiting in the next collective.
-        launch = "eager"
-    if launch == "auto":
-        # Both launch paths run the same kernels on the same streams; which one keeps the GPU busier depends on the host
-        # (Python issue rate vs hipGraphLaunch cost per node).  Decide inside the untimed warm-up, identically on all ranks.
-        # Best of three single steps each, after the path's own warm-up: the first steps of either path pay for allocator growth,
-        # lazily built weight layouts and the side-stream setup (one slow trial step once made this choose the slower path).
-        for _ in range(3):
-            eager_step()
-        t_eager = min(timed(eager_step, 1) for _ in range(3))
-        graph_step(); graph_step(); graph_step()             # eager warm-up on the capture stream + capture + first replay
-        t_graph = min(timed(graph_step, 1) for _ in range(3))
-        launch = "graph" if t_graph < 0.97 * t_eager else "eager"
-        if rank == 0:
-            print("[bench] warm-up: eager %.2f ms/step, hipGraph replay %.2f ms/step -> %s" % (1e3 * t_eager, 1e3 * t_graph, launch),
-                  file=sys.stderr, flush=True)
+    # Launch path: eager issue on the four module streams.  Rounds 1-4 timed a hipGraph replay of the step against it during the
+    # warm-up and took the faster one; the replay has lost every such trial since round 1 (round 5, profiles/round5_eager_vs_trial.log:
+    # 22.4 vs 19.1 ms per step - hipGraphLaunch costs the host more per kernel node than the eager launch it replaces, and its
+    # executor overlaps the branches less than real streams do), and the trial itself changes nothing for the eager path
+    # (19.03 - 19.22 ms with it, 18.97 - 19.20 without), so it is gone: --graph still forces the replay path.
+    launch = "graph" if args.graph else "eager"
+    if launch == "graph" and world > 1:
+        launch = "eager"           # a capture that fails on one rank only would leave the others waiting in the next collective
     step_fn = eager_step if launch == "eager" else graph_step
-    # two extra untimed steps of the chosen path, so that the caching allocator, the weight-layout caches and the batched
-    # re-layout plan (built after the first step; re-derived when the trial above switched between the two launch paths) are
-    # in their steady state before the W warm-up steps even when W is 0 or 1
-    for _ in range(2):
+    # six extra untimed steps of the chosen path, so that the caching allocator, the weight-layout caches, the batched re-layout
+    # plan (built after the first step) and the clocks are in their steady state before the W warm-up steps even when W is 0 or 1
+    # (scripts/secondary_ab.py prints the first eight steps of a process one by one: the first costs 2x, the next ~seven 5 - 10 % more
+    # than the steady state)
+    for _ in range(6):
         step_fn()
     for _ in range(max(args.warmup, 0 if launch == "eager" else 2)):     # graph mode: 1 eager warm-up + 1 capture/replay
         step_fn()

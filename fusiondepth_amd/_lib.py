@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FD_LIBFDHIP") or os.path.join(_HERE, "libfdhip.so")   # FD_LIBFDHIP: ablation builds (scripts/)
-ABI_VERSION = 2
+ABI_VERSION = 3
 PHOTO_OUT_FLOATS = 96        # FD_PHOTO_OUT_FLOATS
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
@@ -31,6 +31,13 @@ class PhotoMsCfg(ctypes.Structure):
     """Mirror of ``fd_photo_ms_cfg``."""
     _fields_ = [("base", PhotoCfg), ("n_scales", _I), ("Hs", _I * 4), ("Ws", _I * 4), ("beam_mask", ctypes.c_uint),
                 ("rows_per_strip", _I)]
+
+
+class RefineCfg(ctypes.Structure):
+    """Mirror of ``fd_refine_cfg``."""
+    _fields_ = [("B", _I), ("H", _I), ("W", _I), ("n_scales", _I), ("Hs", _I * 4), ("Ws", _I * 4),
+                ("crop_y0", _I), ("crop_y1", _I), ("crop_x0", _I), ("crop_x1", _I), ("min_depth", _D), ("max_depth", _D),
+                ("catxy", _I), ("pool_disp0", _I)]
 
 
 class ConvDesc(ctypes.Structure):
@@ -100,6 +107,10 @@ SIGNATURES = {
     "fd_conv3x3_wino_fwd": ("pppppp" "i" "pp", "i"),
     "fd_velo_rasterize_ws_bytes": ("iii", "l"),
     "fd_velo_rasterize": ("pipiiiiipppp", "i"),
+    "fd_masked_median_ws_bytes": ("iii", "l"),
+    "fd_masked_median": ("ppfiiiiiiippp", "i"),
+    "fd_refine_inputs_ws_bytes": ("p", "l"),
+    "fd_refine_inputs": ("ppppppppp", "i"),
     "fd_conv2d_relayout_jobs": ("pippp", "i"),
     "fd_relayout_plan": ("pi", "l"),
     "fd_relayout_batch": ("pilp", "i"),

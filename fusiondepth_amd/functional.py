@@ -1440,6 +1440,51 @@ def spatial_mean(x, scale=1.0):
     return _SpatialMean.apply(x, scale)
 
 
+def masked_median(x, gate, scale=1.0, window=None):
+    """``torch.median(x[mask] * scale)`` with ``mask = gate > 0`` inside ``window`` = (y0, y1, x0, x1) of every plane (default: the
+    whole plane), over the whole batch - refiner.py:327-331.  A 0-dim device tensor; no host round trip, no sort."""
+    x, gate = f32(x.detach()), f32(gate.detach())
+    _need_cuda(x, gate)
+    if x.shape != gate.shape:
+        raise RuntimeError("masked_median: x %s and gate %s differ in shape" % (tuple(x.shape), tuple(gate.shape)))
+    H, W = x.shape[-2:]
+    B = x.numel() // (H * W)
+    y0, y1, x0, x1 = window if window is not None else (0, H, 0, W)
+    out = _empty((2,), x)
+    ws = torch.empty((query("fd_masked_median_ws_bytes", B, H, W),), device=x.device, dtype=torch.uint8)
+    call("fd_masked_median", ptr(x), ptr(gate), float(scale), B, H, W, int(y0), int(y1), int(x0), int(x1), ptr(out), ws.data_ptr(), stream())
+    return out[0]
+
+
+def refine_inputs(disps, beam, two_cha, inv_Ks, height, width, min_depth, max_depth, catxy=True, pool_disp0=True,
+                  crop=(78, 190, 23, 617), return_stats=False):
+    """refiner.py:316-348 for all scales in four launches (csrc/refine.hip): -> list of [B, 1 + 3*catxy + 2, Hs, Ws] tensors, the
+    ``depth_maps`` inputs of the refine decoder (scaled disparity | Cat_xy of the pooled depth | pooled 2-channel LiDAR map).
+    ``disps``: ``outputs[("disp", s)]`` per scale (only ``disps[0]`` is read when ``pool_disp0`` = --refine_a0 true);
+    ``inv_Ks``: ``inputs[("inv_K", s)]`` per scale.  No gradient (the reference computes all of it under no_grad)."""
+    S = len(disps)
+    d0 = f32(disps[0].detach())
+    beam, two_cha = f32(beam.detach()), f32(two_cha.detach())
+    _need_cuda(d0, beam, two_cha)
+    B = d0.shape[0]
+    cfg = _lib.RefineCfg()
+    cfg.B, cfg.H, cfg.W, cfg.n_scales = B, int(height), int(width), S
+    ds, ks = [], []
+    for s in range(S):
+        cfg.Hs[s], cfg.Ws[s] = (int(disps[s].shape[2]), int(disps[s].shape[3]))
+        ds.append(d0 if s == 0 else (None if pool_disp0 else f32(disps[s].detach())))
+        ks.append(f32(inv_Ks[s].detach()) if catxy else None)
+    cfg.crop_y0, cfg.crop_y1, cfg.crop_x0, cfg.crop_x1 = (int(v) for v in crop)
+    cfg.min_depth, cfg.max_depth, cfg.catxy, cfg.pool_disp0 = float(min_depth), float(max_depth), int(bool(catxy)), int(bool(pool_disp0))
+    C = 1 + (3 if catxy else 0) + 2
+    outs = [_empty((B, C, cfg.Hs[s], cfg.Ws[s]), d0) for s in range(S)]
+    ws = torch.empty((query("fd_refine_inputs_ws_bytes", ctypes.byref(cfg)),), device=d0.device, dtype=torch.uint8)
+    stats = _empty((S, 4), d0) if return_stats else None
+    arr = lambda ts: (ctypes.c_void_p * 4)(*[ptr(t) for t in ts] + [None] * (4 - len(ts)))
+    call("fd_refine_inputs", ctypes.byref(cfg), arr(ds), ptr(beam), ptr(two_cha), arr(ks), arr(outs), ptr(stats), ws.data_ptr(), stream())
+    return (outs, stats) if return_stats else outs
+
+
 def depth_errors(gt, pred):
     """layers.py:284-302 on matched 1-D tensors -> 7 scalars (abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3)."""
     gt, pred = f32(gt.detach()).reshape(-1), f32(pred.detach()).reshape(-1)

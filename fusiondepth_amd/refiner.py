@@ -150,7 +150,19 @@ class Refiner(Trainer):
 
     # ------------------------------------------------------------------------------------------------
     def refine_inputs(self, inputs, outputs):
-        """refiner.py:316-348."""
+        """refiner.py:316-348: median scaling of the coarse depth to the LiDAR returns, scaled disparity, Cat_xy, pooled 2-channel
+        map - all scales in four libfdhip launches (``fd_refine_inputs``, csrc/refine.hip: ``torch.median`` of a boolean selection as
+        a radix select, no full-resolution intermediates).  Rounds 2-4 built this from ~60 ATen launches per step (nanmedian = a
+        sort per median, max_pool2d, interpolate, cat); ``refine_inputs_aten`` keeps that form for the A/B in scripts/."""
+        opt = self.opt
+        scales = list(opt.scales)
+        disps = [outputs[("disp", s)] for s in scales]
+        maps = FD.refine_inputs(disps, inputs["4beam"], inputs["2channel"], [inputs[("inv_K", s)] for s in scales], opt.height, opt.width,
+                                opt.min_depth, opt.max_depth, catxy=(opt.catxy == "true"), pool_disp0=(opt.refine_a0 == "true"))
+        return {("disp", s): m for s, m in zip(scales, maps)}
+
+    def refine_inputs_aten(self, inputs, outputs):
+        """The round 2-4 form of ``refine_inputs`` (ATen calls); kept for timing comparisons only."""
         opt = self.opt
         beam, two_cha = inputs["4beam"], inputs["2channel"]
         disp_0 = outputs[("disp", 0)]
@@ -159,9 +171,6 @@ class Refiner(Trainer):
         crop = torch.zeros_like(mask)
         crop[:, :, 78:190, 23:617] = 1
         mask = mask * crop
-        # torch.median(x[mask]) without the host round trip of boolean indexing (its output size has to be read back, which
-        # drains the launch queue once per call, five times a step): masked-out entries become NaN and nanmedian - the same
-        # lower median over the remaining values - skips them
         nan = torch.full((), float("nan"), device=beam.device)
         masked_median = lambda x: torch.nanmedian(torch.where(mask, x, nan))
         beam_med = masked_median(beam * 100.0)

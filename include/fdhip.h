@@ -27,7 +27,7 @@ extern "C" {
 /* 2: fd_tuning / fd_set_tuning added (the library no longer reads the process environment); fd_conv2d_fwd_stats and
  *    fd_bn_train_fwd_parts added, the fd_conv2d_*_pair entry points removed, fd_bn_ws_floats grew by one shift value per
  *    (group, channel) - a client that sized the BatchNorm workspace itself must re-query it. */
-#define FD_ABI_VERSION 2
+#define FD_ABI_VERSION 3
 
 int fd_abi_version(void);
 const char* fd_supported_arch(void); /* "gfx950" */
@@ -432,6 +432,36 @@ int fd_conv3x3_wino_fwd(const fd_conv_desc* d, const float* x, const float* w, c
 long fd_velo_rasterize_ws_bytes(int n_points, int im_h, int im_w);
 int fd_velo_rasterize(const float* points, int n_points, const double* P_velo2im, int im_h, int im_w, int vel_depth, int target_h,
                       int target_w, float* beam_out, double* depth_out, void* ws, void* stream);
+
+/* ------------------------------------------------------------------ refiner inputs ------------- */
+
+/* torch.median(x[mask] * scale) with mask = gate > 0 inside rows [y0,y1) x columns [x0,x1) of every [H][W] plane of the batch
+ * (refiner.py:327-331: `torch.median(beam[mask] * 100.0)`): the LOWER median (rank (n-1)/2) over the whole batch, by radix select on
+ * order-preserving integer keys - no sort, no host round trip for the selection size, result independent of the order in which
+ * the selection was compacted.  out[0] = median (NaN when the selection is empty - the reference raises there - or holds a NaN),
+ * out[1] = n.  x and gate: [B][H][W].  ws: fd_masked_median_ws_bytes(B, H, W) bytes. */
+long fd_masked_median_ws_bytes(int B, int H, int W);
+int fd_masked_median(const float* x, const float* gate, float scale, int B, int H, int W, int y0, int y1, int x0, int x1, float* out,
+                     void* ws, void* stream);
+
+/* refiner.py:316-348: the depth-map inputs of the refine decoder for ALL scales, written straight into the concatenated tensors
+ * out[s] [B][1 + 3*catxy + 2][Hs][Ws] = (scaled_disp | Cat_xy(s-fold max-pooled depth, inv_K[s]) | s-fold max-pooled 2-channel map):
+ * per scale, disp[s] (or, pool_disp0 != 0 = --refine_a0 true, the s-fold 2x2 ceil-mode max-pool of disp[0]) is up-sampled bilinearly
+ * to H x W, turned into depth, scaled by median(beam[mask] * 100) / median(depth[mask]) (mask: beam > 0 inside the crop, medians over
+ * the batch, fd_masked_median's rule), and scaled_disp = (bilinear down-sample of 1 / depth - 0.01) / 9.9.  Four launches, no
+ * full-resolution intermediate.  Hs[s] * r == H, Ws[s] * r == W with r a power of two <= 8.  No gradient (the reference runs this
+ * under no_grad / detaches the ratio; the decoder's inputs are leaves).  stats (may be NULL): [n_scales][4] = ratio,
+ * median(depth[mask]), median(beam[mask] * 100), n.  ws: fd_refine_inputs_ws_bytes(cfg) bytes. */
+typedef struct fd_refine_cfg {
+    int B, H, W, n_scales;
+    int Hs[4], Ws[4];
+    int crop_y0, crop_y1, crop_x0, crop_x1;     /* refiner.py:329: rows 78..189, columns 23..616 */
+    double min_depth, max_depth;
+    int catxy, pool_disp0;
+} fd_refine_cfg;
+long fd_refine_inputs_ws_bytes(const fd_refine_cfg* cfg);
+int fd_refine_inputs(const fd_refine_cfg* cfg, const float* const* disp, const float* beam, const float* two_cha,
+                     const float* const* inv_K, float* const* out, float* stats, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -951,3 +951,74 @@ def test_interleaved_encoders_equal_sequential_passes():
             assert (ga is None) == (gb is None)
             if ga is not None:
                 assert torch.equal(ga, gb)
+
+
+# ---- act' applied where the gradient is produced (fd_upcat_bwd_act / fd_conv2d_bwd_data_inact had no direct tests) --
+_TORCH_ACT = {"relu": torch.relu, "elu": F.elu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "sigmoid", "tanh"])
+@pytest.mark.parametrize("h,w", [(6, 8), (5, 7), (12, 40)])
+def test_upcat_bwd_with_fused_activation_gradient(FD, act, h, w):
+    """upsample_concat(a_act=...) after a conv2d(grad_preact=True): the gradient that reaches the convolution's input and weight is
+    the one torch autograd gives for  cat([up2(act(conv(x))), skip])  - every activation id, even (vector path) and odd (scalar
+    path) widths."""
+    rng = np.random.RandomState(21)
+    mk = lambda *s: torch.from_numpy(rng.randn(*s).astype(np.float32))
+    N, Cin, Ca, Cs = 2, 16, 16, 5
+    x, wgt, bias, skip = mk(N, Cin, h, w), mk(Ca, Cin, 3, 3) * 0.2, mk(Ca) * 0.1, mk(N, Cs, 2 * h, 2 * w)
+    xo, wo, bo, so = (t.clone().requires_grad_(True) for t in (x, wgt, bias, skip))
+    a = _TORCH_ACT[act](F.conv2d(F.pad(xo, (1, 1, 1, 1), mode="reflect"), wo, bo))
+    yo = torch.cat([OL.upsample(a), so], 1)
+    cot = mk(*yo.shape)
+    want = torch.autograd.grad((yo * cot).sum(), [xo, wo, bo, so])
+    for fused in (True, False):
+        xg, wg, bg, sg = (dev(t).requires_grad_(True) for t in (x, wgt, bias, skip))
+        ag = FD.conv2d(xg, wg, bg, 1, 1, "reflect", act, grad_preact=fused)
+        yg = FD.upsample_concat(ag, sg, a_act=act if fused else "none")
+        got = torch.autograd.grad((yg * dev(cot)).sum(), [xg, wg, bg, sg])
+        relclose(cpu(yg), cpu(yo), "forward", rtol=2e-5, arel=2e-5)
+        for name, g1, g2 in zip(("gx", "gw", "gb", "gskip"), got, want):
+            relclose(cpu(g1), cpu(g2), "%s (%s, fused=%s)" % (name, act, fused), rtol=5e-5, arel=5e-5)
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "sigmoid", "tanh"])
+@pytest.mark.parametrize("c1", [1, 0])
+def test_data_gradient_with_input_activation(FD, fdtune, act, c1):
+    """conv2d(in_act=...) as the single consumer of a conv2d(grad_preact=True): the one-output-channel stencil route (dispconv) and,
+    with it switched off (fd_tuning.conv_c1 = 0), the fallback that runs the plain data gradient followed by an in-place act'."""
+    fdtune.lib(conv_c1=c1)
+    rng = np.random.RandomState(22)
+    mk = lambda *s: torch.from_numpy(rng.randn(*s).astype(np.float32))
+    N, Cin, Cm, h, w = 2, 16, 16, 12, 20
+    x, w1, b1, w2, b2 = mk(N, Cin, h, w), mk(Cm, Cin, 3, 3) * 0.2, mk(Cm) * 0.1, mk(1, Cm, 3, 3) * 0.2, mk(1) * 0.1
+    leaves_o = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    pad = lambda t: F.pad(t, (1, 1, 1, 1), mode="reflect")
+    mid = _TORCH_ACT[act](F.conv2d(pad(leaves_o[0]), leaves_o[1], leaves_o[2]))
+    yo = torch.sigmoid(F.conv2d(pad(mid), leaves_o[3], leaves_o[4]))
+    cot = mk(*yo.shape)
+    want = torch.autograd.grad((yo * cot).sum(), leaves_o)
+    for fused in (True, False):
+        lg = [dev(t).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        m = FD.conv2d(lg[0], lg[1], lg[2], 1, 1, "reflect", act, grad_preact=fused)
+        yg = FD.conv2d(m, lg[3], lg[4], 1, 1, "reflect", "sigmoid", in_act=act if fused else "none")
+        got = torch.autograd.grad((yg * dev(cot)).sum(), lg)
+        relclose(cpu(yg), cpu(yo), "forward", rtol=2e-5, arel=2e-5)
+        for name, g1, g2 in zip(("gx", "gw1", "gb1", "gw2", "gb2"), got, want):
+            relclose(cpu(g1), cpu(g2), "%s (%s, conv_c1=%d, fused=%s)" % (name, act, c1, fused), rtol=5e-5, arel=5e-5)
+
+
+def test_input_activation_contract_is_enforced(FD):
+    """a layer built with in_act whose fused data gradient cannot be taken (a second gradient arriving at its input,
+    as through conv2d_tap) must raise instead of silently dropping act'."""
+    rng = np.random.RandomState(23)
+    mk = lambda *s: torch.from_numpy(rng.randn(*s).astype(np.float32))
+    x, wgt = dev(mk(1, 16, 8, 8)), dev(mk(16, 16, 3, 3))
+    c = FD._Part()
+    _, y, _ = FD._conv_forward(c, x, wgt, None, 1, 1, 0, 0, False)
+    c.in_act = FD.ACT["elu"]
+    with pytest.raises(RuntimeError, match="in_act"):
+        FD._conv_backward(c, torch.ones_like(y), gx_add=torch.ones_like(x))
+    c.in_act = 0
+    gx, gw, _ = FD._conv_backward(c, torch.ones_like(y), gx_add=torch.ones_like(x))
+    assert gx.shape == x.shape and gw.shape == wgt.shape

@@ -139,3 +139,101 @@ def test_refiner_train_loop_logs_depth_metrics(tmp_path):
     recs = [json.loads(l) for l in open(tmp_path / "rf" / "train" / "scalars.jsonl")]
     assert len(recs) == 2 and all(np.isfinite(r["loss"]) and np.isfinite(r["de/abs_rel"]) and r["de/abs_rel"] > 0 for r in recs)
     assert rf.adam_step_count == 2
+
+
+# ---- refine-decoder input construction on libfdhip (csrc/refine.hip) --------------------------------------
+def _refine_case(seed, B, H, W, dense=False):
+    """Disparity pyramid, sparse LiDAR map + its 2-channel scatter, intrinsics per scale - on the CPU."""
+    rng = np.random.RandomState(seed)
+    disps = [torch.from_numpy(rng.uniform(0.01, 0.6, (B, 1, H >> s, W >> s)).astype(np.float32)) for s in range(4)]
+    beam = torch.zeros(B, 1, H, W)
+    if dense:        # an r200-like map: returns everywhere, also outside the crop, ties between values
+        m = torch.from_numpy(rng.rand(B, 1, H, W) < 0.3)
+        beam[m] = torch.from_numpy(np.round(rng.uniform(0.03, 0.8, int(m.sum())), 2).astype(np.float32))
+    else:
+        rows = [int(H * f) for f in (0.45, 0.55, 0.7, 0.85)]
+        for r in rows:
+            beam[:, 0, r, 3:W - 3:3] = torch.from_numpy(rng.uniform(0.05, 0.65, (B, len(range(3, W - 3, 3)))).astype(np.float32))
+    two = torch.from_numpy(rng.rand(B, 2, H, W).astype(np.float32)) * (torch.from_numpy(rng.rand(B, 2, H, W)) < 0.2)
+    inv_K = {}
+    for s in range(4):
+        K = np.array([[0.58 * (W >> s), 0, 0.5 * (W >> s), 0], [0, 1.92 * (H >> s), 0.5 * (H >> s), 0], [0, 0, 1, 0], [0, 0, 0, 1]], np.float32)
+        inv_K[s] = torch.from_numpy(np.linalg.pinv(K)).unsqueeze(0).repeat(B, 1, 1)
+    return disps, beam, two.float(), inv_K
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_masked_median_is_torch_median(dense):
+    """fd_masked_median (radix select) == torch.median(x[mask] * scale): the lower median over the whole batch, bit for bit - even /
+    odd counts, ties, negative values, one element, an empty selection (NaN), a NaN in the selection (NaN)."""
+    from fusiondepth_amd import functional as FD
+    rng = np.random.RandomState(3 + dense)
+    for B, H, W, win in ((2, 192, 640, (78, 190, 23, 617)), (3, 40, 70, None), (1, 17, 33, (2, 15, 1, 30))):
+        x = torch.from_numpy(rng.randn(B, 1, H, W).astype(np.float32))
+        if dense:
+            x = torch.round(x * 4) / 4               # many equal values
+        gate = torch.from_numpy((rng.rand(B, 1, H, W) < (0.4 if dense else 0.01)).astype(np.float32))
+        for drop in (0, 1):                           # an even and an odd selection size
+            y0, y1, x0, x1 = win if win is not None else (0, H, 0, W)
+            crop = torch.zeros_like(gate, dtype=torch.bool)
+            crop[:, :, y0:y1, x0:x1] = True
+            m = (gate > 0) & crop
+            if drop:
+                first = m.flatten().nonzero()[0]
+                gate.view(-1)[first] = 0
+                m = (gate > 0) & crop
+            want = torch.median(x[m] * 2.5)
+            got = FD.masked_median(x.cuda(), gate.cuda(), 2.5, win)
+            assert got.cpu().item() == want.item(), (B, H, W, int(m.sum()), got.item(), want.item())
+    x = torch.tensor([[[[3.0, -1.0, 7.0, 2.0]]]])
+    g = torch.tensor([[[[0.0, 1.0, 0.0, 0.0]]]])
+    assert FD.masked_median(x.cuda(), g.cuda()).item() == -1.0
+    assert np.isnan(FD.masked_median(x.cuda(), torch.zeros_like(g).cuda()).item())
+    xn = x.clone(); xn[0, 0, 0, 1] = float("nan")
+    assert np.isnan(FD.masked_median(xn.cuda(), torch.ones_like(g).cuda()).item())
+
+
+@pytest.mark.parametrize("B,H,W,dense", [(2, 192, 640, False), (1, 192, 640, True), (2, 320, 1024, False)])
+@pytest.mark.parametrize("catxy,a0", [("true", "true"), ("true", "false"), ("false", "true")])
+def test_refine_inputs_vs_oracle(B, H, W, dense, catxy, a0):
+    """fd_refine_inputs (four launches) against the oracle's restatement of refiner.py:316-348 (ATen on the CPU): the median ratio
+    of every scale exactly up to the rounding of the depths it selects from, every output channel to 1e-5 relative (pooled channels
+    exact)."""
+    from fusiondepth_amd import functional as FD
+    disps, beam, two, inv_K = _refine_case(11 + B + H, B, H, W, dense)
+    opt = OR.default_opt(batch_size=B, height=H, width=W, catxy=catxy, refine_a0=a0)
+    inputs = {"4beam": beam, "2channel": two}
+    inputs.update({("inv_K", s): inv_K[s] for s in range(4)})
+    want = OR.refine_inputs(opt, inputs, {("disp", s): disps[s] for s in range(4)})
+    got, stats = FD.refine_inputs([d.cuda() for d in disps], beam.cuda(), two.cuda(), [inv_K[s].cuda() for s in range(4)], H, W,
+                                  opt.min_depth, opt.max_depth, catxy=(catxy == "true"), pool_disp0=(a0 == "true"), return_stats=True)
+    stats = stats.cpu().numpy()
+    mask = beam > 0
+    crop = torch.zeros_like(mask); crop[:, :, 78:190, 23:617] = 1
+    mask = mask * crop
+    assert stats[0, 3] == int(mask.sum()) and stats[0, 2] == torch.median(beam[mask] * 100.0).item()
+    for s in range(4):
+        w, g = want[("disp", s)].numpy(), got[s].cpu().numpy()
+        assert w.shape == g.shape
+        nch = w.shape[1]
+        assert np.array_equal(g[:, nch - 2:], w[:, nch - 2:]), "pooled 2-channel map at scale %d" % s
+        assert_close(g[:, 0], w[:, 0], rtol=2e-5, atol=2e-6, what="scaled disparity at scale %d" % s)
+        if catxy == "true":
+            assert_close(g[:, 1:4], w[:, 1:4], rtol=2e-5, atol=2e-5, what="Cat_xy channels at scale %d" % s)
+
+
+def test_refiner_inputs_path_has_no_aten_kernels():
+    """Between the frozen networks and the refine decoder nothing but libfdhip launches: Refiner.refine_inputs equals its ATen form
+    of rounds 2-4 (refine_inputs_aten) on a real batch."""
+    rf, oopt, _ = _make(B=2)
+    from fusiondepth_amd import synthetic
+    inp = synthetic.make_batch(2, 192, 640, seed=5)
+    inp = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in inp.items()}
+    with torch.no_grad():
+        feats = rf.models["encoder"](inp["color_aug", 0, 0])
+        outputs = rf.models["depth"](feats, beam_features=rf.models["beam_encoder"](inp["2channel"])) if rf.opt.refine_depthnet_with_beam == "true" \
+            else rf.models["depth"](feats)
+        a = rf.refine_inputs(inp, outputs)
+        b = rf.refine_inputs_aten(inp, outputs)
+    for s in rf.opt.scales:
+        assert_close(a[("disp", s)].cpu().numpy(), b[("disp", s)].cpu().numpy(), rtol=2e-5, atol=2e-5, what="refine inputs at scale %d" % s)
