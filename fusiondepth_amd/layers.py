@@ -45,11 +45,19 @@ class ConvBlock(nn.Module):
         super().__init__()
         self.conv = Conv3x3(in_channels, out_channels)
 
-    def forward(self, x, grad_preact=False):
+    def forward(self, x, grad_preact=False, channels=None):
         """``grad_preact``: the caller guarantees that the ONE consumer of the result returns the gradient w.r.t. this block's
-        pre-activation (FD.conv2d: the ELU' pass then runs inside that consumer's backward kernel)."""
+        pre-activation (FD.conv2d: the ELU' pass then runs inside that consumer's backward kernel).
+        ``channels`` = (Cin_p, Cout_p): run the block on channel-padded operands - ``x`` carries Cin_p >= Cin channels (the extra ones
+        zero), the result Cout_p >= Cout (the extra ones ELU(0) = 0): the parameters are zero-padded per call (autograd crops their
+        gradients), which puts layers whose channel counts are not multiples of 16 - the refine decoder's 262 / 134 / 102 / 22 - on
+        the MFMA fast-path / Winograd kernels instead of the generic gather GEMM (networks/depth_decoder.py)."""
         c = self.conv.conv
-        return FD.conv2d(x, c.weight, c.bias, stride=1, pad=1, pad_mode="reflect", act="elu", grad_preact=grad_preact)
+        w, b = c.weight, c.bias
+        if channels is not None and (channels[0] != w.shape[1] or channels[1] != w.shape[0]):
+            w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, channels[0] - w.shape[1], 0, channels[1] - w.shape[0]))
+            b = torch.nn.functional.pad(b, (0, channels[1] - b.shape[0]))
+        return FD.conv2d(x, w, b, stride=1, pad=1, pad_mode="reflect", act="elu", grad_preact=grad_preact)
 
 
 class BackprojectDepth(nn.Module):

@@ -60,6 +60,17 @@ class DepthDecoder(nn.Module):
                 self.convs[key] = ConvBlock(cin, cout)
         self.decoder = nn.ModuleList(self.convs.values())
         self.sigmoid = nn.Sigmoid()
+        # (upconv, i, 1) blocks whose input width is not a multiple of 16 (road variants: 262 / 134 / 102 / 22 channels): run
+        # channel-padded (ConvBlock.forward(channels=...)): key -> padded input width
+        self._cin_pad = {}
+        if road:
+            for key, cin, cout in decoder_layer_table(num_ch_enc, scales, num_output_channels, use_skips, cat2end, road, catxy):
+                if key[0] == "upconv" and key[2] == 1 and cin % 16 != 0:
+                    self._cin_pad[key] = (cin + 15) // 16 * 16
+
+    @staticmethod
+    def _block_cin(blk):
+        return (blk[0] if isinstance(blk, _ConvChain) else blk).conv.conv.weight.shape[1]
 
     @staticmethod
     def _disp(conv3x3, x, act, in_act="none"):
@@ -87,10 +98,20 @@ class DepthDecoder(nn.Module):
                     skip_add = beam_features[i - 1]
             if depth_maps is not None and i in self.scales and self.use_skips:
                 extra = depth_maps[("disp", i)]
-            x = FD.upsample_concat(x, skip, skip_add, extra, a_act="elu" if pre0 else "none")
             blk1 = self.convs[("upconv", i, 1)]
+            cin_p = self._cin_pad.get(("upconv", i, 1)) if (extra is not None and tuning.host.pad_odd_channels) else None
+            if cin_p is not None:
+                # zero channels behind the depth maps bring the concatenation to a multiple of 16; the block(s) run channel-padded
+                extra = torch.nn.functional.pad(extra, (0, 0, 0, 0, 0, cin_p - self._block_cin(blk1)))
+            x = FD.upsample_concat(x, skip, skip_add, extra, a_act="elu" if pre0 else "none")
             pre1 = fuse and i == 0 and i in self.scales and not self.cat2end and isinstance(blk1, ConvBlock)
-            x = blk1(x, grad_preact=True) if pre1 else blk1(x)
+            if cin_p is not None and isinstance(blk1, _ConvChain):
+                x = blk1[0](x, channels=(cin_p, cin_p))
+                x = blk1[1](x, channels=(cin_p, blk1[1].conv.conv.weight.shape[0]))
+            elif cin_p is not None:
+                x = blk1(x, grad_preact=pre1, channels=(cin_p, blk1.conv.conv.weight.shape[0]))
+            else:
+                x = blk1(x, grad_preact=True) if pre1 else blk1(x)
             if pre1:
                 self.outputs[("disp", i)] = self._disp(self.convs[("dispconv", i)], x, "tanh" if tanh else "sigmoid", in_act="elu")
             elif i in self.scales:

@@ -237,3 +237,32 @@ def test_refiner_inputs_path_has_no_aten_kernels():
         b = rf.refine_inputs_aten(inp, outputs)
     for s in rf.opt.scales:
         assert_close(a[("disp", s)].cpu().numpy(), b[("disp", s)].cpu().numpy(), rtol=2e-5, atol=2e-5, what="refine inputs at scale %d" % s)
+
+
+def test_channel_padded_refine_decoder_equals_the_unpadded_one(fdtune):
+    """tuning.host.pad_odd_channels: the refine decoder's 262 / 134 / 102 / 22-channel blocks run zero-padded to a multiple of 16 (MFMA
+    fast path / Winograd kernels instead of the generic gather GEMM).  Outputs and every parameter gradient must agree with the
+    unpadded run to float32 rounding (different kernels, different summation order), and the parameters keep the reference's shapes."""
+    from fusiondepth_amd import networks
+    rng = np.random.RandomState(41)
+    B, H, W = 2, 96, 160
+    dec = networks.DepthDecoder(np.array([64, 64, 128, 256, 512]), range(4), road=True, catxy=True, deep=True).cuda()
+    assert dec._cin_pad == {("upconv", 3, 1): 272, ("upconv", 2, 1): 144, ("upconv", 1, 1): 112, ("upconv", 0, 1): 32}
+    assert dec.convs[("upconv", 3, 1)][0].conv.conv.weight.shape == (262, 262, 3, 3)
+    feats = [torch.from_numpy(rng.randn(B, c, H >> (s + 1), W >> (s + 1)).astype(np.float32)).cuda() for s, c in enumerate((64, 64, 128, 256, 512))]
+    maps = {("disp", s): torch.from_numpy(rng.rand(B, 6, H >> s, W >> s).astype(np.float32)).cuda() for s in range(4)}
+    cot = {s: torch.from_numpy(rng.randn(B, 1, H >> s, W >> s).astype(np.float32)).cuda() for s in range(4)}
+    res = {}
+    for on in (True, False):
+        fdtune.host(pad_odd_channels=on)
+        dec.zero_grad()
+        out = dec(feats, depth_maps=maps, tanh=False)
+        sum((out[("disp", s)] * cot[s]).sum() for s in range(4)).backward()
+        res[on] = ({s: out[("disp", s)].detach().cpu().numpy() for s in range(4)},
+                   {n: p.grad.detach().cpu().numpy().copy() for n, p in dec.named_parameters()})
+    for s in range(4):
+        assert_close(res[True][0][s], res[False][0][s], rtol=2e-5, atol=2e-6, what="disp %d" % s)
+    for n in res[True][1]:
+        a, b = res[True][1][n], res[False][1][n]
+        assert a.shape == b.shape
+        assert np.abs(a - b).sum() <= 2e-5 * np.abs(b).sum() + 1e-9, "gradient of %s: %g of %g" % (n, np.abs(a - b).sum(), np.abs(b).sum())

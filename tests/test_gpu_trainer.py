@@ -364,26 +364,25 @@ def test_resnet18_1024x320_batch8_forward_against_float64():
                                    [("disp", s) for s in range(4)] + [("depth", 0, 0)])
 
 
-def test_absrel_distribution_matches_the_oracle(golden):
-    """The long-run form of the north star's AbsRel clause (VERDICT round 3, item 5c; trainer.py:598-630, layers.py:284-302).
-    Trajectory-wise agreement ends after ~4 optimiser steps for ANY two float32 implementations
-    (test_absrel_after_equal_steps_vs_oracle_fixture); over 60 steps the claim that can be true - and is tested here - is
-    statistical: K = 6 independent runs (own initial weights, own stream of scene batches) of the HIP trainer and of the CPU
-    oracle (tests/golden/make_absrel_stat.py, generated in the build container) give AbsRel samples after 20, 40 and 60 steps
-    whose means differ by no more than max(0.001, 2 standard errors of the difference) and whose ranges overlap; the starting
-    points (0 steps) agree run by run to 1e-5."""
-    import conftest
+_ABSREL_RUNS = {}
+
+
+def _hip_absrel_runs(n_streams):
+    """AbsRel of the two held-out scenes after 0 / 20 / 40 / 60 optimiser steps of the HIP trainer on data streams 0 .. n_streams-1 of
+    tests/golden/make_absrel_stat.py (same initial state, same batches, same tie-break noise as the oracle runs of the fixtures);
+    computed once per session, shared by the distribution test (streams 0-5) and the paired test (streams 0-11)."""
     import make_absrel_stat as MS
+    from fusiondepth_amd import functional as FD
     from fusiondepth_amd.trainer import Trainer
-    g = golden(MS.NAME)
-    want = g["metrics"][:, :, 0]                                   # [K, checkpoints]
-    assert want.shape == (MS.K, len(MS.CHECK)) and int(g["steps"]) == MS.STEPS
+    have = _ABSREL_RUNS.get("got")
+    if have is not None and have.shape[0] >= n_streams:
+        return have[:n_streams]
     val = []
     for seed in MS.VAL_SEEDS:
         inp, _ = MS.scene_batch(seed)
         val.append({k: v.cuda() for k, v in inp.items()})
-    got = np.zeros_like(want)
-    for k in range(MS.K):
+    got = np.zeros((n_streams, len(MS.CHECK)))
+    for k in range(n_streams):
         opt = _opts(height=MS.H, width=MS.W, batch_size=MS.B, learning_rate=MS.LR)
         tr = Trainer(opt, verbose=False)
         om = MS.models(MS.oracle_opt(), k)
@@ -391,7 +390,6 @@ def test_absrel_distribution_matches_the_oracle(golden):
             for name, m in om.items():
                 for n_, t in tr.models[name].state_dict().items():
                     t.copy_(m.state_dict()[n_])
-        from fusiondepth_amd import functional as FD
         FD.bump_weights_epoch()
         assert abs(tr.lr - 2.5e-5) < 1e-12 and tr.accumulate_step == 1
         got[k, 0] = float(tr.val_metrics(val)["de/abs_rel"])
@@ -406,6 +404,24 @@ def test_absrel_distribution_matches_the_oracle(golden):
                 ci += 1
         del tr
     assert np.isfinite(got).all()
+    _ABSREL_RUNS["got"] = got
+    return got
+
+
+def test_absrel_distribution_matches_the_oracle(golden):
+    """The long-run form of the north star's AbsRel clause (VERDICT round 3, item 5c; trainer.py:598-630, layers.py:284-302).
+    Trajectory-wise agreement ends after ~4 optimiser steps for ANY two float32 implementations
+    (test_absrel_after_equal_steps_vs_oracle_fixture); over 60 steps the claim that can be true - and is tested here - is
+    statistical: K = 6 independent runs (own stream of scene batches) of the HIP trainer and of the CPU oracle
+    (tests/golden/make_absrel_stat.py, generated in the build container) give AbsRel samples after 20, 40 and 60 steps
+    whose means differ by no more than max(0.001, 2 standard errors of the difference) and whose ranges overlap; the starting
+    points (0 steps) agree run by run to 1e-5.  (A sanity check; the sharper, paired comparison is the next test.)"""
+    import conftest
+    import make_absrel_stat as MS
+    g = golden(MS.NAME)
+    want = g["metrics"][:, :, 0]                                   # [K, checkpoints]
+    assert want.shape == (MS.K, len(MS.CHECK)) and int(g["steps"]) == MS.STEPS
+    got = _hip_absrel_runs(MS.K)
     assert np.abs(got[:, 0] - want[:, 0]).max() <= 1e-5, "initial states differ: %s vs %s" % (got[:, 0], want[:, 0])
     for ci in range(1, len(MS.CHECK)):
         h, o = got[:, ci], want[:, ci]
@@ -416,6 +432,41 @@ def test_absrel_distribution_matches_the_oracle(golden):
                         % (MS.CHECK[ci], MS.K, h.mean(), h.min(), h.max(), o.mean(), o.min(), o.max()), diff, bound, "(2 SE = %.1e)" % (2 * se))
         assert diff <= bound, "AbsRel after %d steps: HIP %s vs oracle %s" % (MS.CHECK[ci], h, o)
         assert h.min() <= o.max() and o.min() <= h.max(), "AbsRel ranges after %d steps do not overlap: HIP %s, oracle %s" % (MS.CHECK[ci], h, o)
+
+
+def test_absrel_paired_gap_vs_oracle(golden):
+    """the PAIRED design.  Twelve data streams; on each, the HIP trainer, the float32 oracle ("base") and the
+    float32 oracle started one ulp away ("ulp") run 60 optimiser steps from one initial state over exactly the same batches and noise
+    (tests/golden/make_absrel_paired.py).  The statistic is the per-stream difference HIP - base of the held-out AbsRel at steps
+    20 / 40 / 60: its mean over the streams must be within max(0.001, 2 standard errors of that mean) of zero; the oracle's own paired
+    gap ulp - base - what two equally valid float32 implementations of the reference differ by - is printed beside it.  What pairing
+    does NOT do here is shrink the spread: the fixture shows the one-ulp partner of a stream as far from it after 20 steps (SE of the
+    paired gap 0.04 - 0.06) as another stream is (unpaired SE 0.04 - 0.06), i.e. the training dynamics have forgotten the common
+    start - which is the reason the 0.001 of the north star can only be shown for the first steps
+    (test_absrel_after_equal_steps_vs_oracle_fixture: 4e-6 after 2 steps)."""
+    import conftest
+    import make_absrel_paired as MP
+    import make_absrel_stat as MS
+    g = golden(MP.NAME)
+    base, ulp = g["base"][:, :, 0], g["ulp"][:, :, 0]              # [K, checkpoints]
+    K = int(g["streams"])
+    assert base.shape == (K, len(MS.CHECK)) and K == MP.K and K >= 12
+    got = _hip_absrel_runs(K)
+    assert np.abs(got[:, 0] - base[:, 0]).max() <= 1e-5, "initial states differ: %s vs %s" % (got[:, 0], base[:, 0])
+    thr = golden(MS.NAME)["metrics"][:, :, 0] - base[:MS.K]        # the SAME oracle on the same streams, generated on 16 threads instead of 4
+    for ci in range(1, len(MS.CHECK)):
+        conftest.report("AbsRel after %2d steps: oracle on 16 CPU threads - oracle on 4 threads, streams 0-5 = %+.4f +- %.4f; largest |gap|"
+                        % (MS.CHECK[ci], thr[:, ci].mean(), thr[:, ci].std(ddof=1) / np.sqrt(MS.K)), np.abs(thr[:, ci]).max(), float("inf"), "(information)")
+    for ci in range(1, len(MS.CHECK)):
+        d_hip, d_ulp = got[:, ci] - base[:, ci], ulp[:, ci] - base[:, ci]
+        mean, se = float(d_hip.mean()), float(d_hip.std(ddof=1) / np.sqrt(K))
+        mean_o, se_o = float(d_ulp.mean()), float(d_ulp.std(ddof=1) / np.sqrt(K))
+        bound = max(1e-3, 2 * se)
+        conftest.report("AbsRel after %2d steps, %d paired streams: HIP - oracle = %+.4f +- %.4f (SE); oracle(one ulp away) - oracle = %+.4f +- %.4f; |mean paired gap|"
+                        % (MS.CHECK[ci], K, mean, se, mean_o, se_o), abs(mean), bound, "(2 SE = %.1e)" % (2 * se))
+        assert abs(mean) <= bound, "paired AbsRel gap after %d steps: %+.4f +- %.4f (per stream: %s)" % (MS.CHECK[ci], mean, se, d_hip)
+        # and the HIP gap is not an outlier against what the oracle differs from itself by: same order of spread
+        assert se <= 3 * se_o + 1e-3, "paired spread after %d steps: HIP %.4f vs oracle-vs-itself %.4f" % (MS.CHECK[ci], se, se_o)
 
 
 def test_depth_monitoring_metrics_vs_reference_golden(golden):

@@ -467,3 +467,26 @@ def test_evaluate_metric_core_matches_reference(golden):
     assert np.array_equal(OE.resize_bilinear(ramp, 4, 8), ramp)
     up = OE.resize_bilinear(ramp, 8, 16)
     assert np.allclose(up[0, 1:-1], (np.arange(16)[1:-1] + 0.5) / 2 - 0.5) and up[0, 0] == 0 and up[0, -1] == 7
+
+
+def test_absrel_fixtures_are_consistent(golden):
+    """The paired AbsRel fixture (tests/golden/make_absrel_paired.py: 12 streams x {oracle, oracle one ulp away}, generated on 4
+    threads) beside the distribution fixture of round 4 (make_absrel_stat.py, 16 threads): every run starts from ONE initial state
+    (equal to 1e-6 across the fixtures), and the one-ulp partner differs from its base from the first checkpoint on (it IS another
+    trajectory).  Streams 0-5 have the same seeds in both fixtures, and the same oracle code produced them - yet their AbsRel differ
+    by up to 0.45 after 20 steps: torch's CPU kernels sum in a thread-count dependent order, which is a one-ulp perturbation of its
+    own.  The reference's arithmetic is not reproducible against ITSELF at the 0.001 level beyond the first steps; no assertion can
+    be made about that except that it is so (recorded here so that nobody tightens the GPU test's bound by mistake)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_absrel_paired as MP
+    import make_absrel_stat as MS
+    p, s = golden(MP.NAME), golden(MS.NAME)
+    base, ulp = p["base"][:, :, 0], p["ulp"][:, :, 0]
+    assert base.shape == ulp.shape == (MP.K, len(MS.CHECK)) and list(p["check"]) == list(MS.CHECK)
+    assert np.allclose(base[:, 0], base[0, 0], rtol=0, atol=1e-7) and np.allclose(ulp[:, 0], base[:, 0], rtol=0, atol=2e-6)
+    assert np.allclose(s["metrics"][:, 0, 0], base[0, 0], rtol=0, atol=1e-6)
+    assert (np.abs(ulp[:, 1:] - base[:, 1:]) > 1e-4).all()
+    other_threads = np.abs(s["metrics"][:, 1:, 0] - base[:MS.K, 1:])
+    assert other_threads.max() > 1e-3, "the oracle became thread-count independent: tighten test_absrel_paired_gap_vs_oracle"
