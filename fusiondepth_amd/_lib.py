@@ -107,6 +107,7 @@ SIGNATURES = {
     "fd_conv3x3_wino_fwd": ("pppppp" "i" "pp", "i"),
     "fd_velo_rasterize_ws_bytes": ("iii", "l"),
     "fd_velo_rasterize": ("pipiiiiipppp", "i"),
+    "fd_resize_linear_cv": ("ppliiiip", "i"),
     "fd_masked_median_ws_bytes": ("iii", "l"),
     "fd_masked_median": ("ppfiiiiiiippp", "i"),
     "fd_refine_inputs_ws_bytes": ("p", "l"),
@@ -121,6 +122,8 @@ SIGNATURES = {
     "fd_bn_train_fwd": ("pppppppppp" "iiiii" "ff" "ip", "i"),
     "fd_bn_eval_fwd": ("ppppppp" "iiii" "f" "ip", "i"),
     "fd_bn_train_bwd": ("ppppppppppp" "iiiii" "iip", "i"),
+    "fd_bn_relu_maxpool_fwd": ("ppppppppppp" "iiiii" "ffp", "i"),
+    "fd_bn_relu_maxpool_bwd": ("pppppppppppp" "iiiii" "ip", "i"),
     "fd_maxpool3x3s2_fwd": ("pppiiiip", "i"),
     "fd_maxpool3x3s2_bwd": ("pppiiiip", "i"),
     "fd_upcat_fwd": ("ppppp" "iiiiii" "p", "i"),

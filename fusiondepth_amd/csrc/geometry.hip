@@ -397,6 +397,46 @@ extern "C" int fd_cat_xy_fwd(const float* depth, const float* inv_K, float* out,
 }
 
 // ---------------------------------------------------------------------------------------------
+// cv2.resize(img, (Wout, Hout)) with INTER_LINEAR on a float32 image (evaluate_depth.py:349): OpenCV's coefficient rule
+// (resize.cpp: scale in double, source coordinate rounded to float, floor, edge rule) and its two float32 passes, horizontal first.
+// Not ATen's rule (k_bilinear_fwd computes the coordinate in float32 throughout): at x ~ 600 the two differ by ~6e-5 in the weight.
+__device__ __forceinline__ void cv_linear_coeff(int d, double scale, int n_in, int& s0, int& s1, float& w0, float& w1) {
+#pragma clang fp contract(off)     // no FMA contraction (HIP's __fmul_rn / __dmul_rn are plain operators): OpenCV's scalar arithmetic
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= n_in - 1) { s = n_in - 1; f = 0.f; }
+    s0 = s; s1 = s + 1 < n_in ? s + 1 : n_in - 1;
+    w0 = 1.0f - f; w1 = f;
+}
+__global__ void k_resize_linear_cv(const float* __restrict__ x, float* __restrict__ y, int Hin, int Win, int Hout, int Wout) {
+    const int pl = blockIdx.y;
+    const long Po = (long)Hout * Wout;
+    const float* xi = x + (long)pl * Hin * Win;
+    const double sy = (double)Hin / (double)Hout, sx = (double)Win / (double)Wout;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < Po; p += (long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
+        const int oy = (int)(p / Wout), ox = (int)(p % Wout);
+        int y0, y1, x0, x1;
+        float b0, b1, a0, a1;
+        cv_linear_coeff(oy, sy, Hin, y0, y1, b0, b1);
+        cv_linear_coeff(ox, sx, Win, x0, x1, a0, a1);
+        // separate multiplies and adds (no contraction): the arithmetic of the numpy restatement in oracle/evaluate.py
+        const float r0 = xi[y0 * Win + x0] * a0 + xi[y0 * Win + x1] * a1;
+        const float r1 = xi[y1 * Win + x0] * a0 + xi[y1 * Win + x1] * a1;
+        y[(long)pl * Po + p] = r0 * b0 + r1 * b1;
+    }
+}
+extern "C" int fd_resize_linear_cv(const float* x, float* y, long planes, int Hin, int Win, int Hout, int Wout, void* stream) {
+    FD_REQUIRE(x && y && planes > 0 && planes < 65536 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "fd_resize_linear_cv: bad args");
+    hipLaunchKernelGGL(k_resize_linear_cv, dim3(ew_grid((long)Hout * Wout), (unsigned)planes), dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win,
+                       Hout, Wout);
+    FD_LAUNCH_CHECK("fd_resize_linear_cv");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // bilinear resize, align_corners=False (trainer.py:434-435)
 __global__ void k_bilinear_fwd(const float* __restrict__ x, float* __restrict__ y, int Hin, int Win, int Hout, int Wout,
                                float sh, float sw) {

@@ -500,6 +500,324 @@ inline bool bn_small(int Ng, long HW, int groups, bool vec) {
     return vec && groups <= 16 && (long)Ng * (HW >> 2) <= (long)NT * SMALL_K;
 }
 
+// ---- the stem's tail as ONE pass: relu(bn1(x)) [-> features[0]] -> MaxPool2d(3, 2, 1)  (resnet_encoder.py:95-98) --------------------
+// The stem's output is the largest activation of an encoder (64 channels at H/2 x W/2: 189 MB for the pose encoders' 24 stacked
+// images at 640x192).  Rounds 1-4 ran apply (read x, write f0), max-pool (read f0, write pooled) and, backward, max-pool adjoint
+// (write g_f0), reduction (read g_f0, f0, x) and apply (read g_f0, f0, x, write gx): 11 passes over a tensor of that size.  Here the
+// normalised, rectified value is a function of x and two per-channel constants and is recomputed where it is needed:
+//   forward   one kernel: pooled + argmax byte from nine taps of max(fma(x, a, b), 0); features[0] is WRITTEN only if somebody reads it
+//             (the depth / LiDAR encoders' skip connection - never for the pose encoders);
+//   backward  d = relu'(.) * (max-pool adjoint of g_pooled [+ g_f0]) is formed from g_pooled, the argmax bytes and x in both the
+//             reduction and the apply pass: 2 reads of x + 1 write of gx.
+// One thread owns a 2x2 block of full-resolution pixels = the taps (1..2, 1..2) of pooling window (p, q), as k_maxpool_bwd.
+__device__ __forceinline__ float bn_act(float x, float a, float b) { return fmaxf(fmaf(x, a, b), 0.f); }
+
+__global__ void __launch_bounds__(NT) k_bn_relu_pool_fwd(const float* __restrict__ x, const float* __restrict__ weight,
+                                                         const float* __restrict__ bias, float* __restrict__ feat,
+                                                         float* __restrict__ pooled, uint8_t* __restrict__ idx,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                         const float* __restrict__ part, const float* __restrict__ shifts, int N, int C,
+                                                         int H, int W, int splits, float eps, float momentum, int G) {
+    const int nc = blockIdx.y, c = nc % C, n = nc / C, g = n / N;
+    const long HW = (long)H * W;
+    const float M = (float)N * (float)HW;
+    const BnStat st = bn_finalize(part, shifts, c, C, g, splits, M);
+    const float invstd = 1.0f / sqrtf(st.var + eps);
+    if (blockIdx.x == 0 && n == g * N && threadIdx.x == 0) { save_mean[g * C + c] = st.mean; save_invstd[g * C + c] = invstd; }
+    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0 && running_mean) {      // the G momentum updates in group order (k_bn_apply_train)
+        float rm = running_mean[c], rv = running_var[c];
+        for (int gg = 0; gg < G; ++gg) {
+            const BnStat sg = bn_finalize(part, shifts, c, C, gg, splits, M);
+            const float unbiased = M > 1.f ? sg.var * (M / (M - 1.f)) : sg.var;
+            rm = (1.f - momentum) * rm + momentum * sg.mean;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        running_mean[c] = rm; running_var[c] = rv;
+    }
+    const float a = invstd * (weight ? weight[c] : 1.f);
+    const float b = (bias ? bias[c] : 0.f) - st.mean * a;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const float* xp = x + (long)nc * HW;
+    float* fp = feat ? feat + (long)nc * HW : nullptr;
+    for (int r = blockIdx.x * NT + threadIdx.x; r < Ho * Wo; r += gridDim.x * NT) {
+        const int ho = r / Wo, wo = r - ho * Wo;
+        float best = 0.f;
+        int bi = -1;
+        float v[3][3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = ho * 2 - 1 + kh;
+            const bool vh = (unsigned)h < (unsigned)H;
+            const int hc = h < 0 ? 0 : (h >= H ? H - 1 : h);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = wo * 2 - 1 + kw;
+                const bool ok = vh & ((unsigned)w < (unsigned)W);
+                const int wc = w < 0 ? 0 : (w >= W ? W - 1 : w);
+                v[kh][kw] = bn_act(xp[hc * W + wc], a, b);
+                const bool take = ok & ((bi < 0) | (v[kh][kw] > best) | (v[kh][kw] != v[kh][kw]));      // first maximum in raster order (k_maxpool_fwd)
+                best = take ? v[kh][kw] : best;
+                bi = take ? kh * 3 + kw : bi;
+            }
+        }
+        pooled[(long)nc * Ho * Wo + r] = best;
+        idx[(long)nc * Ho * Wo + r] = (uint8_t)bi;
+        if (fp) {                                                     // this thread's 2x2 block of features[0]
+            float* o = fp + (2 * ho) * W + 2 * wo;
+            const bool h1 = 2 * ho + 1 < H, w1 = 2 * wo + 1 < W;
+            o[0] = v[1][1];
+            if (w1) o[1] = v[1][2];
+            if (h1) { o[W] = v[2][1]; if (w1) o[W + 1] = v[2][2]; }
+        }
+    }
+}
+
+// Vector form (W % 4 == 0, 16-byte aligned planes - every stem of the step): one thread owns TWO pooling windows (ho, 2j), (ho, 2j+1)
+// = a 2 x 4 block of full-resolution pixels: per tap row one float4 + the column left of it instead of six scalars, features[0] as
+// float4 rows, pooled / argmax as one 8-byte / 2-byte store; a workgroup covers a quarter of a plane, so the statistics prologue
+// (16 partial sums per channel) is paid 4 times per plane instead of 30 times.
+__device__ __forceinline__ void pool_take(float v, int tap, bool ok, float& best, int& bi) {
+    const bool take = ok & ((bi < 0) | (v > best) | (v != v));
+    best = take ? v : best;
+    bi = take ? tap : bi;
+}
+__global__ void __launch_bounds__(NT) k_bn_relu_pool_fwd4(const float* __restrict__ x, const float* __restrict__ weight,
+                                                          const float* __restrict__ bias, float* __restrict__ feat,
+                                                          float* __restrict__ pooled, uint8_t* __restrict__ idx,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                          const float* __restrict__ part, const float* __restrict__ shifts, int N, int C,
+                                                          int H, int W, int splits, float eps, float momentum, int G) {
+    const int nc = blockIdx.y, c = nc % C, n = nc / C, g = n / N;
+    const long HW = (long)H * W;
+    const float M = (float)N * (float)HW;
+    const BnStat st = bn_finalize(part, shifts, c, C, g, splits, M);
+    const float invstd = 1.0f / sqrtf(st.var + eps);
+    if (blockIdx.x == 0 && n == g * N && threadIdx.x == 0) { save_mean[g * C + c] = st.mean; save_invstd[g * C + c] = invstd; }
+    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0 && running_mean) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int gg = 0; gg < G; ++gg) {
+            const BnStat sg = bn_finalize(part, shifts, c, C, gg, splits, M);
+            const float unbiased = M > 1.f ? sg.var * (M / (M - 1.f)) : sg.var;
+            rm = (1.f - momentum) * rm + momentum * sg.mean;
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        running_mean[c] = rm; running_var[c] = rv;
+    }
+    const float a = invstd * (weight ? weight[c] : 1.f);
+    const float b = (bias ? bias[c] : 0.f) - st.mean * a;
+    const int Ho = (H - 1) / 2 + 1, Wo = W >> 1, Wq = W >> 2;        // W % 4 == 0: Wo even
+    const float* xp = x + (long)nc * HW;
+    float* fp = feat ? feat + (long)nc * HW : nullptr;
+    for (int r = blockIdx.x * NT + threadIdx.x; r < Ho * Wq; r += gridDim.x * NT) {
+        const int ho = r / Wq, j = r - ho * Wq;
+        float best0 = 0.f, best1 = 0.f;
+        int bi0 = -1, bi1 = -1;
+        float4 rows[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = ho * 2 - 1 + kh;
+            const bool vh = (unsigned)h < (unsigned)H;
+            const int hc = h < 0 ? 0 : (h >= H ? H - 1 : h);
+            const float* row = xp + hc * W + 4 * j;
+            const float4 q = ld4(row);
+            const float l = j > 0 ? row[-1] : 0.f;
+            float4 v;
+            v.x = bn_act(q.x, a, b); v.y = bn_act(q.y, a, b); v.z = bn_act(q.z, a, b); v.w = bn_act(q.w, a, b);
+            rows[kh] = v;
+            const float vl = bn_act(l, a, b);
+            pool_take(vl, kh * 3 + 0, vh & (j > 0), best0, bi0);      // window 2j: columns 4j-1, 4j, 4j+1
+            pool_take(v.x, kh * 3 + 1, vh, best0, bi0);
+            pool_take(v.y, kh * 3 + 2, vh, best0, bi0);
+            pool_take(v.y, kh * 3 + 0, vh, best1, bi1);               // window 2j+1: columns 4j+1, 4j+2, 4j+3
+            pool_take(v.z, kh * 3 + 1, vh, best1, bi1);
+            pool_take(v.w, kh * 3 + 2, vh, best1, bi1);
+        }
+        const long po = (long)nc * Ho * Wo + (long)ho * Wo + 2 * j;
+        *reinterpret_cast<float2*>(pooled + po) = make_float2(best0, best1);
+        *reinterpret_cast<uint16_t*>(idx + po) = (uint16_t)(bi0 | (bi1 << 8));
+        if (fp) {
+            st4(fp + (2 * ho) * W + 4 * j, rows[1]);
+            if (2 * ho + 1 < H) st4(fp + (2 * ho + 1) * W + 4 * j, rows[2]);
+        }
+    }
+}
+
+// The 2 x 4 block of rows 2p, 2p+1 / columns 4j .. 4j+3: d[8] (row-major) and the x values, from the windows (p .. p+1) x (2j .. 2j+2).
+__device__ __forceinline__ void stem_block_grad4(const float* __restrict__ xp, const float* __restrict__ g, const uint8_t* __restrict__ ix,
+                                                 const float* __restrict__ gf, int H, int W, int Ho, int Wo, int p, int j, float a, float b,
+                                                 float (&o)[8], float (&xs)[8]) {
+    const int q = 2 * j;
+    const bool vp = p + 1 < Ho, vq = q + 2 < Wo;
+    const int p1 = vp ? p + 1 : p, q2 = vq ? q + 2 : q;
+    const uint16_t ia = *reinterpret_cast<const uint16_t*>(ix + p * Wo + q), ib = *reinterpret_cast<const uint16_t*>(ix + p1 * Wo + q);
+    const int i00 = ia & 255, i01 = ia >> 8, i02 = vq ? ix[p * Wo + q2] : 255;
+    const int i10 = vp ? (ib & 255) : 255, i11 = vp ? (ib >> 8) : 255, i12 = (vp & vq) ? ix[p1 * Wo + q2] : 255;
+    const float2 ga = *reinterpret_cast<const float2*>(g + p * Wo + q), gb = *reinterpret_cast<const float2*>(g + p1 * Wo + q);
+    const float g00 = ga.x, g01 = ga.y, g02 = g[p * Wo + q2], g10 = gb.x, g11 = gb.y, g12 = g[p1 * Wo + q2];
+    // block (p, q): k_maxpool_bwd's sums, same order; block (p, q + 1) likewise one window to the right
+    o[0] = (i00 == 4 ? g00 : 0.f);
+    o[1] = (i00 == 5 ? g00 : 0.f) + (i01 == 3 ? g01 : 0.f);
+    o[4] = (i00 == 7 ? g00 : 0.f) + (i10 == 1 ? g10 : 0.f);
+    o[5] = (((i00 == 8 ? g00 : 0.f) + (i01 == 6 ? g01 : 0.f)) + (i10 == 2 ? g10 : 0.f)) + (i11 == 0 ? g11 : 0.f);
+    o[2] = (i01 == 4 ? g01 : 0.f);
+    o[3] = (i01 == 5 ? g01 : 0.f) + (i02 == 3 ? g02 : 0.f);
+    o[6] = (i01 == 7 ? g01 : 0.f) + (i11 == 1 ? g11 : 0.f);
+    o[7] = (((i01 == 8 ? g01 : 0.f) + (i02 == 6 ? g02 : 0.f)) + (i11 == 2 ? g11 : 0.f)) + (i12 == 0 ? g12 : 0.f);
+    const int r0 = 2 * p;
+    const bool h1 = r0 + 1 < H;
+    const int r1 = h1 ? r0 + 1 : r0;
+    const float4 x0 = ld4(xp + r0 * W + 4 * j), x1 = ld4(xp + r1 * W + 4 * j);
+    xs[0] = x0.x; xs[1] = x0.y; xs[2] = x0.z; xs[3] = x0.w; xs[4] = x1.x; xs[5] = x1.y; xs[6] = x1.z; xs[7] = x1.w;
+    if (gf) {
+        const float4 f0 = ld4(gf + r0 * W + 4 * j), f1 = ld4(gf + r1 * W + 4 * j);
+        o[0] += f0.x; o[1] += f0.y; o[2] += f0.z; o[3] += f0.w; o[4] += f1.x; o[5] += f1.y; o[6] += f1.z; o[7] += f1.w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = fmaf(xs[k], a, b) > 0.f ? o[k] : 0.f;
+    if (!h1) { o[4] = o[5] = o[6] = o[7] = 0.f; }
+}
+
+// d(2x2 block (p, q)) = relu'(.) * (adjoint of the pooling [+ g_feat]); o[4] = the block's four values (row-major), xs[4] the x values
+__device__ __forceinline__ void stem_block_grad(const float* __restrict__ xp, const float* __restrict__ g, const uint8_t* __restrict__ ix,
+                                                const float* __restrict__ gf, int H, int W, int Ho, int Wo, int p, int q, float a, float b,
+                                                float (&o)[4], float (&xs)[4]) {
+    const int p1 = p + 1 < Ho ? p + 1 : p, q1 = q + 1 < Wo ? q + 1 : q;
+    const bool vp = p + 1 < Ho, vq = q + 1 < Wo;
+    const int i00 = ix[p * Wo + q], i01 = vq ? ix[p * Wo + q1] : 255, i10 = vp ? ix[p1 * Wo + q] : 255, i11 = (vp & vq) ? ix[p1 * Wo + q1] : 255;
+    const float g00 = g[p * Wo + q], g01 = g[p * Wo + q1], g10 = g[p1 * Wo + q], g11 = g[p1 * Wo + q1];
+    o[0] = (i00 == 4 ? g00 : 0.f);                                    // k_maxpool_bwd's sums, same order
+    o[1] = (i00 == 5 ? g00 : 0.f) + (i01 == 3 ? g01 : 0.f);
+    o[2] = (i00 == 7 ? g00 : 0.f) + (i10 == 1 ? g10 : 0.f);
+    o[3] = (((i00 == 8 ? g00 : 0.f) + (i01 == 6 ? g01 : 0.f)) + (i10 == 2 ? g10 : 0.f)) + (i11 == 0 ? g11 : 0.f);
+    const int r0 = 2 * p, c0 = 2 * q;
+    const bool h1 = r0 + 1 < H, w1 = c0 + 1 < W;
+    const int r1 = h1 ? r0 + 1 : r0, c1 = w1 ? c0 + 1 : c0;
+    xs[0] = xp[r0 * W + c0]; xs[1] = xp[r0 * W + c1]; xs[2] = xp[r1 * W + c0]; xs[3] = xp[r1 * W + c1];
+    if (gf) { o[0] += gf[r0 * W + c0]; o[1] += gf[r0 * W + c1]; o[2] += gf[r1 * W + c0]; o[3] += gf[r1 * W + c1]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaf(xs[k], a, b) > 0.f ? o[k] : 0.f;
+    if (!w1) { o[1] = 0.f; o[3] = 0.f; }                              // cells past the right / lower edge of an odd-sized plane
+    if (!h1) { o[2] = 0.f; o[3] = 0.f; }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_bn_relu_pool_bwd_reduce(const float* __restrict__ x, const float* __restrict__ g_pooled,
+                                                                const uint8_t* __restrict__ idx, const float* __restrict__ g_feat,
+                                                                const float* __restrict__ weight, const float* __restrict__ bias,
+                                                                const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                                float* __restrict__ part, int N, int C, int H, int W, int splits) {
+    __shared__ float red[4 * 2];
+    const int c = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
+    const float mean = save_mean[g * C + c], invstd = save_invstd[g * C + c];
+    const float a = invstd * (weight ? weight[c] : 1.f), b = (bias ? bias[c] : 0.f) - mean * a;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const long HW = (long)H * W;
+    const int Wq = VEC ? (W >> 2) : Wb;                              // items per block row: 2 x 4 blocks (VEC) or 2 x 2 blocks
+    const int nb = Hb * Wq, per = (nb + splits - 1) / splits;
+    const int lo = s * per, hi = lo + per < nb ? lo + per : nb;
+    float acc[2] = {0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+        const long pl = ((long)g * N + n) * C + c;
+        const float* xp = x + pl * HW;
+        const float* gp = g_pooled + pl * Ho * Wo;
+        const uint8_t* ix = idx + pl * Ho * Wo;
+        const float* gf = g_feat ? g_feat + pl * HW : nullptr;
+        for (int r = lo + threadIdx.x; r < hi; r += NT) {
+            const int p = r / Wq, q = r - p * Wq;
+            if (VEC) {
+                float o[8], xs[8];
+                stem_block_grad4(xp, gp, ix, gf, H, W, Ho, Wo, p, q, a, b, o, xs);
+                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    t0 += o[k] + o[k + 1];
+                    t1 += o[k] * ((xs[k] - mean) * invstd) + o[k + 1] * ((xs[k + 1] - mean) * invstd);
+                }
+                acc[0] += t0; acc[1] += t1;
+            } else {
+                float o[4], xs[4];
+                stem_block_grad(xp, gp, ix, gf, H, W, Ho, Wo, p, q, a, b, o, xs);
+                acc[0] += (o[0] + o[1]) + (o[2] + o[3]);
+                acc[1] += (o[0] * ((xs[0] - mean) * invstd) + o[1] * ((xs[1] - mean) * invstd)) +
+                          (o[2] * ((xs[2] - mean) * invstd) + o[3] * ((xs[3] - mean) * invstd));
+            }
+        }
+    }
+    const float r = fd_block_sum_n<2, 4>(acc, red);
+    if (threadIdx.x < 2) part[(((long)g * C + c) * splits + s) * 2 + threadIdx.x] = r;
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_bn_relu_pool_bwd_apply(const float* __restrict__ x, const float* __restrict__ g_pooled,
+                                                               const uint8_t* __restrict__ idx, const float* __restrict__ g_feat,
+                                                               const float* __restrict__ weight, const float* __restrict__ bias,
+                                                               const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
+                                                               float* __restrict__ gx, float* __restrict__ gweight, float* __restrict__ gbias,
+                                                               const float* __restrict__ part, int N, int C, int H, int W, int splits,
+                                                               int accumulate, int G) {
+    const int nc = blockIdx.y, c = nc % C, n = nc / C, g = n / N;
+    float s1 = 0.f, s2 = 0.f;
+    const long pb = ((long)g * C + c) * splits;
+    for (int s = 0; s < splits; ++s) { s1 += part[(pb + s) * 2]; s2 += part[(pb + s) * 2 + 1]; }
+    if (blockIdx.x == 0 && nc < C && threadIdx.x == 0) {   // parameter gradients: sum over the groups, in group order (k_bn_bwd_apply)
+        float t1 = 0.f, t2 = 0.f;
+        for (int gg = 0; gg < G; ++gg) {
+            float u1 = 0.f, u2 = 0.f;
+            const long qb = ((long)gg * C + c) * splits;
+            for (int s = 0; s < splits; ++s) { u1 += part[(qb + s) * 2]; u2 += part[(qb + s) * 2 + 1]; }
+            t1 += u1; t2 += u2;
+        }
+        if (gbias) gbias[c] = (accumulate ? gbias[c] : 0.f) + t1;
+        if (gweight) gweight[c] = (accumulate ? gweight[c] : 0.f) + t2;
+    }
+    const long HW = (long)H * W;
+    const float M = (float)N * (float)HW;
+    const float mean = save_mean[g * C + c], invstd = save_invstd[g * C + c];
+    const float wc = weight ? weight[c] : 1.f;
+    const float a = invstd * wc, b = (bias ? bias[c] : 0.f) - mean * a;
+    const float k = wc * invstd, m1 = s1 / M, m2 = s2 / M;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, Hb = (H + 1) >> 1, Wb = (W + 1) >> 1;
+    const float* xp = x + (long)nc * HW;
+    const float* gp = g_pooled + (long)nc * Ho * Wo;
+    const uint8_t* ix = idx + (long)nc * Ho * Wo;
+    const float* gf = g_feat ? g_feat + (long)nc * HW : nullptr;
+    float* op = gx + (long)nc * HW;
+    if (VEC) {
+        const int Wq = W >> 2;
+        for (int r = blockIdx.x * NT + threadIdx.x; r < Hb * Wq; r += gridDim.x * NT) {
+            const int p = r / Wq, j = r - p * Wq;
+            float o[8], xs[8];
+            stem_block_grad4(xp, gp, ix, gf, H, W, Ho, Wo, p, j, a, b, o, xs);
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = k * (o[t] - m1 - ((xs[t] - mean) * invstd) * m2);
+            st4(op + (2 * p) * W + 4 * j, make_float4(v[0], v[1], v[2], v[3]));
+            if (2 * p + 1 < H) st4(op + (2 * p + 1) * W + 4 * j, make_float4(v[4], v[5], v[6], v[7]));
+        }
+        return;
+    }
+    for (int r = blockIdx.x * NT + threadIdx.x; r < Hb * Wb; r += gridDim.x * NT) {
+        const int p = r / Wb, q = r - p * Wb;
+        float o[4], xs[4];
+        stem_block_grad(xp, gp, ix, gf, H, W, Ho, Wo, p, q, a, b, o, xs);
+        float* w_ = op + (2 * p) * W + 2 * q;
+        const bool h1 = 2 * p + 1 < H, w1 = 2 * q + 1 < W;
+        w_[0] = k * (o[0] - m1 - ((xs[0] - mean) * invstd) * m2);
+        if (w1) w_[1] = k * (o[1] - m1 - ((xs[1] - mean) * invstd) * m2);
+        if (h1) {
+            w_[W] = k * (o[2] - m1 - ((xs[2] - mean) * invstd) * m2);
+            if (w1) w_[W + 1] = k * (o[3] - m1 - ((xs[3] - mean) * invstd) * m2);
+        }
+    }
+}
+
+// vector path of the stem-tail kernels: rows of 4-float groups, planes 16-byte aligned (pooled rows then hold an even number of floats)
+inline bool stem_vec_ok(int W, const void* a, const void* b, const void* c, const void* d, const void* e) {
+    auto al = [](const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+    return (W & 3) == 0 && al(a) && al(b) && al(c) && al(d) && al(e);
+}
 inline int plane_blocks(long HW) {
     long b = (HW + NT * 4 - 1) / (NT * 4);
     return (int)(b < 1 ? 1 : (b > 64 ? 64 : b));
@@ -616,5 +934,60 @@ extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, 
     hipLaunchKernelGGL(apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, y, gy, weight, save_mean,
                        save_invstd, gx, gweight, gbias, g_residual, ws, Ng, C, HW, sp, relu, accumulate, groups);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(apply)");
+    return 0;
+}
+
+extern "C" int fd_bn_relu_maxpool_fwd(const float* x, const float* weight, const float* bias, float* feat, float* pooled, uint8_t* idx,
+                                      float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws, int N, int C,
+                                      int H, int W, int groups, float eps, float momentum, void* stream) {
+    FD_REQUIRE(x && pooled && idx && save_mean && save_invstd && ws && N > 0 && C > 0 && H > 0 && W > 0, "fd_bn_relu_maxpool_fwd: bad args");
+    FD_REQUIRE(groups >= 1 && N % groups == 0, "fd_bn_relu_maxpool_fwd: batch %d is not divisible into %d groups", N, groups);
+    FD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "fd_bn_relu_maxpool_fwd: running stats must come in pairs");
+    FD_REQUIRE((long)H * W < (1L << 30), "fd_bn_relu_maxpool_fwd: plane too large");
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const int Ng = N / groups;
+    const int sp = bn_splits(Ng, C, HW, groups);
+    const bool vec = bn_vec_ok(HW, x, nullptr, nullptr, nullptr, nullptr);
+    float* shifts = ws + (long)groups * C * sp * 2;
+    auto stats = vec ? k_bn_stats<true> : k_bn_stats<false>;
+    hipLaunchKernelGGL(stats, dim3(C, sp, groups), dim3(NT), 0, st, x, ws, shifts, Ng, C, HW, sp);
+    FD_LAUNCH_CHECK("fd_bn_relu_maxpool_fwd(stats)");
+    const long po = (long)((H - 1) / 2 + 1) * ((W - 1) / 2 + 1);
+    if (stem_vec_ok(W, x, feat, pooled, nullptr, idx)) {
+        const long items = (long)((H - 1) / 2 + 1) * (W / 4);
+        const long bx4 = (items + 4 * NT - 1) / (4 * NT);            // ~4 items per thread: the statistics prologue once per quarter plane
+        hipLaunchKernelGGL(k_bn_relu_pool_fwd4, dim3((unsigned)(bx4 < 1 ? 1 : (bx4 > 64 ? 64 : bx4)), N * C), dim3(NT), 0, st, x, weight, bias,
+                           feat, pooled, idx, running_mean, running_var, save_mean, save_invstd, ws, shifts, Ng, C, H, W, sp, eps, momentum, groups);
+        FD_LAUNCH_CHECK("fd_bn_relu_maxpool_fwd(vec)");
+        return 0;
+    }
+    long bx = (po + NT - 1) / NT;
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    hipLaunchKernelGGL(k_bn_relu_pool_fwd, dim3((unsigned)bx, N * C), dim3(NT), 0, st, x, weight, bias, feat, pooled, idx, running_mean,
+                       running_var, save_mean, save_invstd, ws, shifts, Ng, C, H, W, sp, eps, momentum, groups);
+    FD_LAUNCH_CHECK("fd_bn_relu_maxpool_fwd");
+    return 0;
+}
+
+extern "C" int fd_bn_relu_maxpool_bwd(const float* x, const float* g_pooled, const uint8_t* idx, const float* g_feat, const float* weight,
+                                      const float* bias, const float* save_mean, const float* save_invstd, float* gx, float* gweight,
+                                      float* gbias, float* ws, int N, int C, int H, int W, int groups, int accumulate, void* stream) {
+    FD_REQUIRE(x && g_pooled && idx && save_mean && save_invstd && gx && ws && N > 0 && C > 0 && H > 0 && W > 0, "fd_bn_relu_maxpool_bwd: bad args");
+    FD_REQUIRE(groups >= 1 && N % groups == 0, "fd_bn_relu_maxpool_bwd: batch %d is not divisible into %d groups", N, groups);
+    hipStream_t st = (hipStream_t)stream;
+    const long HW = (long)H * W;
+    const int Ng = N / groups;
+    const int sp = bn_splits(Ng, C, HW, groups);
+    const bool vec = stem_vec_ok(W, x, g_feat, g_pooled, gx, idx);
+    hipLaunchKernelGGL((vec ? k_bn_relu_pool_bwd_reduce<true> : k_bn_relu_pool_bwd_reduce<false>), dim3(C, sp, groups), dim3(NT), 0, st, x,
+                       g_pooled, idx, g_feat, weight, bias, save_mean, save_invstd, ws, Ng, C, H, W, sp);
+    FD_LAUNCH_CHECK("fd_bn_relu_maxpool_bwd(reduce)");
+    const long nb = vec ? (long)((H + 1) / 2) * (W / 4) : (long)((H + 1) / 2) * ((W + 1) / 2);
+    long bx = vec ? (nb + 4 * NT - 1) / (4 * NT) : (nb + NT - 1) / NT;
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    hipLaunchKernelGGL((vec ? k_bn_relu_pool_bwd_apply<true> : k_bn_relu_pool_bwd_apply<false>), dim3((unsigned)bx, N * C), dim3(NT), 0, st, x,
+                       g_pooled, idx, g_feat, weight, bias, save_mean, save_invstd, gx, gweight, gbias, ws, Ng, C, H, W, sp, accumulate, groups);
+    FD_LAUNCH_CHECK("fd_bn_relu_maxpool_bwd(apply)");
     return 0;
 }

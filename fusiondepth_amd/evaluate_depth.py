@@ -54,11 +54,9 @@ def evaluate_predictions(pred_disps, gt_depths, eval_split="eigen", pred_depth_s
         gt = torch.as_tensor(gt_depths[i], dtype=torch.float32).cuda()
         gh, gw = gt.shape
         disp = FD.f32(torch.as_tensor(pred_disps[i])).cuda()[None, None]
-        # cv2.resize(pred_disp, (gt_width, gt_height)) = half-pixel-centre bilinear with edge replication (INTER_LINEAR)
-        if gh >= disp.shape[2] and gw >= disp.shape[3]:
-            disp = FD.bilinear_upsample(disp, (gh, gw))
-        else:
-            disp = torch.nn.functional.interpolate(disp, [gh, gw], mode="bilinear", align_corners=False)
+        # cv2.resize(pred_disp, (gt_width, gt_height)): OpenCV's float32 INTER_LINEAR rule on the device (fd_resize_linear_cv; parity
+        # unpinned - no OpenCV in the build image - and restated from its source, like oracle/evaluate.py::resize_bilinear)
+        disp = FD.resize_linear_cv(disp, (gh, gw))
         pred_depth = 1.0 / disp[0, 0]
         if eval_split in ("eigen", "demo"):
             mask = (gt > MIN_DEPTH) & (gt < MAX_DEPTH)

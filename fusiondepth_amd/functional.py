@@ -1297,6 +1297,68 @@ def batch_norm(x, bn, residual=None, relu=False, conv_stats=None):
                             bn.eps, relu, groups, conv_stats if training else None)
 
 
+class _BNReluPool(torch.autograd.Function):
+    """Training-mode ``maxpool3x3s2(relu(bn(x)))`` of the ResNet stem as one node over fd_bn_relu_maxpool_fwd / _bwd (csrc/norm.hip):
+    the full-resolution activation is written only when ``want_feat`` (features[0] has a reader) and never re-read; the backward
+    recomputes the ReLU mask / normalised value from x.  Outputs: pooled, or (pooled, feat)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, groups, want_feat):
+        ctx.params = (weight, bias)
+        _note_use(weight, bias)
+        x = f32(x)
+        _need_cuda(x)
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        pooled = _empty((N, C, Ho, Wo), x)
+        idx = _empty((N, C, Ho, Wo), x, torch.uint8)
+        feat = torch.empty_like(x) if want_feat else None
+        mean, invstd = _empty((groups * C,), x), _empty((groups * C,), x)
+        ws = _empty((query("fd_bn_ws_floats", N, C, H, W, groups),), x)
+        call("fd_bn_relu_maxpool_fwd", ptr(x), ptr(weight), ptr(bias), ptr(feat), ptr(pooled), ptr(idx), ptr(running_mean), ptr(running_var),
+             ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, groups, float(eps), float(momentum), stream())
+        ctx.save_for_backward(x, weight, bias, mean, invstd, idx)
+        ctx.groups = groups
+        ctx.set_materialize_grads(False)
+        return (pooled, feat) if want_feat else pooled
+
+    @staticmethod
+    def backward(ctx, g_pooled, g_feat=None):
+        x, weight, bias, mean, invstd, idx = ctx.saved_tensors
+        N, C, H, W = x.shape
+        if g_pooled is None:                         # only features[0] was used downstream: a zero pooled gradient
+            g_pooled = torch.zeros((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+        g_pooled = f32(g_pooled)
+        g_feat = f32(g_feat) if g_feat is not None else None
+        gx = torch.empty_like(x)
+        tw, tb = _direct_grad_target(ctx.params[0]), _direct_grad_target(ctx.params[1])
+        direct = tw is not None and tb is not None
+        gw, gb = (tw, tb) if direct else (_empty((C,), x), _empty((C,), x))
+        ws = _empty((query("fd_bn_ws_floats", N, C, H, W, ctx.groups),), x)
+        call("fd_bn_relu_maxpool_bwd", ptr(x), ptr(g_pooled), ptr(idx), ptr(g_feat), ptr(weight), ptr(bias), ptr(mean), ptr(invstd), ptr(gx),
+             ptr(gw), ptr(gb), ptr(ws), N, C, H, W, ctx.groups, int(direct), stream())
+        if direct:
+            gw = gb = None
+            _grad_ready(ctx.params[0], ctx.params[1])
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+def bn_relu_maxpool(x, bn, want_feature=True):
+    """``f0 = relu(bn(x)); pooled = max_pool3x3s2(f0)`` (resnet_encoder.py:95-98) -> (f0 or None, pooled).  Training mode: one fused
+    node (``_BNReluPool``); eval mode: the two separate calls."""
+    if not bn.training:
+        f0 = batch_norm(x, bn, relu=True)
+        return f0, max_pool3x3s2(f0)
+    groups = _BN_GROUPS[0]
+    if bn.num_batches_tracked is not None:
+        if _BN_COUNTERS[0] is not None:
+            _BN_COUNTERS[0].append((bn.num_batches_tracked, groups))
+        else:
+            bn.num_batches_tracked.add_(groups)
+    out = _BNReluPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, groups, bool(want_feature))
+    return (out[1], out[0]) if want_feature else (None, out)
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -1438,6 +1500,18 @@ class _SpatialMean(torch.autograd.Function):
 def spatial_mean(x, scale=1.0):
     """scale * x.mean(3).mean(2)  (pose_decoder.py:44-46)."""
     return _SpatialMean.apply(x, scale)
+
+
+def resize_linear_cv(x, size):
+    """``cv2.resize(img, (size[1], size[0]))`` (INTER_LINEAR, float32) for every plane of ``x`` [..., H, W] -> [..., size[0], size[1]]
+    (evaluate_depth.py:349; OpenCV's coefficient rule, see fd_resize_linear_cv)."""
+    x = f32(x.detach())
+    _need_cuda(x)
+    H, W = x.shape[-2:]
+    planes = x.numel() // (H * W)
+    y = _empty(tuple(x.shape[:-2]) + (int(size[0]), int(size[1])), x)
+    call("fd_resize_linear_cv", ptr(x), ptr(y), planes, H, W, int(size[0]), int(size[1]), stream())
+    return y
 
 
 def masked_median(x, gate, scale=1.0, window=None):

@@ -153,6 +153,7 @@ class ResnetEncoder(nn.Module):
                                                               beam_encoder, refine_encoder))
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
+        self.stem_feature_needed = True       # False: features[0] is None in training mode (nobody reads it; saves its write + re-reads)
 
     def forward_steps(self, input_image):
         """The forward pass as a generator that yields after the stem and after every residual block, so that a caller can
@@ -160,10 +161,16 @@ class ResnetEncoder(nn.Module):
         e = self.encoder
         # (x - 0.45) / 0.225 (resnet_encoder.py:94) as its own pass: the 7x7 stem then gathers plain values
         x = FD.conv2d(FD.input_normalize(input_image), e.conv1.weight, None, stride=2, pad=3)
-        f0 = FD.batch_norm(x, e.bn1, relu=True)
-        yield
+        if tuning.host.fused_stem_tail and e.bn1.training:
+            # BatchNorm + ReLU + max-pool of the stem in one pass; features[0] is materialised only for the encoders whose skip
+            # connection reads it (``stem_feature_needed``: the trainer clears it for the pose encoders - PoseDecoder reads features[-1])
+            f0, x = FD.bn_relu_maxpool(x, e.bn1, want_feature=self.stem_feature_needed)
+            yield
+        else:
+            f0 = FD.batch_norm(x, e.bn1, relu=True)
+            yield
+            x = FD.max_pool3x3s2(f0)
         feats = [f0]
-        x = FD.max_pool3x3s2(f0)
         for li in range(1, 5):
             for blk in getattr(e, "layer%d" % li):
                 x = blk(x)

@@ -166,6 +166,9 @@ class Trainer:
         if self.opt.predictive_mask:                                                          # trainer.py:117-127
             m["predictive_mask"] = networks.DepthDecoder(m["encoder"].num_ch_enc, self.opt.scales,
                                                          num_output_channels=len(self.opt.frame_ids) - 1)
+        for k in ("pose_encoder", "beam_encoder_pose"):           # PoseDecoder reads features[-1] only: their features[0] has no reader
+            if k in m:
+                m[k].stem_feature_needed = False
         self.models = {k: m[k].to(self.device) for k in MODEL_ORDER if k in m}
         if world_size > 1:
             dp.broadcast_module_state(self.models.values())
@@ -536,7 +539,8 @@ class Trainer:
         cur = torch.cuda.current_stream()
         cur.wait_stream(st)
         for t in tensors:
-            t.record_stream(cur)
+            if t is not None:
+                t.record_stream(cur)
 
     def process_batch(self, inputs, val=False, groups=1):
         """trainer.py:268-319 (default separate-pose-encoder path).  ``groups`` > 1: ``inputs`` holds that many micro-batches
@@ -716,7 +720,8 @@ class Trainer:
                     if bf is not None:
                         st.wait_stream(st2)
                         for t in bf:
-                            t.record_stream(st)
+                            if t is not None:              # features[0] of a pose encoder is not materialised (stem_feature_needed)
+                                t.record_stream(st)
                 else:
                     self._join(st, pf)
                     if bf is not None:

@@ -349,6 +349,20 @@ int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float
 int fd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream);
 int fd_maxpool3x3s2_bwd(const float* gy, const uint8_t* idx, float* gx, int N, int C, int H, int W, void* stream);
 
+/* The stem's tail in one pass (resnet_encoder.py:95-98: features[0] = relu(bn1(conv1(x))), x = maxpool(features[0])), training mode:
+ * fd_bn_train_fwd(relu = 1) + fd_maxpool3x3s2_fwd without the round trip of the full-resolution activation through memory.
+ *   fwd  x [N,C,H,W] (the convolution's output) -> pooled [N,C,Ho,Wo], idx (argmax tap, u8), and - only when feat != NULL - feat
+ *        [N,C,H,W] = relu(bn(x)) (the encoders whose features[0] nobody reads, the pose encoders, pass NULL); statistics, groups,
+ *        running statistics, save_mean / save_invstd and ws exactly as fd_bn_train_fwd.
+ *   bwd  g_pooled (+ g_feat, the gradient arriving at features[0] from its other consumer, or NULL) -> gx [N,C,H,W], gweight, gbias:
+ *        the ReLU mask and the normalised value are recomputed from x, the pooling adjoint from g_pooled and idx. */
+int fd_bn_relu_maxpool_fwd(const float* x, const float* weight, const float* bias, float* feat, float* pooled, uint8_t* idx,
+                           float* running_mean, float* running_var, float* save_mean, float* save_invstd, float* ws, int N, int C, int H,
+                           int W, int groups, float eps, float momentum, void* stream);
+int fd_bn_relu_maxpool_bwd(const float* x, const float* g_pooled, const uint8_t* idx, const float* g_feat, const float* weight,
+                           const float* bias, const float* save_mean, const float* save_invstd, float* gx, float* gweight, float* gbias,
+                           float* ws, int N, int C, int H, int W, int groups, int accumulate, void* stream);
+
 /* Decoder input assembly (networks/depth_decoder.py:75-83): out = cat([nearest_up2(a), s1 (+ s2), s3], dim=1).
  * a [N,Ca,h,w] -> channels [0,Ca) at (2h,2w); s1,s2 [N,Cs,2h,2w] (s2 optional addend: beam-feature fusion
  * depth_decoder.py:78); s3 [N,C3,2h,2w] optional (refiner depth_maps, :81-82).  Any of s1/s3 may be NULL. */
@@ -432,6 +446,12 @@ int fd_conv3x3_wino_fwd(const fd_conv_desc* d, const float* x, const float* w, c
 long fd_velo_rasterize_ws_bytes(int n_points, int im_h, int im_w);
 int fd_velo_rasterize(const float* points, int n_points, const double* P_velo2im, int im_h, int im_w, int vel_depth, int target_h,
                       int target_w, float* beam_out, double* depth_out, void* ws, void* stream);
+
+/* evaluate_depth.py:349 `cv2.resize(pred_disp, (gt_width, gt_height))` on a float32 image (default INTER_LINEAR): OpenCV's
+ * coefficient rule (source coordinate (float)((d + 0.5) * scale - 0.5) with the scale in double, floor, edges clamp with weight 0)
+ * and its two float32 passes, horizontal first.  x [planes][Hin][Win] -> y [planes][Hout][Wout].  Restated from OpenCV's source
+ * (resize.cpp); OpenCV is not available in the build image, so this entry point is parity-UNPINNED (oracle/evaluate.py). */
+int fd_resize_linear_cv(const float* x, float* y, long planes, int Hin, int Win, int Hout, int Wout, void* stream);
 
 /* ------------------------------------------------------------------ refiner inputs ------------- */
 

@@ -1022,3 +1022,50 @@ def test_input_activation_contract_is_enforced(FD):
     c.in_act = 0
     gx, gw, _ = FD._conv_backward(c, torch.ones_like(y), gx_add=torch.ones_like(x))
     assert gx.shape == x.shape and gw.shape == wgt.shape
+
+
+def _seeded_bn(C, rng_seed):
+    bn = gin.fill_params(torch.nn.BatchNorm2d(C), rng_seed).cuda()
+    bn.train()
+    return bn
+
+
+@pytest.mark.parametrize("N,C,H,W,groups", [(4, 64, 96, 320, 2), (2, 8, 7, 9, 1), (3, 5, 10, 13, 1), (6, 16, 48, 160, 3), (2, 4, 9, 12, 1), (2, 3, 6, 4, 2)])
+@pytest.mark.parametrize("want_feat", [True, False])
+def test_fused_stem_tail_equals_batchnorm_relu_maxpool(FD, N, C, H, W, groups, want_feat):
+    """fd_bn_relu_maxpool_fwd / _bwd (one pass each way over the stem's output, features[0] written only on request) against the
+    separate BatchNorm(+ReLU) and max-pool calls: pooled values, argmax routing, features[0], running statistics and saved statistics
+    identical; input / weight / bias gradients equal up to the summation order of the per-channel reductions.  Even and odd plane
+    sizes, grouped statistics, with and without a second gradient arriving at features[0]."""
+    rng = np.random.RandomState(N * 100 + H)
+    x = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32) * 1.5 + 0.3).cuda()
+    mk_bn = lambda: _seeded_bn(C, rng_seed=5)
+    cot_p = torch.from_numpy(rng.randn(N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1).astype(np.float32)).cuda()
+    cot_f = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32)).cuda()
+    res = {}
+    for fused in (True, False):
+        bn = mk_bn()
+        xg = x.clone().requires_grad_(True)
+        with FD.bn_groups(groups):
+            if fused:
+                f0, p = FD.bn_relu_maxpool(xg, bn, want_feature=want_feat)
+            else:
+                f0 = FD.batch_norm(xg, bn, relu=True)
+                p = FD.max_pool3x3s2(f0)
+        loss = (p * cot_p).sum()
+        if want_feat:
+            loss = loss + (f0 * cot_f).sum()
+        gx, gw, gb = torch.autograd.grad(loss, [xg, bn.weight, bn.bias])
+        res[fused] = (p.detach(), f0.detach() if want_feat else None, gx, gw, gb, bn.running_mean.clone(), bn.running_var.clone(),
+                      int(bn.num_batches_tracked))
+    a, b = res[True], res[False]
+    assert a[7] == b[7] == groups
+    relclose(cpu(a[0]), cpu(b[0]), "pooled", rtol=1e-6, arel=1e-6)
+    if want_feat:
+        relclose(cpu(a[1]), cpu(b[1]), "features[0]", rtol=1e-6, arel=1e-6)
+    else:
+        assert a[1] is None
+    for i, name in ((5, "running_mean"), (6, "running_var")):      # bit-equal on the large planes; tiny ones take the unfused path's
+        relclose(cpu(a[i]), cpu(b[i]), name, rtol=1e-6, arel=1e-6)  # small-plane kernel (statistics shifted by another sample)
+    for i, name in ((2, "gx"), (3, "gweight"), (4, "gbias")):
+        relclose(cpu(a[i]), cpu(b[i]), name, rtol=2e-5, arel=2e-5)

@@ -52,3 +52,16 @@ def test_evaluate_predictions_vs_oracle(split, median, factor):
     assert_close(got[4:], want[4:], rtol=0, atol=3e-4, what="mean a1 / a2 / a3")
     assert_close(got_r, want_r, rtol=1e-5, atol=0, what="ratios")
     assert (len(got_r) == 3) == median
+
+
+@pytest.mark.parametrize("hin,win,hout,wout", [(192, 640, 375, 1242), (192, 640, 370, 1226), (320, 1024, 375, 1242), (33, 41, 17, 90), (8, 8, 8, 8)])
+def test_resize_linear_cv_rule_is_the_oracle_restatement(hin, win, hout, wout):
+    """fd_resize_linear_cv == oracle.evaluate.resize_bilinear bit for bit: both restate OpenCV's float32 INTER_LINEAR (coefficient rule
+    in double -> float, horizontal pass, vertical pass) - up- and down-sampling, identity.  (Unpinned against OpenCV itself: not
+    installed in the build image.)"""
+    from fusiondepth_amd import functional as FD
+    from oracle import evaluate as OE
+    img = np.random.RandomState(hin + wout).uniform(0.01, 0.7, (2, hin, win)).astype(np.float32)
+    got = FD.resize_linear_cv(torch.from_numpy(img).cuda(), (hout, wout)).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(got[i], OE.resize_bilinear(img[i], hout, wout)), np.abs(got[i] - OE.resize_bilinear(img[i], hout, wout)).max()
