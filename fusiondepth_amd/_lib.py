@@ -122,6 +122,7 @@ SIGNATURES = {
     "fd_bn_train_fwd": ("pppppppppp" "iiiii" "ff" "ip", "i"),
     "fd_bn_eval_fwd": ("ppppppp" "iiii" "f" "ip", "i"),
     "fd_bn_train_bwd": ("ppppppppppp" "iiiii" "iip", "i"),
+    "fd_bn_train_bwd_remask": ("pppppppppp" "iiiii" "ip", "i"),
     "fd_bn_relu_maxpool_fwd": ("ppppppppppp" "iiiii" "ffp", "i"),
     "fd_bn_relu_maxpool_bwd": ("pppppppppppp" "iiiii" "ip", "i"),
     "fd_maxpool3x3s2_fwd": ("pppiiiip", "i"),

@@ -255,29 +255,38 @@ __global__ void __launch_bounds__(NT) k_bn_apply_eval(const float* __restrict__ 
 }
 
 // partial sums of dy' and dy'*xhat   (dy' = dy masked by the ReLU)
+// ``y == nullptr`` with ``relu``: the ReLU mask is recomputed from x (a * x + b > 0 with the forward's per-channel a, b) - a BatchNorm
+// without a residual input (bn1 of a BasicBlock, bn1 / bn2 of a Bottleneck) then reads two tensors per pass instead of three.
 template <bool VEC>
 __global__ void __launch_bounds__(NT) k_bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ y,
                                                       const float* __restrict__ gy, const float* __restrict__ save_mean,
                                                       const float* __restrict__ save_invstd, float* __restrict__ part,
-                                                      int N, int C, long HW, int splits, int relu) {
+                                                      int N, int C, long HW, int splits, int relu, const float* __restrict__ weight,
+                                                      const float* __restrict__ bias) {
     __shared__ float red[4 * 2];
     const int c = blockIdx.x, s = blockIdx.y, g = blockIdx.z;
     const float mean = save_mean[g * C + c], invstd = save_invstd[g * C + c];
+    const bool remask = relu && y == nullptr;
+    const float ma = invstd * (weight ? weight[c] : 1.f), mb = (bias ? bias[c] : 0.f) - mean * ma;
     float acc[2] = {0.f, 0.f};
     for_channel_slice<VEC>(N, HW, C, c, (long)g * N, s, splits, [&](long o) {
         if (VEC) {
             float4 d = ld4(gy + o);
-            if (relu) {
+            const float4 xx = ld4(x + o);
+            if (remask) {
+                d.x = fmaf(xx.x, ma, mb) > 0.f ? d.x : 0.f; d.y = fmaf(xx.y, ma, mb) > 0.f ? d.y : 0.f;
+                d.z = fmaf(xx.z, ma, mb) > 0.f ? d.z : 0.f; d.w = fmaf(xx.w, ma, mb) > 0.f ? d.w : 0.f;
+            } else if (relu) {
                 const float4 yy = ld4(y + o);
                 d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f; d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
             }
-            const float4 xx = ld4(x + o);
             acc[0] += (d.x + d.y) + (d.z + d.w);
             acc[1] += (d.x * ((xx.x - mean) * invstd) + d.y * ((xx.y - mean) * invstd)) +
                       (d.z * ((xx.z - mean) * invstd) + d.w * ((xx.w - mean) * invstd));
         } else {
             float d = gy[o];
-            if (relu && !(y[o] > 0.f)) d = 0.f;
+            if (remask) { if (!(fmaf(x[o], ma, mb) > 0.f)) d = 0.f; }
+            else if (relu && !(y[o] > 0.f)) d = 0.f;
             acc[0] += d;
             acc[1] += d * ((x[o] - mean) * invstd);
         }
@@ -293,7 +302,8 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x
                                                      const float* __restrict__ save_invstd, float* __restrict__ gx,
                                                      float* __restrict__ gweight, float* __restrict__ gbias,
                                                      float* __restrict__ g_res, const float* __restrict__ part, int N,
-                                                     int C, long HW, int splits, int relu, int accumulate, int G) {
+                                                     int C, long HW, int splits, int relu, int accumulate, int G,
+                                                     const float* __restrict__ bias) {
     const int nc = blockIdx.y, c = nc % C, n = nc / C, g = n / N;
     float s1 = 0.f, s2 = 0.f;
     const long pb = ((long)g * C + c) * splits;
@@ -314,16 +324,21 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x
     const float k = (weight ? weight[c] : 1.f) * invstd;
     const float m1 = s1 / M, m2 = s2 / M;
     const long base = (long)nc * HW;
+    const bool remask = relu && y == nullptr;
+    const float ma = k, mb = (bias ? bias[c] : 0.f) - mean * ma;
     if (VEC) {
         for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (HW >> 2); i += (long)gridDim.x * NT) {
             const long o = base + 4 * i;
             float4 d = ld4(gy + o);
-            if (relu) {
+            const float4 xx = ld4(x + o);
+            if (remask) {
+                d.x = fmaf(xx.x, ma, mb) > 0.f ? d.x : 0.f; d.y = fmaf(xx.y, ma, mb) > 0.f ? d.y : 0.f;
+                d.z = fmaf(xx.z, ma, mb) > 0.f ? d.z : 0.f; d.w = fmaf(xx.w, ma, mb) > 0.f ? d.w : 0.f;
+            } else if (relu) {
                 const float4 yy = ld4(y + o);
                 d.x = yy.x > 0.f ? d.x : 0.f; d.y = yy.y > 0.f ? d.y : 0.f; d.z = yy.z > 0.f ? d.z : 0.f; d.w = yy.w > 0.f ? d.w : 0.f;
             }
             if (g_res) st4(g_res + o, d);
-            const float4 xx = ld4(x + o);
             float4 r;
             r.x = k * (d.x - m1 - ((xx.x - mean) * invstd) * m2);
             r.y = k * (d.y - m1 - ((xx.y - mean) * invstd) * m2);
@@ -335,7 +350,8 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_apply(const float* __restrict__ x
     }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
         float g = gy[base + i];
-        if (relu && !(y[base + i] > 0.f)) g = 0.f;
+        if (remask) { if (!(fmaf(x[base + i], ma, mb) > 0.f)) g = 0.f; }
+        else if (relu && !(y[base + i] > 0.f)) g = 0.f;
         if (g_res) g_res[base + i] = g;
         const float xh = (x[base + i] - mean) * invstd;
         gx[base + i] = k * (g - m1 - xh * m2);
@@ -443,14 +459,16 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_small(const float* __restrict__ x
                                                      const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
                                                      float* __restrict__ gx, float* __restrict__ gweight, float* __restrict__ gbias,
                                                      float* __restrict__ g_res, int N, int C, int q, int relu, int accumulate,
-                                                     int G) {
+                                                     int G, const float* __restrict__ bias) {
     __shared__ float red[8];
     const int c = blockIdx.x, E = N * q;
     const float M = (float)N * (float)(4 * q);
     const float wc = weight ? weight[c] : 1.f;
+    const bool remask = relu && y == nullptr;
     float t1 = 0.f, t2 = 0.f;
     for (int g = 0; g < G; ++g) {
         const float mean = save_mean[g * C + c], invstd = save_invstd[g * C + c];
+        const float ma = invstd * wc, mb = (bias ? bias[c] : 0.f) - mean * ma;
         float4 d[SMALL_K], xh[SMALL_K];
         long off[SMALL_K];
         float s1 = 0.f, s2 = 0.f;
@@ -462,12 +480,15 @@ __global__ void __launch_bounds__(NT) k_bn_bwd_small(const float* __restrict__ x
                 const int n = e / q, i = e - n * q;
                 off[k] = (((long)g * N + n) * C + c) * 4 * q + 4 * i;
                 d[k] = ld4(gy + off[k]);
-                if (relu) {
+                const float4 xx = ld4(x + off[k]);
+                if (remask) {
+                    d[k].x = fmaf(xx.x, ma, mb) > 0.f ? d[k].x : 0.f; d[k].y = fmaf(xx.y, ma, mb) > 0.f ? d[k].y : 0.f;
+                    d[k].z = fmaf(xx.z, ma, mb) > 0.f ? d[k].z : 0.f; d[k].w = fmaf(xx.w, ma, mb) > 0.f ? d[k].w : 0.f;
+                } else if (relu) {
                     const float4 yy = ld4(y + off[k]);
                     d[k].x = yy.x > 0.f ? d[k].x : 0.f; d[k].y = yy.y > 0.f ? d[k].y : 0.f;
                     d[k].z = yy.z > 0.f ? d[k].z : 0.f; d[k].w = yy.w > 0.f ? d[k].w : 0.f;
                 }
-                const float4 xx = ld4(x + off[k]);
                 xh[k].x = (xx.x - mean) * invstd; xh[k].y = (xx.y - mean) * invstd;
                 xh[k].z = (xx.z - mean) * invstd; xh[k].w = (xx.w - mean) * invstd;
                 s1 += (d[k].x + d[k].y) + (d[k].z + d[k].w);
@@ -899,17 +920,17 @@ extern "C" int fd_bn_eval_fwd(const float* x, const float* weight, const float* 
     return 0;
 }
 
-extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float* weight,
-                               const float* save_mean, const float* save_invstd, float* gx, float* gweight, float* gbias,
-                               float* g_residual, float* ws, int N, int C, int H, int W, int groups, int relu, int accumulate,
-                               void* stream) {
+static int bn_train_bwd_impl(const float* x, const float* y, const float* gy, const float* weight, const float* bias,
+                             const float* save_mean, const float* save_invstd, float* gx, float* gweight, float* gbias,
+                             float* g_residual, float* ws, int N, int C, int H, int W, int groups, int relu, int accumulate,
+                             void* stream) {
     FD_REQUIRE(x && gy && save_mean && save_invstd && gx && ws && N > 0 && C > 0 && H > 0 && W > 0,
                "fd_bn_train_bwd: bad args");
     FD_REQUIRE(groups >= 1 && N % groups == 0, "fd_bn_train_bwd: batch %d is not divisible into %d groups", N, groups);
 #ifdef FD_ABLATE_NO_BN
     return 0;
 #endif
-    FD_REQUIRE(!relu || y, "fd_bn_train_bwd: the forward output is needed for the ReLU mask");
+    FD_REQUIRE(!relu || y || !g_residual, "fd_bn_train_bwd: a BatchNorm with a residual input needs the forward output for its ReLU mask");
     hipStream_t st = (hipStream_t)stream;
     const long HW = (long)H * W;
     const int Ng = N / groups;
@@ -920,7 +941,7 @@ extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, 
         return 0;
 #endif
         hipLaunchKernelGGL(k_bn_bwd_small, dim3(C), dim3(NT), 0, st, x, y, gy, weight, save_mean, save_invstd, gx, gweight, gbias,
-                           g_residual, Ng, C, (int)(HW >> 2), relu, accumulate, groups);
+                           g_residual, Ng, C, (int)(HW >> 2), relu, accumulate, groups, bias);
         FD_LAUNCH_CHECK("fd_bn_train_bwd(small)");
         return 0;
     }
@@ -928,13 +949,28 @@ extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, 
     auto apply = vec ? k_bn_bwd_apply<true> : k_bn_bwd_apply<false>;
 #ifndef FD_ABLATE_NO_BN_STATS
     hipLaunchKernelGGL(reduce, dim3(C, sp, groups), dim3(NT), 0, st, x, y, gy, save_mean, save_invstd, ws, Ng, C, HW,
-                       sp, relu);
+                       sp, relu, weight, bias);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(reduce)");
 #endif
     hipLaunchKernelGGL(apply, dim3(plane_blocks(HW), N * C), dim3(NT), 0, st, x, y, gy, weight, save_mean,
-                       save_invstd, gx, gweight, gbias, g_residual, ws, Ng, C, HW, sp, relu, accumulate, groups);
+                       save_invstd, gx, gweight, gbias, g_residual, ws, Ng, C, HW, sp, relu, accumulate, groups, bias);
     FD_LAUNCH_CHECK("fd_bn_train_bwd(apply)");
     return 0;
+}
+
+extern "C" int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float* weight, const float* save_mean,
+                               const float* save_invstd, float* gx, float* gweight, float* gbias, float* g_residual, float* ws, int N,
+                               int C, int H, int W, int groups, int relu, int accumulate, void* stream) {
+    FD_REQUIRE(!relu || y, "fd_bn_train_bwd: the forward output is needed for the ReLU mask (or use fd_bn_train_bwd_remask)");
+    return bn_train_bwd_impl(x, y, gy, weight, nullptr, save_mean, save_invstd, gx, gweight, gbias, g_residual, ws, N, C, H, W, groups, relu,
+                             accumulate, stream);
+}
+
+extern "C" int fd_bn_train_bwd_remask(const float* x, const float* gy, const float* weight, const float* bias, const float* save_mean,
+                                      const float* save_invstd, float* gx, float* gweight, float* gbias, float* ws, int N, int C, int H,
+                                      int W, int groups, int accumulate, void* stream) {
+    return bn_train_bwd_impl(x, nullptr, gy, weight, bias, save_mean, save_invstd, gx, gweight, gbias, nullptr, ws, N, C, H, W, groups, 1,
+                             accumulate, stream);
 }
 
 extern "C" int fd_bn_relu_maxpool_fwd(const float* x, const float* weight, const float* bias, float* feat, float* pooled, uint8_t* idx,

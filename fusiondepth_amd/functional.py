@@ -1148,7 +1148,9 @@ def _bn_forward(ctx, x, weight, bias, residual, running_mean, running_var, train
             ws = _empty((query("fd_bn_ws_floats", N, C, H, W, groups),), x)
             call("fd_bn_train_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
                  ptr(mean), ptr(invstd), ptr(ws), N, C, H, W, groups, float(eps), float(momentum), int(relu), stream())
-        ctx.save_for_backward(x, y if relu else None, weight, mean, invstd)
+        # ReLU without a residual input: the backward recomputes the mask from x (fd_bn_train_bwd_remask) and does not read y
+        ctx.remask = bool(relu and residual is None and tuning.host.bn_remask)
+        ctx.save_for_backward(x, (bias if ctx.remask else y) if relu else None, weight, mean, invstd)
     else:
         call("fd_bn_eval_fwd", ptr(x), ptr(weight), ptr(bias), ptr(res), ptr(y), ptr(running_mean), ptr(running_var),
              N, C, H, W, float(eps), int(relu), stream())
@@ -1169,8 +1171,12 @@ def _bn_backward(ctx, gy, need_res):
     gw, gb = (tw, tb) if direct else (_empty((C,), x), _empty((C,), x))
     gres = torch.empty_like(x) if ctx.has_res and need_res else None
     ws = _empty((query("fd_bn_ws_floats", N, C, H, W, ctx.groups),), x)
-    call("fd_bn_train_bwd", ptr(x), ptr(y), ptr(gy), ptr(weight), ptr(mean), ptr(invstd), ptr(gx), ptr(gw), ptr(gb),
-         ptr(gres), ptr(ws), N, C, H, W, ctx.groups, ctx.relu, int(direct), stream())
+    if getattr(ctx, "remask", False):             # `y` holds the bias here (see _bn_forward)
+        call("fd_bn_train_bwd_remask", ptr(x), ptr(gy), ptr(weight), ptr(y), ptr(mean), ptr(invstd), ptr(gx), ptr(gw), ptr(gb),
+             ptr(ws), N, C, H, W, ctx.groups, int(direct), stream())
+    else:
+        call("fd_bn_train_bwd", ptr(x), ptr(y), ptr(gy), ptr(weight), ptr(mean), ptr(invstd), ptr(gx), ptr(gw), ptr(gb),
+             ptr(gres), ptr(ws), N, C, H, W, ctx.groups, ctx.relu, int(direct), stream())
     if direct:
         gw = gb = None
         _grad_ready(ctx.params[0], ctx.params[1])
@@ -1356,7 +1362,19 @@ def bn_relu_maxpool(x, bn, want_feature=True):
         else:
             bn.num_batches_tracked.add_(groups)
     out = _BNReluPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, groups, bool(want_feature))
-    return (out[1], out[0]) if want_feature else (None, out)
+    if not want_feature:
+        return None, out
+    out[1]._fd_fused_stem = True           # its backward only READS the gradient arriving at features[0] (see mark_single_consumer)
+    return out[1], out[0]
+
+
+def mark_single_consumer(*tensors):
+    """The caller guarantees that each of these features[0] tensors of fused stem tails is consumed by ONE node (the depth
+    decoder's upsample + concatenation).  ``_UpCat.backward`` then hands both encoders the same gradient tensor instead of cloning
+    it: autograd passes a single incoming gradient on without accumulating into it, and ``_BNReluPool.backward`` only reads it."""
+    for t in tensors:
+        if t is not None and getattr(t, "_fd_fused_stem", False):
+            t._fd_grad_readonly = True
 
 
 class _MaxPool(torch.autograd.Function):
@@ -1389,7 +1407,7 @@ def max_pool3x3s2(x):
 
 class _UpCat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, s1, s2, s3, a_act=0):
+    def forward(ctx, a, s1, s2, s3, a_act=0, share_skip_grad=False):
         a = f32(a)
         ctx.a_act = int(a_act)
         if ctx.a_act:
@@ -1405,6 +1423,7 @@ class _UpCat(torch.autograd.Function):
         call("fd_upcat_fwd", ptr(a), ptr(s1), ptr(s2), ptr(s3), ptr(out), N, Ca, Cs, C3, h, w, stream())
         ctx.dims = (N, Ca, Cs, C3, h, w)
         ctx.has = (s1 is not None, s2 is not None, s3 is not None)
+        ctx.share_skip_grad = bool(share_skip_grad)
         return out
 
     @staticmethod
@@ -1423,16 +1442,19 @@ class _UpCat(torch.autograd.Function):
         # skip and skip_add come from encoders that run their backward on DIFFERENT streams.  Handing both the same tensor is
         # a race: autograd may accumulate a second incoming gradient into it in place on one stream while the other stream's
         # kernels still read it (seen as run-to-run different encoder gradients under GPU contention).  One owner each.
-        both = ctx.has[0] and ctx.has[1] and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
-        return ga, gs if ctx.has[0] else None, (gs.clone() if both else gs) if ctx.has[1] else None, g3, None
+        # ``share_skip_grad``: both skips are features[0] of fused stem tails (_BNReluPool): each has this node as its ONLY consumer, so
+        # autograd hands the tensor on without accumulating into it, and the stem-tail backward kernels only read it - no copy.
+        both = ctx.has[0] and ctx.has[1] and ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and not ctx.share_skip_grad
+        return ga, gs if ctx.has[0] else None, (gs.clone() if both else gs) if ctx.has[1] else None, g3, None, None
 
 
 def upsample_concat(a, skip=None, skip_add=None, extra=None, a_act="none"):
     """cat([nearest_up2(a), skip (+ skip_add), extra], 1)  — depth_decoder.py:75-83 in one pass.  ``a_act``: ``a`` is the output of
     that activation, produced by a ``conv2d(..., grad_preact=True)`` and consumed here alone: its gradient is returned times act'(a)."""
+    share = bool(getattr(skip, "_fd_grad_readonly", False) and getattr(skip_add, "_fd_grad_readonly", False))
     if ACT[a_act] and torch.is_grad_enabled() and a.requires_grad:
-        return _UpCat.apply(a, skip, skip_add, extra, ACT[a_act])
-    return _UpCat.apply(a, skip, skip_add, extra)
+        return _UpCat.apply(a, skip, skip_add, extra, ACT[a_act], share)
+    return _UpCat.apply(a, skip, skip_add, extra, 0, share)
 
 
 class _Up2(torch.autograd.Function):

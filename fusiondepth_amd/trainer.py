@@ -616,6 +616,8 @@ class Trainer:
         if self.opt.cat2end:
             outputs = self.models["depth"](features, two_channel=inputs["2channel"])
         elif beam_features is not None:
+            if not self.opt.predictive_mask:               # features[0] of both encoders feed the depth decoder's last concatenation only
+                FD.mark_single_consumer(features[0], beam_features[0])
             outputs = self.models["depth"](features, beam_features=beam_features)
         else:
             outputs = self.models["depth"](features)

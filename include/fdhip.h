@@ -345,6 +345,13 @@ int fd_bn_train_bwd(const float* x, const float* y, const float* gy, const float
                     const float* save_invstd, float* gx, float* gweight, float* gbias, float* g_residual, float* ws, int N,
                     int C, int H, int W, int groups, int relu, int accumulate /* gweight/gbias += */, void* stream);
 
+/* The same backward for a BatchNorm + ReLU WITHOUT a residual input (bn1 of a BasicBlock, bn1 / bn2 of a Bottleneck): the ReLU mask
+ * is recomputed from x (weight * invstd * (x - mean) + bias > 0), so the forward output is not read - two tensors per pass instead
+ * of three (round 5). */
+int fd_bn_train_bwd_remask(const float* x, const float* gy, const float* weight, const float* bias, const float* save_mean,
+                           const float* save_invstd, float* gx, float* gweight, float* gbias, float* ws, int N, int C, int H, int W,
+                           int groups, int accumulate, void* stream);
+
 /* nn.MaxPool2d(3, stride 2, padding 1) (resnet_encoder.py:98).  idx [N,C,Ho,Wo] u8 = argmax tap (0..8). */
 int fd_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int N, int C, int H, int W, void* stream);
 int fd_maxpool3x3s2_bwd(const float* gy, const uint8_t* idx, float* gx, int N, int C, int H, int W, void* stream);
