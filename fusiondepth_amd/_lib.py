@@ -134,6 +134,7 @@ SIGNATURES = {
     "fd_upsample2x_bwd": ("ppliip", "i"),
     "fd_axpby": ("ppplffp", "i"),
     "fd_input_normalize": ("pplffp", "i"),
+    "fd_stack_normalize": ("pppiiiiiipiffp", "i"),
     "fd_combine_losses_fwd": ("pppifpp", "i"),
     "fd_combine_losses_bwd": ("pifpp", "i"),
     "fd_spatial_mean_fwd": ("ppllfp", "i"),

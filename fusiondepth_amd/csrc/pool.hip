@@ -226,6 +226,22 @@ __global__ void __launch_bounds__(NT) k_input_normalize(const float* __restrict_
     GRID_STRIDE(i, n) y[i] = (x[i] - mean) / std;
 }
 
+// The pose encoders' input (trainer.py:336-351: torch.cat([color_aug[f_i], color_aug[f_j]], 1) per source frame, then resnet_encoder.py:94)
+// assembled and normalised in ONE pass: piece p = `imgs` whole images (C * HW floats each, contiguous in the source) that go to
+// images dst_img[p] .. of the stacked tensor at channel offset dst_ch[p]; out has `Ct` channels per image.
+struct StackArgs { const float* src[16]; int dst_img[16]; int dst_ch[16]; int n_pieces, imgs, C, Ct; long HW; float mean, std; int normalize; };
+__global__ void __launch_bounds__(NT) k_stack_normalize(StackArgs a, float* __restrict__ out) {
+    const int piece = blockIdx.y / a.imgs, b = blockIdx.y - piece * a.imgs;
+    const long n4 = ((long)a.C * a.HW) >> 2;                          // HW % 4 == 0 (checked by the launcher)
+    const float4* s = reinterpret_cast<const float4*>(a.src[piece] + (long)b * a.C * a.HW);
+    float4* d = reinterpret_cast<float4*>(out + ((long)(a.dst_img[piece] + b) * a.Ct + a.dst_ch[piece]) * a.HW);
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+        float4 v = s[i];
+        if (a.normalize) { v.x = (v.x - a.mean) / a.std; v.y = (v.y - a.mean) / a.std; v.z = (v.z - a.mean) / a.std; v.w = (v.w - a.mean) / a.std; }
+        d[i] = v;
+    }
+}
+
 // one wave per plane: out = scale * mean(plane)
 __global__ void __launch_bounds__(64) k_spatial_mean(const float* __restrict__ x, float* __restrict__ out, long plane_size,
                                                      float scale) {
@@ -396,6 +412,24 @@ extern "C" int fd_input_normalize(const float* x, float* y, long n, float mean, 
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_input_normalize, dim3(ew_blocks(n)), dim3(NT), 0, (hipStream_t)stream, x, y, n, mean, std);
     FD_LAUNCH_CHECK("fd_input_normalize");
+    return 0;
+}
+extern "C" int fd_stack_normalize(const float* const* src, const int* dst_img, const int* dst_ch, int n_pieces, int imgs, int C, int Ct,
+                                  int H, int W, float* out, int normalize, float mean, float std, void* stream) {
+    FD_REQUIRE(src && dst_img && dst_ch && out && n_pieces > 0 && n_pieces <= 16 && imgs > 0 && C > 0 && Ct >= C && H > 0 && W > 0 && std != 0.f,
+               "fd_stack_normalize: bad args (at most 16 pieces)");
+    FD_REQUIRE(((long)H * W) % 4 == 0 && ((uintptr_t)out & 15) == 0, "fd_stack_normalize: planes must be multiples of 4 floats, 16-byte aligned");
+    StackArgs a;
+    for (int p = 0; p < 16; ++p) { a.src[p] = nullptr; a.dst_img[p] = 0; a.dst_ch[p] = 0; }
+    for (int p = 0; p < n_pieces; ++p) {
+        FD_REQUIRE(src[p] && ((uintptr_t)src[p] & 15) == 0 && dst_img[p] >= 0 && dst_ch[p] >= 0 && dst_ch[p] + C <= Ct, "fd_stack_normalize: bad piece %d", p);
+        a.src[p] = src[p]; a.dst_img[p] = dst_img[p]; a.dst_ch[p] = dst_ch[p];
+    }
+    a.n_pieces = n_pieces; a.imgs = imgs; a.C = C; a.Ct = Ct; a.HW = (long)H * W; a.mean = mean; a.std = std; a.normalize = normalize;
+    long bx = ((long)C * H * W / 4 + 4 * NT - 1) / (4 * NT);
+    bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+    hipLaunchKernelGGL(k_stack_normalize, dim3((unsigned)bx, (unsigned)(n_pieces * imgs)), dim3(NT), 0, (hipStream_t)stream, a, out);
+    FD_LAUNCH_CHECK("fd_stack_normalize");
     return 0;
 }
 extern "C" int fd_spatial_mean_fwd(const float* x, float* out, long planes, long plane_size, float scale, void* stream) {

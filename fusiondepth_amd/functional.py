@@ -1106,6 +1106,27 @@ class _InputNormalize(torch.autograd.Function):
         return gx, None, None
 
 
+def stack_normalize(pieces, n_images, channels_total, normalize=True, mean=0.45, std=0.225):
+    """One launch for ``torch.cat`` along batch and channels + the encoder's input normalisation: ``pieces`` = [(tensor [imgs, C, H, W]
+    contiguous, first destination image, destination channel offset)]; all pieces have the same shape.  -> [n_images, channels_total,
+    H, W] (fd_stack_normalize).  No gradient (network inputs)."""
+    t0 = f32(pieces[0][0].detach())
+    _need_cuda(t0)
+    imgs, C, H, W = t0.shape
+    out = _empty((n_images, channels_total, H, W), t0)
+    for lo in range(0, len(pieces), 16):
+        part = pieces[lo:lo + 16]
+        ts = [f32(t.detach()) for t, _, _ in part]
+        if any(t.shape != t0.shape for t in ts):
+            raise RuntimeError("stack_normalize: pieces differ in shape")
+        n = len(part)
+        src = (ctypes.c_void_p * n)(*[ptr(t) for t in ts])
+        di = (ctypes.c_int * n)(*[int(d) for _, d, _ in part])
+        dc = (ctypes.c_int * n)(*[int(c) for _, _, c in part])
+        call("fd_stack_normalize", src, di, dc, n, imgs, C, channels_total, H, W, ptr(out), int(bool(normalize)), float(mean), float(std), stream())
+    return out
+
+
 def input_normalize(x, mean=0.45, std=0.225):
     """``(x - mean) / std`` — the encoder's input normalisation (resnet_encoder.py:94) as its own pass, so that the stem
     convolution and its weight gradient gather plain values (the fused ``in_norm`` variant pays a division per tap)."""

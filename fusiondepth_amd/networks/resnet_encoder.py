@@ -159,8 +159,11 @@ class ResnetEncoder(nn.Module):
         """The forward pass as a generator that yields after the stem and after every residual block, so that a caller can
         advance several encoders in turn (``interleaved_forward``).  ``self.features`` is set when it is exhausted."""
         e = self.encoder
-        # (x - 0.45) / 0.225 (resnet_encoder.py:94) as its own pass: the 7x7 stem then gathers plain values
-        x = FD.conv2d(FD.input_normalize(input_image), e.conv1.weight, None, stride=2, pad=3)
+        # (x - 0.45) / 0.225 (resnet_encoder.py:94) as its own pass: the 7x7 stem then gathers plain values.  An input that carries
+        # ``_fd_normalized`` was normalised by its producer (Trainer._stack_pose_inputs: FD.stack_normalize assembles and normalises
+        # the pose networks' input in one launch).
+        xin = input_image if getattr(input_image, "_fd_normalized", False) else FD.input_normalize(input_image)
+        x = FD.conv2d(xin, e.conv1.weight, None, stride=2, pad=3)
         if tuning.host.fused_stem_tail and e.bn1.training:
             # BatchNorm + ReLU + max-pool of the stem in one pass; features[0] is materialised only for the encoders whose skip
             # connection reads it (``stem_feature_needed``: the trainer clears it for the pose encoders - PoseDecoder reads features[-1])

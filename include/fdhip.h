@@ -396,6 +396,12 @@ int fd_combine_losses_bwd(const float* g_total, int n_scales, float smooth_weigh
 /* networks/resnet_encoder.py:94  y = (x - mean) / std  elementwise (the encoder's input normalisation, 0.45 / 0.225).
  * The same arithmetic is available fused into the stem conv through fd_conv_desc.in_norm. */
 int fd_input_normalize(const float* x, float* y, long n, float mean, float std, void* stream);
+/* The pose networks' input in one pass (trainer.py:336-351 `torch.cat([inputs[("color_aug", f_i, 0)], inputs[("color_aug", f_j, 0)]], 1)`
+ * for every source frame, stacked along the batch axis, followed by resnet_encoder.py:94): piece p copies `imgs` whole images
+ * [imgs][C][H][W] from src[p] (device pointers, array on the HOST) to images dst_img[p] .. dst_img[p] + imgs - 1 of out
+ * [n][Ct][H][W] at channel offset dst_ch[p], optionally as (x - mean) / std.  At most 16 pieces per call. */
+int fd_stack_normalize(const float* const* src, const int* dst_img, const int* dst_ch, int n_pieces, int imgs, int C, int Ct, int H,
+                       int W, float* out, int normalize, float mean, float std, void* stream);
 
 /* out = a + b (feature fusion depth_decoder.py:70, pose_decoder.py:31) ; out = alpha*a + beta*b */
 int fd_axpby(const float* a, const float* b, float* out, long n, float alpha, float beta, void* stream);

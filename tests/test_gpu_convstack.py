@@ -1069,3 +1069,24 @@ def test_fused_stem_tail_equals_batchnorm_relu_maxpool(FD, N, C, H, W, groups, w
         relclose(cpu(a[i]), cpu(b[i]), name, rtol=1e-6, arel=1e-6)  # small-plane kernel (statistics shifted by another sample)
     for i, name in ((2, "gx"), (3, "gweight"), (4, "gbias")):
         relclose(cpu(a[i]), cpu(b[i]), name, rtol=2e-5, arel=2e-5)
+
+
+def test_stack_normalize_is_cat_plus_input_normalisation(FD):
+    """fd_stack_normalize: the pose networks' input - torch.cat of frame pairs along the channels, the pairs of all source frames and
+    micro-batches along the batch axis, then (x - 0.45) / 0.225 - in one launch, bit for bit (a true division, like the reference)."""
+    rng = np.random.RandomState(31)
+    G, Bg, C, H, W = 2, 3, 3, 8, 12
+    frames = {f: torch.from_numpy(rng.rand(G * Bg, C, H, W).astype(np.float32)).cuda() for f in (-1, 0, 1)}
+    orders = [(-1, 0), (0, 1)]
+    pieces, want = [], []
+    for g in range(G):
+        for k, o in enumerate(orders):
+            for j, i in enumerate(o):
+                pieces.append((frames[i][g * Bg:(g + 1) * Bg], (g * len(orders) + k) * Bg, j * C))
+            want.append(torch.cat([frames[i][g * Bg:(g + 1) * Bg] for i in o], 1))
+    want = torch.cat(want, 0)
+    got = FD.stack_normalize(pieces, G * len(orders) * Bg, 2 * C)
+    assert torch.equal(got.cpu(), (want.cpu() - 0.45) / 0.225)          # on the CPU: ATen's GPU kernel multiplies by the reciprocal instead
+    assert torch.equal(FD.stack_normalize(pieces, G * len(orders) * Bg, 2 * C, normalize=False), want)
+    many = [(frames[0][:1], i, 0) for i in range(20)]                      # more than 16 pieces: several launches
+    assert torch.equal(FD.stack_normalize(many, 20, C, normalize=False), frames[0][:1].repeat(20, 1, 1, 1))
