@@ -122,7 +122,7 @@ def roofline_probes(args, tr, batch):
     from fusiondepth_amd import tuning as _tuning
     two_p = _tuning.get_lib()["wino_fwd_2dp_min_wgs"] > 0 and Bc * (h8 // 2) * (w8 // 2) // 64 >= _tuning.get_lib()["wino_fwd_2dp_min_wgs"] and h8 % 2 == 0
     executed = 4.0 / 9.0 if two_p else 2.0 / 3.0
-    for name in ("round4_pmc_probe_wino.json", "round3_pmc_probe_wino.json"):
+    for name in ("round5_pmc_probe_wino.json", "round4_pmc_probe_wino.json", "round3_pmc_probe_wino.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -172,7 +172,7 @@ def roofline_probes(args, tr, batch):
     loss_traffic, loss_traffic_src = None, None
     sha = hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "fusiondepth_amd", "csrc",
                                            "photometric_ms.hip"), "rb").read()).hexdigest()
-    for name in ("round4_pmc_loss.json", "round3_pmc_loss.json", "round2_pmc_loss.json"):
+    for name in ("round5_pmc_loss.json", "round4_pmc_loss.json", "round3_pmc_loss.json", "round2_pmc_loss.json"):
         pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         if not os.path.exists(pmc_path):
             continue
