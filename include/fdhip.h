@@ -26,7 +26,9 @@ extern "C" {
 
 /* 2: fd_tuning / fd_set_tuning added (the library no longer reads the process environment); fd_conv2d_fwd_stats and
  *    fd_bn_train_fwd_parts added, the fd_conv2d_*_pair entry points removed, fd_bn_ws_floats grew by one shift value per
- *    (group, channel) - a client that sized the BatchNorm workspace itself must re-query it. */
+ *    (group, channel) - a client that sized the BatchNorm workspace itself must re-query it.
+ * 3: additions only (round 5): fd_masked_median, fd_refine_inputs (+ fd_refine_cfg), fd_resize_linear_cv, fd_bn_relu_maxpool_fwd / _bwd,
+ *    fd_bn_train_bwd_remask, fd_stack_normalize.  Nothing removed, no signature changed. */
 #define FD_ABI_VERSION 3
 
 int fd_abi_version(void);
