@@ -607,16 +607,37 @@ __global__ void k_reflect_fold(const float* __restrict__ gp, float* __restrict__
 // per-channel sum over (n, y, x) — bias gradient.  Two deterministic stages: (channel, slice) partials, then a
 // fixed-order sum over the slices.
 constexpr int CS_SPLITS = 32;
+// Round 5: one 64-bit division per ELEMENT and scalar loads made this pass run at 0.6 TB/s (150 us for the 94 MB of upconv(0, 1)'s
+// gradient); now slice s of every image's plane, float4 loads four at a time, no index arithmetic in the loop.  The summation order
+// changed with it (per thread: images in order, its quads in order; then the fixed block tree) - still deterministic.
+template <bool VEC>
 __global__ void __launch_bounds__(256) k_channel_sum_part(const float* __restrict__ x, float* __restrict__ part, int Nb,
                                                           int C, long plane) {
     __shared__ float red[4];
     const int c = blockIdx.x, s = blockIdx.y;
-    const long total = (long)Nb * plane, per = (total + CS_SPLITS - 1) / CS_SPLITS;
-    const long lo = (long)s * per, hi = lo + per < total ? lo + per : total;
     float v[1] = {0.f};
-    for (long i = lo + threadIdx.x; i < hi; i += 256) {
-        const long n = i / plane, r = i - n * plane;
-        v[0] += x[(n * C + c) * plane + r];
+    if (VEC) {
+        const long q = plane >> 2, per = (q + CS_SPLITS - 1) / CS_SPLITS;
+        const long lo = (long)s * per, hi = lo + per < q ? lo + per : q;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int n = 0; n < Nb; ++n) {
+            const float4* p = reinterpret_cast<const float4*>(x + ((long)n * C + c) * plane);
+            long i = lo + threadIdx.x;
+            for (; i + 768 < hi; i += 1024) {                       // four independent loads in flight
+                const float4 u0 = p[i], u1 = p[i + 256], u2 = p[i + 512], u3 = p[i + 768];
+                a0 += (u0.x + u0.y) + (u0.z + u0.w); a1 += (u1.x + u1.y) + (u1.z + u1.w);
+                a2 += (u2.x + u2.y) + (u2.z + u2.w); a3 += (u3.x + u3.y) + (u3.z + u3.w);
+            }
+            for (; i < hi; i += 256) { const float4 u = p[i]; a0 += (u.x + u.y) + (u.z + u.w); }
+        }
+        v[0] = (a0 + a1) + (a2 + a3);
+    } else {
+        const long per = (plane + CS_SPLITS - 1) / CS_SPLITS;
+        const long lo = (long)s * per, hi = lo + per < plane ? lo + per : plane;
+        for (int n = 0; n < Nb; ++n) {
+            const float* p = x + ((long)n * C + c) * plane;
+            for (long i = lo + threadIdx.x; i < hi; i += 256) v[0] += p[i];
+        }
     }
     const float sum = fd_block_sum_n<1, 4>(v, red);
     if (threadIdx.x == 0) part[(long)c * CS_SPLITS + s] = sum;
@@ -1344,8 +1365,10 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
         }
     }
     if (gbias) {
-        hipLaunchKernelGGL(k_channel_sum_part, dim3(d->Cout, CS_SPLITS), dim3(256), 0, st, gy, ws, d->N, d->Cout,
-                           (long)s.Ho * s.Wo);
+        const long plane = (long)s.Ho * s.Wo;
+        const bool vec = (plane & 3) == 0 && ((uintptr_t)gy & 15) == 0;
+        hipLaunchKernelGGL((vec ? k_channel_sum_part<true> : k_channel_sum_part<false>), dim3(d->Cout, CS_SPLITS), dim3(256), 0, st, gy, ws, d->N,
+                           d->Cout, plane);
         FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(bias)");
         hipLaunchKernelGGL(k_channel_sum_fin, dim3(fd_cdiv(d->Cout, 64)), dim3(64), 0, st, ws, gbias, d->Cout, accumulate);
         FD_LAUNCH_CHECK("fd_conv2d_bwd_weight(bias fin)");

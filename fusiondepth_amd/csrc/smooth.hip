@@ -14,12 +14,28 @@ __device__ __forceinline__ float img_grad(const float* __restrict__ img, long P,
     return (fabsf(img[p] - img[q]) + fabsf(img[P + p] - img[P + q]) + fabsf(img[2 * P + p] - img[2 * P + q])) / 3.0f;
 }
 
-// one workgroup per image: mean over H*W (reference: mean over H then over W — same value)
+// one workgroup per image: mean over H*W (reference: mean over H then over W — same value).  Round 5: float4 loads, four in flight
+// (the scalar loop - 120 dependent rounds for a 192x640 plane - took 179 us at the head of the smoothness chain, forward AND backward,
+// beside a 255 us photometric kernel on the step's serial section).
 __global__ void __launch_bounds__(1024) k_image_mean(const float* __restrict__ x, float* __restrict__ mean, long P) {
     __shared__ float red[16];
     const float* xb = x + (long)blockIdx.x * P;
     float v[1] = {0.f};
-    for (long i = threadIdx.x; i < P; i += 1024) v[0] += xb[i];
+    if ((P & 3) == 0 && (((uintptr_t)xb) & 15) == 0) {
+        const float4* q = reinterpret_cast<const float4*>(xb);
+        const long n4 = P >> 2;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        long i = threadIdx.x;
+        for (; i + 3072 < n4; i += 4096) {
+            const float4 u0 = q[i], u1 = q[i + 1024], u2 = q[i + 2048], u3 = q[i + 3072];
+            a0 += (u0.x + u0.y) + (u0.z + u0.w); a1 += (u1.x + u1.y) + (u1.z + u1.w);
+            a2 += (u2.x + u2.y) + (u2.z + u2.w); a3 += (u3.x + u3.y) + (u3.z + u3.w);
+        }
+        for (; i < n4; i += 1024) { const float4 u = q[i]; a0 += (u.x + u.y) + (u.z + u.w); }
+        v[0] = (a0 + a1) + (a2 + a3);
+    } else {
+        for (long i = threadIdx.x; i < P; i += 1024) v[0] += xb[i];
+    }
     const float s = fd_block_sum_n<1, 16>(v, red);
     if (threadIdx.x == 0) mean[blockIdx.x] = s / (float)P;
 }
