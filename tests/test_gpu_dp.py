@@ -92,13 +92,13 @@ def test_bench_two_ranks_reports_the_exchange(tmp_path, backend):
     assert res["value"] > 0 and res["params_finite"]
 
 
-def _bench_plain(extra, timeout=500):
+def _bench_plain(extra, timeout=500, lean=True):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("FD_DIST_BACKEND", None)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "64",
-           "--width", "96", "--batch_size", "2", "--no_roofline", "--no_cpu_baseline"] + extra
+           "--width", "96", "--batch_size", "2"] + (["--no_roofline", "--no_cpu_baseline"] if lean else []) + extra
     return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
 
 
@@ -122,3 +122,18 @@ def test_plain_bench_gpus2_launches_its_own_ranks():
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["backend"] == want_backend and res["config"]["parallelism"] == "dp2"
     assert res["final_loss"] is not None and res["params_finite"] and res["value"] > 0
+
+
+def test_bench_gpus2_line_carries_roofline_and_cpu_baseline():
+    """the N > 1 line must be complete the first time a multi-GPU node runs it - `roofline` (rank 0's probes)
+    and `cpu_baseline` (rank 0, after the process group is gone so that no collective waits on a CPU run) next to the exchange figures."""
+    import torch
+    r = _bench_plain([] if torch.cuda.device_count() >= 2 else ["--share_device"], timeout=900, lean=False)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2
+    for key in ("roofline", "roofline_loss_path", "cpu_baseline", "cpu_baseline_1thread", "allreduce_ms", "overlap_frac"):
+        assert key in res, (key, sorted(res))
+    assert res["roofline"]["bound"] == "mfma" and res["roofline"]["frac"] > 0 and res["cpu_baseline"]["value"] > 0 and res["cpu_baseline"]["kind"] == "port"
