@@ -96,6 +96,8 @@ SIGNATURES = {
     "fd_conv2d_fwd": ("pppppp" "i" "pp", "i"),
     "fd_conv2d_fwd_stat_slots": ("p", "l"),
     "fd_conv2d_fwd_stats": ("pppppp" "i" "ppp", "i"),
+    "fd_conv2d_fwd_bn_ok": ("pi", "i"),
+    "fd_conv2d_fwd_bn": ("pppppip" "pppppppp" "iffip", "i"),
     "fd_bn_train_fwd_parts": ("pppppppppp" "iiiiii" "ff" "ip", "i"),
     "fd_conv2d_bwd_data_wt_floats": ("p", "l"),
     "fd_conv2d_bwd_data_ws_floats": ("p", "l"),

@@ -857,6 +857,25 @@ extern "C" int fd_conv2d_fwd(const fd_conv_desc* d, const float* x, const float*
                              int wt_ready, float* ws, void* stream) {
     return conv2d_fwd_impl(d, x, w, bias, y, wt, wt_ready, ws, nullptr, stream);
 }
+extern "C" int fd_conv2d_fwd_bn_ok(const fd_conv_desc* d, int groups) {
+    if (!d || check_desc(d, "fd_conv2d_fwd_bn_ok")) return 0;
+    if (!(fast_fwd_ok(d) && wino_use_fwd(d) && wino_fwd_slab_route(d)) || d->act != 0 || c1_shape_ok(d) || n16_shape_ok(d, d->Cout, d->Cin)) return 0;
+    return bn_small_slabs_ok(d->N, d->Cout, d->H, d->W, groups) ? 1 : 0;
+}
+extern "C" int fd_conv2d_fwd_bn(const fd_conv_desc* d, const float* x, const float* w, float* y, float* wt, int wt_ready, float* ws,
+                                const float* bn_weight, const float* bn_bias, const float* residual, float* out, float* running_mean,
+                                float* running_var, float* save_mean, float* save_invstd, int groups, float eps, float momentum, int relu,
+                                void* stream) {
+    FD_REQUIRE(fd_conv2d_fwd_bn_ok(d, groups), "fd_conv2d_fwd_bn: not a slab-route 3x3 convolution followed by a small-plane BatchNorm (fd_conv2d_fwd_bn_ok == 0)");
+    FD_REQUIRE(x && w && y && wt && ws && out && save_mean && save_invstd, "fd_conv2d_fwd_bn: NULL argument");
+    FD_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "fd_conv2d_fwd_bn: running stats must come in pairs");
+    hipStream_t st = (hipStream_t)stream;
+    conv_log("fwd", "wino + bn", d);
+    if (!wt_ready)
+        if (int rc = wino_weight_launch(d, w, wt, 0, st)) return rc;
+    BnAfterConv bn = {bn_weight, bn_bias, residual, out, running_mean, running_var, save_mean, save_invstd, groups, eps, momentum, relu};
+    return wino_conv_launch(d, x, wt, nullptr, y, ws, st, nullptr, nullptr, &bn);
+}
 extern "C" long fd_conv2d_fwd_stat_slots(const fd_conv_desc* d) {
     if (!d || check_desc(d, "fd_conv2d_fwd_stat_slots")) return 0;
     return (fast_fwd_ok(d) && wino_use_fwd(d)) ? wino_stat_slots(d) : 0;

@@ -65,8 +65,18 @@ long wino_wt_floats(const fd_conv_desc* d);
 bool wino_fwd_2d(const fd_conv_desc* d);
 long wino_ws_floats(const fd_conv_desc* d);
 int wino_weight_launch(const fd_conv_desc* d, const float* w, float* U, int flip, hipStream_t st);
+// the BatchNorm that follows a slab-route convolution, fused with the slab reduction (norm.hip: k_bn_train_small_slabs)
+struct BnAfterConv {
+    const float* weight; const float* bias; const float* residual; float* out;
+    float* running_mean; float* running_var; float* save_mean; float* save_invstd;
+    int groups; float eps, momentum; int relu;
+};
+bool bn_small_slabs_ok(int N, int C, int H, int W, int groups);
+int bn_small_slabs_launch(const float* slabs, long slab_stride, int ksplit, float* y, const BnAfterConv& bn, int N, int C, int H, int W,
+                          hipStream_t st);
+bool wino_fwd_slab_route(const fd_conv_desc* d);
 int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st,
-                     const float* add = nullptr, float* stat_part = nullptr);
+                     const float* add = nullptr, float* stat_part = nullptr, const BnAfterConv* bn = nullptr);
 int wino_stat_slots(const fd_conv_desc* d);
 // conv_n16.hip: 3x3 stride-1 convolutions with 16 / 32 channels on either side (the decoder's full-resolution blocks)
 bool n16_shape_ok(const fd_conv_desc* d, int M, int C);

@@ -1700,8 +1700,11 @@ int wino_stat_slots(const fd_conv_desc* d) {
     return (int)(2 * plane2 / WBN);
 }
 
+bool wino_fwd_slab_route(const fd_conv_desc* d) { return wino_fwd_ok(d) && wino_fwd_mode(d) == 1; }
+
 int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, const float* bias, float* y, float* ws, hipStream_t st,
-                     const float* add, float* stat_part) {
+                     const float* add, float* stat_part, const BnAfterConv* bn) {
+    if (bn && (wino_fwd_mode(d) != 1 || bias || add || d->act != 0)) { fd_set_error("wino conv: the fused BatchNorm needs the slab route without bias / activation"); return -1; }
     WinoArgs g = {};
     g.U = U; g.X = x; g.Y = y; g.bias = bias; g.slabs = ws; g.add = add;
     g.stat_part = stat_part; g.stat_slots = stat_part ? wino_stat_slots(d) : 0;
@@ -1758,6 +1761,8 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         if (m128) hipLaunchKernelGGL(k_conv_wino2d_m128, grid, dim3(WNT), sizeof(float) * M2_LDS_FLOATS, st, g);
         else hipLaunchKernelGGL(k_conv_wino2d, grid, dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
         FD_LAUNCH_CHECK("k_conv_wino2d");
+        if (bn)             // the slab reduction + vertical output transform inside the small-plane BatchNorm kernel that follows (round 5)
+            return bn_small_slabs_launch(ws, g.slab_stride, sp / 4, y, *bn, d->N, d->Cout, d->H, d->W, st);
         const unsigned total2 = (unsigned)(out_total / 4);               // one thread per (tile row, column pair)
         const unsigned blocks = (total2 + 255u) / 256u;
         hipLaunchKernelGGL(k_wino2d_finish, dim3(blocks > 4096u ? 4096u : blocks), dim3(256), 0, st, ws, y, bias, add, total2,

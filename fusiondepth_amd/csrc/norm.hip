@@ -8,6 +8,7 @@
 // slice order by every consumer.
 #include "../../include/fdhip.h"
 #include "fd_common.h"
+#include "conv_fast.h"
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -454,6 +455,109 @@ __global__ void __launch_bounds__(NT) k_bn_train_small(const float* __restrict__
     }
 }
 
+// k_bn_train_small fed by the SLABS of the F(2x2, 3x3) convolution in front of it (conv_wino.hip: k_conv_wino2d / _m128 write the
+// horizontally transformed products S_ri [N][C][H/2][W] per row component ri and channel split): the slab reduction and the vertical
+// output transform  y[2 ty] = S0 + S1 + S2,  y[2 ty + 1] = S1 - S2 - S3  of k_wino2d_finish (same order of additions: the convolution
+// output is bit-identical) happen where the values are needed - one launch and one pass over y less per deep-layer convolution.
+// y (the convolution's output = this BatchNorm's input, needed by both backward passes) is written from here.
+__global__ void __launch_bounds__(NT) k_bn_train_small_slabs(const float* __restrict__ slabs, long slab_stride, int ksplit,
+                                                             float* __restrict__ xout, const float* __restrict__ weight,
+                                                             const float* __restrict__ bias, const float* __restrict__ residual,
+                                                             float* __restrict__ y, float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                             float* __restrict__ save_invstd, int N, int C, int H, int W, float eps,
+                                                             float momentum, int relu, int G) {
+    __shared__ float red[8];
+    __shared__ float gstat[16][2];
+    const int q = (H * W) >> 2, W4 = W >> 2, HT = H >> 1;
+    const int c = blockIdx.x, E = N * q;
+    const float M = (float)N * (float)(4 * q);
+    const float wc = weight ? weight[c] : 1.f, bc = bias ? bias[c] : 0.f;
+    for (int g = 0; g < G; ++g) {
+        float4 v[SMALL_K];
+        long off[SMALL_K];
+#pragma unroll
+        for (int k = 0; k < SMALL_K; ++k) {
+            const int e = threadIdx.x + k * NT;
+            off[k] = -1;
+            if (e < E) {
+                const int n = e / q, i = e - n * q;
+                const int r = i / W4, col = 4 * (i - r * W4);
+                const long pl = ((long)g * N + n) * C + c;
+                off[k] = pl * 4 * q + 4 * i;
+                const float* sp = slabs + (pl * HT + (r >> 1)) * W + col;
+                const int odd = r & 1;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, d = a;           // S_odd, S_odd+1, S_odd+2 summed over the channel splits
+                for (int ks = 0; ks < ksplit; ++ks) {
+                    const float4 t0 = ld4(sp + (long)(4 * ks + odd) * slab_stride), t1 = ld4(sp + (long)(4 * ks + odd + 1) * slab_stride),
+                                 t2 = ld4(sp + (long)(4 * ks + odd + 2) * slab_stride);
+                    a.x += t0.x; a.y += t0.y; a.z += t0.z; a.w += t0.w;
+                    b.x += t1.x; b.y += t1.y; b.z += t1.z; b.w += t1.w;
+                    d.x += t2.x; d.y += t2.y; d.z += t2.z; d.w += t2.w;
+                }
+                float4 o;
+                if (odd) { o.x = (a.x - b.x) - d.x; o.y = (a.y - b.y) - d.y; o.z = (a.z - b.z) - d.z; o.w = (a.w - b.w) - d.w; }
+                else { o.x = (a.x + b.x) + d.x; o.y = (a.y + b.y) + d.y; o.z = (a.z + b.z) + d.z; o.w = (a.w + b.w) + d.w; }
+                v[k] = o;
+                st4(xout + off[k], o);
+            }
+        }
+        // statistics: as k_bn_train_small, with the plane's first element taken from the registers of the thread that holds it
+        __shared__ float sh_shift;
+        if (threadIdx.x == 0) sh_shift = v[0].x;
+        __syncthreads();
+        const float shift = sh_shift;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < SMALL_K; ++k) {
+            if (off[k] < 0) continue;
+            const float d0 = v[k].x - shift, d1 = v[k].y - shift, d2 = v[k].z - shift, d3 = v[k].w - shift;
+            s1 += (d0 + d1) + (d2 + d3);
+            s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        block_sum2(s1, s2, red);
+        const float m = s1 / M;
+        const float mean = shift + m;
+        float var = fmaxf(s2 / M - m * m, 0.f);
+        if (m * m > 16.f * var) {
+            float t2 = 0.f, dummy = 0.f;
+#pragma unroll
+            for (int k = 0; k < SMALL_K; ++k) {
+                if (off[k] < 0) continue;
+                const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+                t2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            block_sum2(t2, dummy, red);
+            var = t2 / M;
+        }
+        const float invstd = 1.0f / sqrtf(var + eps);
+        if (threadIdx.x == 0) {
+            save_mean[g * C + c] = mean; save_invstd[g * C + c] = invstd;
+            gstat[g][0] = mean; gstat[g][1] = var;
+        }
+        const float a = invstd * wc, b = bc - mean * a;
+#pragma unroll
+        for (int k = 0; k < SMALL_K; ++k) {
+            if (off[k] < 0) continue;
+            float4 r = v[k];
+            r.x = r.x * a + b; r.y = r.y * a + b; r.z = r.z * a + b; r.w = r.w * a + b;
+            if (residual) { const float4 z = ld4(residual + off[k]); r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w; }
+            if (relu) { r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f; }
+            st4(y + off[k], r);
+        }
+        __syncthreads();                                  // sh_shift is rewritten by the next group
+    }
+    if (threadIdx.x == 0 && running_mean) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int g = 0; g < G; ++g) {
+            const float unbiased = M > 1.f ? gstat[g][1] * (M / (M - 1.f)) : gstat[g][1];
+            rm = (1.f - momentum) * rm + momentum * gstat[g][0];
+            rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        running_mean[c] = rm; running_var[c] = rv;
+    }
+}
+
 __global__ void __launch_bounds__(NT) k_bn_bwd_small(const float* __restrict__ x, const float* __restrict__ y,
                                                      const float* __restrict__ gy, const float* __restrict__ weight,
                                                      const float* __restrict__ save_mean, const float* __restrict__ save_invstd,
@@ -845,6 +949,22 @@ inline int plane_blocks(long HW) {
 }
 
 }  // namespace
+
+bool bn_small_slabs_ok(int N, int C, int H, int W, int groups) {
+    if (groups < 1 || groups > 16 || N % groups || (W & 3) || (H & 1) || C < 1) return false;
+    return bn_small(N / groups, (long)H * W, groups, true);
+}
+int bn_small_slabs_launch(const float* slabs, long slab_stride, int ksplit, float* y, const BnAfterConv& bn, int N, int C, int H, int W,
+                          hipStream_t st) {
+    FD_REQUIRE(slabs && y && bn.out && bn.save_mean && bn.save_invstd && ksplit >= 1, "conv + BatchNorm: NULL argument");
+    FD_REQUIRE(bn_small_slabs_ok(N, C, H, W, bn.groups), "conv + BatchNorm: shape is not a small-plane BatchNorm behind a slab convolution");
+    FD_REQUIRE((((uintptr_t)slabs | (uintptr_t)y | (uintptr_t)bn.out | (uintptr_t)bn.residual) & 15) == 0 && (slab_stride & 3) == 0,
+               "conv + BatchNorm: 16-byte aligned tensors needed");
+    hipLaunchKernelGGL(k_bn_train_small_slabs, dim3(C), dim3(NT), 0, st, slabs, slab_stride, ksplit, y, bn.weight, bn.bias, bn.residual, bn.out,
+                       bn.running_mean, bn.running_var, bn.save_mean, bn.save_invstd, N / bn.groups, C, H, W, bn.eps, bn.momentum, bn.relu, bn.groups);
+    FD_LAUNCH_CHECK("conv + BatchNorm (slabs)");
+    return 0;
+}
 
 extern "C" long fd_bn_ws_floats(int N, int C, int H, int W, int groups) {
     if (groups < 1 || N % groups) return 0;

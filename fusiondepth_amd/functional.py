@@ -823,7 +823,7 @@ _CONV_PLANS_GEN = [0]
 
 
 class _ConvPlan:
-    __slots__ = ("d", "dp", "Ho", "Wo", "fwd_ws", "fwd_wt", "bwd_data_ws", "bwd_data_wt", "bwd_weight_ws", "stat_slots")
+    __slots__ = ("d", "dp", "Ho", "Wo", "fwd_ws", "fwd_wt", "bwd_data_ws", "bwd_data_wt", "bwd_weight_ws", "stat_slots", "bn_fused")
 
     def __init__(self, x, w, stride, pad, pad_mode, act, in_norm):
         self.d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
@@ -833,6 +833,13 @@ class _ConvPlan:
         self.fwd_wt = query("fd_conv2d_fwd_wt_floats", self.dp)
         self.stat_slots = query("fd_conv2d_fwd_stat_slots", self.dp)       # BatchNorm partial sums per (image, channel); 0: none
         self.bwd_data_ws = self.bwd_data_wt = self.bwd_weight_ws = None
+        self.bn_fused = {}                 # BatchNorm groups -> fd_conv2d_fwd_bn_ok
+
+    def fused_bn_ok(self, groups):
+        ok = self.bn_fused.get(groups)
+        if ok is None:
+            ok = self.bn_fused[groups] = bool(query("fd_conv2d_fwd_bn_ok", self.dp, int(groups)))
+        return ok
 
     def data_sizes(self):
         if self.bwd_data_ws is None:
@@ -1224,6 +1231,42 @@ class _Part:
         self.saved_tensors = tensors
 
 
+def _conv_bn_fused_forward(c, b, x, w, bn_w, bn_b, residual, running_mean, running_var, stride, pad, momentum, eps, relu, groups):
+    """``_conv_forward`` + ``_bn_forward`` as ONE library call where the convolution runs as F(2x2, 3x3) slabs and the BatchNorm is a
+    small-plane one (ResNet layer3 / layer4): fd_conv2d_fwd_bn - the slab reduction happens inside the BatchNorm kernel.  Fills the
+    two half-contexts exactly as the separate bodies do; -> (x as float32, conv output, BatchNorm output), or None when the pair does
+    not qualify."""
+    if groups > 16:
+        return None
+    xf, wf = f32(x), f32(w)
+    plan = _conv_plan(xf, wf, stride, pad, 0, 0, False)
+    if not plan.fused_bn_ok(groups):
+        return None
+    cache_id = getattr(w, "_fd_cache_id", None)
+    c.params = (w, None)
+    _note_use(w, None)
+    b.params = (bn_w, bn_b)
+    _note_use(bn_w, bn_b)
+    d, nws, nwt = plan.d, plan.fwd_ws, plan.fwd_wt
+    y = _empty((d.N, d.Cout, plan.Ho, plan.Wo), xf)
+    out = torch.empty_like(y)
+    _tally(d, plan.Ho, plan.Wo)
+    ws = _empty((nws,), xf)
+    wt, ready = _weight_layout(wf, cache_id, "f", nwt, d)
+    res = f32(residual) if residual is not None else None
+    C = d.Cout
+    mean, invstd = _empty((groups * C,), xf), _empty((groups * C,), xf)
+    call("fd_conv2d_fwd_bn", plan.dp, ptr(xf), ptr(wf), ptr(y), ptr(wt), ready, ptr(ws), ptr(bn_w), ptr(bn_b), ptr(res), ptr(out),
+         ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), int(groups), float(eps), float(momentum), int(relu), stream())
+    c.save_for_backward(xf, wf, None)
+    c.desc, c.has_bias, c.cache_id, c.plan = d, False, cache_id, plan
+    b.groups = groups
+    b.remask = bool(relu and residual is None and tuning.host.bn_remask)
+    b.save_for_backward(y, (bn_b if b.remask else out) if relu else None, bn_w, mean, invstd)
+    b.training, b.relu, b.has_res = True, int(relu), residual is not None
+    return xf, y, out
+
+
 class _ConvBN(torch.autograd.Function):
     """Training-mode ``bn(conv(x)) [+ residual] [ReLU]`` of a ResNet block as ONE autograd node (bias-free convolution, zero padding,
     statistics from the convolution's epilogue where its kernel has one): the same C-ABI calls in the same order as ``_Conv2dStats``
@@ -1234,8 +1277,14 @@ class _ConvBN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bn_w, bn_b, residual, running_mean, running_var, stride, pad, momentum, eps, relu, groups, tap):
         c, b = _Part(), _Part()
-        xf, y, part = _conv_forward(c, x, w, None, stride, pad, 0, 0, False, True)
-        out = _bn_forward(b, y, bn_w, bn_b, residual, running_mean, running_var, True, momentum, eps, relu, groups, part)
+        fused = None
+        if tuning.host.fused_finish_bn and x.is_cuda:
+            fused = _conv_bn_fused_forward(c, b, x, w, bn_w, bn_b, residual, running_mean, running_var, stride, pad, momentum, eps, relu, groups)
+        if fused is not None:
+            xf, y, out = fused
+        else:
+            xf, y, part = _conv_forward(c, x, w, None, stride, pad, 0, 0, False, True)
+            out = _bn_forward(b, y, bn_w, bn_b, residual, running_mean, running_var, True, momentum, eps, relu, groups, part)
         ctx.n_conv = len(c.saved_tensors)
         ctx.save_for_backward(*(c.saved_tensors + b.saved_tensors))
         c.saved_tensors = b.saved_tensors = ()

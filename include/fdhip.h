@@ -28,7 +28,7 @@ extern "C" {
  *    fd_bn_train_fwd_parts added, the fd_conv2d_*_pair entry points removed, fd_bn_ws_floats grew by one shift value per
  *    (group, channel) - a client that sized the BatchNorm workspace itself must re-query it.
  * 3: additions only (round 5): fd_masked_median, fd_refine_inputs (+ fd_refine_cfg), fd_resize_linear_cv, fd_bn_relu_maxpool_fwd / _bwd,
- *    fd_bn_train_bwd_remask, fd_stack_normalize.  Nothing removed, no signature changed. */
+ *    fd_bn_train_bwd_remask, fd_stack_normalize, fd_conv2d_fwd_bn(_ok).  Nothing removed, no signature changed. */
 #define FD_ABI_VERSION 3
 
 int fd_abi_version(void);
@@ -324,6 +324,16 @@ int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const float* gy,
                          int accumulate, void* stream);
 
 /* gpre = gy * act'(y)  where y is the activation OUTPUT (1 ReLU, 2 ELU(alpha=1), 3 sigmoid, 4 tanh). */
+/* Convolution + training-mode BatchNorm (+ residual, ReLU) of a deep ResNet block in two launches (round 5): for the 3x3 layers that
+ * run as F(2x2, 3x3) slabs (layer3 / layer4) the slab reduction of the convolution happens inside the small-plane BatchNorm kernel.
+ * fd_conv2d_fwd_bn_ok(d, groups) == 1 says that this convolution (no bias, no activation) + BatchNorm qualifies; then
+ * fd_conv2d_fwd_bn == fd_conv2d_fwd(d, x, w, NULL, y, wt, wt_ready, ws) followed by fd_bn_train_fwd(y, ..., out, ...): same y bit
+ * for bit, same statistics rule as the small-plane kernel.  ws / wt as for fd_conv2d_fwd. */
+int fd_conv2d_fwd_bn_ok(const fd_conv_desc* d, int groups);
+int fd_conv2d_fwd_bn(const fd_conv_desc* d, const float* x, const float* w, float* y, float* wt, int wt_ready, float* ws,
+                     const float* bn_weight, const float* bn_bias, const float* residual, float* out, float* running_mean,
+                     float* running_var, float* save_mean, float* save_invstd, int groups, float eps, float momentum, int relu,
+                     void* stream);
 int fd_act_bwd(const float* y, const float* gy, float* gpre, long n, int act, void* stream);
 
 /* nn.BatchNorm2d in training mode (torchvision ResNet; trainer.py:207-211 set_train), optionally fused with the

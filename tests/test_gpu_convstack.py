@@ -1090,3 +1090,31 @@ def test_stack_normalize_is_cat_plus_input_normalisation(FD):
     assert torch.equal(FD.stack_normalize(pieces, G * len(orders) * Bg, 2 * C, normalize=False), want)
     many = [(frames[0][:1], i, 0) for i in range(20)]                      # more than 16 pieces: several launches
     assert torch.equal(FD.stack_normalize(many, 20, C, normalize=False), frames[0][:1].repeat(20, 1, 1, 1))
+
+
+@pytest.mark.parametrize("N,C,H,W,groups,res", [(8, 256, 12, 40, 2, True), (12, 512, 6, 20, 2, False), (4, 256, 12, 40, 1, True), (24, 512, 6, 20, 4, True)])
+def test_conv_bn_with_the_slab_reduction_inside_the_batchnorm_is_bit_identical(FD, fdtune, N, C, H, W, groups, res):
+    """fd_conv2d_fwd_bn (round 5): for the deep ResNet layers the F(2x2, 3x3) slab reduction runs inside the small-plane BatchNorm kernel
+    instead of as k_wino2d_finish.  Same additions in the same order: the block's output, the running statistics and every gradient of
+    conv_bn must be BIT-identical with the switch on and off."""
+    from fusiondepth_amd import _lib
+    import ctypes
+    rng = np.random.RandomState(C + N)
+    x = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.randn(C, C, 3, 3) * 0.02).astype(np.float32)).cuda()
+    r = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32)).cuda() if res else None
+    cot = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32)).cuda()
+    d = _lib.ConvDesc(N, C, H, W, C, 3, 3, 1, 1, 0, 0, 0)
+    assert _lib.query("fd_conv2d_fwd_bn_ok", ctypes.byref(d), groups) == 1
+    out = {}
+    for on in (True, False):
+        fdtune.host(fused_finish_bn=on)
+        bn = _seeded_bn(C, rng_seed=3)
+        xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        rg = r.clone().requires_grad_(True) if res else None
+        with FD.bn_groups(groups):
+            y = FD.conv_bn(xg, wg, bn, stride=1, pad=1, residual=rg, relu=True)
+        grads = torch.autograd.grad((y * cot).sum(), [xg, wg, bn.weight, bn.bias] + ([rg] if res else []))
+        out[on] = [y.detach(), bn.running_mean.clone(), bn.running_var.clone()] + [g.detach() for g in grads]
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b), float((a - b).abs().max())
