@@ -648,11 +648,21 @@ def bump_weights_epoch():
     _WEIGHTS_EPOCH[0] += 1
 
 
-def enable_weight_cache(params):
+def enable_weight_cache(params, frozen=False):
+    """``frozen``: weights that no optimiser touches (the Refiner's stage-1 networks).  Their layouts are derived once and stay valid
+    across optimiser steps (the epoch stamp that invalidates trained weights' layouts after every Adam launch is ignored; an in-place
+    change through torch - ``load_state_dict`` - still bumps ``_version``), and they stay out of the post-Adam refresh launch.
+    Round 4 re-laid them out on EVERY call: 100 launches per Refiner step."""
     for p in params:
         if p.dim() == 4 and not hasattr(p, "_fd_cache_id"):
             p._fd_cache_id = _NEXT_CACHE_ID[0]
             _NEXT_CACHE_ID[0] += 1
+        if p.dim() == 4 and frozen:
+            p._fd_frozen = True
+
+
+def _layout_stamp(w):
+    return (w._version, 0 if getattr(w, "_fd_frozen", False) else _WEIGHTS_EPOCH[0], w.data_ptr())
 
 
 def enable_direct_grad(params):
@@ -727,7 +737,7 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
     # floats per tap: conv_wino.hip::wino_fwd_mode looks at N*H*W), so a weight used at two batch sizes (the stacked training batch and
     # a smaller validation batch) keeps both layouts resident instead of rebuilding one over the other on every switch
     key = (cache_id, kind, nfloats)
-    stamp = (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
+    stamp = _layout_stamp(w)
     ent = _WT_CACHE.get(key)
     if ent is not None:
         if _LATE["event"] is not None and len(ent) > 4 and ent[4]:
@@ -738,7 +748,8 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
         return ent[1], 0
     buf = torch.empty((nfloats,), device=w.device, dtype=torch.float32)
     _WT_CACHE[key] = [stamp, buf, desc, weakref.ref(w), False]
-    _drop_plan()                        # a layout the plan does not know: fall back to per-call re-layout until rebuilt
+    if not getattr(w, "_fd_frozen", False):
+        _drop_plan()                    # a layout the plan does not know: fall back to per-call re-layout until rebuilt
     return buf, 0
 
 
@@ -751,7 +762,7 @@ def build_weight_plan():
     """Collect the re-layout jobs of every cached weight layout into a device table; returns the number of jobs."""
     from ._lib import RelayoutJob
     evict_dead_weight_layouts()
-    ents = [(k, e) for k, e in _WT_CACHE.items() if len(e) >= 4 and e[2] is not None]
+    ents = [(k, e) for k, e in _WT_CACHE.items() if len(e) >= 4 and e[2] is not None and not getattr(e[3](), "_fd_frozen", False)]
     if not ents:
         _drop_plan()
         return 0
@@ -811,7 +822,7 @@ def refresh_weight_layouts():
             e = _WT_CACHE[k]
             w = e[3]()
             if w is not None:
-                e[0] = (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
+                e[0] = _layout_stamp(w)
     return True
 
 

@@ -91,6 +91,8 @@ class Refiner(Trainer):
         FD.evict_dead_weight_layouts()
         FD.enable_weight_cache(self.parameters_to_train)
         FD.enable_direct_grad(self.parameters_to_train)
+        # the frozen stage-1 networks: kernel-side weight layouts derived once, not on every call
+        FD.enable_weight_cache([p for k, net in self.models.items() if k != "refine2d_decoder" for p in net.parameters()], frozen=True)
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat.flat_param)
         self.adam_step_count = 0
