@@ -65,6 +65,8 @@ SIGNATURES = {
     "fd_disp_to_depth_bwd": ("pppplddp", "i"),
     "fd_pose_matrix_fwd": ("pppiip", "i"),
     "fd_pose_matrix_bwd": ("pppppiip", "i"),
+    "fd_pose_head_fwd": ("ppppiiiiip", "i"),
+    "fd_pose_head_bwd": ("pppiiiiip", "i"),
     "fd_proj_matrix_fwd": ("ppplip", "i"),
     "fd_proj_matrix_bwd": ("pplpip", "i"),
     "fd_backproject_fwd": ("pppiiip", "i"),

@@ -777,13 +777,13 @@ void conv_log(const char* what, const char* path, const fd_conv_desc* d) {
 inline bool wino_use_wgrad(const fd_conv_desc* d) { return fd_tun().wino_wgrad != 0 && wino_wgrad_ok(d); }
 // fd_tuning.wino_fwd = 0: forward and data gradient stay on the direct kernels (A/B runs)
 bool wino_fwd_enabled() { return fd_tun().wino_fwd != 0; }
-inline bool wino_use_fwd(const fd_conv_desc* d) { return wino_fwd_enabled() && wino_fwd_ok(d) && d->Cout >= 64; }
+inline bool wino_use_fwd(const fd_conv_desc* d) { return wino_fwd_enabled() && wino_fwd_ok(d) && d->Cout >= fd_tun().wino_min_cout; }
 // the data gradient of a zero-padded 3x3 stride-1 conv is the same kind of conv over dY (channels swapped, kernel flipped)
 inline bool wino_dgrad_desc(const fd_conv_desc* d, fd_conv_desc& g) {
     if (!(wino_fwd_enabled() && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->pad_mode == 0)) return false;
     g = *d;
     g.Cin = d->Cout; g.Cout = d->Cin; g.act = 0; g.in_norm = 0;
-    return wino_fwd_ok(&g) && g.Cout >= 64;
+    return wino_fwd_ok(&g) && g.Cout >= fd_tun().wino_min_cout;
 }
 
 // The interior of a REFLECT-padded 3x3 data gradient (the padded grid's cells that are real pixels) is the zero-padded data
@@ -799,7 +799,7 @@ bool refl_wino_interior(const fd_conv_desc* d, fd_conv_desc& g) {
     if (!fast_dgrad_ok(d)) return false;                     // the ring runs on the implicit-GEMM kernel
     g = *d;
     g.Cin = d->Cout; g.Cout = d->Cin; g.pad_mode = 0; g.act = 0; g.in_norm = 0;
-    return wino_fwd_ok(&g) && g.Cout >= 64;
+    return wino_fwd_ok(&g) && g.Cout >= fd_tun().wino_min_cout;
 }
 
 // ... and on SMALL planes (below 4 096 pixels: upconv(2..4, *) at 6x20 .. 24x80) the ring's four thin problems -

@@ -1798,7 +1798,7 @@ extern "C" int fd_conv3x3_wino_fwd(const fd_conv_desc* d, const float* x, const 
 
 // ---- weight gradient
 bool wino_wgrad_ok(const fd_conv_desc* d) {
-    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 16 == 0 && d->Cin >= 64 && d->Cout >= 64 &&
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->Cin % 16 == 0 && d->Cin >= 64 && d->Cout >= fd_tun().wino_wgrad_min_cout &&
            d->W % 2 == 0 && !d->in_norm;
 }
 // The 2-D algorithm needs whole 2x2 tiles of dY (fd_tuning.wino_wgrad_2d = 0: the 1-D kernel everywhere, for A/B timing)

@@ -88,13 +88,9 @@ __device__ __forceinline__ Rodrigues fd_rodrigues(float vx, float vy, float vz) 
     r.R[2][0] = zxC - ys;        r.R[2][1] = yzC + xs;          r.R[2][2] = r.z * zC + r.ca;
     return r;
 }
-__global__ void k_pose_fwd(const float* __restrict__ aa, const float* __restrict__ tr, float* __restrict__ T, int B,
-                           int invert) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    Rodrigues r = fd_rodrigues(aa[b * 3 + 0], aa[b * 3 + 1], aa[b * 3 + 2]);
-    float t[3] = {tr[b * 3 + 0], tr[b * 3 + 1], tr[b * 3 + 2]};
-    float* M = T + b * 16;
+__device__ __forceinline__ void pose_fwd_one(const float* __restrict__ aa, const float* __restrict__ tr, float* __restrict__ M, int invert) {
+    Rodrigues r = fd_rodrigues(aa[0], aa[1], aa[2]);
+    float t[3] = {tr[0], tr[1], tr[2]};
     if (!invert) {
         for (int i = 0; i < 3; ++i) {
             for (int j = 0; j < 3; ++j) M[i * 4 + j] = r.R[i][j];
@@ -112,14 +108,18 @@ __global__ void k_pose_fwd(const float* __restrict__ aa, const float* __restrict
     }
     M[12] = 0.f; M[13] = 0.f; M[14] = 0.f; M[15] = 1.f;
 }
-__global__ void k_pose_bwd(const float* __restrict__ aa, const float* __restrict__ tr, const float* __restrict__ gT,
-                           float* __restrict__ g_aa, float* __restrict__ g_tr, int B, int invert) {
+__global__ void k_pose_fwd(const float* __restrict__ aa, const float* __restrict__ tr, float* __restrict__ T, int B,
+                           int invert) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    float vx = aa[b * 3 + 0], vy = aa[b * 3 + 1], vz = aa[b * 3 + 2];
+    pose_fwd_one(aa + b * 3, tr + b * 3, T + b * 16, invert);
+}
+// G: the 4x4 gradient of the matrix, or NULL (the matrix was not used: zero gradients)
+__device__ __forceinline__ void pose_bwd_one(const float* __restrict__ aa, const float* __restrict__ tr, const float* __restrict__ G,
+                                             float* __restrict__ g_aa, float* __restrict__ g_tr, int invert) {
+    float vx = aa[0], vy = aa[1], vz = aa[2];
     Rodrigues r = fd_rodrigues(vx, vy, vz);
-    float t[3] = {tr[b * 3 + 0], tr[b * 3 + 1], tr[b * 3 + 2]};
-    const float* G = gT + b * 16;
+    float t[3] = {tr[0], tr[1], tr[2]};
     float dR[3][3], dt[3];
     if (!invert) {
         for (int i = 0; i < 3; ++i) {
@@ -149,10 +149,52 @@ __global__ void k_pose_bwd(const float* __restrict__ aa, const float* __restrict
     // axis = v * inv, inv = 1/(th + 1e-7)
     dth -= (dx * vx + dy * vy + dz * vz) * r.inv * r.inv;
     float k = r.th > 0.f ? dth / r.th : 0.f;  // d||v||/dv = v/||v|| (0 at the origin, as torch.norm)
-    g_aa[b * 3 + 0] = dx * r.inv + k * vx;
-    g_aa[b * 3 + 1] = dy * r.inv + k * vy;
-    g_aa[b * 3 + 2] = dz * r.inv + k * vz;
-    g_tr[b * 3 + 0] = dt[0]; g_tr[b * 3 + 1] = dt[1]; g_tr[b * 3 + 2] = dt[2];
+    g_aa[0] = dx * r.inv + k * vx;
+    g_aa[1] = dy * r.inv + k * vy;
+    g_aa[2] = dz * r.inv + k * vz;
+    g_tr[0] = dt[0]; g_tr[1] = dt[1]; g_tr[2] = dt[2];
+}
+__global__ void k_pose_bwd(const float* __restrict__ aa, const float* __restrict__ tr, const float* __restrict__ gT,
+                           float* __restrict__ g_aa, float* __restrict__ g_tr, int B, int invert) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    pose_bwd_one(aa + b * 3, tr + b * 3, gT + b * 16, g_aa + b * 3, g_tr + b * 3, invert);
+}
+
+// The pose head of the stacked pose network (trainer.py:338-360 for all frame pairs and accumulated micro-batches in one go).
+// pose [G * nf * Bq][ld]: the pose decoder's output (ld = 6 * frames-to-predict-for; the reference uses prediction 0 = columns 0..5:
+// `axisangle[:, 0]`, `translation[:, 0]`), rows ordered (micro-batch g, frame pair k, sample s).  Per frame pair k: T_k [G * Bq][4][4]
+// (inverted where bit k of invert_mask is set: trainer.py:352 `invert=(f_i < 0)`), and the pair's axisangle / translation
+// [G * Bq][ld / 6][3] as the reference's outputs dictionary holds them.  One thread per (k, g, s).
+struct PoseHeadArgs {
+    const float* pose; float* g_pose;
+    float* T[4]; const float* gT[4]; float* aa[4]; float* tr[4];
+    int G, nf, Bq, ld;
+    unsigned invert_mask;
+};
+__global__ void k_pose_head_fwd(PoseHeadArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, GB = a.G * a.Bq;
+    if (i >= a.nf * GB) return;
+    const int k = i / GB, j = i - k * GB, g = j / a.Bq, s = j - g * a.Bq;
+    const float* row = a.pose + (long)((g * a.nf + k) * a.Bq + s) * a.ld;
+    pose_fwd_one(row, row + 3, a.T[k] + j * 16, (a.invert_mask >> k) & 1u);
+    const int nfp = a.ld / 6;
+    if (a.aa[k])
+        for (int f = 0; f < nfp; ++f)
+            for (int c = 0; c < 3; ++c) {
+                a.aa[k][(j * nfp + f) * 3 + c] = row[6 * f + c];
+                a.tr[k][(j * nfp + f) * 3 + c] = row[6 * f + 3 + c];
+            }
+}
+__global__ void k_pose_head_bwd(PoseHeadArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, GB = a.G * a.Bq;
+    if (i >= a.nf * GB) return;
+    const int k = i / GB, j = i - k * GB, g = j / a.Bq, s = j - g * a.Bq;
+    const long r = (long)((g * a.nf + k) * a.Bq + s) * a.ld;
+    float* go = a.g_pose + r;
+    if (a.gT[k]) pose_bwd_one(a.pose + r, a.pose + r + 3, a.gT[k] + j * 16, go, go + 3, (a.invert_mask >> k) & 1u);
+    else for (int c = 0; c < 6; ++c) go[c] = 0.f;
+    for (int c = 6; c < a.ld; ++c) go[c] = 0.f;              // predictions the reference never uses
 }
 extern "C" int fd_pose_matrix_fwd(const float* axisangle, const float* translation, float* T, int B, int invert,
                                   void* stream) {
@@ -168,6 +210,33 @@ extern "C" int fd_pose_matrix_bwd(const float* axisangle, const float* translati
     hipLaunchKernelGGL(k_pose_bwd, dim3(fd_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, axisangle, translation, gT,
                        g_axisangle, g_translation, B, invert);
     FD_LAUNCH_CHECK("fd_pose_matrix_bwd");
+    return 0;
+}
+
+extern "C" int fd_pose_head_fwd(const float* pose, float* const* T, float* const* axisangle, float* const* translation, int G, int nf,
+                                int Bq, int ld, unsigned invert_mask, void* stream) {
+    FD_REQUIRE(pose && T && G > 0 && nf > 0 && nf <= 4 && Bq > 0 && ld >= 6 && ld % 6 == 0, "fd_pose_head_fwd: bad args (1..4 frame pairs, ld = 6 * predictions)");
+    FD_REQUIRE((axisangle == nullptr) == (translation == nullptr), "fd_pose_head_fwd: axisangle / translation come in pairs");
+    PoseHeadArgs a = {};
+    a.pose = pose; a.G = G; a.nf = nf; a.Bq = Bq; a.ld = ld; a.invert_mask = invert_mask;
+    for (int k = 0; k < nf; ++k) {
+        FD_REQUIRE(T[k], "fd_pose_head_fwd: T[%d] is NULL", k);
+        a.T[k] = T[k];
+        a.aa[k] = axisangle ? axisangle[k] : nullptr; a.tr[k] = translation ? translation[k] : nullptr;
+        FD_REQUIRE((a.aa[k] == nullptr) == (a.tr[k] == nullptr), "fd_pose_head_fwd: axisangle / translation come in pairs");
+    }
+    hipLaunchKernelGGL(k_pose_head_fwd, dim3(fd_cdiv(nf * G * Bq, 64)), dim3(64), 0, (hipStream_t)stream, a);
+    FD_LAUNCH_CHECK("fd_pose_head_fwd");
+    return 0;
+}
+extern "C" int fd_pose_head_bwd(const float* pose, const float* const* gT, float* g_pose, int G, int nf, int Bq, int ld,
+                                unsigned invert_mask, void* stream) {
+    FD_REQUIRE(pose && gT && g_pose && G > 0 && nf > 0 && nf <= 4 && Bq > 0 && ld >= 6 && ld % 6 == 0, "fd_pose_head_bwd: bad args (1..4 frame pairs, ld = 6 * predictions)");
+    PoseHeadArgs a = {};
+    a.pose = pose; a.g_pose = g_pose; a.G = G; a.nf = nf; a.Bq = Bq; a.ld = ld; a.invert_mask = invert_mask;
+    for (int k = 0; k < nf; ++k) a.gT[k] = gT[k];              // NULL: that matrix was not used
+    hipLaunchKernelGGL(k_pose_head_bwd, dim3(fd_cdiv(nf * G * Bq, 64)), dim3(64), 0, (hipStream_t)stream, a);
+    FD_LAUNCH_CHECK("fd_pose_head_bwd");
     return 0;
 }
 

@@ -83,6 +83,54 @@ def transformation_from_parameters(axisangle, translation, invert=False):
     return _PoseMatrix.apply(axisangle, translation, invert)
 
 
+class _PoseHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose, G, nf, Bq, invert_mask):
+        import ctypes
+        pose = f32(pose)
+        _need_cuda(pose)
+        N, ld = pose.shape
+        if N != G * nf * Bq or ld % 6 != 0 or not 1 <= nf <= 4:
+            raise ValueError("pose_head: pose must be [G * nf * Bq, 6 * predictions] with 1..4 frame pairs, got %s for G=%d nf=%d Bq=%d"
+                             % (tuple(pose.shape), G, nf, Bq))
+        Ts = [_empty((G * Bq, 4, 4), pose) for _ in range(nf)]
+        aas = [_empty((G * Bq, ld // 6, 1, 3), pose) for _ in range(nf)]
+        trs = [_empty((G * Bq, ld // 6, 1, 3), pose) for _ in range(nf)]
+        arr = ctypes.c_void_p * nf
+        call("fd_pose_head_fwd", ptr(pose), arr(*[ptr(t) for t in Ts]), arr(*[ptr(t) for t in aas]), arr(*[ptr(t) for t in trs]),
+             G, nf, Bq, ld, int(invert_mask), stream())
+        ctx.save_for_backward(pose)
+        ctx.cfg = (G, nf, Bq, ld, int(invert_mask))
+        ctx.mark_non_differentiable(*aas, *trs)
+        return tuple(Ts) + tuple(aas) + tuple(trs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        (pose,) = ctx.saved_tensors
+        G, nf, Bq, ld, invert_mask = ctx.cfg
+        gTs = [None if g is None else f32(g) for g in grads[:nf]]
+        g_pose = torch.empty_like(pose)
+        call("fd_pose_head_bwd", ptr(pose), (ctypes.c_void_p * nf)(*[ptr(g) for g in gTs]), ptr(g_pose), G, nf, Bq, ld, invert_mask,
+             stream())
+        return g_pose, None, None, None, None
+
+
+def pose_head(pose, groups, n_pairs, batch, inverts):
+    """trainer.py:338-360 for the stacked pose network in ONE launch each way (fd_pose_head_fwd / _bwd): ``pose`` [groups * n_pairs *
+    batch, 6 * predictions] = the pose decoder's output with rows ordered (micro-batch, frame pair, sample) -> per frame pair
+    (cam_T_cam [groups * batch, 4, 4], axisangle, translation [groups * batch, predictions, 1, 3]).  ``inverts[k]``: trainer.py:352
+    ``invert=(f_i < 0)``.  The axisangle / translation entries are what the reference's outputs dictionary holds; here they carry
+    no gradient (the reference's only differentiable use of them is the matrix, except for --pose_model_type posecnn, which does not
+    take this path)."""
+    mask = 0
+    for k, inv in enumerate(inverts):
+        mask |= (1 << k) if inv else 0
+    out = _PoseHead.apply(pose, int(groups), int(n_pairs), int(batch), mask)
+    nf = int(n_pairs)
+    return [(out[k], out[nf + k], out[2 * nf + k]) for k in range(nf)]
+
+
 class _Backproject(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, inv_K):

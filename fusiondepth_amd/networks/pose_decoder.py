@@ -31,7 +31,7 @@ class PoseDecoder(nn.Module):
     def _conv(x, conv, act):
         return FD.conv2d(x, conv.weight, conv.bias, stride=conv.stride[0], pad=conv.padding[0], act=act)
 
-    def forward(self, input_features, beam_inputs=None):
+    def forward(self, input_features, beam_inputs=None, raw=False):
         if beam_inputs is not None:                          # RGB + LiDAR bottleneck features, one input (pose_decoder.py:30-31)
             deepest = [FD.add(input_features[0][-1], beam_inputs[0][-1])]
         else:
@@ -41,5 +41,7 @@ class PoseDecoder(nn.Module):
         for i, act in enumerate(("relu", "relu", "none")):
             out = self._conv(out, self.convs[("pose", i)], act)
         out = FD.spatial_mean(out, 0.01)                     # 0.01 * out.mean(3).mean(2)
+        if raw:                                              # [B, 6 * frames]: the trainer's fused pose head (FD.pose_head) slices it itself
+            return out
         out = out.view(-1, self.num_frames_to_predict_for, 1, 6)
         return out[..., :3], out[..., 3:]

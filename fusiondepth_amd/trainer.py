@@ -735,13 +735,19 @@ class Trainer:
                     if bf is not None:
                         self._join(st2, bf)
             with torch.cuda.stream(pose_stream) if pose_stream is not None else contextlib.nullcontext():
+                heads = None
                 if precomputed is not None:
-                    if bf is not None:
-                        aa_all, tr_all = self.models["pose"]([pf], beam_inputs=[bf])       # batch = len(fids) * B
+                    fused = tuning.host.fused_pose_head and len(fids) <= 4
+                    res = self.models["pose"]([pf], beam_inputs=[bf] if bf is not None else None, raw=fused)   # batch = len(fids) * B
+                    if fused:           # slices, concatenations and pose matrices of every frame pair: one launch each way
+                        nf, G = len(fids), self._groups
+                        heads = FD.pose_head(res, G, nf, res.shape[0] // (nf * G), [f_i < 0 for f_i in fids])
                     else:
-                        aa_all, tr_all = self.models["pose"]([pf])
-                    stacked = (aa_all, tr_all)
+                        stacked = res
                 for k, f_i in enumerate(fids):
+                    if heads is not None:
+                        (outputs[("cam_T_cam", 0, f_i)], outputs[("axisangle", 0, f_i)], outputs[("translation", 0, f_i)]) = heads[k]
+                        continue
                     order = (f_i, 0) if f_i < 0 else (0, f_i)                     # temporal order (trainer.py:338-346)
                     if stacked is not None:
                         nf, G = len(fids), self._groups

@@ -24,7 +24,7 @@ class Tuning(ctypes.Structure):
     _fields_ = [(n, _I) for n in (
         "size", "wino_fwd", "wino_wgrad", "wino_fwd_2d_min", "wino_fwd_2dp_min_wgs", "wino_fwd_2dp_dma", "wino_fwd_2dp_deep", "wino_wgrad_2d", "wino_target", "wino_wgrad_target", "conv_target",
         "wgrad_target", "conv_c1", "conv_n16_min_pixels", "reflect_ring", "reflect_wino", "reflect_wino_min_pixels",
-        "reflect_wino_padded_max", "force_cfg", "force_splits", "stem7", "log", "wino_fwd_2d_m128")]
+        "reflect_wino_padded_max", "force_cfg", "force_splits", "stem7", "log", "wino_fwd_2d_m128", "wino_min_cout", "wino_wgrad_min_cout")]
 
 
 LIB_FIELDS = tuple(n for n, _ in Tuning._fields_ if n != "size")
@@ -99,6 +99,7 @@ class _Host:
     fused_finish_bn = True      # deep-layer conv + BatchNorm: the F(2x2, 3x3) slab reduction inside the small-plane BatchNorm kernel
     bn_remask = True            # BatchNorm + ReLU without a residual: the backward recomputes the ReLU mask from x instead of reading y
     fused_stem_tail = True      # BatchNorm + ReLU + max-pool of the ResNet stems as one pass each way (csrc/norm.hip: k_bn_relu_pool_*)
+    fused_pose_head = True      # stacked pose network: slicing + concatenation + pose matrices of all frame pairs as one launch each way (FD.pose_head)
     pad_odd_channels = True     # refine decoder: blocks with 262 / 134 / 102 / 22 input channels run zero-padded to a multiple of 16
 
     @property
@@ -120,6 +121,7 @@ _ENV_LIB = {
     "FD_CONV_C1": ("conv_c1", int), "FD_CONV_N16_MIN": ("conv_n16_min_pixels", int), "FD_REFLECT_RING": ("reflect_ring", int),
     "FD_REFLECT_WINO": ("reflect_wino", int), "FD_REFLECT_WINO_MIN": ("reflect_wino_min_pixels", int),
     "FD_REFLECT_WINO_PADDED_MAX": ("reflect_wino_padded_max", int), "FD_STEM7": ("stem7", int), "FD_CONV_LOG": ("log", int), "FD_WINO_FWD_2D_M128": ("wino_fwd_2d_m128", int),
+    "FD_WINO_MIN_COUT": ("wino_min_cout", int), "FD_WINO_WGRAD_MIN_COUT": ("wino_wgrad_min_cout", int),
 }
 _ENV_HOST = {
     "FD_LATE_RELAYOUT": ("late_relayout", lambda v: v != "0"), "FD_POSE_STREAM": ("pose_stream", lambda v: v != "0"),
@@ -127,7 +129,7 @@ _ENV_HOST = {
     "FD_SIDE_WGRAD": ("side_wgrad", lambda v: tuple(k for k in v.split(",") if k and k != "none")),
     "FD_NSTREAMS": ("n_streams", int), "FD_INTERLEAVE": ("interleave", lambda v: v != "0"),
     "FD_CONV_STATS": ("conv_stats", lambda v: v != "0"), "FD_FUSED_CONV_BN": ("fused_conv_bn", lambda v: v != "0"), "FD_REFINER_STREAMS": ("refiner_streams", lambda v: v != "0"),
-    "FD_DP_OVERLAP": ("dp_overlap", lambda v: v != "0"), "FD_PAD_ODD_CHANNELS": ("pad_odd_channels", lambda v: v != "0"), "FD_FUSED_STEM_TAIL": ("fused_stem_tail", lambda v: v != "0"), "FD_BN_REMASK": ("bn_remask", lambda v: v != "0"), "FD_FUSED_FINISH_BN": ("fused_finish_bn", lambda v: v != "0"), "FD_DECODER_FUSED_ACT": ("decoder_fused_act", lambda v: v != "0"), "FD_HOST_DELAY_US": ("host_delay_us", float),
+    "FD_DP_OVERLAP": ("dp_overlap", lambda v: v != "0"), "FD_PAD_ODD_CHANNELS": ("pad_odd_channels", lambda v: v != "0"), "FD_FUSED_POSE_HEAD": ("fused_pose_head", lambda v: v != "0"), "FD_FUSED_STEM_TAIL": ("fused_stem_tail", lambda v: v != "0"), "FD_BN_REMASK": ("bn_remask", lambda v: v != "0"), "FD_FUSED_FINISH_BN": ("fused_finish_bn", lambda v: v != "0"), "FD_DECODER_FUSED_ACT": ("decoder_fused_act", lambda v: v != "0"), "FD_HOST_DELAY_US": ("host_delay_us", float),
 }
 
 

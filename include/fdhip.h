@@ -28,7 +28,8 @@ extern "C" {
  *    fd_bn_train_fwd_parts added, the fd_conv2d_*_pair entry points removed, fd_bn_ws_floats grew by one shift value per
  *    (group, channel) - a client that sized the BatchNorm workspace itself must re-query it.
  * 3: additions only (round 5): fd_masked_median, fd_refine_inputs (+ fd_refine_cfg), fd_resize_linear_cv, fd_bn_relu_maxpool_fwd / _bwd,
- *    fd_bn_train_bwd_remask, fd_stack_normalize, fd_conv2d_fwd_bn(_ok).  Nothing removed, no signature changed. */
+ *    fd_bn_train_bwd_remask, fd_stack_normalize, fd_conv2d_fwd_bn(_ok), fd_pose_head_fwd / _bwd; fd_tuning grew at its end
+ *    (wino_min_cout, wino_wgrad_min_cout).  Nothing removed, no signature changed. */
 #define FD_ABI_VERSION 3
 
 int fd_abi_version(void);
@@ -67,6 +68,9 @@ typedef struct fd_tuning {
     int stem7;                    /* 1   7x7 stride-2 stems (Cin 2..6) on the dedicated patch kernels (conv_stem.hip) */
     int log;                      /* 0   1: one stderr line per convolution call with the kernel family it was routed to */
     int wino_fwd_2d_m128;         /* 1   the slab variant with 128 output channels per workgroup (k_conv_wino2d_m128) wherever it can run (Cout % 128 == 0, W % 4 == 0); 2: only where its launch fills the chip better; 0: never */
+    int wino_min_cout;            /* 32  fewest output channels of a forward / data-gradient launch on the Winograd kernels (their tile is 64 channels
+                                         tall: below that, rows of the tile are idle; 32 = the depth decoder's upconv(1, *) as well; rounds 1-4: 64) */
+    int wino_wgrad_min_cout;      /* 32  ... of a weight-gradient launch */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);
@@ -87,6 +91,18 @@ int fd_disp_to_depth_bwd(const float* disp, const float* g_scaled, const float* 
 int fd_pose_matrix_fwd(const float* axisangle, const float* translation, float* T, int B, int invert, void* stream);
 int fd_pose_matrix_bwd(const float* axisangle, const float* translation, const float* gT, float* g_axisangle,
                        float* g_translation, int B, int invert, void* stream);
+
+/* trainer.py:338-360 for the STACKED pose network (all frame pairs x accumulated micro-batches in one batch): pose [G*nf*Bq][ld] = the
+ * pose decoder's output (networks/pose_decoder.py:47-51: 0.01 * mean, ld = 6 * predictions; prediction 0 = columns 0..5 is the one
+ * trainer.py:350-352 uses), rows ordered (micro-batch g, frame pair k, sample s) -> per frame pair k: T[k] [G*Bq][4][4] (bit k of
+ * invert_mask: trainer.py:352 invert=(f_i < 0)) and, if given, axisangle[k] / translation[k] [G*Bq][ld/6][3] (the outputs dictionary's
+ * entries).  T / axisangle / translation / gT: HOST arrays of nf (<= 4) device pointers.  Replaces, per frame pair, the slicing +
+ * concatenation + fd_pose_matrix_fwd / _bwd launches (and autograd's ~20 element-wise launches per pair behind them).
+ * bwd: g_pose [G*nf*Bq][ld], fully written (unused predictions: 0); gT[k] == NULL: that matrix received no gradient. */
+int fd_pose_head_fwd(const float* pose, float* const* T, float* const* axisangle, float* const* translation, int G, int nf, int Bq,
+                     int ld, unsigned invert_mask, void* stream);
+int fd_pose_head_bwd(const float* pose, const float* const* gT, float* g_pose, int G, int nf, int Bq, int ld, unsigned invert_mask,
+                     void* stream);
 
 /* layers.py:217 `P = matmul(K, T)[:, :3, :]`.  K,T: [B,4,4]; P: [B,3,4] written at P + b*p_batch_stride. */
 int fd_proj_matrix_fwd(const float* K, const float* T, float* P, long p_batch_stride, int B, void* stream);

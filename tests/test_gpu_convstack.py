@@ -183,6 +183,33 @@ def test_conv2d_fwd_bwd(FD, case):
         relclose(cpu(got[2]), cpu(want[2]), "conv bias grad")
 
 
+@pytest.mark.parametrize("min_cout", [32, 64])
+@pytest.mark.parametrize("N,Cin,Cout,H,W,mode", [
+    (2, 96, 32, 24, 40, "reflect"),      # upconv(1,1)'s channels: 1.5 input-channel tiles, half an output-channel tile
+    (3, 64, 32, 12, 20, "reflect"),      # upconv(1,0)'s
+    (2, 64, 48, 8, 12, "zero"),          # zero padding: the data gradient is itself a Winograd convolution with 64 "output" channels
+    (2, 96, 32, 7, 10, "reflect"),       # odd height: F(2,3) along x / the 1-D weight gradient
+])
+def test_conv3x3_with_fewer_than_64_output_channels_on_the_winograd_kernels(FD, fdtune, N, Cin, Cout, H, W, mode, min_cout):
+    """fd_tuning.wino_min_cout / wino_wgrad_min_cout = 32 route the decoder's 32-channel blocks (forward, data gradient, weight gradient)
+    to the Winograd kernels with rows of their 64-channel tile idle; 64 keeps them on the direct kernels.  Both against torch float64."""
+    fdtune.lib(wino_min_cout=min_cout, wino_wgrad_min_cout=min_cout)
+    torch.manual_seed(N * 100 + Cin + Cout + H)
+    x = torch.randn(N, Cin, H, W, device="cuda", requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    b = (torch.randn(Cout, device="cuda") * 0.1).requires_grad_(True)
+    y = FD.conv2d(x, w, b, 1, 1, mode, "elu")
+    cot = torch.randn_like(y)
+    got = torch.autograd.grad((y * cot).sum(), [x, w, b])
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    xp = F.pad(xd, (1, 1, 1, 1), mode="reflect" if mode == "reflect" else "constant")
+    yd = F.elu(F.conv2d(xp, wd, bd))
+    want = torch.autograd.grad((yd * cot.double()).sum(), [xd, wd, bd])
+    relclose(cpu(y), cpu(yd.float()), "y", rtol=1e-5, arel=3e-6)
+    for g, r, what in zip(got, want, ("dx", "dw", "db")):
+        relclose(cpu(g), cpu(r.float()), what, rtol=1e-4, arel=1e-5)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(2, 3, 192, 640), (2, 6, 192, 640), (3, 2, 96, 320), (2, 4, 70, 150), (1, 5, 8, 8), (1, 1, 33, 9)])
 def test_stem_convolution_on_the_patch_kernel(FD, N, C, H, W, fdtune):
     """conv_stem.hip (7x7 stride-2 pad-3 stems, networks/resnet_encoder.py:95) against torch float64 conv2d, and against the generic

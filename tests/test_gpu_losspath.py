@@ -67,6 +67,40 @@ def test_disp_to_depth_and_pose_matrix(FD, golden):
     assert torch.isfinite(gz).all() and torch.isfinite(M).all()
 
 
+@pytest.mark.parametrize("G,nf,Bq,npred", [(2, 2, 3, 2), (1, 2, 6, 2), (2, 1, 4, 1), (3, 4, 2, 2)])
+def test_pose_head_equals_slices_plus_pose_matrices(FD, G, nf, Bq, npred):
+    """fd_pose_head_fwd / _bwd (one launch each way for every frame pair and accumulated micro-batch of the stacked pose network) against
+    the path it replaces - trainer.py:338-360 as slices, concatenations and one fd_pose_matrix_* call per frame pair: bit for bit, forward
+    and backward, including a frame pair whose matrix receives no gradient."""
+    torch.manual_seed(G * 100 + nf * 10 + Bq)
+    pose = (torch.randn(G * nf * Bq, 6 * npred, device="cuda") * 0.05)
+    inverts = [k % 2 == 0 for k in range(nf)]
+    cots = [torch.randn(G * Bq, 4, 4, device="cuda") for _ in range(nf)]
+    unused = nf - 1 if nf > 1 else None                       # this pair's matrix takes no part in the loss
+    p1 = pose.clone().requires_grad_(True)
+    heads = FD.pose_head(p1, G, nf, Bq, inverts)
+    loss = sum((heads[k][0] * cots[k]).sum() for k in range(nf) if k != unused)
+    g1 = torch.autograd.grad(loss, p1)[0]
+    p2 = pose.clone().requires_grad_(True)
+    out = p2.view(-1, npred, 1, 6)
+    aa_all, tr_all = out[..., :3], out[..., 3:]
+    loss2 = 0
+    for k in range(nf):
+        sl = [slice((g * nf + k) * Bq, (g * nf + k + 1) * Bq) for g in range(G)]
+        aa = torch.cat([aa_all[q] for q in sl], 0)
+        tr = torch.cat([tr_all[q] for q in sl], 0)
+        T = FD.transformation_from_parameters(aa[:, 0], tr[:, 0], invert=inverts[k])
+        assert torch.equal(heads[k][0], T), "T of pair %d" % k
+        assert torch.equal(heads[k][1], aa) and torch.equal(heads[k][2], tr)
+        assert not heads[k][1].requires_grad and not heads[k][2].requires_grad
+        if k != unused:
+            loss2 = loss2 + (T * cots[k]).sum()
+    g2 = torch.autograd.grad(loss2, p2)[0]
+    assert torch.equal(g1, g2), "%d gradient entries differ" % int((g1 != g2).sum())
+    with pytest.raises(ValueError):
+        FD.pose_head(pose[:-1], G, nf, Bq, inverts)
+
+
 def test_backproject_project_against_golden(FD, golden):
     g = golden("layers_b2_32x64")
     B, H, W = 2, 32, 64

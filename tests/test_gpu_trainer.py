@@ -814,6 +814,45 @@ def test_fused_conv_batchnorm_node_is_bit_identical(layers, fdtune):
     assert torch.equal(res[True][1], res[False][1])
 
 
+def test_fused_pose_head_is_bit_identical(fdtune):
+    """tuning.host.fused_pose_head (FD.pose_head: the stacked pose network's slices, concatenations and pose matrices as one launch each
+    way) against the slice-by-slice path: parameters after three optimiser steps of two accumulated micro-batches identical bit for
+    bit, and the fused node really used."""
+    from fusiondepth_amd import functional as FD
+    from fusiondepth_amd.trainer import Trainer
+    B, H, W = 12, 64, 96                 # --batch_size 12 = two accumulated micro-batches of 6 (trainer.py:28-41)
+    res = {}
+    for fused in (True, False):
+        fdtune.host(fused_pose_head=fused)
+        n_apply = [0]
+        orig = FD._PoseHead.forward
+
+        def counting(ctx, *a, _orig=orig):
+            n_apply[0] += 1
+            return _orig(ctx, *a)
+        FD._PoseHead.forward = staticmethod(counting)
+        try:
+            torch.manual_seed(1357)
+            tr = Trainer(_opts(batch_size=B), verbose=False)
+            assert tr.accumulate_step == 2
+            for i in range(3):
+                mbs = []
+                for j in range(tr.accumulate_step):
+                    inp, noise = _batch(tr.batch_size, H, W, 900 + 10 * i + j)
+                    ginp = {k: v.cuda() for k, v in inp.items()}
+                    ginp["_noise"] = [n.cuda() for n in noise]
+                    mbs.append(ginp)
+                tr.train_step(mbs)
+            torch.cuda.synchronize()
+        finally:
+            FD._PoseHead.forward = staticmethod(orig)
+        assert (n_apply[0] > 0) == fused, n_apply
+        res[fused] = tr.flat.flat_param.clone()
+        del tr
+    assert torch.isfinite(res[True]).all()
+    assert torch.equal(res[True], res[False]), "%d parameters differ" % int((res[True] != res[False]).sum())
+
+
 def test_decoder_weight_gradients_on_the_side_stream_are_bit_identical(fdtune):
     """functional.enable_side_wgrad (default for the depth decoder): its weight gradients, slab reductions and bias sums run on a side
     stream beside the data gradients of the following layers.  Same kernels, same accumulation targets: the gradient buffer after a
