@@ -1209,8 +1209,9 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
         f.osy = 2; f.osx = 2;
         f.out_total = (long)d->N * g.out_ns; f.slab_stride = f.out_total; f.slabs = nullptr;
         f.add = add_in_kernel ? gx_add : nullptr;
-        for (int ph = 0; ph < 2; ++ph)
-            for (int pw = 0; pw < 2; ++pw) {
+        // (classes with the most taps first: their workgroups are the launch's longest - 4, 2, 2, 1 taps for a 3x3 kernel with pad 1)
+        for (int ph = 1; ph >= 0; --ph)
+            for (int pw = 1; pw >= 0; --pw) {
                 const int kh0 = (ph + d->pad) & 1, kw0 = (pw + d->pad) & 1;
                 if (kh0 >= KH || kw0 >= KW) continue;
                 const int TA = (KH - kh0 + 1) / 2, TB = (KW - kw0 + 1) / 2;

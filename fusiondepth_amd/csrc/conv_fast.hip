@@ -644,7 +644,10 @@ int fast_gemm_group_launch(const FastGemmArgs& a, const FastGemmGroup& q, hipStr
     for (int j = 0; j < q.n; ++j)
         if ((double)a.M * q.K[j] * 4.0 >= 2147483648.0) { fd_set_error("conv: weights exceed the 2 GiB addressing range of the fast path"); return -1; }
     const bool b32 = a.C % 32 == 0;
-    if (a.M > 32) { if (b32) launch_grp<2, 2, 1, 2, 32>(a, q, st); else launch_grp<2, 2, 1, 2, 16>(a, q, st); }
+    long wgs128 = 0;                                         // workgroups of the 64 x 128 tiling
+    for (int j = 0; j < q.n; ++j) wgs128 += fd_cdiv((long)a.Nb * q.NY[j] * q.NX[j], 128) * fd_cdiv(a.M, 64);
+    if (a.M > 32 && b32 && wgs128 < (long)fd_tun().grp_tile64_below) launch_grp<2, 2, 1, 1, 32>(a, q, st);
+    else if (a.M > 32) { if (b32) launch_grp<2, 2, 1, 2, 32>(a, q, st); else launch_grp<2, 2, 1, 2, 16>(a, q, st); }
     else { if (b32) launch_grp<1, 4, 1, 2, 32>(a, q, st); else launch_grp<1, 4, 1, 2, 16>(a, q, st); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_conv_fast_grp launch failed: %s", hipGetErrorString(e)); return (int)e; }

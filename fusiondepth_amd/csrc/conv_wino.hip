@@ -1348,6 +1348,7 @@ struct WinoWgradArgs {
     long pairs_per_split;
     int slice_major;     // 1: grid x = pixel slice (XCD-aligned), z = (ky, c tile); 0: x = (ky, c tile), z = slice
     int slab_rows;       // rows per output channel in a slab: 9 = [ky][kx], 12 = [ri][kx] (k_wgrad_wino<.., true>)
+    int xcds_per_slice;  // slice_major == 2 with fewer than 8 slices: XCDs per slice (8 / slices), else 1
     int adv_n, adv_y, adv_j;   // one chunk of WGP pairs = adv_n images + adv_y rows + adv_j pairs (host: divisions once per launch)
 };
 constexpr int WGP = 16;                                          // pairs per chunk (GEMM-K 16 -> 8 MFMA k-steps)
@@ -1397,8 +1398,11 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         // dY / X rows in that XCD's L2 (the 3 kernel rows alone re-read both operands: 3x the HBM traffic when they sit on 3 XCDs).
         const int mtiles = (g.M + WBM - 1) / WBM, nt = R * ctiles * mtiles;
         const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
-        const int t = k % nt;
-        bs = (k / nt) * 8 + xcd;
+        int t;
+        if (g.xcds_per_slice <= 1) { t = k % nt; bs = (k / nt) * 8 + xcd; }
+        // fewer than 8 slices (2 or 4: ResNet layer3 at the step's batch sizes): a slice owns 8 / slices XCDs, each of which takes a
+        // contiguous range of the slice's tiles (m-tile major): it reads the slice's X rows once and only its own m tiles' dY rows
+        else { const int per = nt / g.xcds_per_slice; bs = xcd / g.xcds_per_slice; t = (xcd % g.xcds_per_slice) * per + k; }
         by = t / (R * ctiles);
         bt = t - by * R * ctiles;
     } else {
@@ -1849,7 +1853,12 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
     g.slice_major = slice_major;
     const int nt = (twod ? 4 : 3) * fd_cdiv(d->Cin, WBN);
     const int mt = fd_cdiv(d->Cout, WBM);
-    if (slice_major == 2 && sp % 8 != 0) g.slice_major = 0;               // the XCD map needs whole groups of 8 slices
+    g.xcds_per_slice = 1;
+    if (slice_major == 2 && sp % 8 != 0) {                                // the XCD map needs whole groups of 8 slices ...
+        const int q = (sp == 2 || sp == 4) ? 8 / sp : 0;                  // ... or 2 / 4 slices that own 4 / 2 XCDs each
+        if (q > 0 && (nt * mt) % q == 0 && fd_tun().wino_wgrad_xcd_few != 0) g.xcds_per_slice = q;
+        else g.slice_major = 0;
+    }
     const dim3 grid = g.slice_major == 2 ? dim3((unsigned)(nt * mt * sp)) : (g.slice_major ? dim3(sp, mt, nt) : dim3(nt, mt, sp));
     const size_t lds = sizeof(float) * WG_LDS_FLOATS;
     if (twod) {

@@ -71,6 +71,9 @@ typedef struct fd_tuning {
     int wino_min_cout;            /* 32  fewest output channels of a forward / data-gradient launch on the Winograd kernels (their tile is 64 channels
                                          tall: below that, rows of the tile are idle; 32 = the depth decoder's upconv(1, *) as well; rounds 1-4: 64) */
     int wino_wgrad_min_cout;      /* 32  ... of a weight-gradient launch */
+    int wino_wgrad_xcd_few;       /* 1   Winograd weight gradients with 2 or 4 pixel slices on the XCD-aware grid as well (each slice owns 4 / 2 XCDs) */
+    int grp_tile64_below;         /* 0   grouped launches (the four parity classes of a stride-2 data gradient) with fewer than this many 64x128
+                                         workgroups run on 64x64 tiles (twice the workgroups, half the work of the longest one); 0: never */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);

@@ -12,5 +12,5 @@ head -60 $R/gpurun_out/${TAG}_bench_kernel_stats.md
 python $R/scripts/rocprof_timeline.py $DB > $R/gpurun_out/${TAG}_bench_timeline.md
 cat $R/gpurun_out/${TAG}_bench_timeline.md
 python $R/scripts/rocprof_top.py $DB 7 > $R/gpurun_out/${TAG}_bench_top_dispatches.md
-python $R/scripts/rocprof_stream_chain.py $DB k_adam_dev 1 > $R/gpurun_out/${TAG}_bench_stream_chain_main.md 2>&1
+python $R/scripts/rocprof_stream_chain.py $DB k_adam_dev k_photo_ms > $R/gpurun_out/${TAG}_bench_stream_chain_main.md 2>&1   # the depth network's stream
 python $R/scripts/rocprof_stream_chain.py $DB k_adam_dev 0 > $R/gpurun_out/${TAG}_bench_stream_chain_0.md 2>&1

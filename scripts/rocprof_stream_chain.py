@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """The kernels of ONE steady-state optimiser step on the busiest HIP stream (the step's serial chain), in launch order, with their
-durations: rocprof_stream_chain.py results.db [delimiter=k_adam_dev] [rank of the stream by kernel time = 0]"""
+durations: rocprof_stream_chain.py results.db [delimiter=k_adam_dev] [rank of the stream by kernel time = 0 | substring of a kernel name:
+the stream that kernel runs on, e.g. k_photo_ms for the depth network's stream]"""
 import collections, re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 delim = sys.argv[2] if len(sys.argv) > 2 else "k_adam_dev"
@@ -11,8 +12,11 @@ step = [(n, s, e, st) for n, s, e, st in rows if s >= lo and e <= hi]
 per = collections.Counter()
 for n, s, e, st in step:
     per[st] += e - s
-rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-main = per.most_common(rank + 1)[rank][0]
+sel = sys.argv[3] if len(sys.argv) > 3 else "0"
+if sel.lstrip("-").isdigit():
+    main = per.most_common(int(sel) + 1)[int(sel)][0]
+else:
+    main = collections.Counter(st for n, s, e, st in step if sel in n).most_common(1)[0][0]
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"\((?:[^()]|\([^()]*\))*\)$", "", n)
     return re.sub(r"^void ", "", n)[:40]

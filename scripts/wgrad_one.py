@@ -2,7 +2,7 @@
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from fusiondepth_amd import _lib
+from fusiondepth_amd import _lib, tuning  # noqa: F401  (tuning maps the FD_* variables onto fd_set_tuning at import)
 ci, co, h, w, B = (int(a) for a in sys.argv[1:6]); n = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 x = torch.randn(B, ci, h, w, device="cuda"); gy = torch.randn(B, co, h, w, device="cuda"); gw = torch.zeros(co, ci, 3, 3, device="cuda")
 d = _lib.ConvDesc(B, ci, h, w, co, 3, 3, 1, 1, 0, 0, 0)
