@@ -1137,8 +1137,12 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
 // 128 consecutive columns of one tile row (or wrap into the next), exactly the 1-D kernel's scheme with H / 2 rows.
 constexpr int W2D_BUF_FLOATS = 4 * WBKC * LDU + 2 * V_RAW_FLOATS;
 constexpr int W2D_LDS_FLOATS = 2 * W2D_BUF_FLOATS;
-template <bool STATS>
+// HALFM (round 5): at most 32 output channels (upconv(1, *) of the depth decoder) - the tile's rows 32 .. 63 do not exist, so the wave pair that
+// would own them (wm = 1) takes the second half of every chunk's k-steps of rows 0 .. 31, and the two partial results (the folded accumulator
+// pairs) meet in LDS once, in front of the epilogue, in a fixed order.
+template <bool STATS, bool HALFM = false>
 __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_conv_wino2p_dma(WinoArgs g) {
+    static_assert(!(STATS && HALFM), "no statistics epilogue for the 32-channel variant");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1209,8 +1213,10 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
         pc_c0 = wrap ? 0 : pc_c0;
         pc_ri += wrap ? 1 : 0;
     };
-    auto load_u = [&](int t) __attribute__((always_inline)) { ru[t] = fd_ldg128(rsU, u_off + (unsigned)t * u_comp); };
+    const bool u_rows = !HALFM || wave < 2;                          // HALFM: weight rows 0 .. 31 = the loader threads of waves 0 and 1
+    auto load_u = [&](int t) __attribute__((always_inline)) { if (u_rows) ru[t] = fd_ldg128(rsU, u_off + (unsigned)t * u_comp); };
     auto store_u = [&](int buf, int t) __attribute__((always_inline)) {
+        if (!u_rows) return;
         float* q = smem + buf * W2D_BUF_FLOATS + t * WBKC * LDU + (4 * a4) * LDU + ar;
         q[0] = ru[t].x; q[LDU] = ru[t].y; q[2 * LDU] = ru[t].z; q[3 * LDU] = ru[t].w;
     };
@@ -1243,6 +1249,8 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 
     constexpr int NK = WBKC / 2, LS = NK / 2;
+    constexpr int NKW = HALFM ? NK / 2 : NK;                         // k-steps per wave and chunk (HALFM: wave pair wm takes k-steps NKW wm ...)
+    const int kb2 = HALFM ? 2 * NKW * wm : 0;                        // first LDS operand row (= input channel of the chunk) of this wave's k-steps
     const int arow = lane >> 5, acol = lane & 31;
     {
         prep();                                                      // chunk 0
@@ -1263,8 +1271,8 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int cur = ch & 1;
             float sgn = ri_cur == 1 ? 1.f : -1.f;                    // this chunk's row combination: rowA + sgn * rowB
             asm volatile("" : "+v"(sgn));                            // in a VGPR: an SGPR operand halves the VALU rate on gfx950
-            const float* pa = smem + cur * W2D_BUF_FLOATS + arow * LDU + 32 * wm + acol;
-            const float* pr = smem + cur * W2D_BUF_FLOATS + 4 * WBKC * LDU + arow * LDR;
+            const float* pa = smem + cur * W2D_BUF_FLOATS + (arow + kb2) * LDU + (HALFM ? 0 : 32 * wm) + acol;
+            const float* pr = smem + cur * W2D_BUF_FLOATS + 4 * WBKC * LDU + (arow + kb2) * LDR;
             typedef const __attribute__((address_space(3))) float* lds_cf;       // (stays an LDS pointer through the asm: a generic one
             typedef const __attribute__((address_space(3))) f32x2* lds_cf2;      //  turns the reads into flat loads)
             lds_cf pe = (lds_cf)(pr + V_RAW_FLOATS);                     // row set B through its own address register: with one base hipcc
@@ -1287,28 +1295,36 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int t = 0; t < 4; ++t) read_a(0, 0, t);
             read_b(0); xform_b(0);
 #pragma unroll
-            for (int kk = 0; kk < NK; ++kk) {
+            for (int kk = 0; kk < NKW; ++kk) {
                 const int cb = kk & 1, nb = cb ^ 1;
                 __builtin_amdgcn_sched_barrier(0);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < NK) { read_b(2 * (kk + 1)); read_a(nb, 2 * (kk + 1), 0); read_a(nb, 2 * (kk + 1), 1); }
-                if (kk >= LS && !(FD_W2P_ABLATE & 4)) store_u(cur ^ 1, kk - LS);
+                if (kk + 1 < NKW) { read_b(2 * (kk + 1)); read_a(nb, 2 * (kk + 1), 0); read_a(nb, 2 * (kk + 1), 1); }
+                if (!HALFM && kk >= LS && !(FD_W2P_ABLATE & 4)) store_u(cur ^ 1, kk - LS);
+                if (HALFM && kk >= 2) { store_u(cur ^ 1, 2 * (kk - 2)); store_u(cur ^ 1, 2 * (kk - 2) + 1); }     // loaded in k-steps 0, 1
                 __builtin_amdgcn_sched_barrier(0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < NK) { read_a(nb, 2 * (kk + 1), 2); read_a(nb, 2 * (kk + 1), 3); }
-                if (kk < LS) load_u(kk);
+                if (kk + 1 < NKW) { read_a(nb, 2 * (kk + 1), 2); read_a(nb, 2 * (kk + 1), 3); }
+                if (!HALFM && kk < LS) load_u(kk);
+                if (HALFM && kk < 2) { load_u(2 * kk); load_u(2 * kk + 1); }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < NK) xform_b(nb);
+                if (kk + 1 < NKW) xform_b(nb);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk < 4) dma_v(cur ^ 1, kk >> 1, kk & 1);         // row set A: pieces 0, 1; row set B: pieces 0, 1
-                if (kk == 4 && wave == 0) { dma_v(cur ^ 1, 0, 2); dma_v(cur ^ 1, 1, 2); }
-                if (kk == NK - 2) prep();                            // chunk ch + 2; every fetch of chunk ch + 1 has been issued by now
+                if constexpr (!HALFM) {
+                    if (kk < 4) dma_v(cur ^ 1, kk >> 1, kk & 1);         // row set A: pieces 0, 1; row set B: pieces 0, 1
+                    if (kk == 4 && wave == 0) { dma_v(cur ^ 1, 0, 2); dma_v(cur ^ 1, 1, 2); }
+                    if (kk == NK - 2) prep();                            // chunk ch + 2; every fetch of chunk ch + 1 has been issued by now
+                } else {                                                 // the same six fetches in three k-steps, the offsets of chunk ch + 2 in the fourth
+                    if (kk < 2) { dma_v(cur ^ 1, kk, 0); dma_v(cur ^ 1, kk, 1); }
+                    if (kk == 2 && wave == 0) { dma_v(cur ^ 1, 0, 2); dma_v(cur ^ 1, 1, 2); }
+                    if (kk == 3) prep();
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (ch == next_fold && !(FD_W2P_ABLATE & 1)) {
@@ -1330,7 +1346,22 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (!(FD_W2P_ABLATE & 8)) __syncthreads();
         }
     }
-    w2p_epilogue<STATS>(g, ya, yb, p0, m0, lim, plane2, W2, hw, lane, wm, wn);
+    if constexpr (HALFM) {                                           // wm = 0 keeps (its own) + (wm = 1's) partial outputs
+        float* red = smem + ((wn * 64) << 6) + lane;                 // [wn][64 registers][lane]; the chunk loop ended with a barrier
+        if (wm == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[r << 6] = ya[0][r]; red[(16 + r) << 6] = ya[1][r]; red[(32 + r) << 6] = yb[0][r]; red[(48 + r) << 6] = yb[1][r];
+            }
+        }
+        __syncthreads();
+        if (wm == 1) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ya[0][r] += red[r << 6]; ya[1][r] += red[(16 + r) << 6]; yb[0][r] += red[(32 + r) << 6]; yb[1][r] += red[(48 + r) << 6];
+        }
+    }
+    w2p_epilogue<STATS>(g, ya, yb, p0, m0, lim, plane2, W2, hw, lane, HALFM ? 0 : wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -1377,7 +1408,10 @@ constexpr int WG_LDS_FLOATS = 2 * WG_BUF_FLOATS;
 // that - LDS layout, operand reads, the horizontal transforms, the MFMA loop, the horizontal output transform - is the 1-D kernel's.
 // 4 components x half the K of 3 kernel rows: 16 products per 2x2 tile instead of 24 (direct: 36).  Slab rows are [ri][kx]; the
 // vertical output transform dW[ky] = (T0 + (T1+T2)/2, (T1-T2)/2, (T1+T2)/2 - T3) is applied by k_wgrad_finish9<12> while it sums the slices.
-template <bool REFL, bool TWOD>      // REFL: reflection (decoder) or zero (ResNet trunk) padding - a template flag keeps the border selects out of the trunk's loop
+// HALFM (round 5): at most 32 output channels (the depth decoder's upconv(1, *)) - rows 32 .. 63 of the tile do not exist, so the two waves that
+// would own them (wm = 1) take the SECOND HALF OF EVERY CHUNK'S K-STEPS of the first 32 rows instead, and the two partial sums meet in LDS
+// once, in front of the epilogue (fixed order: deterministic).  Without it half of the launch's matrix instructions multiply clamped rows.
+template <bool REFL, bool TWOD, bool HALFM = false>      // REFL: reflection (decoder) or zero (ResNet trunk) padding - a template flag keeps the border selects out of the trunk's loop
 __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1485,21 +1519,21 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         cn += g.adv_n + (c2 ? 1 : 0);
     };
     auto load_row = [&](int i) __attribute__((always_inline)) {
-        ra[i] = fd_ldg64(rsY, a_off + a_row[i]);                          // FD_OOB + (< 2^31) stays out of range: reads 0
+        if (!HALFM || i < 2) ra[i] = fd_ldg64(rsY, a_off + a_row[i]);     // FD_OOB + (< 2^31) stays out of range: reads 0  (HALFM: dY rows 0 .. 31 only)
         rx[i] = fd_ldg128(rsX, x_off + b_row[i]);
         if constexpr (TWOD) {
-            rb[i] = fd_ldg64(rsY, a_off2 + a_row[i]);
+            if (!HALFM || i < 2) rb[i] = fd_ldg64(rsY, a_off2 + a_row[i]);
             rz[i] = fd_ldg128(rsX, x_off2 + b_row[i]);
         }
     };
     auto store_row = [&](int buf, int i) __attribute__((always_inline)) {
         float* qa = smem + buf * WG_BUF_FLOATS + (rw + 16 * i) * LDG + 2 * p;
         if constexpr (TWOD) {                                             // the row combinations (exact products: a +- b)
-            ra[i].x = fmaf(y_sgn, rb[i].x, ra[i].x); ra[i].y = fmaf(y_sgn, rb[i].y, ra[i].y);
+            if (!HALFM || i < 2) { ra[i].x = fmaf(y_sgn, rb[i].x, ra[i].x); ra[i].y = fmaf(y_sgn, rb[i].y, ra[i].y); }
             rx[i].x = fmaf(x_sgn, rz[i].x, rx[i].x); rx[i].y = fmaf(x_sgn, rz[i].y, rx[i].y);
             rx[i].z = fmaf(x_sgn, rz[i].z, rx[i].z); rx[i].w = fmaf(x_sgn, rz[i].w, rx[i].w);
         }
-        *reinterpret_cast<f32x2*>(qa) = ra[i];
+        if (!HALFM || i < 2) *reinterpret_cast<f32x2*>(qa) = ra[i];
         // (d0, d1, d2, d3) of the pair; column -1 is column 1 (reflect) or 0, column W is column W - 2 (reflect) or 0
         const bool L = rf & 1, R = rf & 2;
         float4 d;
@@ -1522,6 +1556,9 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     constexpr int NK = WGP / 2, LS = NK / 2;
+    constexpr int NKW = HALFM ? NK / 2 : NK;                     // k-steps per wave and chunk
+    static_assert(!HALFM || NKW == LS, "HALFM: the four row loads / stores of a chunk sit in its four k-steps");
+    const int kb = HALFM ? wm * NKW : 0;
     if (nchunk > 0) {
         prep_chunk(true);
         rf = pf;
@@ -1538,8 +1575,9 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
         for (int ch = 0; ch < nchunk; ++ch) {
             const int cur = ch & 1;
             // operands of pair k = 2 kk + arow: A = P(dY row 32 wm + acol), B = Q(X row 32 wn + acol)
-            const float* pa = smem + cur * WG_BUF_FLOATS + (32 * wm + acol) * LDG + 2 * arow;
-            const float* pb = smem + cur * WG_BUF_FLOATS + WBM * LDG + (32 * wn + acol) * LDX + 4 * arow;
+            // (HALFM: every wave reads dY rows 0 .. 31; wave pair wm takes the k-steps kb .. kb + NKW - 1 of the chunk)
+            const float* pa = smem + cur * WG_BUF_FLOATS + ((HALFM ? 0 : 32 * wm) + acol) * LDG + 2 * arow + 4 * kb;
+            const float* pb = smem + cur * WG_BUF_FLOATS + WBM * LDG + (32 * wn + acol) * LDX + 4 * arow + 8 * kb;
             float av[2][4], bv[2][4];
             f32x2 yy;
             float4 dd;
@@ -1553,12 +1591,12 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
             };
             read_ops(0); xform(0);
 #pragma unroll
-            for (int kk = 0; kk < NK; ++kk) {
+            for (int kk = 0; kk < NKW; ++kk) {
                 const int cb = kk & 1, nb = cb ^ 1;
                 __builtin_amdgcn_sched_barrier(0);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][0], bv[cb][0], acc[0], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < NK && !(FD_WGRAD_ABLATE & 64)) read_ops(kk + 1);
+                if (kk + 1 < NKW && !(FD_WGRAD_ABLATE & 64)) read_ops(kk + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][1], bv[cb][1], acc[1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1566,26 +1604,41 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
                 __builtin_amdgcn_sched_barrier(0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][2], bv[cb][2], acc[2], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (kk + 1 < NK) { if (!(FD_WGRAD_ABLATE & 32)) xform(nb); else { for (int t = 0; t < 4; ++t) { av[nb][t] = av[cb][t]; bv[nb][t] = bv[cb][t]; } } }
+                if (kk + 1 < NKW) { if (!(FD_WGRAD_ABLATE & 32)) xform(nb); else { for (int t = 0; t < 4; ++t) { av[nb][t] = av[cb][t]; bv[nb][t] = bv[cb][t]; } } }
                 __builtin_amdgcn_sched_barrier(0);
                 acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][3], bv[cb][3], acc[3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kk < LS && !(FD_WGRAD_ABLATE & 1)) load_row(kk);                        // ... and re-loaded with the chunk after next
-                if (kk == LS) rf = pf;                                                      // the flags travel with the registers
-                if (kk == NK - 1 && !(FD_WGRAD_ABLATE & 8)) prep_chunk(ch + 3 < nchunk);
+                if (kk == (HALFM ? NKW - 1 : LS)) rf = pf;                                  // the flags travel with the registers (all four rows re-loaded by now)
+                if (kk == NKW - 1 && !(FD_WGRAD_ABLATE & 8)) prep_chunk(ch + 3 < nchunk);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(FD_WGRAD_ABLATE & 16)) __syncthreads();
         }
     }
 
+    if constexpr (HALFM) {                                       // the two K halves of the 32 rows meet: wm = 0 keeps acc(wm = 0) + acc(wm = 1)
+        float* red = smem + ((wn * 64) << 6) + lane;             // [wn][component * 16 + register][lane]; the chunk loop ended with a barrier
+        if (wm == 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(t * 16 + r) << 6] = acc[t][r];
+        }
+        __syncthreads();
+        if (wm == 1) return;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += red[(t * 16 + r) << 6];
+    }
     // ---- epilogue: slab[z][m][ky*3 + kx][c] from the four accumulators (C/D layout: column = lane & 31, row = (reg & 3) +
     //      8 * (reg >> 2) + 4 * (lane >> 5))
     const int c = c0 + 32 * wn + acol;
     // this slice's slab through a buffer resource: 32-bit offsets (a slab is M * 9 * C floats < 2^29), rows / columns past the tensor
     // are dropped by an out-of-range offset instead of a branch per row
     const __amdgpu_buffer_rsrc_t rsS = fd_make_rsrc(g.slabs + (size_t)bs * ((size_t)g.M * (3 * R) * g.C));
-    const int mb = m0 + 32 * wm + 4 * arow;
+    const int mb = m0 + (HALFM ? 0 : 32 * wm) + 4 * arow;
     const unsigned col = (c < g.C) ? 4u * (unsigned)(ky * 3 * g.C + c) : FD_OOB;
     const unsigned row_step = 4u * (3u * R) * (unsigned)g.C, kx_step = 4u * (unsigned)g.C;
 #pragma unroll
@@ -1745,6 +1798,11 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         if (aligned && !vdma) { fd_set_error("wino conv: the statistics epilogue of this shape needs a 16-byte aligned input"); return -1; }
         if (vdma) {
             if (stat_part) hipLaunchKernelGGL(k_conv_wino2p_dma<true>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
+            else if (d->Cout <= 32 && fd_tun().wino_fwd_halfm != 0) {          // the decoder's 32-channel blocks: both wave pairs on rows 0 .. 31
+                static bool attr_h = false;
+                if (!attr_h) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p_dma<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_h = true; }
+                hipLaunchKernelGGL((k_conv_wino2p_dma<false, true>), dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
+            }
             else hipLaunchKernelGGL(k_conv_wino2p_dma<false>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
         } else if (stat_part) hipLaunchKernelGGL(k_conv_wino2p<true>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
         else hipLaunchKernelGGL(k_conv_wino2p<false>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
@@ -1861,7 +1919,24 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
     }
     const dim3 grid = g.slice_major == 2 ? dim3((unsigned)(nt * mt * sp)) : (g.slice_major ? dim3(sp, mt, nt) : dim3(nt, mt, sp));
     const size_t lds = sizeof(float) * WG_LDS_FLOATS;
-    if (twod) {
+    const bool halfm = d->Cout <= 32 && fd_tun().wino_wgrad_halfm != 0;   // at most 32 output channels: two waves per K half (k_wgrad_wino<.., HALFM>)
+    if (halfm) {
+        static bool attr_h = false;
+        if (!attr_h) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_h = true;
+        }
+        if (twod) {
+            if (d->pad_mode == 1) hipLaunchKernelGGL((k_wgrad_wino<true, true, true>), grid, dim3(WNT), lds, st, g);
+            else hipLaunchKernelGGL((k_wgrad_wino<false, true, true>), grid, dim3(WNT), lds, st, g);
+        } else {
+            if (d->pad_mode == 1) hipLaunchKernelGGL((k_wgrad_wino<true, false, true>), grid, dim3(WNT), lds, st, g);
+            else hipLaunchKernelGGL((k_wgrad_wino<false, false, true>), grid, dim3(WNT), lds, st, g);
+        }
+    } else if (twod) {
         if (d->pad_mode == 1) hipLaunchKernelGGL((k_wgrad_wino<true, true>), grid, dim3(WNT), lds, st, g);
         else hipLaunchKernelGGL((k_wgrad_wino<false, true>), grid, dim3(WNT), lds, st, g);
     } else {

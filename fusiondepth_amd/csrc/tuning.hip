@@ -21,7 +21,7 @@ fd_tuning make_defaults() {
     t.log = 0;
     t.wino_fwd_2d_m128 = 1;
     t.grp_tile64_below = 0;
-    t.wino_wgrad_xcd_few = 1;
+    t.wino_wgrad_xcd_few = 1; t.wino_fwd_halfm = 1; t.wino_wgrad_halfm = 1;
     t.wino_min_cout = 32; t.wino_wgrad_min_cout = 32;     // the decoder's 32-channel blocks with half a tile idle: profiles/round5_decoder_m32_time.log
     return t;
 }

@@ -72,6 +72,8 @@ typedef struct fd_tuning {
                                          tall: below that, rows of the tile are idle; 32 = the depth decoder's upconv(1, *) as well; rounds 1-4: 64) */
     int wino_wgrad_min_cout;      /* 32  ... of a weight-gradient launch */
     int wino_wgrad_xcd_few;       /* 1   Winograd weight gradients with 2 or 4 pixel slices on the XCD-aware grid as well (each slice owns 4 / 2 XCDs) */
+    int wino_fwd_halfm;           /* 1   k_conv_wino2p_dma with <= 32 output channels likewise (forward of the decoder's upconv(1, *)) */
+    int wino_wgrad_halfm;         /* 1   Winograd weight gradients with <= 32 output channels: the tile's idle wave pair takes half of every chunk's K-steps */
     int grp_tile64_below;         /* 0   grouped launches (the four parity classes of a stride-2 data gradient) with fewer than this many 64x128
                                          workgroups run on 64x64 tiles (twice the workgroups, half the work of the longest one); 0: never */
 } fd_tuning;

@@ -785,6 +785,9 @@ def _wino_conv(x, w, bias, reflect, act=0):
     (2, 64, 64, 2, 4, True, 0),          # one tile row: both vertical mirrors in the same tile
     (2, 64, 64, 2, 4, False, 0),
     (3, 512, 512, 6, 20, False, 1),      # layer4: the 2-D kernel also splits the input channels
+    (2, 96, 32, 24, 40, True, 2),        # 32 output channels (upconv(1,1) of the depth decoder): two_d = 2 is k_conv_wino2p_dma<false, HALFM>
+    (3, 64, 32, 12, 20, False, 1),       # ... zero padding, pixel tiles across image borders
+    (2, 32, 16, 8, 12, True, 0),         # 16 output channels, two chunks per row component
 ])
 def test_winograd_conv_vs_float64_reference(N, Ci, Co, H, W, reflect, act, two_d, fdtune):
     """conv_wino.hip through its own entry point against torch float64 conv2d: error within a few fp32 ulps of the output scale,
