@@ -29,7 +29,7 @@ extern "C" {
  *    (group, channel) - a client that sized the BatchNorm workspace itself must re-query it.
  * 3: additions only (round 5): fd_masked_median, fd_refine_inputs (+ fd_refine_cfg), fd_resize_linear_cv, fd_bn_relu_maxpool_fwd / _bwd,
  *    fd_bn_train_bwd_remask, fd_stack_normalize, fd_conv2d_fwd_bn(_ok), fd_pose_head_fwd / _bwd; fd_tuning grew at its end
- *    (wino_min_cout, wino_wgrad_min_cout, wino_wgrad_xcd_few, grp_tile64_below).  Nothing removed, no signature changed. */
+ *    (wino_min_cout, wino_wgrad_min_cout, wino_wgrad_xcd_few, wino_fwd_halfm, wino_wgrad_halfm, grp_tile64_below).  Nothing removed, no signature changed. */
 #define FD_ABI_VERSION 3
 
 int fd_abi_version(void);
