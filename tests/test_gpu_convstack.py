@@ -210,6 +210,33 @@ def test_conv3x3_with_fewer_than_64_output_channels_on_the_winograd_kernels(FD, 
         relclose(cpu(g), cpu(r.float()), what, rtol=1e-4, arel=1e-5)
 
 
+@pytest.mark.parametrize("fields", [dict(grp_tile64_below=100000), dict(wino_wgrad_xcd_few=0), dict(wino_fwd_halfm=0, wino_wgrad_halfm=0),
+                                    dict(wino_min_cout=64, wino_wgrad_min_cout=64)],
+                         ids=lambda f: ",".join("%s=%s" % kv for kv in f.items()))
+def test_round5_tuning_switches_keep_the_results(FD, fdtune, fields):
+    """The A/B switches fd_tuning grew in round 5 choose between kernels, not between results: a ResNet stage transition (stride-2 3x3 + 1x1
+    downsample: the grouped data gradient on 64x64 tiles), a 256-channel layer whose weight gradient has 4 pixel slices (3-D grid instead of
+    the XCD-aware one) and a 32-output-channel reflect-padded block (wave-pair variants off / direct kernels) against torch float64."""
+    fdtune.lib(wino_fwd_2dp_min_wgs=1, **fields)
+    torch.manual_seed(4242)
+    cases = [(2, 64, 128, 24, 40, 3, 2, "zero"), (2, 64, 128, 24, 40, 1, 2, "zero"), (1, 256, 256, 12, 40, 3, 1, "zero"),
+             (2, 96, 32, 24, 40, 3, 1, "reflect")]
+    for N, Ci, Co, H, W, K, stride, mode in cases:
+        x = torch.randn(N, Ci, H, W, device="cuda", requires_grad=True)
+        w = (torch.randn(Co, Ci, K, K, device="cuda") * 0.05).requires_grad_(True)
+        y = FD.conv2d(x, w, None, stride, K // 2, mode, "none")
+        cot = torch.randn_like(y)
+        gx, gw = torch.autograd.grad((y * cot).sum(), [x, w])
+        xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+        xp = F.pad(xd, (K // 2,) * 4, mode="reflect" if mode == "reflect" else "constant")
+        yd = F.conv2d(xp, wd, None, stride)
+        gxd, gwd = torch.autograd.grad((yd * cot.double()).sum(), [xd, wd])
+        what = "%dx%d k%d s%d %s" % (Ci, Co, K, stride, mode)
+        relclose(cpu(y), cpu(yd.float()), "y " + what, rtol=1e-5, arel=3e-6)
+        relclose(cpu(gx), cpu(gxd.float()), "dx " + what, rtol=1e-4, arel=1e-5)
+        relclose(cpu(gw), cpu(gwd.float()), "dw " + what, rtol=1e-4, arel=1e-5)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(2, 3, 192, 640), (2, 6, 192, 640), (3, 2, 96, 320), (2, 4, 70, 150), (1, 5, 8, 8), (1, 1, 33, 9)])
 def test_stem_convolution_on_the_patch_kernel(FD, N, C, H, W, fdtune):
     """conv_stem.hip (7x7 stride-2 pad-3 stems, networks/resnet_encoder.py:95) against torch float64 conv2d, and against the generic
