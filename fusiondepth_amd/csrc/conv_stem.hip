@@ -33,6 +33,11 @@ struct StemArgs {
     int tiles_x, tiles_y;
 };
 
+// Round 5: PERSISTENT workgroups (one per CU, looping over tiles).  The first version staged the weights (76 KB out of L2) and the patch for
+// every tile and ran load -> compute -> store strictly one after the other: 54 us per tile against 31 us of matrix work (two waves per
+// SIMD), 5.6 tiles per CU at batch 24.  Now the weights are staged once per workgroup, and the NEXT tile's patch is fetched into registers
+// (33 per thread for six channels) in front of the current tile's MFMA loop - in flight during it - and written to LDS behind it; the
+// current tile's output stores are issued after that, so they drain under the next tile's loop.  Same arithmetic, same order: bit-identical.
 template <int CP>
 __global__ void __launch_bounds__(ST_NT) k_conv7s2_stem(StemArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -40,26 +45,61 @@ __global__ void __launch_bounds__(ST_NT) k_conv7s2_stem(StemArgs a) {
     float* patch = smem + CP * 49 * 2 * ST_LDW;                 // [2 CP][ST_PR][2][ST_PC2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int blk = blockIdx.x;
-    const int bx = blk % a.tiles_x; blk /= a.tiles_x;
-    const int by = blk % a.tiles_y;
-    const int n = blk / a.tiles_y;
-    const int oy0 = by * ST_TR, ox0 = bx * ST_TC;
-    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
     const int C = a.C;
+    const int ntiles = a.Nb * a.tiles_y * a.tiles_x;
+    constexpr int per_c = ST_PR * ST_PW, totp = 2 * CP * per_c, NV = (totp + ST_NT - 1) / ST_NT;
+    const __amdgpu_buffer_rsrc_t rsX = fd_make_rsrc(a.X);       // the whole tensor: < 2^29 floats (size guard of the entry point)
+    float v[NV];
+    // the tile's patch -> registers: element e = tid + u * ST_NT of [2 CP][ST_PR][ST_PW]; out-of-image elements and the padding channel read 0.0
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        int blk = tile;
+        const int bx = blk % a.tiles_x; blk /= a.tiles_x;
+        const int by = blk % a.tiles_y;
+        const int n = blk / a.tiles_y;
+        const int iy0 = 2 * by * ST_TR - 3, ix0 = 2 * bx * ST_TC - 3;
+        const unsigned nb = (unsigned)n * (unsigned)C * (unsigned)(a.H * a.W);
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));        // opaque per call: the element -> (channel, row, column) arithmetic is the same for every tile, and hoisted out of
+                                            // the tile loop it costs ~130 registers (256 + spills instead of ~130)
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e = t0 + u * ST_NT;
+            const int c = e / per_c;
+            const int r2 = e - c * per_c;
+            const int r = r2 / ST_PW, j = r2 - r * ST_PW;
+            const int iy = iy0 + r, ix = ix0 + j;
+            const bool in = e < totp && c < C && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            v[u] = fd_ldg32(rsX, in ? 4u * (nb + (unsigned)((c * a.H + iy) * a.W + ix)) : FD_OOB);       // out of range reads 0
+        }
+    };
+    // registers -> LDS, de-interleaved by column parity
+    auto stash = [&]() __attribute__((always_inline)) {
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e = t0 + u * ST_NT;
+            if (e < totp) {
+                const int c = e / per_c;
+                const int r2 = e - c * per_c;
+                const int r = r2 / ST_PW, j = r2 - r * ST_PW;
+                patch[((c * ST_PR + r) * 2 + (j & 1)) * ST_PC2 + (j >> 1)] = v[u];
+            }
+        }
+    };
 
-    // ---- weights: flat OIHW read (coalesced), scattered to [k = (cp, t)][parity][m]; input patch, de-interleaved by column parity
-    //      (out-of-image elements and the padding channel are zeros).  Both in batches of 8 independent loads per thread (the loop
-    //      with one load -> one LDS store per trip serialised ~35 memory latencies per workgroup: 23 us of a 54 us workgroup)
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile);
+    // ---- weights, once per workgroup: flat OIHW read (coalesced), scattered to [k = (cp, t)][parity][m], in batches of 8 independent loads
     {
         const __amdgpu_buffer_rsrc_t rsW = fd_make_rsrc(a.Wt);
         const int total = 64 * C * 49;
         for (int f0 = tid; f0 < total; f0 += 8 * ST_NT) {
-            float v[8];
+            float w8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int f = f0 + u * ST_NT;
-                v[u] = fd_ldg32(rsW, f < total ? 4u * (unsigned)f : FD_OOB);
+                w8[u] = fd_ldg32(rsW, f < total ? 4u * (unsigned)f : FD_OOB);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -68,7 +108,7 @@ __global__ void __launch_bounds__(ST_NT) k_conv7s2_stem(StemArgs a) {
                     const int m = f / (C * 49);
                     const int r = f - m * (C * 49);
                     const int c = r / 49, t = r - c * 49;
-                    Wl[(((c >> 1) * 49 + t) * 2 + (c & 1)) * ST_LDW + m] = v[u];
+                    Wl[(((c >> 1) * 49 + t) * 2 + (c & 1)) * ST_LDW + m] = w8[u];
                 }
             }
         }
@@ -78,80 +118,86 @@ __global__ void __launch_bounds__(ST_NT) k_conv7s2_stem(StemArgs a) {
                 Wl[(((CP - 1) * 49 + t) * 2 + 1) * ST_LDW + m] = 0.f;
             }
         }
-        const __amdgpu_buffer_rsrc_t rsX = fd_make_rsrc(a.X + (size_t)n * C * a.H * a.W);
-        const int per_c = ST_PR * ST_PW, totp = 2 * CP * per_c;
-        for (int e0 = tid; e0 < totp; e0 += 8 * ST_NT) {
-            float v[8];
-            int dst[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * ST_NT;
-                const int c = e / per_c;
-                const int r2 = e - c * per_c;
-                const int r = r2 / ST_PW, j = r2 - r * ST_PW;
-                const int iy = iy0 + r, ix = ix0 + j;
-                const bool in = e < totp && c < C && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                v[u] = fd_ldg32(rsX, in ? 4u * (unsigned)((c * a.H + iy) * a.W + ix) : FD_OOB);       // out of range reads 0
-                dst[u] = e < totp ? ((c * ST_PR + r) * 2 + (j & 1)) * ST_PC2 + (j >> 1) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (dst[u] >= 0) patch[dst[u]] = v[u];
-        }
     }
+    if (tile < ntiles) stash();
     __syncthreads();
 
     typedef float f32x16 __attribute__((ext_vector_type(16)));
-    f32x16 acc[2][2];                                           // [channel block][column block]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int arow = lane >> 5, l31 = lane & 31;
     const float* pa = Wl + arow * ST_LDW + l31;                                              // + k-step * 2 LDW (+ 32: channels 32..63)
     const float* pb = patch + ((arow * ST_PR + 2 * wave) * 2) * ST_PC2 + l31;               // + tap offset (+ 32: columns 32..63)
-#pragma unroll 1
-    for (int cp = 0; cp < CP; ++cp) {
-        const float* qa = pa + cp * 49 * 2 * ST_LDW;
-        const float* qb = pb + cp * 2 * ST_PR * 2 * ST_PC2;
-        float a0 = qa[0], a1 = qa[32], b0 = qb[0], b1 = qb[32];
-#pragma unroll
-        for (int t = 0; t < 49; ++t) {
-            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-            if (t + 1 < 49) {
-                const int t1 = t + 1, ky = t1 / 7, kx = t1 - 7 * ky;
-                const int ob = (ky * 2 + (kx & 1)) * ST_PC2 + (kx >> 1);
-                na0 = qa[t1 * 2 * ST_LDW]; na1 = qa[t1 * 2 * ST_LDW + 32];
-                nb0 = qb[ob]; nb1 = qb[ob + 32];
-            }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-        }
-    }
-
-    // ---- epilogue (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5))
-    const int oy = oy0 + wave;
-    if (oy >= a.Ho) return;
-    float* yn = a.Y + (size_t)n * 64 * a.Ho * a.Wo + (size_t)oy * a.Wo;
     const size_t cs = (size_t)a.Ho * a.Wo;
+    for (; tile < ntiles; tile += (int)gridDim.x) {
+        const int next = tile + (int)gridDim.x;
+        if (next < ntiles) fetch(next);                         // in flight during the MFMA loop
+        __builtin_amdgcn_sched_barrier(0);                      // (nothing of the stash's address arithmetic hoisted above the loop: registers)
+        f32x16 acc[2][2];                                       // [channel block][column block]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ox = ox0 + 32 * j + l31;
-            if (ox < a.Wo) {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * arow;
-                    yn[m * cs + ox] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int cp = 0; cp < CP; ++cp) {
+            const float* qa = pa + cp * 49 * 2 * ST_LDW;
+            const float* qb = pb + cp * 2 * ST_PR * 2 * ST_PC2;
+            float a0 = qa[0], a1 = qa[32], b0 = qb[0], b1 = qb[32];
+#pragma unroll
+            for (int t = 0; t < 49; ++t) {
+                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                if (t + 1 < 49) {
+                    const int t1 = t + 1, ky = t1 / 7, kx = t1 - 7 * ky;
+                    const int ob = (ky * 2 + (kx & 1)) * ST_PC2 + (kx >> 1);
+                    na0 = qa[t1 * 2 * ST_LDW]; na1 = qa[t1 * 2 * ST_LDW + 32];
+                    nb0 = qb[ob]; nb1 = qb[ob + 32];
                 }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                        // every wave is done with this tile's patch
+        if (next < ntiles) stash();
+        // ---- epilogue (C/D layout: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)); issued behind the LDS writes of
+        //      the next patch: the stores drain under the next tile's loop
+        int blk = tile;
+        const int bx = blk % a.tiles_x; blk /= a.tiles_x;
+        const int by = blk % a.tiles_y;
+        const int n = blk / a.tiles_y;
+        const int oy = by * ST_TR + wave, ox0 = bx * ST_TC;
+        if (oy < a.Ho) {
+            float* yn = a.Y + (size_t)n * 64 * a.Ho * a.Wo + (size_t)oy * a.Wo;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ox = ox0 + 32 * j + l31;
+                    if (ox < a.Wo) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * arow;
+                            yn[m * cs + ox] = acc[i][j][r];
+                        }
+                    }
+                }
+        }
+        __syncthreads();                                        // the next patch is in LDS
+    }
+}
+
+// CUs of the current device (256 on MI355X), asked once
+inline int stem_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
 }
 
 template <int CP>
@@ -162,7 +208,10 @@ int stem_go(const StemArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv7s2_stem<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_conv7s2_stem<CP>, dim3((unsigned)(a.Nb * a.tiles_y * a.tiles_x)), dim3(ST_NT), lds, st, a);
+    const int ntiles = a.Nb * a.tiles_y * a.tiles_x;
+    // one workgroup per CU (145 KB of LDS for six channels), looping over the tiles; with fewer tiles than CUs one tile each
+    const int nwg = ntiles < stem_num_cus() ? ntiles : stem_num_cus();
+    hipLaunchKernelGGL(k_conv7s2_stem<CP>, dim3((unsigned)nwg), dim3(ST_NT), lds, st, a);
     FD_LAUNCH_CHECK("k_conv7s2_stem");
     return 0;
 }
