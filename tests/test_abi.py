@@ -119,3 +119,23 @@ def test_integration_stub_executes(lib_path, monkeypatch):
         if fn.argtypes is not None and name in _lib.SIGNATURES:
             assert len(fn.argtypes) == len(_lib.SIGNATURES[name][0]), (name, len(fn.argtypes), _lib.SIGNATURES[name][0])
     assert callable(ns["ssim"]) and callable(ns["get_4beam_2channel"]) and callable(ns["get_4beam"])
+
+
+def test_tuning_mirror_matches_the_header():
+    """fusiondepth_amd.tuning.Tuning mirrors `fd_tuning` field for field, in order (the struct is append-only: a field inserted in the middle
+    on one side only would silently shift every later threshold), and the library reports the mirror's size."""
+    import ctypes
+    import re
+    from fusiondepth_amd import _lib, tuning
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fdhip.h")).read()
+    body = text[text.index("typedef struct fd_tuning {"):text.index("} fd_tuning;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in re.findall(r"\bint\s+([^;]+);", body):
+        names += [n.strip() for n in decl.split(",")]
+    assert names == [n for n, _ in tuning.Tuning._fields_], (names, [n for n, _ in tuning.Tuning._fields_])
+    t = tuning.lib_defaults()
+    assert t.size == ctypes.sizeof(tuning.Tuning) == 4 * len(names)
+    assert set(tuning.LIB_FIELDS) == set(names) - {"size"}
+    for var, (name, _) in tuning._ENV_LIB.items():
+        assert name in names, (var, name)
