@@ -15,6 +15,7 @@
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include "conv_fast.h"
+#include "conv_limb.h"
 #include <stdio.h>
 #include "conv_narrow.h"
 
@@ -495,6 +496,23 @@ __global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* _
                 float* o = dg ? j.dst + ((size_t)(ci0 + c) * 4 + ri) * Co + co0 + r : j.dst + ((size_t)(co0 + r) * 4 + ri) * Ci + ci0 + c;
                 o[0] = v[0]; o[n] = 0.5f * (v[0] + v[1] + v[2]); o[2 * n] = 0.5f * (v[0] - v[1] + v[2]); o[3 * n] = v[2];
             }
+        } else if (j.mode == 7 || j.mode == 8) {         // 1x1 weights pre-split into bf16 limbs (conv_limb.h): 7 A[m = co][k = ci], 8 A[m = ci][k = co]
+            const bool tr = j.mode == 8;
+            const unsigned nm = tr ? nci : nco, nk8 = (tr ? nco : nci) / 8;
+            const long Mrows = tr ? Ci : Co;
+            uint4* A3 = reinterpret_cast<uint4*>(j.dst);
+            for (unsigned i = threadIdx.x; i < nm * nk8; i += 256) {
+                const unsigned k8 = i % nk8, mm = i / nk8;
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = tr ? tile[k8 * 8 + e][mm] : tile[mm][k8 * 8 + e];
+                uint4 h, md, l;
+                fdlimb::split8(x, h, md, l);
+                const long kk = (tr ? co0 : ci0) + k8 * 8, m = (tr ? ci0 : co0) + mm;
+                A3[fdlimb::a3_piece(kk, 0, m, Mrows)] = h;
+                A3[fdlimb::a3_piece(kk, 1, m, Mrows)] = md;
+                A3[fdlimb::a3_piece(kk, 2, m, Mrows)] = l;
+            }
         } else if (j.mode == 1) {                        // dst[(ci * T + t) * Co + co], co fastest
             for (unsigned i = threadIdx.x; i < nci * T * nco; i += 256) {
                 const unsigned r = i % nco, q = i / nco, t = q % T, c = q / T;
@@ -834,6 +852,7 @@ void fill_fwd_args(const fd_conv_desc* d, const ConvShape& s, FastGemmArgs& f) {
 extern "C" long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d) {
     if (!d || c1_shape_ok(d) || !fast_fwd_ok(d)) return 0;
     if (n16_shape_ok(d, d->Cout, d->Cin)) return 0;              // reads the weights as they are
+    if (limb_fwd_ok(d)) return align4(limb_wt_floats(d->Cout, d->Cin));
     if (wino_use_fwd(d)) return align4(wino_wt_floats(d));
     return align4((long)d->Cout * d->Cin * d->KH * d->KW);
 }
@@ -843,6 +862,7 @@ extern "C" long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d) {
     ConvShape s;
     if (!conv_out_shape(d, s) || c1_shape_ok(d) || !fast_fwd_ok(d)) return 0;
     if (n16_shape_ok(d, d->Cout, d->Cin)) return 0;
+    if (limb_fwd_ok(d)) return limb_gemm_ws_floats(d->Cout, d->Cin, d->N, d->H * d->W);
     if (wino_use_fwd(d)) return wino_ws_floats(d);
     FastGemmArgs f;
     fill_fwd_args(d, s, f);
@@ -913,6 +933,13 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
     }
     if (fast_fwd_ok(d)) {
         FD_REQUIRE(wt, "fd_conv2d_fwd: weight-layout buffer required (fd_conv2d_fwd_wt_floats)");
+        if (limb_fwd_ok(d)) {
+            FD_REQUIRE(!stat_part, "fd_conv2d_fwd_stats: no statistics epilogue for this shape");
+            conv_log("fwd", "limb 1x1", d);
+            if (!wt_ready)
+                if (int rc = limb_weight_split_launch(w, wt, d->Cout, d->Cin, 0, st)) return rc;
+            return limb_gemm_launch(wt, x, y, bias, nullptr, ws, d->Cout, d->Cin, d->N, d->H * d->W, d->act, st);
+        }
         if (wino_use_fwd(d)) {
             conv_log("fwd", "wino", d);
             if (!wt_ready)
@@ -946,6 +973,7 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
 
 extern "C" long fd_conv2d_bwd_data_wt_floats(const fd_conv_desc* d) {
     if (!d || c1_shape_ok(d)) return 0;
+    if (limb_dgrad_ok(d)) return align4(limb_wt_floats(d->Cin, d->Cout));
     fd_conv_desc g;
     if (wino_dgrad_desc(d, g)) return align4(wino_wt_floats(&g));
     if (refl_wino_padded(d, g)) return align4(wino_wt_floats(&g));
@@ -958,6 +986,7 @@ extern "C" long fd_conv2d_bwd_data_ws_floats(const fd_conv_desc* d) {
     if (!d) return 0;
     ConvShape s;
     if (!conv_out_shape(d, s) || c1_shape_ok(d)) return 0;
+    if (limb_dgrad_ok(d)) return limb_gemm_ws_floats(d->Cin, d->Cout, d->N, d->H * d->W);
     {
         fd_conv_desc g;
         if (wino_dgrad_desc(d, g)) return wino_ws_floats(&g);
@@ -1034,6 +1063,12 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
                "fd_conv2d_bwd_data: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
     const int KH = d->KH, KW = d->KW;
+    if (limb_dgrad_ok(d)) {                              // 1x1 stride 1: gx[n][ci][p] = sum_co W[co][ci] gy[n][co][p], one GEMM with the transposed weights
+        conv_log("dgrad", "limb 1x1", d);
+        if (!wt_ready)
+            if (int rc = limb_weight_split_launch(w, wt_base, d->Cin, d->Cout, 1, st)) return rc;
+        return limb_gemm_launch(wt_base, gy, gx, nullptr, gx_add, ws, d->Cin, d->Cout, d->N, d->H * d->W, 0, st);
+    }
     {
         fd_conv_desc gd;
         conv_log("dgrad", wino_dgrad_desc(d, gd) ? "wino" : "direct", d);
@@ -1261,10 +1296,12 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
     if (c1_shape_ok(d)) return 0;                        // stencil kernels: no layouts
     if (kind == 0) {
         if (!fast_fwd_ok(d) || n16_shape_ok(d, d->Cout, d->Cin)) return 0;
+        if (limb_fwd_ok(d)) { fill(jobs[0], wt, 1, 1, 0, 1, 0, 1, 7); return 1; }
         fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? (wino_fwd_2d(d) ? 5 : 3) : 0);
         return 1;
     }
     const int KH = d->KH, KW = d->KW;
+    if (limb_dgrad_ok(d)) { fill(jobs[0], wt, 1, 1, 0, 1, 0, 1, 8); return 1; }
     {
         fd_conv_desc gd;
         if (wino_dgrad_desc(d, gd)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, wino_fwd_2d(&gd) ? 6 : 4); return 1; }
@@ -1331,6 +1368,7 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     else if (wino_use_wgrad(d)) slabs = wino_wgrad_ws_floats(d);
     else if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
     else { const int sp = wgrad_splits(d, s); slabs = sp > 1 ? (long)sp * wsz : 0; }
+    if (limb_wgrad_ok(d)) { const long l = limb_wgrad_ws_floats(d->Cout, d->Cin, d->N, d->H * d->W); slabs = l > slabs ? l : slabs; }   // (the direct kernel stays the fallback for unaligned tensors)
     const long bias_part = (long)d->Cout * CS_SPLITS;
     if (slabs < wsz) slabs = wsz;                            // accumulate mode stages a single slab
     return slabs > bias_part ? slabs : bias_part;          // the two uses are sequential on the stream
@@ -1346,8 +1384,11 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
                "fd_conv2d_bwd_weight: tensor too large for 32-bit byte offsets (2 GiB per tensor)");
     hipStream_t st = (hipStream_t)stream;
     const long Np = (long)d->N * s.Ho * s.Wo;
-    conv_log("wgrad", narrow_wgrad_ok(d) ? "narrow" : stem_wgrad_ok(d) ? "stem" : wino_use_wgrad(d) ? "wino" : fast_wgrad_ok(d) ? "direct" : "generic", d);
-    if (narrow_wgrad_ok(d)) {
+    const bool limb_w = limb_wgrad_ok(d) && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
+    conv_log("wgrad", limb_w ? "limb 1x1" : narrow_wgrad_ok(d) ? "narrow" : stem_wgrad_ok(d) ? "stem" : wino_use_wgrad(d) ? "wino" : fast_wgrad_ok(d) ? "direct" : "generic", d);
+    if (limb_w) {
+        if (int rc = limb_wgrad_launch(x, gy, gw, ws, d->Cout, d->Cin, d->N, d->H * d->W, accumulate, st)) return rc;
+    } else if (narrow_wgrad_ok(d)) {
         if (int rc = narrow_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
     } else if (stem_wgrad_ok(d)) {
         if (int rc = stem_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;

@@ -94,3 +94,15 @@ long wino_wgrad_ws_floats(const fd_conv_desc* d);
 int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, float* gw, float* ws, int accumulate, hipStream_t st);
 // gw[m][c][t] (+)= sum_z slabs[z][m][t][c]
 int fast_wgrad_finish_launch(const float* slabs, float* gw, int M, int C, int T, int splits, int accumulate, hipStream_t st);
+
+// conv_limb.hip: 1x1 stride-1 convolutions as split-precision (3 x bf16 limbs, six products, fp32 accumulate) GEMMs on the bf16 MFMA
+bool limb_fwd_ok(const fd_conv_desc* d);
+bool limb_dgrad_ok(const fd_conv_desc* d);
+bool limb_wgrad_ok(const fd_conv_desc* d);
+long limb_wt_floats(long M, long K);                       // the pre-split weight image (conv_limb.h), in floats
+long limb_gemm_ws_floats(int M, int K, int Nb, int HW);    // split-K slabs of the forward / data-gradient GEMM
+int limb_weight_split_launch(const float* w, float* wt, int M, int K, int transposed, hipStream_t st);
+int limb_gemm_launch(const float* wt, const float* x, float* y, const float* bias, const float* add, float* ws, int M, int K, int Nb, int HW,
+                     int act, hipStream_t st);
+long limb_wgrad_ws_floats(int M, int C, int Nb, int HW);
+int limb_wgrad_launch(const float* x, const float* gy, float* gw, float* ws, int M, int C, int Nb, int HW, int accumulate, hipStream_t st);

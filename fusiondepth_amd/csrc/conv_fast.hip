@@ -566,10 +566,10 @@ void launch_cfg(const FastGemmArgs& a, int splits, hipStream_t st) {
     g.xcd_swizzle = (gx % 8 == 0 && gx >= 16) ? 1 : 0;
     const size_t lds = sizeof(float) * 2 * BKC * ((BM + 1) + BN);
     auto kern = k_conv_fast<WAVES_M, WAVES_N, WM, WN, BKC>;
-    static bool attr_set = false;
-    if (!attr_set) {   // allow > 64 KiB of dynamic LDS
+    static FdLdsAttrOnce attr_set;
+    if (attr_set.needed()) {   // allow > 64 KiB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(64 * WAVES_M * WAVES_N), lds, st, g);
 }
@@ -628,10 +628,10 @@ void launch_grp(const FastGemmArgs& a, const FastGemmGroup& q, hipStream_t st) {
     grp.first_bx[q.n] = gx;
     const size_t lds = sizeof(float) * 2 * BKC * ((BM + 1) + BN);
     auto kern = k_conv_fast_grp<WAVES_M, WAVES_N, WM, WN, BKC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static FdLdsAttrOnce attr_set;
+    if (attr_set.needed()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(kern, dim3(gx, fd_cdiv(a.M, BM), 1), dim3(64 * WAVES_M * WAVES_N), lds, st, a, grp);
 }

@@ -196,10 +196,10 @@ int n16_go2(const N16Args& a, hipStream_t st) {
     static_assert((4 * CG) * n16_cs(TR) >= 16 * MB * 4 * CG * 9, "the patch area also stages the weights");
     const size_t lds = sizeof(float) * (size_t)(4 * CG) * n16_cs(TR);
     auto kern = k_conv3x3_n16<CG, MB, TR, ACT>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static FdLdsAttrOnce attr_set;
+    if (attr_set.needed()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)((long)g.tiles_x * g.tiles_y * a.Nb)), dim3(256), lds, st, g);
     FD_LAUNCH_CHECK("k_conv3x3_n16");

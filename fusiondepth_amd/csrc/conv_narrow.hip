@@ -349,10 +349,10 @@ int narrow_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, 
     if (cg == 1) {
         hipLaunchKernelGGL(k_wgrad_narrow<1>, dim3(blocks), dim3(256), lds, st, a);
     } else {
-        static bool attr = false;
-        if (!attr) {
+        static FdLdsAttrOnce attr;
+        if (attr.needed()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_narrow<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr = true;
+            attr.mark();
         }
         hipLaunchKernelGGL(k_wgrad_narrow<2>, dim3(blocks), dim3(256), lds, st, a);
     }

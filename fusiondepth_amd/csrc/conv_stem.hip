@@ -203,10 +203,10 @@ inline int stem_num_cus() {
 template <int CP>
 int stem_go(const StemArgs& a, hipStream_t st) {
     const size_t lds = sizeof(float) * ((size_t)CP * 49 * 2 * ST_LDW + (size_t)2 * CP * ST_PR * 2 * ST_PC2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static FdLdsAttrOnce attr_set;
+    if (attr_set.needed()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv7s2_stem<CP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     const int ntiles = a.Nb * a.tiles_y * a.tiles_x;
     // one workgroup per CU (145 KB of LDS for six channels), looping over the tiles; with fewer tiles than CUs one tile each

@@ -1774,8 +1774,8 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
     const bool twod = mode == 1;
     const int sp = twod ? 4 * wino2d_ksplits(d) : (mode == 2 ? 1 : wino_splits(d, d->Cout, d->Cin));
     if (sp > 1 && !ws) { fd_set_error("wino conv: split-K workspace missing"); return -1; }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static FdLdsAttrOnce attr_set;
+    if (attr_set.needed()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2d), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1785,7 +1785,7 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p_dma<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p_dma<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     if (mode == 2) {
         const long img_tiles = (long)(d->H / 2) * (d->W / 2);
@@ -1799,8 +1799,8 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         if (vdma) {
             if (stat_part) hipLaunchKernelGGL(k_conv_wino2p_dma<true>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
             else if (d->Cout <= 32 && fd_tun().wino_fwd_halfm != 0) {          // the decoder's 32-channel blocks: both wave pairs on rows 0 .. 31
-                static bool attr_h = false;
-                if (!attr_h) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p_dma<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_h = true; }
+                static FdLdsAttrOnce attr_h;
+                if (attr_h.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2p_dma<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_h.mark(); }
                 hipLaunchKernelGGL((k_conv_wino2p_dma<false, true>), dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
             }
             else hipLaunchKernelGGL(k_conv_wino2p_dma<false>, dim3(gx2, gy2), dim3(WNT), sizeof(float) * W2D_LDS_FLOATS, st, g);
@@ -1899,13 +1899,13 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
         const int rem = WGP - g.adv_n * plane2;
         g.adv_y = rem / W2; g.adv_j = rem - g.adv_y * W2;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static FdLdsAttrOnce attr_set;
+    if (attr_set.needed()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     const int slice_major = 2;        // XCD-aware 1-D grid: layer1 HBM traffic 157 -> 76 MB per launch, step -0.5 %; (1: slice-major 3-D grid measured slower than 0)
     g.slice_major = slice_major;
@@ -1921,13 +1921,13 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
     const size_t lds = sizeof(float) * WG_LDS_FLOATS;
     const bool halfm = d->Cout <= 32 && fd_tun().wino_wgrad_halfm != 0;   // at most 32 output channels: two waves per K half (k_wgrad_wino<.., HALFM>)
     if (halfm) {
-        static bool attr_h = false;
-        if (!attr_h) {
+        static FdLdsAttrOnce attr_h;
+        if (attr_h.needed()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_h = true;
+            attr_h.mark();
         }
         if (twod) {
             if (d->pad_mode == 1) hipLaunchKernelGGL((k_wgrad_wino<true, true, true>), grid, dim3(WNT), lds, st, g);

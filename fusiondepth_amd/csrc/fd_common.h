@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 
 #define FD_WAVE 64
 
@@ -29,6 +30,16 @@ void fd_set_error(const char* fmt, ...);
             return (int)e__;                                                               \
         }                                                                                  \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize (> 64 KiB of dynamic LDS) is a PER-DEVICE property of a kernel: a launcher keeps one
+// of these per kernel family - bit d says that device d has the attribute.  Two host threads may both set it (idempotent); the bit
+// is published after the attribute is in place, so a thread that sees it never launches without.
+struct FdLdsAttrOnce {
+    std::atomic<unsigned long long> done{0};
+    static int dev_bit() { int dev = 0; (void)hipGetDevice(&dev); return dev & 63; }
+    bool needed() const { return !((done.load(std::memory_order_acquire) >> dev_bit()) & 1ull); }
+    void mark() { done.fetch_or(1ull << dev_bit(), std::memory_order_release); }
+};
 
 static inline int fd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(NT) k_bn_apply_train(const float* __restrict__
     if (VEC) {
         for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (HW >> 2); i += (long)gridDim.x * NT) {
             float4 v = ld4(x + base + 4 * i);
-            v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+            v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
             if (residual) { const float4 r = ld4(residual + base + 4 * i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
             if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
             st4(y + base + 4 * i, v);
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(NT) k_bn_apply_train(const float* __restrict__
         return;
     }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
-        float v = x[base + i] * a + b;
+        float v = fmaf(x[base + i], a, b);
         if (residual) v += residual[base + i];
         if (relu) v = v > 0.f ? v : 0.f;
         y[base + i] = v;
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(NT) k_bn_apply_parts(const float* __restrict__
     if (VEC) {
         for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (HW >> 2); i += (long)gridDim.x * NT) {
             float4 v = ld4(x + base + 4 * i);
-            v.x = v.x * a + b; v.y = v.y * a + b; v.z = v.z * a + b; v.w = v.w * a + b;
+            v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
             if (residual) { const float4 r = ld4(residual + base + 4 * i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
             if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
             st4(y + base + 4 * i, v);
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(NT) k_bn_apply_parts(const float* __restrict__
         return;
     }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
-        float v = x[base + i] * a + b;
+        float v = fmaf(x[base + i], a, b);
         if (residual) v += residual[base + i];
         if (relu) v = v > 0.f ? v : 0.f;
         y[base + i] = v;
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(NT) k_bn_apply_eval(const float* __restrict__ 
     const float b = (bias ? bias[c] : 0.f) - running_mean[c] * a;
     const long base = (long)nc * HW;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
-        float v = x[base + i] * a + b;
+        float v = fmaf(x[base + i], a, b);
         if (residual) v += residual[base + i];
         if (relu) v = v > 0.f ? v : 0.f;
         y[base + i] = v;
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(NT) k_bn_train_small(const float* __restrict__
         for (int k = 0; k < SMALL_K; ++k) {
             if (off[k] < 0) continue;
             float4 r = v[k];
-            r.x = r.x * a + b; r.y = r.y * a + b; r.z = r.z * a + b; r.w = r.w * a + b;
+            r.x = fmaf(r.x, a, b); r.y = fmaf(r.y, a, b); r.z = fmaf(r.z, a, b); r.w = fmaf(r.w, a, b);
             if (residual) { const float4 z = ld4(residual + off[k]); r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w; }
             if (relu) { r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f; }
             st4(y + off[k], r);
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(NT) k_bn_train_small_slabs(const float* __rest
         for (int k = 0; k < SMALL_K; ++k) {
             if (off[k] < 0) continue;
             float4 r = v[k];
-            r.x = r.x * a + b; r.y = r.y * a + b; r.z = r.z * a + b; r.w = r.w * a + b;
+            r.x = fmaf(r.x, a, b); r.y = fmaf(r.y, a, b); r.z = fmaf(r.z, a, b); r.w = fmaf(r.w, a, b);
             if (residual) { const float4 z = ld4(residual + off[k]); r.x += z.x; r.y += z.y; r.z += z.z; r.w += z.w; }
             if (relu) { r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f; }
             st4(y + off[k], r);

@@ -219,7 +219,8 @@ int check_refine(const fd_refine_cfg* c, const char* who) {
     FD_REQUIRE(c, "%s: cfg is NULL", who);
     FD_REQUIRE(c->B > 0 && c->H > 0 && c->W > 0 && c->n_scales >= 1 && c->n_scales <= 4, "%s: bad sizes", who);
     FD_REQUIRE(c->min_depth > 0 && c->max_depth > c->min_depth, "%s: bad depth range", who);
-    FD_REQUIRE(0 <= c->crop_y0 && c->crop_y0 < c->crop_y1 && c->crop_y1 <= c->H && 0 <= c->crop_x0 && c->crop_x0 < c->crop_x1 && c->crop_x1 <= c->W,
+    // an EMPTY window (y0 == y1 or x0 == x1) is legal: nothing is selected, the medians are NaN like torch.median of an empty selection
+    FD_REQUIRE(0 <= c->crop_y0 && c->crop_y0 <= c->crop_y1 && c->crop_y1 <= c->H && 0 <= c->crop_x0 && c->crop_x0 <= c->crop_x1 && c->crop_x1 <= c->W,
                "%s: crop [%d,%d) x [%d,%d) outside %dx%d", who, c->crop_y0, c->crop_y1, c->crop_x0, c->crop_x1, c->H, c->W);
     for (int s = 0; s < c->n_scales; ++s) {
         const int r = c->Hs[s] > 0 ? c->H / c->Hs[s] : 0;

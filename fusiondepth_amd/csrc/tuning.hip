@@ -22,6 +22,7 @@ fd_tuning make_defaults() {
     t.wino_fwd_2d_m128 = 1;
     t.grp_tile64_below = 0;
     t.wino_wgrad_xcd_few = 1; t.wino_fwd_halfm = 1; t.wino_wgrad_halfm = 1;
+    t.limb_1x1 = 1; t.limb_depth = 2; t.limb_target = 256; t.limb_split_max_out = 4194304; t.limb_wgrad_target = 256;
     t.wino_min_cout = 32; t.wino_wgrad_min_cout = 32;     // the decoder's 32-channel blocks with half a tile idle: profiles/round5_decoder_m32_time.log
     return t;
 }
@@ -44,6 +45,7 @@ extern "C" int fd_set_tuning(const fd_tuning* t) {
     n.size = (int)sizeof(fd_tuning);
     FD_REQUIRE(n.wino_target >= 1 && n.wino_wgrad_target >= 1 && n.conv_target >= 1 && n.wgrad_target >= 1,
                "fd_set_tuning: workgroup targets must be >= 1");
+    FD_REQUIRE(n.limb_depth >= 2 && n.limb_depth <= 4 && n.limb_target >= 1 && n.limb_wgrad_target >= 1, "fd_set_tuning: limb_depth must be 2..4, limb_target >= 1");
     FD_REQUIRE(n.wino_min_cout >= 1 && n.wino_wgrad_min_cout >= 1, "fd_set_tuning: wino_min_cout / wino_wgrad_min_cout must be >= 1");
     FD_REQUIRE(n.force_cfg >= -1 && n.force_cfg <= 2 && n.force_splits >= 1, "fd_set_tuning: force_cfg must be -1..2, force_splits >= 1");
     g_tuning = n;

@@ -198,3 +198,7 @@ def broadcast_module_state(modules, src=0, group=None):
     for m in modules:
         for t in list(m.parameters()) + list(m.buffers()):
             dist.broadcast(t.data, src=src, group=group)
+    # the writes went through .data: torch's version counters did not move, so the cached kernel-side weight layouts must be told
+    from . import functional as FD
+    FD.bump_weights_epoch()
+    FD.invalidate_frozen_layouts()

@@ -696,6 +696,17 @@ def bump_weights_epoch():
     _WEIGHTS_EPOCH[0] += 1
 
 
+_FROZEN_EPOCH = [0]
+
+
+def invalidate_frozen_layouts():
+    """Frozen weights' layouts ignore the per-optimiser-step epoch; their stamp is (``_version``, this epoch, ``data_ptr``).  A write that
+    torch's version counter does not see - ``p.data.copy_``, a broadcast into ``p.data``, a raw kernel - must be followed by this call
+    (``Refiner._load_pretrained``, ``Trainer.load_model`` and ``dp.broadcast_module_state`` do it): every frozen layout is re-derived
+    at its next use."""
+    _FROZEN_EPOCH[0] += 1
+
+
 def enable_weight_cache(params, frozen=False):
     """``frozen``: weights that no optimiser touches (the Refiner's stage-1 networks).  Their layouts are derived once and stay valid
     across optimiser steps (the epoch stamp that invalidates trained weights' layouts after every Adam launch is ignored; an in-place
@@ -705,12 +716,18 @@ def enable_weight_cache(params, frozen=False):
         if p.dim() == 4 and not hasattr(p, "_fd_cache_id"):
             p._fd_cache_id = _NEXT_CACHE_ID[0]
             _NEXT_CACHE_ID[0] += 1
-        if p.dim() == 4 and frozen:
-            p._fd_frozen = True
+        if p.dim() == 4:
+            if frozen:
+                p._fd_frozen = True
+            elif getattr(p, "_fd_frozen", False):          # a formerly frozen parameter that is trained now: back under the optimiser epoch
+                p._fd_frozen = False
+                _drop_plan()
 
 
 def _layout_stamp(w):
-    return (w._version, 0 if getattr(w, "_fd_frozen", False) else _WEIGHTS_EPOCH[0], w.data_ptr())
+    if getattr(w, "_fd_frozen", False):
+        return (w._version, -1 - _FROZEN_EPOCH[0], w.data_ptr())
+    return (w._version, _WEIGHTS_EPOCH[0], w.data_ptr())
 
 
 def enable_direct_grad(params):
@@ -719,6 +736,9 @@ def enable_direct_grad(params):
     which would launch one ATen add per parameter per micro-batch (~600 tiny kernels per optimiser step)."""
     for p in params:
         p._fd_direct_grad = True
+        if getattr(p, "_fd_frozen", False):                # it gets gradients, so something will change it
+            p._fd_frozen = False
+            _drop_plan()
 
 
 # ---- "this parameter's gradient is complete" notifications ------------------------------------------------------------------
@@ -788,14 +808,18 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
     stamp = _layout_stamp(w)
     ent = _WT_CACHE.get(key)
     if ent is not None:
-        if _LATE["event"] is not None and len(ent) > 4 and ent[4]:
+        if _LATE["event"] is not None and ent[4]:
             _wait_late_layouts()
+        if ent[6] and not getattr(w, "_fd_frozen", False) and _WEIGHTS_EPOCH[0] - ent[5] > _PLAN_IDLE_STEPS:
+            _drop_plan()                # it left the per-step refresh while idle and is in use again: let the next plan include it
+        ent[5] = _WEIGHTS_EPOCH[0]
         if ent[0] == stamp:
             return ent[1], 1
         ent[0] = stamp
         return ent[1], 0
     buf = torch.empty((nfloats,), device=w.device, dtype=torch.float32)
-    _WT_CACHE[key] = [stamp, buf, desc, weakref.ref(w), False]
+    # [stamp, layout buffer, conv descriptor, weakref(parameter), refreshed on the side stream, epoch of the last use, left out of the plan]
+    _WT_CACHE[key] = [stamp, buf, desc, weakref.ref(w), False, _WEIGHTS_EPOCH[0], False]
     if not getattr(w, "_fd_frozen", False):
         _drop_plan()                    # a layout the plan does not know: fall back to per-call re-layout until rebuilt
     return buf, 0
@@ -803,14 +827,31 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
 
 # One-launch refresh of every cached layout (fd_relayout_batch): built once the cache is populated (after the first full
 # forward + backward), run by adam_step* right after the weights change.
+# A trained weight keeps one layout per input shape it was used at (the stacked training batch AND the validation batch: the format
+# depends on the kernel family).  A layout that no convolution has used for _PLAN_IDLE_STEPS optimiser steps stays OUT of the per-step
+# refresh - it is re-derived lazily by its next user through the stamp mismatch, which also drops the plan so that the layout is
+# refreshed with the others again while it stays in use (a validation pass of several batches: one rebuild, then one launch per step) -
+# and after _RETIRE_IDLE_STEPS its buffer is released (a rare shape no longer costs traffic and memory on every step).
 _WT_PLAN = [None]
+_PLAN_IDLE_STEPS = 8
+_RETIRE_IDLE_STEPS = 512
 
 
 def build_weight_plan():
     """Collect the re-layout jobs of every cached weight layout into a device table; returns the number of jobs."""
     from ._lib import RelayoutJob
     evict_dead_weight_layouts()
-    ents = [(k, e) for k, e in _WT_CACHE.items() if len(e) >= 4 and e[2] is not None and not getattr(e[3](), "_fd_frozen", False)]
+    _PLAN_STALE[0] = False
+    now = _WEIGHTS_EPOCH[0]
+    for k in [k for k, e in _WT_CACHE.items() if now - e[5] > _RETIRE_IDLE_STEPS and not getattr(e[3](), "_fd_frozen", False)]:
+        _WT_RETIRED.append(_WT_CACHE.pop(k)[1])
+    ents = []
+    for k, e in _WT_CACHE.items():
+        if e[2] is None or getattr(e[3](), "_fd_frozen", False):
+            continue
+        e[6] = now - e[5] > _PLAN_IDLE_STEPS
+        if not e[6]:
+            ents.append((k, e))
     if not ents:
         _drop_plan()
         return 0
@@ -830,8 +871,6 @@ def build_weight_plan():
         return (dev, n, blocks, [k for k, _ in part]), n
     is_late = lambda k, e: k[1] != "f" or e[1].numel() >= _LATE_MIN_FLOATS
     for k, e in ents:
-        while len(e) < 5:
-            e.append(False)
         e[4] = bool(is_late(k, e))
     early, n_early = table([(k, e) for k, e in ents if not e[4]])
     late, n_late = table([(k, e) for k, e in ents if e[4]])
@@ -871,7 +910,17 @@ def refresh_weight_layouts():
             w = e[3]()
             if w is not None:
                 e[0] = _layout_stamp(w)
+            if _WEIGHTS_EPOCH[0] - e[5] > _PLAN_IDLE_STEPS:
+                _PLAN_STALE[0] = True          # refreshed, but nobody has read it for a while: the owner rebuilds the plan without it
     return True
+
+
+_PLAN_STALE = [False]
+
+
+def weight_plan_needs_rebuild():
+    """No plan yet, or the plan carries layouts that have gone idle (``_PLAN_IDLE_STEPS``): ``build_weight_plan`` leaves those out."""
+    return _WT_PLAN[0] is None or _PLAN_STALE[0]
 
 
 # Shape-keyed plans: the descriptor of a convolution and the workspace / layout sizes the library reports for it depend only on
@@ -1699,7 +1748,12 @@ def refine_inputs(disps, beam, two_cha, inv_Ks, height, width, min_depth, max_de
         cfg.Hs[s], cfg.Ws[s] = (int(disps[s].shape[2]), int(disps[s].shape[3]))
         ds.append(d0 if s == 0 else (None if pool_disp0 else f32(disps[s].detach())))
         ks.append(f32(inv_Ks[s].detach()) if catxy else None)
-    cfg.crop_y0, cfg.crop_y1, cfg.crop_x0, cfg.crop_x1 = (int(v) for v in crop)
+    # the reference writes `crop_mask[:, :, 78:190, 23:617] = 1` (refiner.py:329): a slice, i.e. silently clamped to the plane - at 96x320 or
+    # 128x416 the window shrinks, below 79 rows it is empty (medians NaN, as torch.median of an empty selection); ADVICE round 5
+    y0, y1, x0, x1 = (int(v) for v in crop)
+    y1, x1 = min(y1, int(height)), min(x1, int(width))
+    y0, x0 = min(y0, y1), min(x0, x1)
+    cfg.crop_y0, cfg.crop_y1, cfg.crop_x0, cfg.crop_x1 = y0, y1, x0, x1
     cfg.min_depth, cfg.max_depth, cfg.catxy, cfg.pool_disp0 = float(min_depth), float(max_depth), int(bool(catxy)), int(bool(pool_disp0))
     C = 1 + (3 if catxy else 0) + 2
     outs = [_empty((B, C, cfg.Hs[s], cfg.Ws[s]), d0) for s in range(S)]

@@ -144,6 +144,7 @@ class Refiner(Trainer):
                     if k in own:
                         own[k].copy_(v)
         FD.bump_weights_epoch()
+        FD.invalidate_frozen_layouts()
 
     def set_train(self):
         """refiner.py:80-160: the depth / pose networks stay in eval mode; only the refine decoder trains."""

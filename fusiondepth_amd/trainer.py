@@ -311,8 +311,10 @@ class Trainer:
         """After the first full forward + backward every conv weight has its cached kernel-side layouts: collect their
         re-layout work into one device job table, so that from now on Adam is followed by ONE re-layout launch instead of
         ~220 small ones spread over the next step.  (Not capturable: call outside graph capture.)"""
-        if FD._WT_PLAN[0] is None and FD.build_weight_plan() > 0:
-            FD.refresh_weight_layouts()
+        if FD.weight_plan_needs_rebuild():
+            had_plan = FD._WT_PLAN[0] is not None
+            if FD.build_weight_plan() > 0 and not had_plan:
+                FD.refresh_weight_layouts()
 
     def optimizer_step(self, grad_scale=1.0):
         """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8).step(); zero_grad()  as one fused kernel.  The step
@@ -1088,6 +1090,7 @@ class Trainer:
                     if k in model_dict:
                         model_dict[k].copy_(v)              # in place: parameters stay views of the flat buffer
         FD.bump_weights_epoch()
+        FD.invalidate_frozen_layouts()
         FD.refresh_weight_layouts()       # a captured step holds no per-conv re-layout launches: refresh the cached copies now
         adam = os.path.join(folder, "adam.pth")
         if os.path.isfile(adam):

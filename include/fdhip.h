@@ -76,6 +76,13 @@ typedef struct fd_tuning {
     int wino_wgrad_halfm;         /* 1   Winograd weight gradients with <= 32 output channels: the tile's idle wave pair takes half of every chunk's K-steps */
     int grp_tile64_below;         /* 0   grouped launches (the four parity classes of a stride-2 data gradient) with fewer than this many 64x128
                                          workgroups run on 64x64 tiles (twice the workgroups, half the work of the longest one); 0: never */
+    int limb_1x1;                 /* 1   1x1 stride-1 convolutions with >= 64 channels on both sides (ResNet-50 bottlenecks) as split-precision GEMMs on the
+                                         bf16 MFMA: every fp32 operand = 3 bf16 limbs, six limb products, fp32 accumulation - fp32 accuracy
+                                         (csrc/conv_limb.hip); 0: the f32-MFMA direct kernels */
+    int limb_depth;               /* 2   K-chunks (16 channels each) of operands a thread of the limb GEMMs keeps in flight (2 or 4) */
+    int limb_target;              /* 256 workgroups a limb forward / data-gradient launch is split-K'd up to ... */
+    int limb_split_max_out;       /* 4194304   ... when its output has at most this many floats (a split costs a slab round trip of the output) */
+    int limb_wgrad_target;        /* 256 workgroups a limb weight-gradient launch is pixel-sliced up to (x2 for its 4-wave tiles) */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);

@@ -44,6 +44,19 @@ def lidar_4beam(rng, B, H, W, density=3):
     return beam
 
 
+def lidar_random(rng, B, H, W, n_points, roi=(76, 190, 2, 638), lo=5.0, hi=65.0):
+    """The r100 / r200 inputs of BASELINE config 5: ``n_points`` uniformly random pixels of the ROI per image
+    carry a return, depth U[lo, hi] m, stored / 100 like the 4-beam maps (the reference's ``random100`` / ``random200`` scans)."""
+    beam = np.zeros((B, 1, H, W), dtype=np.float32)
+    r0, r1, c0, c1 = roi
+    r0, r1, c0, c1 = min(r0, H - 1), min(r1, H), min(c0, W - 1), min(c1, W)
+    for b in range(B):
+        flat = rng.choice((r1 - r0) * (c1 - c0), size=n_points, replace=False)
+        rows, cols = r0 + flat // (c1 - c0), c0 + flat % (c1 - c0)
+        beam[b, 0, rows, cols] = rng.uniform(lo, hi, size=n_points).astype(np.float32) / 100.0
+    return beam
+
+
 def batch_inputs(seed, B, H, W, num_scales=4, frame_ids=(0, -1, 1)):
     """Dict with the schema of mono_dataset.py:109-228 (tensor entries only)."""
     rng = np.random.RandomState(seed)

@@ -266,3 +266,78 @@ def test_channel_padded_refine_decoder_equals_the_unpadded_one(fdtune):
         a, b = res[True][1][n], res[False][1][n]
         assert a.shape == b.shape
         assert np.abs(a - b).sum() <= 2e-5 * np.abs(b).sum() + 1e-9, "gradient of %s: %g of %g" % (n, np.abs(a - b).sum(), np.abs(b).sum())
+
+
+def _sparse_refiner_inputs(seed, B, H, W, n_points):
+    """refiner inputs whose LiDAR maps are r100 / r200 samples (~3.5 - 7 m returns, like gin.refiner_inputs) instead of 4 scan lines"""
+    from oracle import scatter as OS
+    inp, noise = gin.refiner_inputs(seed, B, H, W)
+    roi = (76, 190, 2, 638)
+    for i, f in enumerate((0, -1, 1)):
+        beam = gin.lidar_random(np.random.RandomState(seed + 30 + i), B, H, W, n_points, roi, lo=3.5, hi=7.0)
+        two = np.stack([np.stack(OS.scatter_2channel_c(beam[b, 0], roi)) for b in range(B)])
+        inp[("2channel", f, 0)] = torch.from_numpy(two)
+        if f == 0:
+            inp["2channel"] = torch.from_numpy(two)
+            inp["4beam"] = torch.from_numpy(beam)
+    return inp, noise
+
+
+@pytest.mark.parametrize("n_points", [100, 200], ids=["r100", "r200"])
+def test_refiner_step_on_random_sample_lidar_vs_oracle(n_points):
+    """BASELINE config 5's sparse inputs through a Refiner step ("missing" 4): r100 / r200 maps - 100 / 200 returns per
+    image - make the masked medians of refiner.py:316-348 and the SI-log reductions of refiner.py:557-563 run on a few dozen selected
+    pixels (the small-count path of the radix select and of the masked sums).  One process_batch + backward against the oracle's
+    refiner: every loss, the refined disparities, the gradient of every refine-decoder parameter."""
+    import conftest
+    B, H, W = 1, 192, 640
+    rf, oopt, omodels = _make(B, H, W)
+    inp, noise = _sparse_refiner_inputs(860 + n_points, B, H, W, n_points)
+    assert int((inp["4beam"] > 0).sum()) == B * n_points
+    ginp = {k: v.cuda() for k, v in inp.items()}
+    ginp["_noise"] = [n.cuda() for n in noise]
+    outs_o, lo = OR.process_batch(oopt, omodels, inp, noise)
+    for p in omodels["refine2d_decoder"].parameters():
+        p.grad = None
+    lo["loss"].backward()
+    outputs, losses = rf.process_batch(ginp)
+    assert set(losses) == set(lo)
+    for k in lo:
+        a, b = float(losses[k].detach()), float(lo[k])
+        assert np.isnan(a) == np.isnan(b), "%s: HIP %r, oracle %r" % (k, a, b)
+        if not np.isnan(b):
+            conftest.report("refiner %s-point LiDAR: %s |HIP - oracle| / |oracle|" % (n_points, k), abs(a - b) / max(abs(b), 1e-30), 3e-4)
+            assert_close(a, b, rtol=3e-4, atol=1e-7, what=k)
+    for s in range(4):
+        assert_close(outputs[("disp", s)].detach().cpu().numpy(), outs_o[("disp", s)].detach().numpy(), rtol=1e-3, atol=1e-4,
+                     what="refined disp%d" % s)
+    losses["loss"].backward()
+    num = den = 0.0
+    for (n, p), po in zip(rf.models["refine2d_decoder"].named_parameters(), omodels["refine2d_decoder"].parameters()):
+        assert (p.grad is None) == (po.grad is None), n
+        if po.grad is None:
+            continue
+        d = p.grad.cpu().double() - po.grad.double()
+        num += float((d * d).sum()); den += float((po.grad.double() ** 2).sum())
+    e = (num / den) ** 0.5
+    conftest.report("refiner %s-point LiDAR: refine-decoder gradient, relative L2 vs the float32 oracle" % n_points, e, 5e-3)
+    assert den > 0 and e <= 5e-3
+
+
+@pytest.mark.parametrize("H,W", [(96, 320), (128, 416)])
+def test_refine_inputs_clamp_the_crop_like_the_reference(H, W):
+    """refiner.py:329 ``crop_mask[:, :, 78:190, 23:617] = 1`` is a slice: on a plane smaller than the window it is clamped silently
+    (the library rejected the unclamped window).  FD.refine_inputs == the oracle's refine_inputs at 96x320 / 128x416."""
+    from fusiondepth_amd import functional as FD
+    from oracle import layers as OL
+    B = 2
+    rng = np.random.RandomState(5)
+    disps = [torch.from_numpy(rng.uniform(0.05, 0.9, size=(B, 1, H >> s, W >> s)).astype(np.float32)) for s in range(4)]
+    beam = torch.from_numpy(gin.lidar_random(rng, B, H, W, 150, roi=(H // 3, H - 2, 2, W - 2), lo=3.5, hi=7.0))
+    two = torch.from_numpy(rng.uniform(0, 1, size=(B, 2, H, W)).astype(np.float32))
+    inv_K = [gin.intrinsics(B, H, W, s)[1] for s in range(4)]
+    oopt = OR.default_opt(batch_size=B, height=H, width=W)
+    want = OR.refine_inputs(oopt, {("disp", s): disps[s] for s in range(4)}, {"4beam": beam, "2channel": two, **{("inv_K", s): inv_K[s] for s in range(4)}})
+    got = FD.refine_inputs([d.cuda() for d in disps], beam.cuda(), two.cuda(), [k.cuda() for k in inv_K], H, W, oopt.min_depth, oopt.max_depth)
+    for s in range(4):
+        assert_close(got[s].cpu().numpy(), want[s].numpy(), rtol=2e-5, atol=2e-6, what="refine inputs scale %d at %dx%d" % (s, H, W))

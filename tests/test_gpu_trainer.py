@@ -348,6 +348,103 @@ def test_resnet50_full_size_backward_against_float64():
         assert e_hip <= bound, "disp grad %d: HIP %.3g, float32 oracle %.3g" % (s_, e_hip, e_ref)
 
 
+def _oracle_backward_accumulated(models, opt, mbs, double):
+    """The reference's accumulate-then-step window (trainer.py:237-248): per micro-batch ``(loss / accumulate_step).backward()``,
+    parameter gradients summed by autograd.  -> (flat gradient per network, [per micro-batch {scale: d window-loss / d disp}], window loss)"""
+    for m in models.values():
+        for p_ in m.parameters():
+            p_.grad = None
+    disp, total = [], 0.0
+    for inp, noise in mbs:
+        i = _to64(inp) if double else {k: v.clone() for k, v in inp.items()}
+        n = [x.double() for x in noise] if double else noise
+        outs, losses = OT.process_batch(opt, models, i, n)
+        for s_ in range(4):
+            outs[("disp", s_)].retain_grad()
+        (losses["loss"] / len(mbs)).backward()
+        total += float(losses["loss"]) / len(mbs)
+        disp.append({s_: outs[("disp", s_)].grad.double().numpy() for s_ in range(4)})
+    per_net = {}
+    for k, m in models.items():
+        gs = [p_.grad.reshape(-1).double() if p_.grad is not None else torch.zeros(p_.numel(), dtype=torch.float64) for p_ in m.parameters()]
+        per_net[k] = torch.cat(gs).numpy()
+    return per_net, disp, total
+
+
+def _full_size_backward_against_float64(tag, H, W, B, groups, seed):
+    """BACKWARD of one optimiser step's window at a BASELINE configuration's real size ("missing" 3): the gradient of
+    the window loss w.r.t. every parameter of every network (flat per network: relative L2 distance and norm) and w.r.t. every
+    ("disp", s), of the HIP trainer's ONE stacked pass over the ``groups`` micro-batches (grouped BatchNorm statistics, per-group loss
+    reductions: trainer.py:237-248, 268-319, 425-596) against ``groups`` separate passes of the oracle's graph in float64, summed.
+    Yardstick: the float32 oracle's own distance from float64 on the same quantity; bounds as in the ResNet-50 test
+    (max(1e-3, 2x) on relative L2 / L1, max(1e-4, 3x) on the norms)."""
+    import conftest
+    opt = _opts(num_layers=18, height=H, width=W, batch_size=B * groups)
+    tr, ot = _make_pair(opt)
+    assert tr.batch_size == B and tr.accumulate_step == groups
+    mbs = [_batch(B, H, W, seed + g) for g in range(groups)]
+    ginps = []
+    for inp, noise in mbs:
+        g = {k: v.cuda() for k, v in inp.items()}
+        g["_noise"] = [n.cuda() for n in noise]
+        ginps.append(g)
+    tr.flat.zero_grad()
+    if groups == 1:
+        outs_g, losses_g = tr.process_batch(ginps[0])
+    else:
+        outs_g, losses_g = tr.process_batch(tr.stack_micro_batches(ginps), groups=groups)
+    for s_ in range(4):
+        outs_g[("disp", s_)].retain_grad()
+    losses_g["loss"].backward()
+    tr._join_side_streams()
+    torch.cuda.synchronize()
+    hip_net, off = {}, 0
+    flat = tr.flat.flat_grad.double().cpu().numpy()
+    for k, m in tr.models.items():
+        n = sum(p_.numel() for p_ in m.parameters())
+        hip_net[k] = flat[off:off + n]
+        off += n
+    assert off == flat.size
+    hip_disp = {s_: outs_g[("disp", s_)].grad.double().cpu().numpy() for s_ in range(4)}
+    m64 = _float64_models(ot.models)          # (copied before the float32 pass leaves non-leaf tensors on the modules)
+    n32, d32, l32 = _oracle_backward_accumulated(ot.models, ot.opt, mbs, False)
+    n64, d64, l64 = _oracle_backward_accumulated(m64, ot.opt, mbs, True)
+    assert abs(float(losses_g["loss"]) - l64) <= 1e-4 * abs(l64)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    for k in n64:
+        assert hip_net[k].shape == n64[k].shape, k
+        assert np.linalg.norm(n64[k]) > 0, k
+        e_hip, e_ref = rel(hip_net[k], n64[k]), rel(n32[k], n64[k])
+        bound = max(1e-3, 2 * e_ref)
+        conftest.report("%s backward: %s parameter gradient, relative L2 vs float64" % (tag, k), e_hip, bound, "(float32 oracle %.2e)" % e_ref)
+        assert e_hip <= bound, "%s: HIP %.3g, float32 oracle %.3g" % (k, e_hip, e_ref)
+        g64 = float(np.linalg.norm(n64[k]))
+        e_hip, e_ref = abs(float(np.linalg.norm(hip_net[k])) - g64) / g64, abs(float(np.linalg.norm(n32[k])) - g64) / g64
+        bound = max(1e-4, 3 * e_ref)
+        conftest.report("%s backward: %s gradient norm" % (tag, k), e_hip, bound, "(float32 oracle %.2e)" % e_ref)
+        assert e_hip <= bound, "%s norm: HIP %.3g, float32 oracle %.3g" % (k, e_hip, e_ref)
+    l1 = lambda a, b: float(np.abs(a - b).sum() / np.abs(b).sum())
+    for g in range(groups):
+        for s_ in range(4):
+            got = hip_disp[s_][g * B:(g + 1) * B]
+            e_hip, e_ref = l1(got, d64[g][s_]), l1(d32[g][s_], d64[g][s_])
+            bound = max(1e-3, 2 * e_ref)
+            conftest.report("%s backward: micro-batch %d d loss / d disp scale %d, relative L1 vs float64" % (tag, g, s_), e_hip, bound,
+                            "(float32 oracle %.2e)" % e_ref)
+            assert e_hip <= bound, "micro-batch %d disp grad %d: HIP %.3g, float32 oracle %.3g" % (g, s_, e_hip, e_ref)
+
+
+def test_resnet18_batch12_stacked_backward_against_float64():
+    """BASELINE.json config 2 exactly - what bench.py times: ResNet-18, 640x192, --batch_size 12 = 2 micro-batches of 6 as ONE stacked
+    pass; parameter gradients of all six networks and d loss / d disp_s against two float64 oracle passes summed."""
+    _full_size_backward_against_float64("R18 640x192 b6x2 (BASELINE config 2)", 192, 640, 6, 2, 770)
+
+
+def test_resnet18_1024x320_batch8_backward_against_float64():
+    """One rank's share of BASELINE.json config 4 at its real size, backward: ResNet-18, 1024x320, --batch_size 8."""
+    _full_size_backward_against_float64("R18 1024x320 b8 (BASELINE config 4, one rank)", 320, 1024, 8, 1, 775)
+
+
 def test_resnet18_1024x320_batch8_forward_against_float64():
     """One rank's share of BASELINE.json config 4 at its real size: ResNet-18, 1024x320, --batch_size 8
     (one micro-batch of 8) - every ("disp", s), ("depth", 0, 0) and every loss of a training forward against float64."""
