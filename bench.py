@@ -35,6 +35,13 @@ import torch.distributed as dist  # noqa: E402
 CONV_GFLOP_FWD_BWD = {(18, 192, 640): 187.3, (50, 192, 640): 406.1, (18, 320, 1024): 499.4, (50, 320, 1024): 1083.0}
 LOSS_BYTES_PER_PIXEL = 343.7          # compulsory fwd+bwd HBM traffic of the fused loss path per image
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+# what the arithmetic is, next to `dtype` (an undisclosed precision change would void the line).  Every tensor is fp32;
+# products and sums are fp32 (v_mfma_f32_32x32x2_f32 / 16x16x4: exact fp32, Winograd transforms in fp32) EXCEPT the 1x1 stride-1
+# convolutions with >= 64 channels on both sides (csrc/conv_limb.hip: ResNet-50 bottlenecks; on the ResNet-18 configurations only the
+# PoseDecoder's 512 -> 256 squeeze): each fp32 operand is split exactly into three bf16 limbs, the product is six bf16 MFMAs accumulated
+# in fp32 - error against float64 equal to the f32 kernels' (tests/test_gpu_limb.py), all float64-anchored parity bounds unchanged.
+ARITH_NOTE = ("fp32 storage, fp32 accumulate; products fp32-exact (f32 MFMA) except 1x1 stride-1 convolutions with >= 64 channels: "
+              "bf16x3 split, six products, fp32 accumulate (fp32-equal error vs float64; fd_tuning.limb_1x1 = 0 restores the f32 kernels)")
 PEAK_HBM_GBS = 8000.0
 
 
@@ -188,6 +195,21 @@ def roofline_probes(args, tr, batch):
                                  "frac": byts / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": loss_traffic,
                                  "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE of the three kernels, profiles/%s)"
                                                  % loss_traffic_src, "us_per_launch": ms * 1e3, "bytes_per_launch": byts}
+    if loss_traffic is not None:
+        # The bound that binds: this path is vector-issue-bound, not HBM-bound.  The instruction count is a
+        # property of the (unchanged, sha-checked) kernel at this batch and size - profiles/round3_pmc_loss.md: SQ_INSTS_VALU of
+        # k_photo_ms<true,true>, 102.4 M wave-instructions = 6.55 G lane-instructions per launch; pure issue time at the measured
+        # per-instruction rates 145.5 us (profiles/round5_pmc_loss.md).  Peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz.
+        lane_instr, issue_us, peak_slots = 102.4e6 * 64, 145.5, 256 * 4 * 32 * 2.4e9
+        out["roofline_loss_path"]["valu"] = {
+            "bound": "vector issue", "lane_instructions_per_launch": lane_instr, "peak_lane_slots_per_s": peak_slots,
+            "achieved_lane_instructions_per_s": lane_instr / (ms * 1e-3), "frac": lane_instr / (ms * 1e-3) / peak_slots,
+            "issue_us_at_measured_rates": issue_us, "issue_efficiency": issue_us / (ms * 1e3),
+            "note": "k_photo_ms executes 1 110 lane-instructions per pixel-visit; `frac` = lane-instructions / s over one lane-slot per "
+                    "lane and clock (an fp32 add / mul / fma issues a wave in 2.6 - 3.3 cycles, DPP / compare / convert in 4.3 - 5: the "
+                    "mix's own ceiling is 0.45 of the slot peak); `issue_efficiency` = the kernel's pure issue time over the whole path's "
+                    "time (k_photo_ms alone: 0.55).  0.40 of the HBM roofline would need the path in 158 us - below the 145.5 us of "
+                    "issue plus the 47 us of the path's other launches: unreachable for this arithmetic in fp32 (profiles/round5_pmc_loss.md)"}
     return out
 
 
@@ -368,7 +390,8 @@ def run_other_config(args):
         r.update({"final_loss": loss if loss == loss else None,
              "final_loss_photometric": float(sum(losses["loss/%d" % s_].detach() for s_ in range(4)) / 4.0),
              "params_finite": bool(torch.isfinite(tr.flat.flat_param).all()),
-             "workload": "ResNet-%d, %dx%d, --batch_size %d (= %d micro-batches of %d stacked), fwd+bwd+Adam" % (layers, W, H, opt.batch_size, tr.accumulate_step, tr.batch_size)})
+             "workload": "ResNet-%d, %dx%d, --batch_size %d (= %d micro-batches of %d stacked), fwd+bwd+Adam" % (layers, W, H, opt.batch_size, tr.accumulate_step, tr.batch_size),
+             "arith": ARITH_NOTE})
         key = (layers, H, W)
         if key in CONV_GFLOP_FWD_BWD:
             r["step_mfma_frac"] = CONV_GFLOP_FWD_BWD[key] * 1e9 * opt.batch_size / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS
@@ -579,20 +602,29 @@ def main():
     # K timed steps, bracketed by barrier + synchronize on both sides - `--windows` times over (default 3): a window of 20 steps is
     # 0.4 s, short enough for clock ramps and neighbours on the box to move it by a few percent, so the line reports the MEDIAN
     # window (value, ms_per_step) with the fastest / slowest beside it.  Every window is the MAX over ranks.
-    win, win_host = [], []
+    win, win_host, win_ranks = [], [], []
     for _ in range(max(args.windows, 1)):
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             losses = step_fn()
         t_host = time.perf_counter() - t0            # host time to ISSUE the steps (no sync): == dt when launch-bound
+        per_rank = None
+        if world > 1:
+            torch.cuda.synchronize()
+            t_own = time.perf_counter() - t0         # this rank's own K steps (its last all-reduce included), before it waits for the others
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], device="cuda", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        win.append(dt); win_host.append(t_host)
+            mine = torch.tensor([t_own, t_host], device="cuda", dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [(float(a[0]), float(a[1])) for a in allr]
+            t_host = max(h for _, h in per_rank)      # the slowest host decides when the step's last launch is out
+        win.append(dt); win_host.append(t_host); win_ranks.append(per_rank)
     order = sorted(range(len(win)), key=lambda i: win[i])
     mid = order[len(order) // 2]                 # the median window (an even count: the slower of the two middle ones)
     dt, t_host = win[mid], win_host[mid]
@@ -607,17 +639,25 @@ def main():
     flat64 = tr.flat.flat_param.double()
     param_checksum = [float(flat64.sum()), float(flat64.abs().sum())]        # equal between two runs of one build: the step is deterministic
     abs_rel_after = float(tr.val_metrics([val_batch])["de/abs_rel"])
+    rank_spread = None
+    if win_ranks[mid]:
+        own = [1e3 * a / args.steps for a, _ in win_ranks[mid]]
+        rank_spread = {"ms_per_step_by_rank": own, "ms_per_step_min": min(own), "ms_per_step_max": max(own),
+                       "host_issue_ms_per_step_by_rank": [1e3 * h / args.steps for _, h in win_ranks[mid]],
+                       "note": "each rank's own time for the window's steps up to its local synchronize (before the closing barrier): "
+                               "the spread is what the stragglers cost; ranks are pinned to their GPU's NUMA node (dp.pin_to_gpu_numa)"}
     if rank == 0:
         print("[bench] timed %d steps in %.3f s (host issue time %.3f s; median of %d windows: %s ms/step)"
               % (args.steps, dt, t_host, len(win), ", ".join("%.2f" % (1e3 * w / args.steps) for w in win)), file=sys.stderr, flush=True)
     result = {
         "metric": "training images/sec (%dx%d, ResNet-%d, 4-beam)" % (args.width, args.height, args.num_layers), "value": images / dt, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "arith": ARITH_NOTE, "data": "synthetic",
         "windows": {"n": len(win), "steps_each": args.steps, "ms_per_step": [1e3 * w / args.steps for w in win],
                     "ms_per_step_min": 1e3 * min(win) / args.steps, "ms_per_step_max": 1e3 * max(win) / args.steps,
                     "value_min": images / max(win), "value_max": images / min(win), "reported": "median window",
-                    "host_issue_ms_per_step": 1e3 * t_host / args.steps},
+                    "host_issue_ms_per_step": 1e3 * t_host / args.steps,
+                    "host_issue_note": "host time to issue one step's launches (no synchronisation); N > 1: the MAX over ranks"},
         "config": {"workload": "ResNet-%d encoders + DepthDecoder + PoseDecoder, %dx%d, 4-beam LiDAR, --batch_size %d per GPU "
                                "(= %d accumulated micro-batches of %d), frames [0,-1,1], 4 scales, fwd+bwd+Adam"
                                % (args.num_layers, args.width, args.height, opt.batch_size, tr.accumulate_step, tr.batch_size),
@@ -633,6 +673,7 @@ def main():
         result["step_mfma_frac"] = tf / PEAK_FP32_MFMA_TFLOPS
         result["step_conv_tflops_per_gpu"] = tf
     if world > 1:
+        result["rank_spread"] = rank_spread
         result.update(dp_probe(tr, step_fn, dt / args.steps, barrier))
         if result["ranks_seen"] != args.gpus or (result["backend"] != "nccl" and not args.share_device):
             sys.exit("bench.py: %d ranks answered over %r, expected %d over nccl (= RCCL)" % (result["ranks_seen"], result["backend"], args.gpus))

@@ -14,11 +14,120 @@ import torch
 import torch.distributed as dist
 
 
+# ---- host placement -----------------------------------------------------------------------------------------------------------
+# One process per GPU issues ~830 launches per step from Python; the step is within 1.2 - 1.6x of that issue time, so a rank whose
+# threads wander over both sockets (or share cores with another rank) becomes the straggler every all-reduce waits for.  Each rank is
+# pinned to cores of ITS GPU's NUMA node, the node's cores divided among the ranks whose GPUs hang off it.
+def _read(path):
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
+def _parse_cpulist(text):
+    cpus = []
+    for part in (text or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_nodes(n_gpus, sysfs="/sys", pci_ids=None):
+    """NUMA node of local GPU 0 .. n_gpus-1 (-1: unknown).  ``pci_ids`` (``"0000:c1:00.0"`` per device, from the HIP runtime) name the
+    devices exactly; without them the AMD display-class functions under ``<sysfs>/class/drm/card*/device`` are taken in PCI-address
+    order - the order HIP enumerates them in when HIP_VISIBLE_DEVICES does not permute it."""
+    if pci_ids:
+        return [int(_read(os.path.join(sysfs, "bus/pci/devices", a, "numa_node")) or -1) for a in pci_ids[:n_gpus]]
+    import glob
+    cards = {}
+    for dev in glob.glob(os.path.join(sysfs, "class/drm/card*/device")):
+        if "-" in os.path.basename(os.path.dirname(dev)):            # connectors (card0-DP-1)
+            continue
+        vendor = _read(os.path.join(dev, "vendor"))
+        if vendor is not None and vendor.lower() != "0x1002":
+            continue
+        addr = os.path.basename(os.path.realpath(dev)) if os.path.islink(dev) else (_read(os.path.join(dev, "pci_address")) or os.path.dirname(dev))
+        cards[addr] = int(_read(os.path.join(dev, "numa_node")) or -1)
+    nodes = [cards[a] for a in sorted(cards)]
+    return (nodes + [-1] * n_gpus)[:n_gpus]
+
+
+def affinity_plan(local_world, sysfs="/sys", pci_ids=None, online=None):
+    """-> one sorted CPU list per local rank: the cores of the rank's GPU's NUMA node, split evenly among the ranks on that node
+    in whole physical cores (hyper-thread siblings stay with their core); ranks with an unknown node share ``online`` (default:
+    this process's current affinity) the same way.  Pure function of the sysfs tree: testable on a faked topology."""
+    nodes = gpu_numa_nodes(local_world, sysfs, pci_ids)
+    if online is None:
+        online = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    allowed = set(online)
+    plan = [None] * local_world
+    for node in sorted(set(nodes)):
+        ranks = [r for r in range(local_world) if nodes[r] == node]
+        cpus = _parse_cpulist(_read(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node))) if node >= 0 else []
+        cpus = [c for c in cpus if c in allowed] or sorted(allowed)
+        # physical cores = groups of hyper-thread siblings (Linux lists a socket as "0-95,192-287": cores, then their siblings):
+        # a rank gets whole cores, never the sibling threads of another rank's cores
+        groups, seen = [], {}
+        for c in cpus:
+            sib = _parse_cpulist(_read(os.path.join(sysfs, "devices/system/cpu/cpu%d/topology/thread_siblings_list" % c))) or [c]
+            key = min(sib)
+            if key not in seen:
+                seen[key] = len(groups)
+                groups.append([])
+            groups[seen[key]].append(c)
+        per = max(len(groups) // len(ranks), 1)
+        for i, r in enumerate(ranks):
+            lo = (i * per) % len(groups)
+            plan[r] = sorted(c for grp in groups[lo:lo + per] for c in grp)
+    return plan
+
+
+def pin_to_gpu_numa(local_rank, local_world, sysfs="/sys", verbose=False):
+    """Pin this process (all its threads: called before the autograd / RCCL threads exist) to its share of its GPU's NUMA node.
+    Returns the CPU set, or None when the platform cannot (no sched_setaffinity) or FD_NO_AFFINITY is set."""
+    if os.environ.get("FD_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return None
+    pci = None
+    try:
+        if torch.cuda.is_available():
+            pci = []
+            for i in range(min(local_world, torch.cuda.device_count())):
+                p = torch.cuda.get_device_properties(i)
+                pci.append("%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id))
+            if len(pci) < local_world:
+                pci = None
+    except Exception:
+        pci = None
+    plan = affinity_plan(local_world, sysfs, pci)
+    mine = plan[local_rank]
+    shared = [r for r in range(local_world) if r != local_rank and set(plan[r]) & set(mine)]
+    if shared:
+        import warnings
+        warnings.warn("fusiondepth_amd.dp: rank %d shares host cores with local ranks %s (%d cores for %d ranks on its NUMA node) - the "
+                      "step is host-sensitive, expect stragglers" % (local_rank, shared, len(mine), local_world))
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    if verbose:
+        print("fusiondepth_amd.dp: local rank %d pinned to %d cores (%d..%d)" % (local_rank, len(mine), mine[0], mine[-1]))
+    return mine
+
+
 def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's env (RANK/WORLD_SIZE/MASTER_*) if world > 1."""
+    """Initialise torch.distributed from torchrun's env (RANK/WORLD_SIZE/MASTER_*) if world > 1; with more than one rank on this
+    host each rank is pinned to cores of its GPU's NUMA node first (``pin_to_gpu_numa``)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1 and local_world > 1 and not dist.is_initialized():
+        pin_to_gpu_numa(local_rank, local_world)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -287,3 +287,71 @@ def test_trainer_bucket_layout_for_the_real_networks():
     sizes = [4 * (x[1] - x[0]) for x in b]
     assert max(sizes) < 2 * (25 << 20) + (10 << 20) and 6 <= len(b) <= 16, sizes
     assert flat.numel() == 49182752 + 4 * (512 * 1000 + 1000)          # SURVEY 8e's 49 182 752 trained parameters + the four unused fc heads
+
+
+# ---- host placement ---------------------------------------------------------------------------------
+def _fake_topology(root, n_gpus=8, nodes=2, cpus_per_node=96, smt=True):
+    """An MI300X / MI355X-like host under ``root``: n_gpus AMD display devices, half per socket; each socket's cpulist = its physical
+    cores followed by their hyper-thread siblings ("0-95,192-287"), as Linux prints it."""
+    for g in range(n_gpus):
+        d = os.path.join(root, "class/drm/card%d/device" % g)
+        os.makedirs(d)
+        open(os.path.join(d, "vendor"), "w").write("0x1002\n")
+        open(os.path.join(d, "pci_address"), "w").write("0000:%02x:00.0\n" % (0x10 + 0x10 * g))
+        open(os.path.join(d, "numa_node"), "w").write("%d\n" % (g * nodes // n_gpus))
+    os.makedirs(os.path.join(root, "class/drm/card0-DP-1/device"))      # a connector entry: must be ignored
+    total = nodes * cpus_per_node
+    for n in range(nodes):
+        d = os.path.join(root, "devices/system/node/node%d" % n)
+        os.makedirs(d)
+        lo = n * cpus_per_node
+        txt = "%d-%d" % (lo, lo + cpus_per_node - 1)
+        if smt:
+            txt += ",%d-%d" % (total + lo, total + lo + cpus_per_node - 1)
+        open(os.path.join(d, "cpulist"), "w").write(txt + "\n")
+    for c in range(total * (2 if smt else 1)):
+        d = os.path.join(root, "devices/system/cpu/cpu%d/topology" % c)
+        os.makedirs(d)
+        open(os.path.join(d, "thread_siblings_list"), "w").write(("%d,%d\n" % (c % total, c % total + total)) if smt else ("%d\n" % c))
+    return list(range(total * (2 if smt else 1)))
+
+
+def _worker_affinity(rank, world, port, root, online, out):
+    from fusiondepth_amd import dp
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = dp.affinity_plan(world, sysfs=root, online=online)[rank]             # every rank derives the same plan on its own
+    sets = [None] * world
+    dist.all_gather_object(sets, mine)
+    if rank == 0:
+        torch.save(sets, out)
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_get_disjoint_cores_of_their_gpus_numa_node(tmp_path):
+    """8 ranks on a faked 2-socket, 8-GPU topology: every rank's CPU set lies inside its GPU's NUMA node, the sets are pairwise disjoint
+    and together use the node's cores evenly; a host with fewer cores than ranks is reported (overlapping sets)."""
+    from fusiondepth_amd import dp
+    root = str(tmp_path / "sys")
+    online = _fake_topology(root)
+    assert dp.gpu_numa_nodes(8, root) == [0, 0, 0, 0, 1, 1, 1, 1]
+    out = str(tmp_path / "sets.pt")
+    mp.spawn(_worker_affinity, args=(8, _free_port(), root, online, out), nprocs=8, join=True)
+    sets = torch.load(out)
+    node_cpus = [set(range(0, 96)) | set(range(192, 288)), set(range(96, 192)) | set(range(288, 384))]
+    for r, cpus in enumerate(sets):
+        assert len(cpus) == 48 and set(cpus) <= node_cpus[r // 4], (r, cpus[:4])
+        for q in range(r):
+            assert not (set(cpus) & set(sets[q])), "ranks %d and %d share cores" % (q, r)
+    assert set().union(*[set(c) for c in sets[:4]]) == node_cpus[0]
+    assert sets[0] == list(range(0, 24)) + list(range(192, 216)), "24 physical cores with their hyper-thread siblings"
+    # a cgroup that leaves 2 cores for 4 ranks of a node: the plan still gives everybody a core, and says so through overlap
+    tight = dp.affinity_plan(8, sysfs=root, online=[0, 1, 96, 97])            # (4 cores for 8 ranks)
+    assert all(len(c) >= 1 for c in tight) and set(tight[0]) & set(tight[2])
+    # unknown NUMA nodes (-1: VMs, single-socket hosts): the online cores are split among all local ranks
+    root2 = str(tmp_path / "sys2")
+    _fake_topology(root2, nodes=1, cpus_per_node=64, smt=False)
+    for g in range(8):
+        open(os.path.join(root2, "class/drm/card%d/device/numa_node" % g), "w").write("-1\n")
+    flat = dp.affinity_plan(8, sysfs=root2, online=list(range(64)))
+    assert sorted(c for s_ in flat for c in s_) == list(range(64)) and all(len(s_) == 8 for s_ in flat)

@@ -160,3 +160,64 @@ def test_completor_val_best_rms_bookkeeping(tmp_path):
     assert all(m.training for m in cp.models.values())                     # set_train() restored
     again, saved2 = cp.val(batches)                                        # not better than itself: no new checkpoint
     assert saved2 is None
+
+
+def _sparse_batch(B, H, W, seed, n_points):
+    """test_gpu_trainer._batch with r100 / r200 LiDAR maps (n_points random ROI pixels per image, 3.5 - 7 m) instead of 4 scan lines"""
+    from oracle import scatter as OS
+    from fusiondepth_amd import functional as FD
+    inp, _ = gin.batch_inputs(seed, B, H, W)
+    roi = FD.scaled_roi(H, W)
+    for i, f in enumerate((0, -1, 1)):
+        beam = gin.lidar_random(np.random.RandomState(seed + 30 + i), B, H, W, n_points, roi, lo=3.5, hi=7.0)
+        two = np.stack([np.stack(OS.scatter_2channel_c(beam[b, 0], roi)) for b in range(B)])
+        inp[("2channel", f, 0)] = torch.from_numpy(two)
+        if f == 0:
+            inp["2channel"] = torch.from_numpy(two)
+            inp["4beam"] = torch.from_numpy(beam)
+    noise = [torch.from_numpy(np.random.RandomState(seed + 50 + s).randn(B, 2, H, W).astype(np.float32)) for s in range(4)]
+    return inp, noise
+
+
+@pytest.mark.parametrize("n_points,flags", [(100, []), (200, ["--completion_siloss", "--completion_l1loss"])], ids=["r100-si", "r200-l1"])
+def test_completor_step_on_random_sample_lidar_vs_oracle(n_points, flags):
+    """BASELINE config 5's sparse inputs through a Completor step ("missing" 4): r100 / r200 maps at 640x192 - the LiDAR
+    term's masked reductions (completor.py:621-725: SI-log or masked L1) run on at most n_points pixels per image, the beam encoders see a
+    nearly empty 2-channel map.  One process_batch + backward: every loss against the oracle, the parameter gradient of every network
+    in relative L2 (float32 oracle; train-mode BatchNorm over 2 images: the bound is the one of the dense-LiDAR trainer tests)."""
+    import conftest
+    B, H, W = 2, 192, 640
+    opt = _opts("--completion_not_full_res", "--height", str(H), "--width", str(W), *flags, batch_size=B, completion_num_layers=18)
+    cp, oopt, om = _pair(opt)
+    for m in om.values():
+        m.train()
+    inp, noise = _sparse_batch(B, H, W, 940 + n_points, n_points)
+    assert int((inp["4beam"] > 0).sum()) == B * n_points
+    ginp = {k: v.cuda() for k, v in inp.items()}
+    ginp["_noise"] = [n.cuda() for n in noise]
+    for m in om.values():
+        for p_ in m.parameters():
+            p_.grad = None
+    _, lo = OC.process_batch(oopt, om, inp, noise)
+    lo["loss"].backward()
+    cp.flat.zero_grad()
+    _, lg = cp.process_batch(ginp)
+    assert set(lg) == set(lo)
+    for k in lo:
+        a, b = float(lg[k].detach()), float(lo[k])
+        assert np.isnan(a) == np.isnan(b), "%s: HIP %r, oracle %r" % (k, a, b)
+        if not np.isnan(b):
+            conftest.report("completor %d-point LiDAR: %s |HIP - oracle| / |oracle|" % (n_points, k), abs(a - b) / max(abs(b), 1e-30), 5e-4)
+            assert_close(a, b, rtol=5e-4, atol=1e-6, what=k)
+    lg["loss"].backward()
+    cp._join_side_streams()
+    torch.cuda.synchronize()
+    for name, m in cp.models.items():
+        got = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in m.parameters()]).double().cpu()
+        want = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in om[name].parameters()]).double()
+        if float(want.norm()) == 0.0:
+            assert float(got.norm()) == 0.0, name
+            continue
+        e = float((got - want).norm() / want.norm())
+        conftest.report("completor %d-point LiDAR: %s parameter gradient, relative L2 vs the float32 oracle" % (n_points, name), e, 5e-2)
+        assert e <= 5e-2, "%s: %.3g" % (name, e)
