@@ -336,8 +336,11 @@ def test_refine_inputs_clamp_the_crop_like_the_reference(H, W):
     beam = torch.from_numpy(gin.lidar_random(rng, B, H, W, 150, roi=(H // 3, H - 2, 2, W - 2), lo=3.5, hi=7.0))
     two = torch.from_numpy(rng.uniform(0, 1, size=(B, 2, H, W)).astype(np.float32))
     inv_K = [gin.intrinsics(B, H, W, s)[1] for s in range(4)]
-    oopt = OR.default_opt(batch_size=B, height=H, width=W)
-    want = OR.refine_inputs(oopt, {("disp", s): disps[s] for s in range(4)}, {"4beam": beam, "2channel": two, **{("inv_K", s): inv_K[s] for s in range(4)}})
-    got = FD.refine_inputs([d.cuda() for d in disps], beam.cuda(), two.cuda(), [k.cuda() for k in inv_K], H, W, oopt.min_depth, oopt.max_depth)
+    oopt = OR.default_opt(batch_size=B, height=H, width=W, catxy="true", refine_a0="true")
+    inputs = {"4beam": beam, "2channel": two}
+    inputs.update({("inv_K", s): inv_K[s] for s in range(4)})
+    want = OR.refine_inputs(oopt, inputs, {("disp", s): disps[s] for s in range(4)})
+    got = FD.refine_inputs([d.cuda() for d in disps], beam.cuda(), two.cuda(), [k.cuda() for k in inv_K], H, W, oopt.min_depth, oopt.max_depth,
+                           catxy=True, pool_disp0=True)
     for s in range(4):
-        assert_close(got[s].cpu().numpy(), want[s].numpy(), rtol=2e-5, atol=2e-6, what="refine inputs scale %d at %dx%d" % (s, H, W))
+        assert_close(got[s].cpu().numpy(), want[("disp", s)].numpy(), rtol=2e-5, atol=2e-5, what="refine inputs scale %d at %dx%d" % (s, H, W))
