@@ -15,16 +15,23 @@ SHAPES = [  # Cin, Cout, H, W
     (512, 2048, 6, 20), (2048, 512, 6, 20)]
 
 
-def timed(fn, n=40):
-    for _ in range(5):
+def timed(fn, n=20, reps=5):
+    """kernel time only: n launches captured into a hipGraph, replayed reps times (issued from Python one call costs 10 - 25 us of
+    host time - more than most of these kernels take, which is what the first versions of this script measured)"""
+    for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        fn()
+    for _ in range(reps):
+        g.replay()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1000 / n
+    return e0.elapsed_time(e1) * 1000 / (n * reps)
 
 
 def err(a, ref):
@@ -46,12 +53,12 @@ def run(B, ci, co, h, w, limb, **extra):
     d_ws_n, d_wt_n = plan.data_sizes()
     d_ws = torch.empty(max(d_ws_n, 1), device="cuda"); d_wt = torch.empty(max(d_wt_n, 1), device="cuda")
     w_ws = torch.empty(plan.weight_ws(), device="cuda")
-    st = stream()
-    call("fd_conv2d_fwd", dp, ptr(x), ptr(wt), None, ptr(y), ptr(f_wt), 0, ptr(f_ws), st)          # writes the layouts
-    call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(wt), ptr(gx), ptr(d_wt), 0, ptr(d_ws), st)
-    t_f = timed(lambda: call("fd_conv2d_fwd", dp, ptr(x), ptr(wt), None, ptr(y), ptr(f_wt), 1, ptr(f_ws), st))
-    t_d = timed(lambda: call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(wt), ptr(gx), ptr(d_wt), 1, ptr(d_ws), st))
-    t_w = timed(lambda: call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), None, ptr(w_ws), 0, st))
+    call("fd_conv2d_fwd", dp, ptr(x), ptr(wt), None, ptr(y), ptr(f_wt), 0, ptr(f_ws), stream())          # writes the layouts
+    call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(wt), ptr(gx), ptr(d_wt), 0, ptr(d_ws), stream())
+    torch.cuda.synchronize()
+    t_f = timed(lambda: call("fd_conv2d_fwd", dp, ptr(x), ptr(wt), None, ptr(y), ptr(f_wt), 1, ptr(f_ws), stream()))
+    t_d = timed(lambda: call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(wt), ptr(gx), ptr(d_wt), 1, ptr(d_ws), stream()))
+    t_w = timed(lambda: call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), None, ptr(w_ws), 0, stream()))
     return (t_f, t_d, t_w), (x, wt, gy, y, gx, gw)
 
 
@@ -84,10 +91,9 @@ def main():
             say(line)
             if os.environ.get("LIMB_SWEEP"):
                 for dep in (2, 4):
-                    for tgt in (256, 512):
-                        t, _ = run(B, ci, co, h, w, 1, limb_depth=dep, limb_wgrad_target=tgt, limb_target=tgt // 2)
-                        say("      depth %d wgrad target %4d, fwd target %4d: fwd %6.1f dgrad %6.1f wgrad %6.1f us" % (dep, tgt, tgt // 2, t[0], t[1], t[2]))
-                tuning.set_lib(limb_depth=4, limb_target=256, limb_wgrad_target=256)
+                    t, _ = run(B, ci, co, h, w, 1, limb_depth=dep)
+                    say("      depth %d: fwd %6.1f dgrad %6.1f wgrad %6.1f us" % (dep, t[0], t[1], t[2]))
+                tuning.set_lib(limb_depth=2)
         say("b%-2d sum: fwd %.0f -> %.0f us, dgrad %.0f -> %.0f us, wgrad %.0f -> %.0f us" % (
             B, tot[0][0], tot[1][0], tot[0][1], tot[1][1], tot[0][2], tot[1][2]))
     tuning.set_lib(limb_1x1=1)
