@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FD_LIBFDHIP") or os.path.join(_HERE, "libfdhip.so")   # FD_LIBFDHIP: ablation builds (scripts/)
-ABI_VERSION = 3
+ABI_VERSION = 4
 PHOTO_OUT_FLOATS = 96        # FD_PHOTO_OUT_FLOATS
 
 _P, _I, _L, _F, _D = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
@@ -147,6 +147,10 @@ SIGNATURES = {
     "fd_post_process_disparity": ("ppplii" "p", "i"),
     "fd_adam_step": ("ppppl" "fffffff" "p", "i"),
     "fd_adam_step_dev": ("ppppl" "p" "ffff" "p", "i"),
+    "fd_replay_function_count": ("", "i"),
+    "fd_replay_function_name": ("i", "s"),
+    "fd_replay_function_signature": ("i", "s"),
+    "fd_replay": ("pippip", "i"),
 }
 
 _lock = threading.Lock()
@@ -185,9 +189,18 @@ def last_error():
 HOST_DELAY_US = 0.0
 
 
+# replay.py: while a region is being recorded, every entry-point call and every tensor handed to ``ptr`` is reported to the recorder
+# (one list lookup per call otherwise); HOST_PERSISTENT = host addresses that may appear as literal pointer arguments of a recorded
+# call (the shape-keyed convolution descriptors, kept alive by functional._CONV_PLANS and by the plans that reference them)
+RECORDER = [None]
+HOST_PERSISTENT = set()
+
+
 def call(name, *args):
     """Invoke an ``int``-returning entry point and raise RuntimeError on a non-zero status."""
     lib = load()
+    if RECORDER[0] is not None and name != "fd_replay":
+        RECORDER[0].saw_call(name, args)
     if HOST_DELAY_US:
         import time
         t0 = time.perf_counter()
@@ -213,6 +226,8 @@ def ptr(t):
         raise RuntimeError("tensor must be contiguous")
     if t.dtype not in (torch.float32, torch.uint8):
         raise RuntimeError("tensor must be float32 (or uint8 for masks), got %s" % t.dtype)
+    if RECORDER[0] is not None:
+        RECORDER[0].saw_tensor(t)
     return t.data_ptr()
 
 

@@ -46,8 +46,14 @@ def _compile(src, headers, force):
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
+    sys.path.insert(0, HERE)
+    try:
+        import gen_replay                      # csrc/replay_table.inc from _lib.SIGNATURES (rewritten only when it changes)
+        gen_replay.write()
+    finally:
+        sys.path.remove(HERE)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(INCLUDE, "*.h")))
+    headers = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc"))) + sorted(glob.glob(os.path.join(INCLUDE, "*.h")))
     if not srcs:
         raise RuntimeError("no HIP sources under %s" % CSRC)
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:

@@ -928,6 +928,7 @@ def weight_plan_needs_rebuild():
 # convolutions forward and as many backward; the size queries alone were ~1 300 library calls per step).
 _CONV_PLANS = {}
 _CONV_PLANS_GEN = [0]
+_PLANS_EVER = []          # every descriptor ever created stays allocated (a few hundred bytes each; recorded call sequences hold their addresses)
 
 
 class _ConvPlan:
@@ -936,6 +937,8 @@ class _ConvPlan:
     def __init__(self, x, w, stride, pad, pad_mode, act, in_norm):
         self.d = _conv_desc(x, w, stride, pad, pad_mode, act, in_norm)
         self.dp = ctypes.addressof(self.d)
+        _lib.HOST_PERSISTENT.add(self.dp)          # may appear as a literal in a recorded call sequence (replay.py)
+        _PLANS_EVER.append(self)                   # ... so the descriptor must outlive a cleared plan table
         self.Ho, self.Wo = _conv_out_hw(self.d)
         self.fwd_ws = query("fd_conv2d_fwd_ws_floats", self.dp)
         self.fwd_wt = query("fd_conv2d_fwd_wt_floats", self.dp)

@@ -99,6 +99,7 @@ class Refiner(Trainer):
         self.lr = self.learning_rate
         self.adam_state = torch.tensor([0.0, self.lr], device=self.device)
         self._graph, self._streams = None, []
+        self._replays = {}
         self.parallel_streams = tuning.host.refiner_streams
         self.stack_microbatches = False
         self._groups = 1
@@ -237,18 +238,36 @@ class Refiner(Trainer):
             pose_out = self._launch_pose_encoders(inputs)
             st = self._fork(0)
             with torch.cuda.stream(st):
-                beam_features = self.models["beam_encoder"](inputs["2channel"])
-        features = self.models["encoder"](inputs["color_aug", 0, 0])
+                beam_features = self._run_module("beam_encoder", inputs["2channel"])
+        features = self._run_module("encoder", inputs["color_aug", 0, 0])
         if par:
             self._join(st, beam_features)
         else:
-            beam_features = self.models["beam_encoder"](inputs["2channel"])
+            beam_features = self._run_module("beam_encoder", inputs["2channel"])
         if self.opt.refine_depthnet_with_beam == "true":
-            depth = dict(self.models["depth"](features, beam_features=beam_features))
+            depth = dict(self._run_module("depth", *features, *beam_features))
         else:
-            depth = dict(self.models["depth"](features))
+            depth = dict(self._run_module("depth", *features))
         poses = self.predict_poses(inputs, features, pose_out) if want_poses else {}
         return features, beam_features, depth, poses
+
+    def _run_module(self, name, *tensors):
+        """A frozen stage-1 network under no_grad: its libfdhip calls are recorded once per input signature and replayed by ONE
+        ``fd_replay`` call afterwards (replay.py; ~45 launches per ResNet-18 encoder, ~40 per depth decoder: the step was host-bound).
+        ``depth`` takes the encoder features (+ the LiDAR encoder's) as a flat argument list."""
+        net = self.models[name]
+        if name == "depth":
+            n = len(net.num_ch_enc)
+            call = lambda *f: net(list(f[:n]), beam_features=list(f[n:])) if len(f) > n else net(list(f))
+        else:
+            call = lambda x: list(net(x))
+        if name == "refine2d_decoder" or torch.is_grad_enabled() or net.training:
+            return call(*tensors)
+        rp = self._replays.get(name)
+        if rp is None:
+            from .replay import Replayable
+            rp = self._replays[name] = Replayable(call, lambda: list(net.parameters()) + list(net.buffers()), name="Refiner." + name)
+        return rp(*tensors)
 
     def generate_images_pred(self, inputs, outputs, frame_ids):
         """refiner.py:487-541 fused with the per-pixel part of compute_losses; the SI term is the GDC loss (compute_losses)."""

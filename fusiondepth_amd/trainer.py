@@ -657,15 +657,19 @@ class Trainer:
         st_rgb = self._fork(1)
         with torch.cuda.stream(st_rgb):
             with FD.bn_groups(G * len(fids)):
-                pf = self.models["pose_encoder"](stack("color_aug"))
+                pf = self._run_module("pose_encoder", stack("color_aug"))
         bf, st_beam = None, None
         if self.opt.beam_encoder:
             st_beam = self._fork(2)
             with torch.cuda.stream(st_beam):
                 with FD.bn_groups(G * len(fids)):
-                    bf = self.models["beam_encoder_pose"](stack("2channel"))
+                    bf = self._run_module("beam_encoder_pose", stack("2channel"))
         res["stacked"] = (pf, st_rgb, bf, st_beam)
         return res
+
+    def _run_module(self, name, *tensors):
+        """``self.models[name](*tensors)``; the Refiner routes its frozen networks through recorded call sequences here (replay.py)."""
+        return self.models[name](*tensors)
 
     def _stack_pose_inputs(self, inputs, key):
         """The (source, target) frame pairs of all source frames stacked along the batch axis, in the reference's pass order:

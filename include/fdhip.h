@@ -29,8 +29,11 @@ extern "C" {
  *    (group, channel) - a client that sized the BatchNorm workspace itself must re-query it.
  * 3: additions only (round 5): fd_masked_median, fd_refine_inputs (+ fd_refine_cfg), fd_resize_linear_cv, fd_bn_relu_maxpool_fwd / _bwd,
  *    fd_bn_train_bwd_remask, fd_stack_normalize, fd_conv2d_fwd_bn(_ok), fd_pose_head_fwd / _bwd; fd_tuning grew at its end
- *    (wino_min_cout, wino_wgrad_min_cout, wino_wgrad_xcd_few, wino_fwd_halfm, wino_wgrad_halfm, grp_tile64_below).  Nothing removed, no signature changed. */
-#define FD_ABI_VERSION 3
+ *    (wino_min_cout, wino_wgrad_min_cout, wino_wgrad_xcd_few, wino_fwd_halfm, wino_wgrad_halfm, grp_tile64_below).  Nothing removed, no signature changed.
+ * 4: additions only (round 6): fd_replay (+ fd_call_rec, fd_replay_function_count / _name / _signature); fd_tuning grew at its end (limb_1x1,
+ *    limb_depth, limb_target, limb_split_max_out, limb_wgrad_target); fd_relayout_job.mode 7 / 8 (weights pre-split into bf16 limbs);
+ *    fd_refine_cfg accepts an empty crop window.  Nothing removed, no signature changed. */
+#define FD_ABI_VERSION 4
 
 int fd_abi_version(void);
 const char* fd_supported_arch(void); /* "gfx950" */
@@ -535,6 +538,28 @@ typedef struct fd_refine_cfg {
 long fd_refine_inputs_ws_bytes(const fd_refine_cfg* cfg);
 int fd_refine_inputs(const fd_refine_cfg* cfg, const float* const* disp, const float* beam, const float* two_cha,
                      const float* const* inv_K, float* const* out, float* stats, void* ws, void* stream);
+
+/* ------------------------------------------------------------------ replay (round 6) ------------
+ * Issue a recorded sequence of entry-point calls from ONE host call.  The Python layer pays 10 - 18 us of interpreter / ctypes /
+ * autograd time per launch; the parts of a step that repeat the same calls on the same shapes and need no autograd graph - the
+ * frozen stage-1 networks of refiner.py:299-330, validation forwards (trainer.py:390-423) - are recorded once and replayed here.
+ *   fd_call_rec      one call: `fn` = index into the table of stream-ordered entry points (fd_replay_function_name / _signature:
+ *                    every int-status entry point of this header whose last argument is the stream), `arg[i]` its arguments as
+ *                    64-bit words (float / double arguments: the bits of a double), `kind[i]` & 15 = how arg[i] becomes the value:
+ *                    0 literal, 1 arena + arg[i] bytes, 2 inputs[kind[i] >> 4] + arg[i] bytes, 3 the stream passed to fd_replay.
+ *   fd_replay        runs the records in order on `stream`; stops at the first non-zero status and returns it.  Nothing is allocated
+ *                    or synchronised: the caller owns `arena` (the records' intermediates and outputs live in it), the tensors
+ *                    behind literal pointers (parameters, cached weight layouts, descriptors) and the inputs. */
+#define FD_REPLAY_MAX_ARGS 24
+typedef struct fd_call_rec {
+    int fn, nargs;
+    long long arg[FD_REPLAY_MAX_ARGS];
+    unsigned short kind[FD_REPLAY_MAX_ARGS];
+} fd_call_rec;
+int fd_replay_function_count(void);
+const char* fd_replay_function_name(int i);
+const char* fd_replay_function_signature(int i);
+int fd_replay(const fd_call_rec* recs, int n, void* arena, const void* const* inputs, int n_inputs, void* stream);
 
 #ifdef __cplusplus
 }
