@@ -777,6 +777,8 @@ def param_uses(p):
 
 
 def _note_use(*params):
+    if _lib.RECORDER[0] is not None:
+        _lib.RECORDER[0].side("note_use", params)
     if _GRAD_READY:
         for p in params:
             if p is not None:
@@ -784,6 +786,11 @@ def _note_use(*params):
 
 
 def _grad_ready(*params):
+    rec = _lib.RECORDER[0]
+    if rec is not None:
+        rec.side("grad_ready", params)
+        if rec.mute_grad_ready:
+            return                      # an isolated recording pass: its gradients are thrown away, nobody may be told
     if _GRAD_READY:
         for cb in _live_grad_ready():
             for p in params:
@@ -807,6 +814,8 @@ def _weight_layout(w, cache_id, kind, nfloats, desc=None):
     key = (cache_id, kind, nfloats)
     stamp = _layout_stamp(w)
     ent = _WT_CACHE.get(key)
+    if _lib.RECORDER[0] is not None:
+        _lib.RECORDER[0].side("layout", (w, key))
     if ent is not None:
         if _LATE["event"] is not None and ent[4]:
             _wait_late_layouts()
@@ -1421,10 +1430,7 @@ def conv_bn(x, conv_weight, bn, stride=1, pad=0, residual=None, relu=False, tap=
     """``batch_norm(conv2d(x, w), bn, residual, relu)`` in training mode as one autograd node -> out, or (out, x_tap) with ``tap``."""
     groups = _BN_GROUPS[0]
     if bn.num_batches_tracked is not None:
-        if _BN_COUNTERS[0] is not None:
-            _BN_COUNTERS[0].append((bn.num_batches_tracked, groups))
-        else:
-            bn.num_batches_tracked.add_(groups)
+        bump_bn_counter(bn.num_batches_tracked, groups)
     want_tap = bool(tap and x.requires_grad)
     res = _ConvBN.apply(x, conv_weight, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, int(stride), int(pad),
                         bn.momentum, bn.eps, bool(relu), groups, want_tap)
@@ -1435,6 +1441,18 @@ def conv_bn(x, conv_weight, bn, stride=1, pad=0, residual=None, relu=False, tap=
 
 _BN_GROUPS = [1]
 _BN_COUNTERS = [None]
+
+
+def bump_bn_counter(counter, groups):
+    """``num_batches_tracked += groups`` - deferred to one multi-tensor launch inside ``defer_bn_counters``; reported to an active call
+    recorder (replay.py replays the bump with the network's recorded calls)."""
+    rec = _lib.RECORDER[0]
+    if rec is not None:
+        rec.side("bn_counter", (counter, groups))
+    if _BN_COUNTERS[0] is not None:
+        _BN_COUNTERS[0].append((counter, groups))
+    else:
+        counter.add_(groups)
 
 
 class defer_bn_counters:
@@ -1476,10 +1494,7 @@ def batch_norm(x, bn, residual=None, relu=False, conv_stats=None):
     training = bn.training
     groups = _BN_GROUPS[0] if training else 1
     if training and bn.num_batches_tracked is not None:
-        if _BN_COUNTERS[0] is not None:
-            _BN_COUNTERS[0].append((bn.num_batches_tracked, groups))       # one multi-tensor add per step (trainer)
-        else:
-            bn.num_batches_tracked.add_(groups)
+        bump_bn_counter(bn.num_batches_tracked, groups)                    # one multi-tensor add per step (trainer)
     return _BatchNorm.apply(x, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, training, bn.momentum,
                             bn.eps, relu, groups, conv_stats if training else None)
 
@@ -1538,10 +1553,7 @@ def bn_relu_maxpool(x, bn, want_feature=True):
         return f0, max_pool3x3s2(f0)
     groups = _BN_GROUPS[0]
     if bn.num_batches_tracked is not None:
-        if _BN_COUNTERS[0] is not None:
-            _BN_COUNTERS[0].append((bn.num_batches_tracked, groups))
-        else:
-            bn.num_batches_tracked.add_(groups)
+        bump_bn_counter(bn.num_batches_tracked, groups)
     out = _BNReluPool.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, groups, bool(want_feature))
     if not want_feature:
         return None, out

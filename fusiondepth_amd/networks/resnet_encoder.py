@@ -155,9 +155,8 @@ class ResnetEncoder(nn.Module):
             self.num_ch_enc[1:] *= 4
         self.stem_feature_needed = True       # False: features[0] is None in training mode (nobody reads it; saves its write + re-reads)
 
-    def forward_steps(self, input_image):
-        """The forward pass as a generator that yields after the stem and after every residual block, so that a caller can
-        advance several encoders in turn (``interleaved_forward``).  ``self.features`` is set when it is exhausted."""
+    def stem(self, input_image):
+        """normalise, conv1, bn1, ReLU -> features[0]; max-pool -> the input of layer1 (resnet_encoder.py:94-98)"""
         e = self.encoder
         # (x - 0.45) / 0.225 (resnet_encoder.py:94) as its own pass: the 7x7 stem then gathers plain values.  An input that carries
         # ``_fd_normalized`` was normalised by its producer (Trainer._stack_pose_inputs: FD.stack_normalize assembles and normalises
@@ -168,11 +167,17 @@ class ResnetEncoder(nn.Module):
             # BatchNorm + ReLU + max-pool of the stem in one pass; features[0] is materialised only for the encoders whose skip
             # connection reads it (``stem_feature_needed``: the trainer clears it for the pose encoders - PoseDecoder reads features[-1])
             f0, x = FD.bn_relu_maxpool(x, e.bn1, want_feature=self.stem_feature_needed)
-            yield
         else:
             f0 = FD.batch_norm(x, e.bn1, relu=True)
-            yield
             x = FD.max_pool3x3s2(f0)
+        return f0, x
+
+    def forward_steps(self, input_image):
+        """The forward pass as a generator that yields after the stem and after every residual block, so that a caller can
+        advance several encoders in turn (``interleaved_forward``).  ``self.features`` is set when it is exhausted."""
+        e = self.encoder
+        f0, x = self.stem(input_image)
+        yield
         feats = [f0]
         for li in range(1, 5):
             for blk in getattr(e, "layer%d" % li):

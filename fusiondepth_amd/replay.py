@@ -51,10 +51,15 @@ def _fn_table():
 class Recorder:
     """Active while a region runs eagerly; ``_lib.call`` / ``_lib.ptr`` report to it."""
 
-    def __init__(self):
+    def __init__(self, mute_grad_ready=False):
         self.calls = []          # (name, args as passed)
         self.tensors = {}        # data_ptr -> tensor (kept alive until the plan is built)
         self.stream = None
+        self.effects = []        # host-side effects the region has besides its calls: ("note_use" | "grad_ready" | "bn_counter" | "layout", payload)
+        self.mute_grad_ready = mute_grad_ready
+
+    def side(self, kind, payload):
+        self.effects.append((kind, payload))
 
     def saw_tensor(self, t):
         self.tensors[t.data_ptr()] = t
@@ -73,7 +78,7 @@ class Plan:
         self.out_specs, self.out_tree, self.in_specs = out_specs, out_tree, in_specs
         self.keep, self.fingerprint, self.tally = keep, fingerprint, tally
 
-    def replay(self, inputs):
+    def replay(self, inputs, keep_arena=False):
         arena = torch.empty((max(self.arena_bytes, 256),), dtype=torch.uint8, device=inputs[0].device)
         ptrs = (ctypes.c_void_p * len(inputs))(*[t.data_ptr() for t in inputs])
         _lib.call("fd_replay", ctypes.addressof(self.recs), self.n_recs, arena.data_ptr(), ctypes.addressof(ptrs), len(inputs), _lib.stream())
@@ -91,7 +96,8 @@ class Plan:
         from . import functional as FD
         if FD.CONV_FLOP_TALLY is not None:
             FD.CONV_FLOP_TALLY[0] += self.tally
-        return _pytree.tree_unflatten(outs, self.out_tree)
+        res = _pytree.tree_unflatten(outs, self.out_tree) if self.out_tree is not None else outs
+        return (res, arena) if keep_arena else res
 
 
 def _storage_span(t):
@@ -99,8 +105,9 @@ def _storage_span(t):
     return st.data_ptr(), st.nbytes()
 
 
-def build_plan(rec, inputs, outputs_flat, out_tree, persistent, tally):
-    """Classify the recorded pointers and lay the intermediates out in an arena -> Plan (raises NotRecordable)."""
+def build_plan(rec, inputs, outputs_flat, out_tree, persistent, tally, foreign=None):
+    """Classify the recorded pointers and lay the intermediates out in an arena -> Plan (raises NotRecordable).  ``foreign``: pointer ->
+    (input slot, byte offset) or None, asked first (a backward plan finds the forward pass's saved tensors in the forward arena)."""
     table = _fn_table()
     in_spans = []
     for i, t in enumerate(inputs):
@@ -166,8 +173,8 @@ def build_plan(rec, inputs, outputs_flat, out_tree, persistent, tally):
                         r.arg[i], r.kind[i] = a, 0
                         continue
                     raise NotRecordable("%s argument %d: a pointer that did not come from a tensor" % (name, i))
-                slot = None
-                for lo, hi, idx, dptr in in_spans:
+                slot = foreign(a) if foreign is not None else None
+                for lo, hi, idx, dptr in (in_spans if slot is None else ()):
                     if lo <= a < hi:
                         slot = (idx, a - dptr)
                         break
@@ -198,7 +205,9 @@ def build_plan(rec, inputs, outputs_flat, out_tree, persistent, tally):
         out_specs.append(("arena", arena_of[base][0] + (p - base), tuple(t.shape), t.dtype, -1))
     in_specs = [(tuple(t.shape), t.dtype) for t in inputs]
     used = [t for t in persistent if _storage_span(t)[0] in pers_hit]
-    return Plan(recs, len(rec.calls), arena_bytes[0], out_specs, out_tree, in_specs, used, None, tally, True)
+    plan = Plan(recs, len(rec.calls), arena_bytes[0], out_specs, out_tree, in_specs, used, None, tally, True)
+    plan.arena_map = arena_of
+    return plan
 
 
 class Replayable:
@@ -277,3 +286,269 @@ class Replayable:
         frozen_only = all(getattr(t, "_fd_frozen", False) or not isinstance(t, torch.nn.Parameter) or t.dim() != 4 for t in self.persistent())
         self.plans[key] = (plan, self._fingerprint(frozen_only), [(t.data_ptr(), t._version) for t in plan.keep], frozen_only)
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------------ training
+class _ReplayedNet(torch.autograd.Function):
+    """ONE autograd node for a whole network: forward = its recorded calls replayed into a fresh arena (which is what the backward's
+    saved tensors live in), backward = the recorded calls of its backward pass.  Parameter gradients accumulate straight into the flat
+    gradient buffer (functional.enable_direct_grad), so the node returns no gradient at all for them."""
+
+    @staticmethod
+    def forward(ctx, state, x, anchor):
+        from . import functional as FD
+        if state.late_f:
+            FD._wait_late_layouts()
+        for kind, payload in state.fwd_effects:
+            if kind == "note_use":
+                FD._note_use(*payload)
+            elif kind == "bn_counter":
+                FD.bump_bn_counter(*payload)
+        outs, arena = state.fwd.replay([x], keep_arena=True)
+        ctx.state, ctx.arena, ctx.x = state, arena, x
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        from . import functional as FD
+        st = ctx.state
+        got = tuple(i for i, g in enumerate(gouts) if g is not None)
+        if got != st.pattern:
+            raise RuntimeError("fusiondepth_amd.replay: %s was recorded with gradients arriving at outputs %s, this backward pass brings %s "
+                               "(set tuning.host.replay_train = False for this graph)" % (st.name, st.pattern, got))
+        gs = [_lib.f32(gouts[i]) for i in st.pattern]
+        if st.late_b or st.late_f:
+            FD._wait_late_layouts()
+        out = st.bwd.replay(gs + [ctx.x, ctx.arena])
+        ctx.arena = None
+        for kind, payload in st.bwd_effects:
+            if kind == "grad_ready":
+                FD._grad_ready(*payload)
+        return None, (out[0] if out else None), None
+
+
+class _TrainState:
+    def __init__(self, name):
+        self.name, self.calls, self.fwd, self.bwd = name, 0, None, None
+        self.seen_grads, self.pattern = set(), None
+        self.fwd_effects, self.bwd_effects, self.layouts = [], [], []
+        self.late_f = self.late_b = True
+
+
+class TrainReplayable:
+    """A network's TRAINING forward + backward as two recorded call sequences behind one autograd node.
+
+    ``TrainReplayable(net, call, name)(x)``: the first calls per input signature run eagerly (and note which outputs receive a
+    gradient); then one call is recorded - it is still the real, eager forward of that step - followed by an isolated recording of the
+    backward pass on random gradients (its parameter gradients are thrown away again); both sequences are validated bit for bit
+    (outputs, BatchNorm buffers, parameter gradients) before the node replaces the eager graph.  Requirements: parameters with direct
+    gradient accumulation, one stream, no operation outside libfdhip inside the network - otherwise it stays eager and says why."""
+    WARM = 2
+
+    def __init__(self, modules, call, name, key_extra=lambda: None):
+        self.modules, self.call, self.name, self.key_extra = list(modules), call, name, key_extra
+        self.states, self.disabled = {}, None
+        self.params = [p for m in self.modules for p in m.parameters()]
+        self.anchor = next((p for p in self.params if p.requires_grad), None)
+
+    @property
+    def training(self):
+        return all(m.training for m in self.modules)
+
+    def _eager(self, st, x):
+        outs = self.call(x)
+        idx = st.seen_grads
+        for i, t in enumerate(outs):
+            if t is not None and t.requires_grad:
+                t.register_hook(lambda g, i=i: idx.add(i))
+        return outs
+
+    def __call__(self, x):
+        from . import functional as FD
+        if (self.disabled is not None or not tuning.host.replay_train or not torch.is_grad_enabled() or not self.training
+                or self.anchor is None or torch.cuda.is_current_stream_capturing() or not (x.is_cuda and x.is_contiguous())):
+            return self.call(x)
+        key = (tuple(x.shape), x.dtype, getattr(x, "_fd_normalized", False), bool(x.requires_grad), FD._BN_GROUPS[0], tuning.generation(),
+               self.key_extra())
+        st = self.states.get(key)
+        if st is None:
+            st = self.states[key] = _TrainState(self.name)
+        if st.fwd is None:
+            st.calls += 1
+            if st.calls <= self.WARM:
+                return self._eager(st, x)
+            return self._record(st, x)
+        late_f = late_b = False
+        for w, k, ptr_ in st.layouts:                         # every weight layout the recorded calls read must be current
+            ent = FD._WT_CACHE.get(k)
+            if ent is None or ent[0] != FD._layout_stamp(w) or ent[1].data_ptr() != ptr_:
+                return self.call(x)                           # (the eager call re-derives it; the plan stays valid for the next step)
+            ent[5] = FD._WEIGHTS_EPOCH[0]
+            if ent[4]:                                        # refreshed on the side stream behind Adam: its readers wait for that launch
+                if k[1] == "f":
+                    late_f = True
+                else:
+                    late_b = True
+        # (only the segments that READ such a layout wait: the stems and first blocks start beside the re-layout launch, like the eager path)
+        st.late_f, st.late_b = late_f, late_b
+        return list(_ReplayedNet.apply(st, x, self.anchor))
+
+    # -- recording -------------------------------------------------------------------------------------------------------------
+    def _buffers(self):
+        return [b for m in self.modules for b in m.buffers() if b.is_floating_point()]
+
+    def _record(self, st, x):
+        from . import functional as FD
+        try:
+            return self._record_inner(st, x, FD)
+        except NotRecordable as e:
+            self.disabled = str(e)
+            warnings.warn("fusiondepth_amd.replay: %s stays on the eager path: %s" % (self.name, e))
+            return self.call(x) if not hasattr(e, "outs") else e.outs
+
+    def _record_inner(self, st, x, FD):
+        if not all(getattr(p, "_fd_direct_grad", False) and p.grad is not None for p in self.params if p.requires_grad):
+            raise NotRecordable("parameters without direct gradient accumulation")
+        bufs = self._buffers()
+        before = [b.clone() for b in bufs]
+        rec = Recorder()
+        rec.stream = _lib.stream()
+        _lib.RECORDER[0] = rec
+        try:
+            outs = self.call(x)                               # the real forward of this step (eager graph)
+        finally:
+            _lib.RECORDER[0] = None
+        def fail(msg):
+            e = NotRecordable(msg)
+            e.outs = outs
+            return e
+        after = [b.clone() for b in bufs]
+        pattern = tuple(sorted(st.seen_grads))
+        flat = list(outs)
+        persistent = [t for t in self.params + [b for m in self.modules for b in m.buffers()] if t.is_cuda]
+        persistent += [p.grad for p in self.params if p.grad is not None]
+        persistent += [e[1] for e in FD._WT_CACHE.values()]
+        try:
+            fwd = build_plan(rec, [x], flat, None, persistent, 0.0)
+        except NotRecordable as e:
+            raise fail(str(e))
+        # validate the forward: BatchNorm buffers back to their state before this step's forward, replay, compare outputs + buffers
+        with torch.no_grad():
+            for b, v in zip(bufs, before):
+                b.copy_(v)
+            again, arena = fwd.replay([x], keep_arena=True)
+            ok = all((a is None and b is None) or (a is not None and b is not None and a.shape == b.shape and torch.equal(a, b)) for a, b in zip(flat, again))
+            ok = ok and all(torch.equal(b, v) for b, v in zip(bufs, after))
+            for b, v in zip(bufs, after):
+                b.copy_(v)
+        if not ok:
+            raise fail("the forward replay does not reproduce the eager outputs / BatchNorm buffers bit for bit")
+        # the backward pass, recorded in isolation on random gradients (the gradient pattern of the warm-up steps)
+        if not pattern or any(flat[i] is None or not flat[i].requires_grad for i in pattern):
+            raise fail("no output of the network received a gradient in the warm-up steps")
+        touched = [p.grad for p in self.params if p.grad is not None]
+        saved = [g.clone() for g in touched]                  # (zero at this point of a step, but a caller may accumulate)
+        gen = torch.Generator(device=x.device).manual_seed(1)
+        gs = [torch.randn(flat[i].shape, device=x.device, generator=gen) for i in pattern]
+        rec2 = Recorder(mute_grad_ready=True)
+        rec2.stream = _lib.stream()
+        _lib.RECORDER[0] = rec2
+        try:
+            # (every trainable parameter is asked for, so that each node's needs_input_grad is what loss.backward() makes it)
+            wrt = ([x] if x.requires_grad else []) + [p for p in self.params if p.requires_grad]
+            got = torch.autograd.grad([flat[i] for i in pattern], wrt, gs, retain_graph=True, allow_unused=True)
+            torch.cuda.current_stream().synchronize()         # (the engine's worker thread has issued everything)
+        finally:
+            _lib.RECORDER[0] = None
+        gx = got[0] if x.requires_grad else None
+        if x.requires_grad and gx is None:
+            raise fail("the input requires a gradient but the backward pass produced none")
+        want = [g.clone() for g in touched]
+        amap = fwd.arena_map
+        fwd_tensors = rec.tensors
+
+        n_g = len(gs)
+
+        def foreign_slot(p):                                  # a tensor the forward pass saved: it lives in the forward arena
+            t = fwd_tensors.get(p)
+            if t is None:
+                return None
+            base, _ = _storage_span(t)
+            hit = amap.get(base)
+            return (n_g + 1, hit[0] + (p - base)) if hit is not None else None      # inputs of the backward plan: gradients..., x, arena
+
+        try:
+            bwd = build_plan(rec2, gs + [x], [gx] if gx is not None else [], None, persistent, 0.0, foreign=foreign_slot)
+        except NotRecordable as e:
+            with torch.no_grad():
+                for g, v in zip(touched, saved):
+                    g.copy_(v)
+            raise fail("backward: " + str(e))
+        with torch.no_grad():                                 # validate: same gradients from the replayed backward on the replayed forward
+            for g, v in zip(touched, saved):
+                g.copy_(v)
+            gx2 = bwd.replay(gs + [x, arena])
+            ok = all(torch.equal(g, w_) for g, w_ in zip(touched, want)) and (gx is None or torch.equal(gx2[0], gx))
+            for g, v in zip(touched, saved):
+                g.copy_(v)
+        del arena
+        if not ok:
+            raise fail("the backward replay does not reproduce the eager parameter gradients bit for bit")
+        st.fwd, st.bwd, st.pattern = fwd, bwd, pattern
+        st.fwd_effects = [e for e in rec.effects if e[0] in ("note_use", "bn_counter")]
+        st.bwd_effects = [e for e in rec2.effects if e[0] == "grad_ready"]
+        lay = {}
+        for kind, payload in rec.effects + rec2.effects:
+            if kind == "layout":
+                w, k = payload
+                ent = FD._WT_CACHE.get(k)
+                if ent is not None:
+                    lay[k] = (w, k, ent[1].data_ptr())
+        st.layouts = list(lay.values())
+        return outs
+
+
+class ReplayedEncoder:
+    """A ResnetEncoder's training pass as FIVE replayed segments - stem, layer1 .. layer4 - each one autograd node: the gradients that
+    arrive at the intermediate feature maps (the decoder's skip connections) are summed with the chain's own by autograd BETWEEN the
+    segments, exactly as in the eager graph, so no operation outside libfdhip falls inside a recorded sequence."""
+
+    def __init__(self, net, name):
+        e = net.encoder
+        self.net = net
+        self.stem = TrainReplayable([_Holder(e.conv1, e.bn1)], lambda x: list(net.stem(x)), name + ".stem",
+                                    key_extra=lambda: (net.stem_feature_needed, tuning.host.fused_stem_tail))
+        self.layers = [TrainReplayable([getattr(e, "layer%d" % i)], (lambda x, m=getattr(e, "layer%d" % i): [m(x)]), "%s.layer%d" % (name, i))
+                       for i in range(1, 5)]
+
+    def segments(self):
+        return [self.stem] + self.layers
+
+    def __call__(self, x):
+        f0, x = self.stem(x)
+        feats = [f0]
+        for seg in self.layers:
+            x = seg(x)[0]
+            feats.append(x)
+        self.net.features = feats
+        return feats
+
+
+class _Holder:
+    """the stem's two modules as one parameter / buffer / training-flag scope"""
+
+    def __init__(self, *mods):
+        self._mods = mods
+
+    def parameters(self):
+        for m in self._mods:
+            yield from m.parameters()
+
+    def buffers(self):
+        for m in self._mods:
+            yield from m.buffers()
+
+    @property
+    def training(self):
+        return all(m.training for m in self._mods)

@@ -608,11 +608,11 @@ class Trainer:
                 if par:
                     st = self._fork(0)
                     with torch.cuda.stream(st), FD.bn_groups(groups):
-                        beam_features = self.models["beam_encoder"](inputs["2channel"])
+                        beam_features = self._run_module("beam_encoder", inputs["2channel"])
                 else:
-                    beam_features = self.models["beam_encoder"](inputs["2channel"])
+                    beam_features = self._run_module("beam_encoder", inputs["2channel"])
             with FD.bn_groups(groups):
-                features = self.models["encoder"](enc_in)
+                features = self._run_module("encoder", enc_in)
             if par and beam_features is not None:
                 self._join(self._streams[0], beam_features)
         if self.opt.cat2end:
@@ -667,9 +667,22 @@ class Trainer:
         res["stacked"] = (pf, st_rgb, bf, st_beam)
         return res
 
+    _REPLAYED = ("encoder", "beam_encoder", "pose_encoder", "beam_encoder_pose")
+
     def _run_module(self, name, *tensors):
-        """``self.models[name](*tensors)``; the Refiner routes its frozen networks through recorded call sequences here (replay.py)."""
-        return self.models[name](*tensors)
+        """``self.models[name](*tensors)``.  The four ResNet encoders in training mode go through ``replay.TrainReplayable``: after two
+        eager steps their forward and backward passes are recorded call sequences behind FIVE autograd nodes each (stem, layer1 .. 4),
+        issued by one ``fd_replay`` call per node and direction instead of ~45 + ~90 Python-issued launches (the step's host issue
+        time); the Refiner routes its frozen networks through recorded sequences here too (its own override)."""
+        net = self.models[name]
+        if name in self._REPLAYED and tuning.host.replay_train and net.training and torch.is_grad_enabled() and len(tensors) == 1:
+            reps = self.__dict__.setdefault("_train_replays", {})
+            rp = reps.get(name)
+            if rp is None:
+                from .replay import ReplayedEncoder
+                rp = reps[name] = ReplayedEncoder(net, "Trainer." + name)
+            return rp(tensors[0])
+        return net(*tensors)
 
     def _stack_pose_inputs(self, inputs, key):
         """The (source, target) frame pairs of all source frames stacked along the batch axis, in the reference's pass order:

@@ -104,3 +104,51 @@ def test_refiner_steps_with_replayed_frozen_networks_are_bit_identical():
     used = res[True][2]
     for name in ("encoder", "beam_encoder", "depth", "pose_encoder", "beam_encoder_pose"):
         assert name in used and used[name] == (None, 1), (name, used)
+
+
+@pytest.mark.parametrize("layers,H,W,bs", [(18, 128, 192, 4), (50, 64, 96, 2)])
+def test_training_steps_with_replayed_encoders_are_bit_identical(layers, H, W, bs):
+    """six optimiser steps of the Trainer with the four encoders' forward + backward behind replayed call sequences (from the third
+    step on) against the same steps issued from Python: every loss and every parameter bit for bit, BatchNorm buffers included;
+    the replay really is in use ('bit-identical parameters vs the Python-issued step')"""
+    from fusiondepth_amd import tuning
+    from fusiondepth_amd.options import MonodepthOptions
+    from fusiondepth_amd.trainer import Trainer
+    from test_gpu_trainer import _batch
+    res = {}
+    for mode in (False, True):
+        tuning.host.replay_train = mode
+        try:
+            torch.manual_seed(5)
+            opt = MonodepthOptions().parse(["--num_layers", str(layers), "--weights_init", "scratch", "--batch_size", str(bs), "--height", str(H),
+                                            "--width", str(W)])
+            tr = Trainer(opt, verbose=False)
+            for k, m in tr.models.items():
+                gin.fill_params(m, 100 + len(k))
+            from fusiondepth_amd import functional as FD
+            FD.bump_weights_epoch()
+            losses = []
+            for step in range(6):
+                mbs = []
+                for g in range(tr.accumulate_step):
+                    inp, noise = _batch(tr.batch_size, H, W, 300 + 10 * step + g)
+                    b = {k: v.cuda() for k, v in inp.items()}
+                    b["_noise"] = [n.cuda() for n in noise]
+                    mbs.append(b)
+                lg = tr.train_step(mbs if tr.accumulate_step > 1 or not tr.stack_microbatches else mbs)
+                losses.append(float(lg["loss"].detach()))
+            torch.cuda.synchronize()
+            bufs = torch.cat([b.detach().reshape(-1).float() for m in tr.models.values() for b in m.buffers()])
+            reps = getattr(tr, "_train_replays", {})
+            res[mode] = (losses, tr.flat.flat_param.clone(), bufs.clone(),
+                         {seg.name: (seg.disabled, [(s.fwd is not None, s.pattern) for s in seg.states.values()]) for r in reps.values() for seg in r.segments()})
+            del tr
+        finally:
+            tuning.host.replay_train = True
+    assert res[True][3], "the encoders were not routed through TrainReplayable"
+    for name, (disabled, states) in res[True][3].items():
+        assert disabled is None, (name, disabled)
+        assert states and all(ok for ok, _ in states), (name, states)
+    assert np.array_equal(np.array(res[False][0]), np.array(res[True][0]), equal_nan=True), (res[False][0], res[True][0])     # (NaN: an empty SI-log mask)
+    assert torch.equal(res[False][1], res[True][1]), "parameters differ"
+    assert torch.equal(res[False][2], res[True][2]), "BatchNorm buffers differ"
