@@ -7,7 +7,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats -d /tmp/profb_$TAG -- python 
 echo "rocprof rc=$?"; tail -2 $R/gpurun_out/profb_$TAG.log | cut -c1-300
 DB=$(find /tmp/profb_$TAG -name "*_results.db" | head -1)
 # 2 steady-state + 2 warm-up + 4 timed = 8 optimiser steps traced
-python $R/scripts/rocprof_summary.py $DB 8 50 k_adam_dev > $R/gpurun_out/${TAG}_bench_kernel_stats.md
+python $R/scripts/rocprof_summary.py $DB 8 50 k_adam_dev 5 > $R/gpurun_out/${TAG}_bench_kernel_stats.md
 head -60 $R/gpurun_out/${TAG}_bench_kernel_stats.md
 python $R/scripts/rocprof_timeline.py $DB > $R/gpurun_out/${TAG}_bench_timeline.md
 cat $R/gpurun_out/${TAG}_bench_timeline.md

@@ -15,10 +15,12 @@ steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 where, note = "", ""
 if len(sys.argv) > 4:
     ends = [r[0] for r in db.execute("select end from kernels where name like ? order by end", ("%" + sys.argv[4] + "%",))]
-    if len(ends) >= 2:
+    skip = int(sys.argv[5]) if len(sys.argv) > 5 else 0      # leave out the first `skip` steps as well (the steps in which replay.py records)
+    if len(ends) >= skip + 2:
+        ends = ends[skip:]
         where = " where start >= %d and end <= %d" % (ends[0], ends[-1])
         steps = len(ends) - 1
-        note = " (steady state: between the first and the last `%s`)" % sys.argv[4]
+        note = " (steady state: between the %s and the last `%s`)" % ("first" if skip == 0 else "%d-th" % (skip + 1), sys.argv[4])
 rows = list(db.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
                        "from kernels" + where + " group by name order by 3 desc"))
 tot = sum(r[2] for r in rows)
