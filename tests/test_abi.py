@@ -139,3 +139,22 @@ def test_tuning_mirror_matches_the_header():
     assert set(tuning.LIB_FIELDS) == set(names) - {"size"}
     for var, (name, _) in tuning._ENV_LIB.items():
         assert name in names, (var, name)
+
+
+def test_replay_dispatch_table_is_generated_from_the_signature_list():
+    """csrc/replay_table.inc (the typed dispatch of fd_replay) is what gen_replay.py derives from _lib.SIGNATURES: a stale committed
+    copy - an entry point added without regenerating - would dispatch recorded calls to the wrong function index"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_replay", os.path.join(root, "fusiondepth_amd", "gen_replay.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    from fusiondepth_amd import _lib
+    text, names = gen.generate(_lib.SIGNATURES)
+    with open(os.path.join(root, "fusiondepth_amd", "csrc", "replay_table.inc")) as fh:
+        assert fh.read() == text
+    lib = _lib.load()
+    assert lib.fd_replay_function_count() == len(names)
+    for i, n in enumerate(names):
+        assert lib.fd_replay_function_name(i).decode() == n and lib.fd_replay_function_signature(i).decode() == _lib.SIGNATURES[n][0]
+    assert "fd_conv2d_fwd" in names and "fd_bn_train_fwd" in names and "fd_set_tuning" not in names
