@@ -314,10 +314,12 @@ class _ReplayedNet(torch.autograd.Function):
         from . import functional as FD
         st = ctx.state
         got = tuple(i for i, g in enumerate(gouts) if g is not None)
-        if got != st.pattern:
+        if not set(got) <= set(st.pattern):
+            # a gradient at an output the recorded backward pass does not start from would be dropped silently
             raise RuntimeError("fusiondepth_amd.replay: %s was recorded with gradients arriving at outputs %s, this backward pass brings %s "
                                "(set tuning.host.replay_train = False for this graph)" % (st.name, st.pattern, got))
-        gs = [_lib.f32(gouts[i]) for i in st.pattern]
+        # an output of the pattern without a gradient this time (a loss that skips a scale): zeros give the same sums
+        gs = [_lib.f32(gouts[i]) if gouts[i] is not None else torch.zeros(st.out_shapes[i], device=ctx.x.device) for i in st.pattern]
         if st.late_b or st.late_f:
             FD._wait_late_layouts()
         out = st.bwd.replay(gs + [ctx.x, ctx.arena])
@@ -496,6 +498,7 @@ class TrainReplayable:
         if not ok:
             raise fail("the backward replay does not reproduce the eager parameter gradients bit for bit")
         st.fwd, st.bwd, st.pattern = fwd, bwd, pattern
+        st.out_shapes = [tuple(t.shape) if t is not None else None for t in flat]
         st.fwd_effects = [e for e in rec.effects if e[0] in ("note_use", "bn_counter")]
         st.bwd_effects = [e for e in rec2.effects if e[0] == "grad_ready"]
         lay = {}
