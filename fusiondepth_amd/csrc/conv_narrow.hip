@@ -1,5 +1,7 @@
 // Weight gradient of the narrow 3x3 stride-1 pad-1 convolutions of the DepthDecoder's full-resolution levels
-// (networks/depth_decoder.py:63-96: upconv(0,*) 16/32 -> 16 channels, dispconv(0/1) 16/32 -> 1): Cin in {16, 32}, Cout <= 16.
+// (networks/depth_decoder.py:63-96: upconv(0,*) 16/32 -> 16 channels, dispconv(0/1) 16/32 -> 1): Cin in {16, 32}, Cout <= 16;
+// and, with two row groups (MG = 2), the 32 -> 32 layers of the Refiner's decoder at the two finest levels
+// (networks/refine_decoder.py, 22 -> 32 after channel padding), which the generic gather kernel took 125 / 510 us for.
 //
 // As a GEMM this is M = Cout <= 16 rows x J = 9*Cin columns x K = N*H*W pixels: 0.1 GFLOP per megapixel of work on 190 MB
 // of operands - memory-bound.  The generic gather kernel pads M and J up to 32x128 MFMA tiles and gathers every tap
@@ -31,12 +33,12 @@ __device__ __forceinline__ int refl_clamp_idx(int i, int n) {
     return i < 0 ? 0 : (i >= n ? n - 1 : i);   // far-out halo positions of partial tiles: any in-range value (their dY is 0)
 }
 
-template <int CG>   // channel groups of 16
+template <int CG, int MG = 1>   // input-channel groups of 16, output-row groups of 16
 __global__ void __launch_bounds__(256) k_wgrad_narrow(NarrowWgradArgs g) {
     constexpr int C = 16 * CG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sX = smem;                          // [C][XCS]
-    float* sY = smem + C * XCS;                // [16][YS]
+    float* sY = smem + C * XCS;                // [16 * MG][YS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
     const __amdgpu_buffer_rsrc_t rsX = fd_make_rsrc(g.X), rsY = fd_make_rsrc(g.dY);
@@ -45,11 +47,11 @@ __global__ void __launch_bounds__(256) k_wgrad_narrow(NarrowWgradArgs g) {
     const int ntiles = g.N * tiles_per_img;
     const unsigned hw = (unsigned)(g.H * g.W);
 
-    f32x4 acc[9][CG];
+    f32x4 acc[9][CG * MG];                      // [tap][cg * MG + mg]
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int c = 0; c < CG; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < CG * MG; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int n = tile / tiles_per_img, r = tile - n * tiles_per_img;
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(256) k_wgrad_narrow(NarrowWgradArgs g) {
         __syncthreads();                        // previous tile's readers are done
         // ---- X halo patch (rows y0-1 .. y0+TH, columns x0-1 .. x0+TW) and the dY tile (rows >= M and pixels outside the
         //      image read 0): the loads of a 16-channel group are all issued before its first LDS store (latencies overlap)
-        constexpr int NXI = (16 * PR * PCW + 255) / 256, NYI = 16 * TH * TW / 256;   // per 16-channel group (bounds the registers)
+        constexpr int NXI = (16 * PR * PCW + 255) / 256, NYI = MG * 16 * TH * TW / 256;   // X: per 16-channel group (bounds the registers)
         float vy[NYI];
 #pragma unroll
         for (int it = 0; it < NYI; ++it) {
@@ -109,7 +111,9 @@ __global__ void __launch_bounds__(256) k_wgrad_narrow(NarrowWgradArgs g) {
         const float* pb = sX + li * XCS + wave * XRS + lk;
 #pragma unroll 2
         for (int ks = 0; ks < TW / 4; ++ks) {
-            const float a = pa[4 * ks];
+            float a[MG];
+#pragma unroll
+            for (int mg = 0; mg < MG; ++mg) a[mg] = pa[mg * 16 * YS + 4 * ks];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -117,27 +121,31 @@ __global__ void __launch_bounds__(256) k_wgrad_narrow(NarrowWgradArgs g) {
 #pragma unroll
                     for (int c = 0; c < CG; ++c) {
                         const float b = pb[c * 16 * XCS + dy * XRS + 4 * ks + dx];
-                        acc[dy * 3 + dx][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[dy * 3 + dx][c], 0, 0, 0);
+#pragma unroll
+                        for (int mg = 0; mg < MG; ++mg)
+                            acc[dy * 3 + dx][c * MG + mg] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mg], b, acc[dy * 3 + dx][c * MG + mg], 0, 0, 0);
                     }
         }
     }
     // ---- sum the four waves (fixed order) and write this workgroup's partial slab [m][c][tap]
     float* slab = g.slabs + (size_t)blockIdx.x * g.M * C * 9;
-    float* red = smem;                          // [4 waves][CG][64 lanes][4 regs]
+    float* red = smem;                          // [4 waves][CG * MG][64 lanes][4 regs]
+    constexpr int NA = CG * MG;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < CG; ++c)
+        for (int c = 0; c < NA; ++c)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) red[((wave * CG + c) * 64 + lane) * 4 + rg] = acc[t][c][rg];
+            for (int rg = 0; rg < 4; ++rg) red[((wave * NA + c) * 64 + lane) * 4 + rg] = acc[t][c][rg];
         __syncthreads();
-        for (int i = tid; i < CG * 256; i += 256) {
+        for (int i = tid; i < NA * 256; i += 256) {
             const int c = i >> 8, q = i & 255, ln = q >> 2, rg = q & 3;
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) s += red[((w * CG + c) * 64 + ln) * 4 + rg];
-            const int m = 4 * (ln >> 4) + rg, ch = c * 16 + (ln & 15);      // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
+            for (int w = 0; w < 4; ++w) s += red[((w * NA + c) * 64 + ln) * 4 + rg];
+            // C/D layout: row = 4*(lane>>4)+reg, col = lane&15
+            const int m = (c % MG) * 16 + 4 * (ln >> 4) + rg, ch = (c / MG) * 16 + (ln & 15);
             if (m < g.M) slab[(m * C + ch) * 9 + t] = s;
         }
     }
@@ -329,7 +337,7 @@ int stem_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
 
 bool narrow_wgrad_ok(const fd_conv_desc* d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->in_norm && (d->Cin == 16 || d->Cin == 32) &&
-           d->Cout <= 16 && (double)d->N * d->Cin * d->H * d->W * 4.0 < 2147483648.0;
+           (d->Cout <= 16 || (d->Cout <= 32 && d->Cin == 32)) && (double)d->N * d->Cin * d->H * d->W * 4.0 < 2147483648.0;
 }
 
 int narrow_wgrad_blocks(const fd_conv_desc* d) {
@@ -344,10 +352,18 @@ int narrow_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, 
     NarrowWgradArgs a;
     a.X = x; a.dY = gy; a.slabs = ws; a.N = d->N; a.M = d->Cout; a.H = d->H; a.W = d->W; a.pad_mode = d->pad_mode;
     const int blocks = narrow_wgrad_blocks(d);
-    const int cg = d->Cin / 16;
-    const size_t lds = sizeof(float) * ((size_t)d->Cin * XCS + 16 * YS);
+    const int cg = d->Cin / 16, mg = (d->Cout + 15) / 16;
+    const size_t lds = sizeof(float) * ((size_t)d->Cin * XCS + 16 * mg * YS);
     if (cg == 1) {
         hipLaunchKernelGGL(k_wgrad_narrow<1>, dim3(blocks), dim3(256), lds, st, a);
+    } else if (mg == 2) {                       // the Refiner decoder's 32 -> 32 layers (refine_decoder: upconv(1,*) / (0,*) after padding)
+        static FdLdsAttrOnce attr2;
+        if (attr2.needed()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_narrow<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            attr2.mark();
+        }
+        hipLaunchKernelGGL((k_wgrad_narrow<2, 2>), dim3(blocks), dim3(256), lds, st, a);
     } else {
         static FdLdsAttrOnce attr;
         if (attr.needed()) {

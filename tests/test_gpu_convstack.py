@@ -75,6 +75,9 @@ CONV_CASES = [
     (3, 32, 9, 70, 1, 3, 1, 1, "reflect", "sigmoid", True, False), # dispconv(1) shape class, Cout = 1
     (2, 16, 21, 67, 12, 3, 1, 1, "zero", "none", False, False),    # narrow kernel with zero padding
     (12, 16, 96, 128, 16, 3, 1, 1, "reflect", "none", False, False),  # > 512 tiles: persistent workgroups take several
+    (2, 32, 37, 130, 32, 3, 1, 1, "reflect", "elu", True, False),  # Refiner decoder 32 -> 32: narrow wgrad kernel with two row groups
+    (2, 32, 21, 67, 24, 3, 1, 1, "zero", "none", False, False),    # ... partial second row group, zero padding
+    (6, 32, 96, 320, 32, 3, 1, 1, "reflect", "elu", True, False),  # ... at the Refiner's half-resolution level (persistent loop)
 ]
 
 
