@@ -501,8 +501,9 @@ __global__ void __launch_bounds__(384) k_wgrad_finish9(const float* __restrict__
     const int r = threadIdx.x >> 5, c = threadIdx.x & 31;
     const size_t n = (size_t)M * R * C;
     const int m_hi = min(M, ((int)blockIdx.y + 1) * mb);
+    const int cw = min(32, C - c0);             // the last block of a channel count that is not a multiple of 32 is narrower
     for (int m = blockIdx.y * mb; m < m_hi; ++m) {
-        if (r < R) {
+        if (r < R && c < cw) {
             const float* p = slabs + ((size_t)m * R + r) * C + c0 + c;
             float s = 0.f;
             int z = 0;
@@ -518,7 +519,7 @@ __global__ void __launch_bounds__(384) k_wgrad_finish9(const float* __restrict__
         }
         __syncthreads();
         const int j = threadIdx.x;
-        if (j < 288) {
+        if (j < 9 * cw) {
             const int cc = j / 9, tt = j - cc * 9;
             float v;
             if constexpr (R == 9) v = tile[tt][cc];
@@ -680,18 +681,18 @@ int fast_wgrad_finish_launch(const float* slabs, float* gw, int M, int C, int T,
 #ifdef FD_ABLATE_NO_FINISH      // timing experiment only (wrong results): what the step would gain if the slab reductions cost nothing
     return 0;
 #endif
-    if ((T == 9 || T == 12) && C % 32 == 0) {
+    if ((T == 9 && C % 32 == 0) || T == 12) {
         // enough (m, c block) pairs for every CU, several output channels per workgroup beyond that
-        int mb = (int)(((long)M * (C / 32)) / 1024);
+        const int cb = (C + 31) / 32;
+        int mb = (int)(((long)M * cb) / 1024);
         mb = mb < 1 ? 1 : (mb > 8 ? 8 : mb);
-        const dim3 grid(C / 32, (M + mb - 1) / mb);
+        const dim3 grid(cb, (M + mb - 1) / mb);
         if (T == 9) hipLaunchKernelGGL(k_wgrad_finish9<9>, grid, dim3(384), 0, st, slabs, gw, M, C, splits, accumulate, mb);
         else hipLaunchKernelGGL(k_wgrad_finish9<12>, grid, dim3(384), 0, st, slabs, gw, M, C, splits, accumulate, mb);
         hipError_t e9 = hipGetLastError();
         if (e9 != hipSuccess) { fd_set_error("k_wgrad_finish9 launch failed: %s", hipGetErrorString(e9)); return (int)e9; }
         return 0;
     }
-    if (T == 12) { fd_set_error("k_wgrad_finish9<12> needs Cin %% 32 == 0 (got %d)", C); return 1; }
     hipLaunchKernelGGL(k_wgrad_finish, dim3(ew_blocks((long)M * C * T)), dim3(256), 0, st, slabs, gw, M, C, T, splits, accumulate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { fd_set_error("k_wgrad_finish launch failed: %s", hipGetErrorString(e)); return (int)e; }

@@ -1865,7 +1865,10 @@ bool wino_wgrad_ok(const fd_conv_desc* d) {
 }
 // The 2-D algorithm needs whole 2x2 tiles of dY (fd_tuning.wino_wgrad_2d = 0: the 1-D kernel everywhere, for A/B timing)
 bool wino_wgrad_2d(const fd_conv_desc* d) {
-    return fd_tun().wino_wgrad_2d != 0 && d->H % 2 == 0 && d->Cin % 32 == 0;      // (k_wgrad_finish9<12> works on blocks of 32 input channels)
+    // wino_wgrad_2d = 1: where Cin is a multiple of 32 (rounds 4-5); 2: every Cin the Winograd path takes (multiples of 16: the
+    // Refiner decoder's 272 / 144 / 112-channel layers)
+    const int mode = fd_tun().wino_wgrad_2d;
+    return mode != 0 && d->H % 2 == 0 && (d->Cin % 32 == 0 || mode >= 2);
 }
 int wino_wgrad_splits(const fd_conv_desc* d) {
     const bool twod = wino_wgrad_2d(d);

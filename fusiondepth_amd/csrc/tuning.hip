@@ -11,7 +11,7 @@ fd_tuning make_defaults() {
     memset(&t, 0, sizeof(t));
     t.size = (int)sizeof(fd_tuning);
     t.wino_fwd = 1; t.wino_wgrad = 1;
-    t.wino_fwd_2d_min = 65536; t.wino_fwd_2dp_min_wgs = 160; t.wino_fwd_2dp_dma = 1; t.wino_fwd_2dp_deep = 0; t.wino_wgrad_2d = 1;
+    t.wino_fwd_2d_min = 65536; t.wino_fwd_2dp_min_wgs = 160; t.wino_fwd_2dp_dma = 1; t.wino_fwd_2dp_deep = 0; t.wino_wgrad_2d = 2;
     t.wino_target = 384; t.wino_wgrad_target = 256;      // alone on the GPU 768 is best; inside the step 256 - 384 (less slab traffic; round 4: profiles/round4_targets.log)
     t.conv_target = 768; t.wgrad_target = 768;
     t.conv_c1 = 1; t.conv_n16_min_pixels = 16384;

@@ -55,7 +55,7 @@ typedef struct fd_tuning {
                                          the launch has at least this many 64x64 output tiles (0: never - F(2,3) along x as in rounds 1-3) */
     int wino_fwd_2dp_dma;         /* 1   ... with its activations on the direct-to-LDS path where W % 4 == 0 (0: register-staged loader) */
     int wino_fwd_2dp_deep;        /* 0   1: the one-workgroup kernel also above wino_fwd_2d_min when the launch has enough tiles (A/B) */
-    int wino_wgrad_2d;            /* 1   weight gradient as transposed F(2x2,3x3) where the height is even and Cin % 32 == 0 */
+    int wino_wgrad_2d;            /* 2   weight gradient as transposed F(2x2,3x3) where the height is even (1: and Cin % 32 == 0; 0: never) */
     int wino_target;              /* 384 workgroups a Winograd forward launch is split-K'd up to */
     int wino_wgrad_target;        /* 256 ... a Winograd weight-gradient launch is pixel-sliced up to */
     int conv_target;              /* 768 ... a direct forward / data-gradient launch */

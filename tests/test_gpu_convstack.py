@@ -938,8 +938,12 @@ def test_winograd_routing_forward_and_data_gradient_match_torch(Ci, Co, two_d_mi
     relclose(cpu(gx2), cpu(1.5 * gx), "dx after batched re-layout", rtol=1e-6, arel=1e-6)
 
 
-@pytest.mark.parametrize("two_d", [1, 0])
+@pytest.mark.parametrize("two_d", [2, 1, 0])
 @pytest.mark.parametrize("N,Ci,Co,H,W,mode", [
+    (2, 272, 128, 24, 80, "reflect"),   # Refiner decoder (channel-padded concatenations): Cin % 32 == 16, 2-D only with two_d = 2
+    (1, 144, 144, 8, 12, "reflect"),
+    (2, 112, 32, 10, 16, "reflect"),    # ... with at most 32 output channels (HALFM)
+    (1, 80, 64, 4, 6, "zero"),
     (2, 64, 64, 24, 80, "zero"),        # 3 (4) tiles x many pixel slices
     (1, 96, 80, 7, 10, "zero"),         # partial channel tiles on both sides, 35 pairs (< one slice of 64); odd height: 1-D kernel
     (1, 96, 80, 8, 10, "zero"),         # the same with whole 2x2 tiles
@@ -953,7 +957,7 @@ def test_winograd_routing_forward_and_data_gradient_match_torch(Ci, Co, two_d_mi
 ])
 def test_winograd_weight_gradient_vs_float64_reference(N, Ci, Co, H, W, mode, two_d, fdtune):
     """k_wgrad_wino through FD.conv2d's backward, against torch float64 autograd: the transposed F(2x2, 3x3) algorithm (16
-    products per 2x2 tile of dY; two_d = 1, the default wherever the height is even) and the transposed F(2, 3) algorithm per
+    products per 2x2 tile of dY; two_d = 2, the default wherever the height is even; 1: only where Cin % 32 == 0 as in rounds 4-5) and the transposed F(2, 3) algorithm per
     kernel row (4 products per pixel pair and row; fd_tuning.wino_wgrad_2d = 0, and odd heights); also accumulation into an existing
     gradient (the trainer's direct-gradient mode)."""
     import fusiondepth_amd.functional as FD
