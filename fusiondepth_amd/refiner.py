@@ -29,6 +29,19 @@ from .trainer import Outputs, Trainer, derived_hparams
 REFINER_MODEL_ORDER = ["encoder", "beam_encoder", "beam_encoder_pose", "depth", "pose_encoder", "pose", "refine2d_decoder"]
 
 
+def _lookahead(loader):
+    """(batch, next batch or None) pairs of an iterable."""
+    it = iter(loader)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 class Refiner(Trainer):
     """Same method names as the reference's ``Refiner``; batches are dicts with the reference's keys (+ ``"inf_gdc"``)."""
 
@@ -100,6 +113,7 @@ class Refiner(Trainer):
         self.adam_state = torch.tensor([0.0, self.lr], device=self.device)
         self._graph, self._streams = None, []
         self._replays = {}
+        self._frozen_stream, self._prefetched = None, None
         self.parallel_streams = tuning.host.refiner_streams
         self.stack_microbatches = False
         self._groups = 1
@@ -199,12 +213,14 @@ class Refiner(Trainer):
                 res[("disp", scale)] = torch.cat([scaled_disp, two_cha], 1)
         return res
 
-    def process_batch(self, inputs, val=False):
-        """refiner.py:299-382 (train_entire_net=False)."""
+    def _to_device(self, inputs):
         for key, ipt in inputs.items():
             if torch.is_tensor(ipt) and ipt.device != self.device:
                 inputs[key] = ipt.to(self.device)
-        FD.begin_forward_pass()
+
+    def _frozen_block(self, inputs, val):
+        """Everything of refiner.py:299-330 that involves only the batch and frozen networks (no parameter that is trained, no
+        autograd graph): the frozen forward passes, the refine decoder's input maps and the poses -> (features, beam_features, outputs)."""
         # The four frozen encoders are independent and, at the Refiner's batch of 6, none of them fills 256 CUs: like the
         # Trainer they run on one HIP stream per module, the two pose passes (frames -1 / +1) stacked into one pass per module.
         # Eval-mode BatchNorm is per sample, so stacking changes nothing; no autograd graph is recorded for any of them.
@@ -217,6 +233,47 @@ class Refiner(Trainer):
             outputs = Outputs.for_options(self.opt, depth)
             outputs.update(self.refine_inputs(inputs, outputs))
             outputs.update(poses)
+        return features, beam_features, outputs
+
+    def prefetch_frozen(self, next_inputs):
+        """Issue the frozen block of the NEXT batch now, on its own stream, so that the GPU runs it beside this batch's refine-decoder
+        forward / loss / backward (a serial chain of batch-6 launches that leaves most CUs idle).  Nothing in the block reads a trained
+        parameter, so its results are those of issuing it at the start of the next ``train_step`` - which then picks them up (matched
+        by the identity of the ``next_inputs`` dict) instead of recomputing.  The stream waits for everything queued on the current
+        stream up to here, so tensors of ``next_inputs`` that the caller is still producing on it are complete."""
+        self._to_device(next_inputs)
+        cur = torch.cuda.current_stream()
+        if self._frozen_stream is None:
+            self._frozen_stream = torch.cuda.Stream()
+        st = self._frozen_stream
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            frozen = self._frozen_block(next_inputs, False)
+            done = torch.cuda.Event()
+            done.record(st)
+        self._prefetched = (next_inputs, frozen, done)
+
+    def _take_prefetched(self, inputs):
+        pre, self._prefetched = self._prefetched, None
+        if pre is None or pre[0] is not inputs:
+            return None
+        _, frozen, done = pre
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        features, beam_features, outputs = frozen
+        for t in list(features) + list(beam_features or []) + list(outputs.values()):
+            if torch.is_tensor(t):
+                t.record_stream(cur)          # allocated on the prefetch stream's pool, read (and released) on this one
+        return frozen
+
+    def process_batch(self, inputs, val=False, frozen=None):
+        """refiner.py:299-382 (train_entire_net=False).  ``frozen``: the result of ``_frozen_block`` for this batch, if the caller
+        already has it (``train_step`` with a prefetched block)."""
+        self._to_device(inputs)
+        FD.begin_forward_pass()
+        if frozen is None:
+            frozen = self._frozen_block(inputs, val)
+        features, beam_features, outputs = frozen
         losses = {"loss": 0.0}
         n_iter = self.opt.refine_iter
         for it in range(n_iter):
@@ -330,10 +387,10 @@ class Refiner(Trainer):
     def run_epoch(self):
         """refiner.py:264-297: one optimiser step per batch, the trainer's logging / validation cadence, StepLR at the end."""
         self.set_train()
-        for batch_idx, inputs in enumerate(self.train_loader):
+        for batch_idx, (inputs, next_inputs) in enumerate(_lookahead(self.train_loader)):
             t0 = time.time()
             step0 = self.step
-            losses = self.train_step(inputs)
+            losses = self.train_step(inputs, next_inputs)
             if self.rank == 0 and self._log_due(batch_idx, step0):
                 self.log_time(batch_idx, time.time() - t0, float(losses["loss"]))
                 if "depth_gt" in inputs:
@@ -344,11 +401,19 @@ class Refiner(Trainer):
                     self.set_train()
         self.lr_scheduler_step()
 
-    def train_step(self, inputs):
+    def train_step(self, inputs, next_inputs=None):
         """One optimiser step of refiner.py:272-278: zero_grad, backward, step for every batch (the reference's Refiner never
-        accumulates, whatever --batch_size is).  With several ranks the refine decoder's gradient is all-reduced (mean)."""
+        accumulates, whatever --batch_size is).  With several ranks the refine decoder's gradient is all-reduced (mean).
+        ``next_inputs``: the batch of the following call, if the caller has it (``run_epoch`` reads one batch ahead): its frozen
+        forward passes are issued first and overlap this step (``prefetch_frozen``, tuning.host.refiner_prefetch)."""
         self.grad_sync.arm()
-        outputs, losses = self.process_batch(inputs)
+        self._to_device(inputs)
+        frozen = self._take_prefetched(inputs)
+        if frozen is None:                                     # first step of a loop, or a caller that does not look ahead
+            frozen = self._frozen_block(inputs, False)
+        if next_inputs is not None and tuning.host.refiner_prefetch:
+            self.prefetch_frozen(next_inputs)                  # queued in front of this step's refine-decoder work
+        outputs, losses = self.process_batch(inputs, frozen=frozen)
         losses["loss"].backward()
         scale = self.grad_sync.finish() if self.world_size > 1 else 1.0
         self.optimizer_step(scale)

@@ -118,6 +118,44 @@ def test_refiner_steps_are_reproducible_under_gpu_contention():
     assert torch.equal(finals[0], finals[1]) and torch.equal(finals[0], finals[2])
 
 
+def test_refiner_prefetched_frozen_block_changes_nothing(fdtune):
+    """``train_step(inputs, next_inputs)`` issues the next batch's frozen forward passes on their own stream beside this step's
+    refine-decoder work (Refiner.prefetch_frozen).  Six steps over three batches, with background load on another stream: losses and
+    refine-decoder parameters bit-identical to the plain ``train_step(inputs)`` loop; a caller that passes a DIFFERENT batch than it
+    announced gets that batch's own (recomputed) result."""
+    B, H, W = 2, 192, 640
+    batches = []
+    for k in range(3):
+        inp, noise = gin.refiner_inputs(860 + k, B, H, W)
+        g = {k_: v.cuda() for k_, v in inp.items()}
+        g["_noise"] = [n.cuda() for n in noise]
+        batches.append(g)
+    order = [0, 1, 2, 0, 2, 1]
+    bg = torch.cuda.Stream()
+    junk = torch.randn(2048, 2048, device="cuda")
+
+    def run(prefetch, lie=False):
+        fdtune.host(refiner_prefetch=prefetch)
+        rf, _, _ = _make(B, H, W)
+        losses = []
+        for i, b in enumerate(order):
+            with torch.cuda.stream(bg):
+                for _ in range(6 + 5 * i):
+                    junk @ junk
+            nxt = batches[order[i + 1]] if i + 1 < len(order) else None
+            if lie and i == 2:
+                nxt = batches[order[i]]                 # announced batch != the batch of the next call
+            losses.append(rf.train_step(batches[b], nxt)["loss"].detach().clone())
+        torch.cuda.synchronize()
+        return torch.stack(losses), torch.cat([p.detach().reshape(-1) for p in rf.models["refine2d_decoder"].parameters()]).clone()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    l2, p2 = run(True, lie=True)
+    assert torch.equal(l0, l1) and torch.equal(p0, p1), "prefetched frozen block changes the step"
+    assert torch.equal(l0, l2) and torch.equal(p0, p2), "a mis-announced next batch must be recomputed"
+
+
 def test_refiner_train_loop_logs_depth_metrics(tmp_path):
     """Refiner.train() / run_epoch (refiner.py:264-297) over batches that carry ``depth_gt``: the logged batches go through
     compute_depth_losses, which reads ("depth", 0, 0) - derived lazily from the refined disparity (the Refiner's
