@@ -104,6 +104,10 @@ class Refiner(Trainer):
         FD.evict_dead_weight_layouts()
         FD.enable_weight_cache(self.parameters_to_train)
         FD.enable_direct_grad(self.parameters_to_train)
+        # the refine decoder is the step's serial chain (one batch-6 launch at a time): its weight gradients - leaves of the backward
+        # graph - run on a side stream beside the following layers' data gradients, like the depth decoder's in the Trainer
+        if "refine2d_decoder" in tuning.host.side_wgrad:
+            FD.enable_side_wgrad(self.parameters_to_train)
         # the frozen stage-1 networks: kernel-side weight layouts derived once, not on every call
         FD.enable_weight_cache([p for k, net in self.models.items() if k != "refine2d_decoder" for p in net.parameters()], frozen=True)
         self.exp_avg = torch.zeros_like(self.flat.flat_param)
@@ -415,6 +419,7 @@ class Refiner(Trainer):
             self.prefetch_frozen(next_inputs)                  # queued in front of this step's refine-decoder work
         outputs, losses = self.process_batch(inputs, frozen=frozen)
         losses["loss"].backward()
+        FD.join_wgrad_streams()
         scale = self.grad_sync.finish() if self.world_size > 1 else 1.0
         self.optimizer_step(scale)
         self._ensure_weight_plan()

@@ -89,7 +89,7 @@ class _Host:
     pose_stream = True          # pose decoder on the pose encoder's stream (-3.2 % when off)
     smooth_stream = True        # smoothness terms beside the photometric kernel (-0.5 % when off)
     photo_ms = True             # the all-scales loss kernel for the default configuration (off: per-scale kernels)
-    side_wgrad = ("depth",)     # networks whose weight gradients run on a side stream
+    side_wgrad = ("depth", "refine2d_decoder")     # networks whose weight gradients run on a side stream (the steps' serial chains)
     n_streams = 8               # HIP streams of the training step (4 are used; 1 = everything on one stream)
     interleave = False          # the four encoders issued block by block in turns
     conv_stats = True           # BatchNorm statistics from the convolution epilogue where the kernel has one
