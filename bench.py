@@ -129,7 +129,7 @@ def roofline_probes(args, tr, batch):
     from fusiondepth_amd import tuning as _tuning
     two_p = _tuning.get_lib()["wino_fwd_2dp_min_wgs"] > 0 and Bc * (h8 // 2) * (w8 // 2) // 64 >= _tuning.get_lib()["wino_fwd_2dp_min_wgs"] and h8 % 2 == 0
     executed = 4.0 / 9.0 if two_p else 2.0 / 3.0
-    for name in ("round5_pmc_probe_wino.json", "round4_pmc_probe_wino.json", "round3_pmc_probe_wino.json"):
+    for name in ("round6_pmc_probe_wino.json", "round5_pmc_probe_wino.json", "round4_pmc_probe_wino.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
