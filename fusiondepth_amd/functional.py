@@ -1426,6 +1426,34 @@ class _ConvBN(torch.autograd.Function):
         return (gx, gw, gbw, gbb, gres) + (None,) * 9
 
 
+_FOLDED = {}               # id(conv weight) -> [stamp, weakref(conv weight), folded weight, folded bias]
+
+
+def folded_tensors():
+    """The folded weight / bias tensors of ``conv_bn_frozen`` (persistent storage for a call recorder)."""
+    return [t for e in _FOLDED.values() for t in e[2:4]]
+
+
+def conv_bn_frozen(x, conv_weight, bn, stride=1, pad=0, relu=False):
+    """Eval-mode ``relu?(bn(conv(x)))`` of a FROZEN network (the Refiner's stage-1 ResNets, refiner.py:56-60) with the BatchNorm folded
+    into the convolution: w' = w * a[co], b' = bias - running_mean * a, a = weight / sqrt(running_var + eps) (the per-channel constants
+    of k_bn_apply_eval), ReLU in the convolution's epilogue - the pass over the activation that applied them is gone.  The folded pair
+    is derived once and kept until the weights / statistics change (their version counters, ``invalidate_frozen_layouts``).  The
+    result differs from the two-launch form by the rounding of w * a (one ulp per weight)."""
+    stamp = (conv_weight._version, _FROZEN_EPOCH[0], conv_weight.data_ptr(), bn.weight._version, bn.bias._version,
+             bn.running_mean._version, bn.running_var._version)
+    ent = _FOLDED.get(id(conv_weight))
+    if ent is None or ent[0] != stamp or ent[1]() is not conv_weight:
+        with torch.no_grad():
+            a = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+            wf = (conv_weight.detach() * a.view(-1, 1, 1, 1)).contiguous()
+            bf = (bn.bias.detach() - bn.running_mean * a).contiguous()
+        enable_weight_cache([wf], frozen=True)
+        key = id(conv_weight)
+        ent = _FOLDED[key] = [stamp, weakref.ref(conv_weight, lambda _r, k=key: _FOLDED.pop(k, None)), wf, bf]
+    return conv2d(x, ent[2], ent[3], stride, pad, "zero", "relu" if relu else "none")
+
+
 def conv_bn(x, conv_weight, bn, stride=1, pad=0, residual=None, relu=False, tap=False):
     """``batch_norm(conv2d(x, w), bn, residual, relu)`` in training mode as one autograd node -> out, or (out, x_tap) with ``tap``."""
     groups = _BN_GROUPS[0]

@@ -33,6 +33,10 @@ def _conv_bn(x, conv, bn, residual=None, relu=False, tap=False):
         y, stats = res[0], res[1]
         out = FD.batch_norm(y, bn, residual=residual, relu=relu, conv_stats=stats)
         return (out, res[2]) if tap else out
+    if (not bn.training and residual is None and conv.bias is None and tuning.host.fold_frozen_bn and not torch.is_grad_enabled()
+            and getattr(conv.weight, "_fd_frozen", False) and bn.weight is not None):
+        y = FD.conv_bn_frozen(x, conv.weight, bn, stride=conv.stride[0], pad=conv.padding[0], relu=relu)   # frozen network: BN folded
+        return (y, x) if tap else y
     if tap:
         y, x = _conv_tap(x, conv)
         return FD.batch_norm(y, bn, residual=residual, relu=relu), x

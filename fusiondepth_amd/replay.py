@@ -267,7 +267,7 @@ class Replayable:
             if not all(t is None or torch.is_tensor(t) for t in flat):
                 raise NotRecordable("the region returns non-tensor leaves")
             persistent = [t for t in self.persistent() if torch.is_tensor(t) and t.is_cuda]
-            persistent += [e[1] for e in FD._WT_CACHE.values()]
+            persistent += [e[1] for e in FD._WT_CACHE.values()] + FD.folded_tensors()
             plan = build_plan(rec, list(inputs), flat, tree, persistent, tally)
             again = plan.replay(list(inputs))
             flat2, _ = _pytree.tree_flatten(again)

@@ -95,6 +95,7 @@ class _Host:
     conv_stats = True           # BatchNorm statistics from the convolution epilogue where the kernel has one
     fused_conv_bn = True        # conv + BatchNorm of a ResNet block as ONE autograd node (host time only: same launches)
     refiner_streams = True      # the Refiner's frozen encoders on per-module streams
+    fold_frozen_bn = True       # eval-mode BatchNorm of a frozen ResNet block folded into its convolution (no residual input)
     refiner_prefetch = True     # Refiner.train_step(inputs, next_inputs): the next batch's frozen forward passes overlap this step
     decoder_fused_act = True    # ELU' of the decoder's single-consumer blocks applied where the gradient is produced (-0.15 ms when on)
     dp_overlap = True           # per-network gradient buckets all-reduced from inside the backward pass
@@ -133,7 +134,7 @@ _ENV_HOST = {
     "FD_SIDE_WGRAD": ("side_wgrad", lambda v: tuple(k for k in v.split(",") if k and k != "none")),
     "FD_NSTREAMS": ("n_streams", int), "FD_INTERLEAVE": ("interleave", lambda v: v != "0"),
     "FD_CONV_STATS": ("conv_stats", lambda v: v != "0"), "FD_FUSED_CONV_BN": ("fused_conv_bn", lambda v: v != "0"), "FD_REFINER_STREAMS": ("refiner_streams", lambda v: v != "0"),
-    "FD_REFINER_PREFETCH": ("refiner_prefetch", lambda v: v != "0"),
+    "FD_REFINER_PREFETCH": ("refiner_prefetch", lambda v: v != "0"), "FD_FOLD_FROZEN_BN": ("fold_frozen_bn", lambda v: v != "0"),
     "FD_DP_OVERLAP": ("dp_overlap", lambda v: v != "0"), "FD_REPLAY_FROZEN": ("replay_frozen", lambda v: v != "0"), "FD_REPLAY_TRAIN": ("replay_train", lambda v: v != "0"), "FD_PAD_ODD_CHANNELS": ("pad_odd_channels", lambda v: v != "0"), "FD_FUSED_POSE_HEAD": ("fused_pose_head", lambda v: v != "0"), "FD_FUSED_STEM_TAIL": ("fused_stem_tail", lambda v: v != "0"), "FD_BN_REMASK": ("bn_remask", lambda v: v != "0"), "FD_FUSED_FINISH_BN": ("fused_finish_bn", lambda v: v != "0"), "FD_DECODER_FUSED_ACT": ("decoder_fused_act", lambda v: v != "0"), "FD_HOST_DELAY_US": ("host_delay_us", float),
 }
 

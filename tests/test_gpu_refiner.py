@@ -156,6 +156,50 @@ def test_refiner_prefetched_frozen_block_changes_nothing(fdtune):
     assert torch.equal(l0, l2) and torch.equal(p0, p2), "a mis-announced next batch must be recomputed"
 
 
+@pytest.mark.parametrize("layers", [18, 50])
+def test_frozen_batchnorm_folded_into_the_convolution(layers, fdtune):
+    """functional.conv_bn_frozen: the eval-mode BatchNorms of a frozen ResNet that have no residual input (bn1 of every block, the
+    downsample branches; bn1 / bn2 of a Bottleneck) are folded into their convolutions.  Features vs the two-launch form: relative L2
+    <= 2e-6 per level (rounding of w * a only); new statistics (load_state_dict) are picked up."""
+    from fusiondepth_amd import networks
+    import fusiondepth_amd.functional as FD
+    torch.manual_seed(layers)
+    enc = networks.ResnetEncoder(layers, False).cuda().eval()
+    with torch.no_grad():
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    FD.enable_weight_cache(list(enc.parameters()), frozen=True)
+    x = torch.rand(2, 3, 64, 96, device="cuda")
+
+    def both():
+        with torch.no_grad():
+            fdtune.host(fold_frozen_bn=False)
+            plain = [f.clone() for f in enc(x)]
+            fdtune.host(fold_frozen_bn=True)
+            folded = [f.clone() for f in enc(x)]
+        return plain, folded
+    plain, folded = both()
+    n0 = len(FD._FOLDED)
+    assert n0 >= (11 if layers == 18 else 36)
+    for i, (a, b) in enumerate(zip(plain, folded)):
+        err = float((a - b).norm() / a.norm())
+        assert err <= 2e-6, "features[%d]: folded vs two-launch BatchNorm relative L2 %.3e" % (i, err)
+    with torch.no_grad():
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.mul_(0.5)                       # version counter bumps: the folded pairs are stale
+    plain2, folded2 = both()
+    assert float((plain2[-1] - plain[-1]).norm() / plain[-1].norm()) > 1e-3
+    for a, b in zip(plain2, folded2):
+        assert float((a - b).norm() / a.norm()) <= 2e-6
+
+
 def test_refiner_train_loop_logs_depth_metrics(tmp_path):
     """Refiner.train() / run_epoch (refiner.py:264-297) over batches that carry ``depth_gt``: the logged batches go through
     compute_depth_losses, which reads ("depth", 0, 0) - derived lazily from the refined disparity (the Refiner's

@@ -42,7 +42,7 @@ def test_replayed_encoder_is_the_eager_encoder_bit_for_bit(layers):
                 assert torch.equal(a, b), "call %d" % k
         assert rp.disabled is None and len(rp.plans) == 1
         plan = next(iter(rp.plans.values()))[0]
-        assert plan.n_recs >= 40 and plan.arena_bytes > 0
+        assert plan.n_recs >= 30 and plan.arena_bytes > 0          # (~45 calls before the frozen BatchNorms were folded into their convolutions)
         x2 = torch.rand(1, 3, 96, 160, device="cuda", generator=g)         # another shape: its own plan
         for k in range(3):
             for a, b in zip(rp(x2), net(x2)):
