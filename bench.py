@@ -307,13 +307,19 @@ class _flop_tally:
     the configurations that have no analytic table (Refiner: frozen encoders forward only + the refine decoder; Completor)."""
 
     def __enter__(self):
-        from fusiondepth_amd import functional as FD
-        self.FD = FD
+        from fusiondepth_amd import functional as FD, tuning
+        self.FD, self.host = FD, tuning.host
         FD.CONV_FLOP_TALLY = self.t = [0.0]
+        # the counter sits in the Python wrappers: the counted (untimed) step issues every network eagerly - a recorded call sequence
+        # (replay.py) goes to the library in one C call and would not be seen (round 6's first lines under-reported the Refiner /
+        # Completor fractions by the replayed networks' share)
+        self.saved = (self.host.replay_train, self.host.replay_frozen)
+        self.host.replay_train = self.host.replay_frozen = False
         return self
 
     def __exit__(self, *exc):
         self.FD.CONV_FLOP_TALLY = None
+        self.host.replay_train, self.host.replay_frozen = self.saved
 
     def flops(self):
         return self.t[0]
@@ -423,9 +429,8 @@ def run_other_config(args):
             k[0] += 1
             return rf.train_step(pool[k[0] % 3], pool[(k[0] + 1) % 3])
         st, losses = _short_run(step, n, warm=WARM)
-        inp = pool[0]
-        with _flop_tally() as tally:
-            rf.train_step(inp)
+        with _flop_tally() as tally:       # one step of the loop above: the announced batch's frozen block + this batch's refine-decoder passes
+            step()
         loss = float(losses["loss"].detach())
         r = _timing_fields(st, B)
         tf = tally.flops() / st["dt"] / 1e12

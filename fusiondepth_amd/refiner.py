@@ -291,6 +291,10 @@ class Refiner(Trainer):
                 losses = self.compute_losses(inputs, outputs, losses, gama=gama)
         return outputs, losses
 
+    def _early_loss_inputs(self, inputs, st):
+        """(Trainer's hoist of the identity losses / noise: the Refiner's own ``generate_images_pred`` evaluates them per refine iteration)"""
+        self._loss_pre = None
+
     def _frozen_forward(self, inputs, par, want_poses):
         """The part of refiner.py:299-330 that involves only frozen networks: depth / beam encoders, depth decoder and (training)
         the pose networks -> (features, beam_features, {("disp", s)}, {cam_T_cam / axisangle / translation}).  Call under no_grad."""

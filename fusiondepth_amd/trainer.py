@@ -665,7 +665,29 @@ class Trainer:
                 with FD.bn_groups(G * len(fids)):
                     bf = self._run_module("beam_encoder_pose", stack("2channel"))
         res["stacked"] = (pf, st_rgb, bf, st_beam)
+        self._early_loss_inputs(inputs, st_beam if st_beam is not None else st_rgb)
         return res
+
+    def _early_loss_inputs(self, inputs, st):
+        """The identity reprojection losses (trainer.py:515-528) and the tie-break noise (trainer.py:551-552) are functions of the batch
+        alone, but the reference - and rounds 1-5 here - evaluate them between the depth decoder and the loss kernel: the one place of
+        the step where every stream waits for the main one.  Issued here instead, behind the shortest encoder stream's forward pass;
+        ``generate_images_pred`` joins that stream (it is joined for the poses anyway).  Same kernels, same order of random draws."""
+        self._loss_pre = None
+        o = self.opt
+        if (not tuning.host.early_loss_inputs or o.disable_automasking or o.v1_multiscale or torch.cuda.is_current_stream_capturing()
+                or not self._multiscale_loss_ok(self._loss_fids())):
+            return
+        with torch.cuda.stream(st):
+            ident0 = self.identity_losses(inputs, 0)
+            noise = None
+            if inputs.get("_noise") is None:
+                B, _, H, W = inputs[("color", 0, 0)].shape
+                noise = torch.randn((len(o.scales), B, ident0.shape[1], H, W), device=ident0.device)
+        self._loss_pre = (inputs, ident0, noise, st)
+
+    def _loss_fids(self):
+        return [f for f in self.opt.frame_ids[1:]]
 
     _REPLAYED = ("encoder", "beam_encoder", "pose_encoder", "beam_encoder_pose")
 
@@ -724,6 +746,7 @@ class Trainer:
                 (self.models["encoder"], enc_in, None, groups)]
         pf, bf, beam_features, features = networks.interleaved_forward(jobs)
         self._join(st_lidar, beam_features)
+        self._early_loss_inputs(inputs, st_beam)
         return features, beam_features, {"stacked": (pf, st_rgb, bf, st_beam)}
 
     def predict_poses(self, inputs, features, precomputed=None):
@@ -840,7 +863,13 @@ class Trainer:
             return
         automask = not self.opt.disable_automasking
         si_scales = self._lidar_term()[0]
-        ident0 = self.identity_losses(inputs, 0) if (automask and not self.opt.v1_multiscale) else None
+        pre, self._loss_pre = getattr(self, "_loss_pre", None), None
+        early_noise = None
+        if pre is not None and pre[0] is inputs and automask and not self.opt.v1_multiscale:     # issued beside the encoders (_early_loss_inputs)
+            ident0, early_noise = pre[1], pre[2]
+            self._join(pre[3], [ident0, early_noise])
+        else:
+            ident0 = self.identity_losses(inputs, 0) if (automask and not self.opt.v1_multiscale) else None
         noise_in = inputs.get("_noise")               # injected tie-break noise (tests); else drawn like trainer.py:551-552
         if self._multiscale_loss_ok(fids):
             # default configuration: ALL scales in one launch that also produces the gradients (csrc/photometric_ms.hip)
@@ -848,8 +877,11 @@ class Trainer:
             B, _, H, W = inputs[("color", 0, 0)].shape
             noise = None
             if ident0 is not None:
-                noise = [noise_in[s] for s in scales] if noise_in is not None else \
-                    list(torch.randn((len(scales), B, ident0.shape[1], H, W), device=ident0.device))
+                if noise_in is not None:
+                    noise = [noise_in[s] for s in scales]
+                else:
+                    noise = list(early_noise if early_noise is not None else
+                                 torch.randn((len(scales), B, ident0.shape[1], H, W), device=ident0.device))
             lidar = [i for i, s in enumerate(scales) if s in si_scales]
             photo, si, sel = FD.photo_loss_ms(
                 [outputs[("disp", s)] for s in scales], [outputs[("cam_T_cam", 0, f)] for f in fids], inputs[("K", 0)],

@@ -105,6 +105,8 @@ class _Host:
     fused_pose_head = True      # stacked pose network: slicing + concatenation + pose matrices of all frame pairs as one launch each way (FD.pose_head)
     replay_frozen = True        # frozen no-grad sub-networks (the Refiner's stage-1 encoders / depth decoder) recorded once and replayed by ONE C call each (replay.py)
     replay_train = True         # the four ResNet encoders' TRAINING forward + backward as recorded call sequences behind one autograd node each (replay.TrainReplayable)
+    early_loss_inputs = False   # identity reprojection losses + tie-break noise issued beside the encoders instead of between decoder and loss kernel
+                                # (bit-identical; measured 665.1 vs 665.2 images/s same box, profiles/round6_early_loss_inputs_ab.log: off)
     pad_odd_channels = True     # refine decoder: blocks with 262 / 134 / 102 / 22 input channels run zero-padded to a multiple of 16
 
     @property
@@ -135,7 +137,7 @@ _ENV_HOST = {
     "FD_NSTREAMS": ("n_streams", int), "FD_INTERLEAVE": ("interleave", lambda v: v != "0"),
     "FD_CONV_STATS": ("conv_stats", lambda v: v != "0"), "FD_FUSED_CONV_BN": ("fused_conv_bn", lambda v: v != "0"), "FD_REFINER_STREAMS": ("refiner_streams", lambda v: v != "0"),
     "FD_REFINER_PREFETCH": ("refiner_prefetch", lambda v: v != "0"), "FD_FOLD_FROZEN_BN": ("fold_frozen_bn", lambda v: v != "0"),
-    "FD_DP_OVERLAP": ("dp_overlap", lambda v: v != "0"), "FD_REPLAY_FROZEN": ("replay_frozen", lambda v: v != "0"), "FD_REPLAY_TRAIN": ("replay_train", lambda v: v != "0"), "FD_PAD_ODD_CHANNELS": ("pad_odd_channels", lambda v: v != "0"), "FD_FUSED_POSE_HEAD": ("fused_pose_head", lambda v: v != "0"), "FD_FUSED_STEM_TAIL": ("fused_stem_tail", lambda v: v != "0"), "FD_BN_REMASK": ("bn_remask", lambda v: v != "0"), "FD_FUSED_FINISH_BN": ("fused_finish_bn", lambda v: v != "0"), "FD_DECODER_FUSED_ACT": ("decoder_fused_act", lambda v: v != "0"), "FD_HOST_DELAY_US": ("host_delay_us", float),
+    "FD_DP_OVERLAP": ("dp_overlap", lambda v: v != "0"), "FD_REPLAY_FROZEN": ("replay_frozen", lambda v: v != "0"), "FD_REPLAY_TRAIN": ("replay_train", lambda v: v != "0"), "FD_PAD_ODD_CHANNELS": ("pad_odd_channels", lambda v: v != "0"), "FD_EARLY_LOSS_INPUTS": ("early_loss_inputs", lambda v: v != "0"), "FD_FUSED_POSE_HEAD": ("fused_pose_head", lambda v: v != "0"), "FD_FUSED_STEM_TAIL": ("fused_stem_tail", lambda v: v != "0"), "FD_BN_REMASK": ("bn_remask", lambda v: v != "0"), "FD_FUSED_FINISH_BN": ("fused_finish_bn", lambda v: v != "0"), "FD_DECODER_FUSED_ACT": ("decoder_fused_act", lambda v: v != "0"), "FD_HOST_DELAY_US": ("host_delay_us", float),
 }
 
 

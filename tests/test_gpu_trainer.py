@@ -844,6 +844,46 @@ def test_pose_decoder_and_smoothness_on_side_streams_are_bit_identical(fdtune):
     assert torch.equal(grads["0"][0], grads["1"][0]), "%d gradient entries differ" % int((grads["0"][0] != grads["1"][0]).sum())
 
 
+def test_early_loss_inputs_are_bit_identical(fdtune):
+    """tuning.host.early_loss_inputs: the identity reprojection losses and the tie-break noise (trainer.py:515-528, 551-552) are issued
+    on an encoder's stream at the start of the step instead of between the depth decoder and the loss kernel.  Same kernels, same order
+    of random draws (the noise is DRAWN here, not injected): parameters and losses over three optimiser steps equal the late-issue run
+    bit for bit, with a background stream keeping the GPU busy."""
+    from fusiondepth_amd.trainer import Trainer
+    B, H, W = 2, 64, 96
+    batches = []
+    for i in range(3):
+        inp, _ = _batch(B, H, W, 1201 + i)
+        batches.append({k: v.cuda() for k, v in inp.items()})
+    bg = torch.cuda.Stream()
+    junk = [torch.randn(s, s, device="cuda") for s in (512, 2048)]
+    res = {}
+    for early in (False, True):
+        fdtune.host(early_loss_inputs=early)
+        torch.manual_seed(2468)
+        tr = Trainer(_opts(batch_size=B), verbose=False)
+        assert tr.accumulate_step == 1
+        losses = []
+        for rep, b in enumerate(batches):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(bg):
+                for i in range(6 + 5 * rep):
+                    junk[i % 2] @ junk[i % 2]
+            seen = []
+            orig = tr.identity_losses
+            tr.identity_losses = lambda *a, **k: (seen.append(torch.cuda.current_stream().cuda_stream), orig(*a, **k))[1]
+            losses.append(float(tr.train_step([dict(b)])["loss"]))
+            tr.identity_losses = orig
+            main = torch.cuda.current_stream().cuda_stream
+            assert len(seen) == 1 and (seen[0] != main) == early, (seen, main, early)
+        torch.cuda.synchronize()
+        res[early] = (tr.flat.flat_param.clone(), losses)
+        del tr
+    assert res[False][1] == res[True][1], (res[False][1], res[True][1])
+    assert torch.isfinite(res[True][0]).all()
+    assert torch.equal(res[False][0], res[True][0]), "%d parameters differ" % int((res[False][0] != res[True][0]).sum())
+
+
 def test_late_weight_relayout_is_ordered_before_its_readers(fdtune):
     """functional.refresh_weight_layouts sends the big half of the post-Adam re-layout (data-gradient layouts, forward layouts from
     1 MB up) to a side stream and lets every stream that is about to use such a layout wait for it first.  Five optimiser steps with
