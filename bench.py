@@ -36,12 +36,14 @@ CONV_GFLOP_FWD_BWD = {(18, 192, 640): 187.3, (50, 192, 640): 406.1, (18, 320, 10
 LOSS_BYTES_PER_PIXEL = 343.7          # compulsory fwd+bwd HBM traffic of the fused loss path per image
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 # what the arithmetic is, next to `dtype` (an undisclosed precision change would void the line).  Every tensor is fp32;
-# products and sums are fp32 (v_mfma_f32_32x32x2_f32 / 16x16x4: exact fp32, Winograd transforms in fp32) EXCEPT the 1x1 stride-1
-# convolutions with >= 64 channels on both sides (csrc/conv_limb.hip: ResNet-50 bottlenecks; on the ResNet-18 configurations only the
-# PoseDecoder's 512 -> 256 squeeze): each fp32 operand is split exactly into three bf16 limbs, the product is six bf16 MFMAs accumulated
-# in fp32 - error against float64 equal to the f32 kernels' (tests/test_gpu_limb.py), all float64-anchored parity bounds unchanged.
-ARITH_NOTE = ("fp32 storage, fp32 accumulate; products fp32-exact (f32 MFMA) except 1x1 stride-1 convolutions with >= 64 channels: "
-              "bf16x3 split, six products, fp32 accumulate (fp32-equal error vs float64; fd_tuning.limb_1x1 = 0 restores the f32 kernels)")
+# products and sums are fp32 (v_mfma_f32_32x32x2_f32 / 16x16x4: exact fp32, Winograd transforms in fp32) EXCEPT the convolutions no Winograd
+# form exists for, with >= 64 channels on both sides (csrc/conv_limb.hip): the 1x1 stride-1 layers (ResNet-50 bottlenecks; on the ResNet-18
+# configurations only the PoseDecoder's 512 -> 256 squeeze) in all three directions, and the 3x3 stride-2 layers (layerN.0.conv1 of every
+# ResNet) forward + data gradient: each fp32 operand is split exactly into three bf16 limbs, the product is six bf16 MFMAs accumulated in
+# fp32 - error against float64 equal to the f32 kernels' (tests/test_gpu_limb.py), all float64-anchored parity bounds unchanged.
+ARITH_NOTE = ("fp32 storage, fp32 accumulate; products fp32-exact (f32 MFMA) except 1x1 stride-1 (all directions) and 3x3 stride-2 (forward, "
+              "data gradient) convolutions with >= 64 channels: bf16x3 split, six products, fp32 accumulate (fp32-equal error vs float64; "
+              "fd_tuning.limb_1x1 = limb_conv = 0 restores the f32 kernels)")
 PEAK_HBM_GBS = 8000.0
 
 

@@ -513,6 +513,25 @@ __global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* _
                 A3[fdlimb::a3_piece(kk, 1, m, Mrows)] = md;
                 A3[fdlimb::a3_piece(kk, 2, m, Mrows)] = l;
             }
+        } else if (j.mode == 9 || j.mode == 10) {        // the taps' matrix [m][(t, c)] pre-split into bf16 limbs: 9 m = co, c = ci (forward), 10 m = ci, c = co (data gradient)
+            const bool tr = j.mode == 10;
+            const unsigned nm = tr ? nci : nco, nk8 = (tr ? nco : nci) / 8;
+            const long Mrows = tr ? Ci : Co, Cr = tr ? Co : Ci;
+            uint4* A3 = reinterpret_cast<uint4*>(j.dst);
+            for (unsigned i = threadIdx.x; i < nm * T * nk8; i += 256) {
+                const unsigned k8 = i % nk8, q = i / nk8, t = q % T, mm = q / T;
+                const unsigned a = t / TB, bb = t - a * TB;
+                const unsigned tap = (unsigned)(j.kh0 + j.dkh * (int)a) * (unsigned)j.KW + (unsigned)(j.kw0 + j.dkw * (int)bb);
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = tr ? tile[k8 * 8 + e][mm * KK + tap] : tile[mm][(k8 * 8 + e) * KK + tap];
+                uint4 h, md, l;
+                fdlimb::split8(x, h, md, l);
+                const long kk = (long)t * Cr + (tr ? co0 : ci0) + k8 * 8, m = (tr ? ci0 : co0) + mm;
+                A3[fdlimb::a3_piece(kk, 0, m, Mrows)] = h;
+                A3[fdlimb::a3_piece(kk, 1, m, Mrows)] = md;
+                A3[fdlimb::a3_piece(kk, 2, m, Mrows)] = l;
+            }
         } else if (j.mode == 1) {                        // dst[(ci * T + t) * Co + co], co fastest
             for (unsigned i = threadIdx.x; i < nci * T * nco; i += 256) {
                 const unsigned r = i % nco, q = i / nco, t = q % T, c = q / T;
@@ -782,6 +801,15 @@ namespace {
 inline long align4(long n) { return (n + 3) / 4 * 4; }
 inline bool fast_fwd_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->in_norm; }
 inline bool fast_dgrad_ok(const fd_conv_desc* d) { return d->Cout % 16 == 0; }
+// the stride-2 layers on the split-precision implicit GEMM (conv_limb.hip: k_conv_limb), forward and data gradient
+// (kernels with more than one tap: the 1x1 stride-2 downsample layers are launch-bound GEMMs with K = Cin only - 11 - 26 us on either
+// arithmetic, and the limb kernel's split-K finish launch makes them slower: profiles/round6_limb_s2_ab.log)
+inline bool limb_conv_fwd_ok(const fd_conv_desc* d) {
+    return d->stride == 2 && d->KH * d->KW > 1 && !d->in_norm && limb_conv_problem_ok(d->Cout, d->Cin, d->pad_mode, d->act);
+}
+inline bool limb_conv_dgrad_ok(const fd_conv_desc* d) {
+    return d->stride == 2 && d->KH * d->KW > 1 && d->pad_mode == 0 && limb_conv_problem_ok(d->Cin, d->Cout, 0, 0);
+}
 inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && d->Cin >= 64 && !d->in_norm; }   // narrow layers: a (tap, channel) tile would be mostly padding
 
 // fd_tuning.log: one stderr line per convolution call (which kernel family it was routed to) - a tuning aid
@@ -854,6 +882,7 @@ extern "C" long fd_conv2d_fwd_wt_floats(const fd_conv_desc* d) {
     if (n16_shape_ok(d, d->Cout, d->Cin)) return 0;              // reads the weights as they are
     if (limb_fwd_ok(d)) return align4(limb_wt_floats(d->Cout, d->Cin));
     if (wino_use_fwd(d)) return align4(wino_wt_floats(d));
+    if (limb_conv_fwd_ok(d)) return align4(limb_wt_floats(d->Cout, (long)d->KH * d->KW * d->Cin));
     return align4((long)d->Cout * d->Cin * d->KH * d->KW);
 }
 
@@ -866,6 +895,7 @@ extern "C" long fd_conv2d_fwd_ws_floats(const fd_conv_desc* d) {
     if (wino_use_fwd(d)) return wino_ws_floats(d);
     FastGemmArgs f;
     fill_fwd_args(d, s, f);
+    if (limb_conv_fwd_ok(d)) return limb_conv_ws_floats(f);
     return fast_splitk_slab_floats(f, nullptr);
 }
 
@@ -946,9 +976,18 @@ int conv2d_fwd_impl(const fd_conv_desc* d, const float* x, const float* w, const
                 if (int rc = wino_weight_launch(d, w, wt, 0, st)) return rc;
             return wino_conv_launch(d, x, wt, bias, y, ws, st, nullptr, stat_part);
         }
-        conv_log("fwd", "direct", d);
         FastGemmArgs f;
         fill_fwd_args(d, s, f);
+        if (limb_conv_fwd_ok(d)) {
+            FD_REQUIRE(!stat_part, "fd_conv2d_fwd_stats: no statistics epilogue for this shape");
+            conv_log("fwd", "limb direct", d);
+            if (!wt_ready)
+                if (int rc = limb_conv_weight_split_launch(w, wt, d->Cout, d->Cin, d->KH, d->KW, d->KH, d->KW, 0, 1, 0, 1, 0, st)) return rc;
+            f.A = wt; f.X = x; f.Y = y; f.bias = bias;
+            f.slabs = ws;
+            return limb_conv_launch(f, st);
+        }
+        conv_log("fwd", "direct", d);
         if (!wt_ready)
             if (int rc = fast_weight_relayout(w, wt, d->Cout, d->Cin, d->KH, d->KW, d->KH, d->KW, 0, 1, 0, 1, 0, st)) return rc;
         f.A = wt; f.X = x; f.Y = y; f.bias = bias;
@@ -1071,7 +1110,7 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
     }
     {
         fd_conv_desc gd;
-        conv_log("dgrad", wino_dgrad_desc(d, gd) ? "wino" : "direct", d);
+        conv_log("dgrad", wino_dgrad_desc(d, gd) ? "wino" : (d->stride == 2 && fast_dgrad_ok(d) && limb_conv_dgrad_ok(d)) ? "limb direct" : "direct", d);
         if (wino_dgrad_desc(d, gd)) {
             if (!wt_ready)
                 if (int rc = wino_weight_launch(&gd, w, wt_base, 1, st)) return rc;
@@ -1244,6 +1283,9 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
         f.osy = 2; f.osx = 2;
         f.out_total = (long)d->N * g.out_ns; f.slab_stride = f.out_total; f.slabs = nullptr;
         f.add = add_in_kernel ? gx_add : nullptr;
+        // the classes' weights: [Cin][(tap, Cout)] fp32 for k_conv_fast_grp, or its pre-split image for k_conv_limb_grp (in the same slots:
+        // 1.5 x (<= 4 of 9 taps) of a slot; a 1x1 kernel has one class and four slots)
+        const bool limb_s2 = limb_conv_dgrad_ok(d);
         // (classes with the most taps first: their workgroups are the launch's longest - 4, 2, 2, 1 taps for a 3x3 kernel with pad 1)
         for (int ph = 1; ph >= 0; --ph)
             for (int pw = 1; pw >= 0; --pw) {
@@ -1253,8 +1295,10 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
                 const int NY = (d->H - ph + 1) / 2, NX = (d->W - pw + 1) / 2;
                 if (NY <= 0 || NX <= 0) continue;
                 float* wc = wt_base + (long)(ph * 2 + pw) * wt_n;
-                if (!wt_ready)
-                    if (int rc = fast_weight_relayout(w, wc, d->Cout, d->Cin, KH, KW, TA, TB, kh0, 2, kw0, 2, 1, st)) return rc;
+                if (!wt_ready) {
+                    if (limb_s2) { if (int rc = limb_conv_weight_split_launch(w, wc, d->Cout, d->Cin, KH, KW, TA, TB, kh0, 2, kw0, 2, 1, st)) return rc; }
+                    else if (int rc = fast_weight_relayout(w, wc, d->Cout, d->Cin, KH, KW, TA, TB, kh0, 2, kw0, 2, 1, st)) return rc;
+                }
                 const int j = q.n++;
                 q.A[j] = wc; q.NY[j] = NY; q.NX[j] = NX;
                 q.oy[j] = (ph + d->pad - kh0) / 2; q.ox[j] = (pw + d->pad - kw0) / 2;
@@ -1263,7 +1307,8 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
             }
         if (q.n > 0) {
             f.A = q.A[0]; f.NY = q.NY[0]; f.NX = q.NX[0]; f.T = q.T[0]; f.TB = q.TB[0]; f.K = q.K[0];
-            if (int rc = fast_gemm_group_launch(f, q, st)) return rc;
+            if (limb_s2) { if (int rc = limb_conv_group_launch(f, q, st)) return rc; }
+            else if (int rc = fast_gemm_group_launch(f, q, st)) return rc;
         }
         return add_in_kernel ? 0 : add_after();
     }
@@ -1297,7 +1342,7 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
     if (kind == 0) {
         if (!fast_fwd_ok(d) || n16_shape_ok(d, d->Cout, d->Cin)) return 0;
         if (limb_fwd_ok(d)) { fill(jobs[0], wt, 1, 1, 0, 1, 0, 1, 7); return 1; }
-        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? (wino_fwd_2d(d) ? 5 : 3) : 0);
+        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? (wino_fwd_2d(d) ? 5 : 3) : (limb_conv_fwd_ok(d) ? 9 : 0));
         return 1;
     }
     const int KH = d->KH, KW = d->KW;
@@ -1325,7 +1370,7 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
             if (kh0 >= KH || kw0 >= KW) continue;
             const int TA = (KH - kh0 + 1) / 2, TB = (KW - kw0 + 1) / 2;
             if ((d->H - ph + 1) / 2 <= 0 || (d->W - pw + 1) / 2 <= 0) continue;
-            fill(jobs[n++], wt + (long)(ph * 2 + pw) * wt_n, TA, TB, kh0, 2, kw0, 2, mode);
+            fill(jobs[n++], wt + (long)(ph * 2 + pw) * wt_n, TA, TB, kh0, 2, kw0, 2, (mode == 1 && limb_conv_dgrad_ok(d)) ? 10 : mode);
         }
     return n;
 }

@@ -106,3 +106,11 @@ int limb_gemm_launch(const float* wt, const float* x, float* y, const float* bia
                      int act, hipStream_t st);
 long limb_wgrad_ws_floats(int M, int C, int Nb, int HW);
 int limb_wgrad_launch(const float* x, const float* gy, float* gw, float* ws, int M, int C, int Nb, int HW, int accumulate, hipStream_t st);
+// ... and the direct convolutions Winograd cannot take (stride 2) as implicit GEMMs on the same arithmetic (k_conv_limb): a problem in
+// FastGemmArgs terms whose A is the pre-split image of [M][(tap, channel)] (limb_wt_floats(M, T * C) floats)
+bool limb_conv_problem_ok(int M, int C, int pad_mode, int act);
+int limb_conv_weight_split_launch(const float* w, float* wt, int Co, int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh, int kw0, int dkw,
+                                  int mode, hipStream_t st);
+long limb_conv_ws_floats(const FastGemmArgs& a);
+int limb_conv_launch(const FastGemmArgs& a, hipStream_t st);
+int limb_conv_group_launch(const FastGemmArgs& a, const FastGemmGroup& q, hipStream_t st);

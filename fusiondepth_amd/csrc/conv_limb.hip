@@ -219,6 +219,220 @@ __global__ void __launch_bounds__(256, 2) k_gemm_limb(LimbGemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ implicit-GEMM convolution
+// k_gemm_limb with the GEMM-K index running over (tap, channel) - the direct convolutions Winograd cannot take: the 3x3 and 1x1
+// STRIDE-2 layers of a ResNet (layer2/3/4.0.conv1 + downsample: networks/resnet_encoder.py, torchvision BasicBlock / Bottleneck) forward,
+// and the four output-parity classes of their data gradients in one grouped launch.  Problem description = conv_fast.h's
+// FastGemmArgs (g.A = the pre-split weights A3 of the matrix [M][K = (tap, channel)]), zero padding only.
+//   * a K-chunk = 16 channels of ONE tap; the lane's pixel offset of a tap is one per-lane value (border test included: a tap that
+//     falls outside the image gets the out-of-range offset and reads zeros), the channel part rides in the loads' scalar offset;
+//     tap / chunk counters are wave-uniform scalars advanced per load (no division, no divergent branch in the loop);
+//   * everything else - X straight from registers into MFMA fragments, weights through double-buffered LDS, branch-free loop unrolled D
+//     times, XCD-aware 1-D grid - is k_gemm_limb's; the epilogue takes the affine output map of the parity classes (osy / osx = 2).
+template <int MB, int D>
+__device__ __forceinline__ void conv_limb_body(const FastGemmArgs& g, unsigned char* smem, int tm, int tn, int zs, int nsplit) {
+    constexpr int NT = 256;
+    constexpr int BM = 32 * MB, BN = 128;
+    constexpr int A_BYTES = 96 * BM;
+    constexpr int A_PIECES = 6 * BM, NA = (A_PIECES + NT - 1) / NT;
+    static_assert(D % 2 == 0, "LDS buffer parity");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = tm * BM;
+    const int plane = g.NY * g.NX;
+    const long p0 = (long)tn * BN, Np = (long)g.Nb * plane;
+    const int cpt = g.C >> 4;                                         // chunks per tap
+    const int nch = g.T * cpt;
+    const int per = nch / nsplit;                                     // a multiple of D (launcher)
+    const int c_lo = zs * per, c_hi = c_lo + per;
+
+    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(g.A), rsX = fd_make_rsrc(g.X);
+    unsigned a_base[NA];
+    const unsigned a_step = 96u * (unsigned)g.M;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int q = tid + NT * i;
+        const int lh = q / BM, row = q - lh * BM;
+        int m = m0 + row;
+        m = m < g.M ? m : g.M - 1;
+        a_base[i] = (A_PIECES % NT != 0 && q >= A_PIECES) ? FD_OOB : 16u * ((unsigned)lh * (unsigned)g.M + (unsigned)m);
+    }
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned chw = (unsigned)(g.Hi * g.Wi), hw4 = 4u * chw;
+    int ry0, cx0;
+    unsigned nb8;
+    bool pvalid;
+    {
+        const long pg = p0 + wave * 32 + l31;
+        pvalid = pg < Np;
+        const long pp = pvalid ? pg : 0;
+        const int n = (int)(pp / plane);
+        const int rem = (int)(pp - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        ry0 = y * g.sy + g.oy; cx0 = x * g.sx + g.ox;
+        nb8 = ((unsigned)n * (unsigned)g.C + 8u * (unsigned)half) * chw;
+    }
+    // (tap row, tap column, channel chunk of the tap) of the next chunk to load: wave-uniform
+    int pc_ta, pc_tb, pc_cc;
+    { const int t = c_lo / cpt; pc_cc = c_lo - t * cpt; pc_ta = t / g.TB; pc_tb = t - pc_ta * g.TB; }
+
+    uint4 ra[D][NA];
+    float rb[D][8];
+    auto load_ab = [&](auto slot_tag, int c) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        const bool live = c < c_hi;
+        const int ce = live ? c : c_hi - 1;                    // past the end: the last chunk's weights again, zeros for X (never used)
+        const unsigned sa = (unsigned)ce * a_step;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            ra[S][i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_base[i], (int)sa, 0));
+        const int r = ry0 + pc_ta * g.da, cc = cx0 + pc_tb * g.db;
+        const bool inb = ((unsigned)r < (unsigned)g.Hi) & ((unsigned)cc < (unsigned)g.Wi);
+        const unsigned boff = (pvalid & inb & live) ? 4u * (nb8 + (unsigned)(r * g.Wi + cc)) : FD_OOB;
+        const unsigned sb = (unsigned)pc_cc * 16u * hw4;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            rb[S][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, (int)boff, (int)(sb + (unsigned)e * hw4), 0));
+        ++pc_cc;
+        const bool w1 = pc_cc == cpt;
+        pc_cc = w1 ? 0 : pc_cc;
+        pc_tb += w1 ? 1 : 0;
+        const bool w2 = pc_tb == g.TB;
+        pc_tb = w2 ? 0 : pc_tb;
+        pc_ta += w2 ? 1 : 0;
+    };
+    auto store_a = [&](auto slot_tag, int buf) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        unsigned char* base = smem + buf * A_BYTES;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int q = tid + NT * i;
+            if (A_PIECES % NT == 0 || q < A_PIECES) *reinterpret_cast<uint4*>(base + 16 * q) = ra[S][i];
+        }
+    };
+    f32x16 acc[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    auto mfma_chunk = [&](auto slot_tag, int buf) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        uint4 bf[3];
+        split8(rb[S], bf[0], bf[1], bf[2]);
+        const unsigned char* sa = smem + buf * A_BYTES + 16 * (half * BM + l31);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            uint4 af[3];
+#pragma unroll
+            for (int L = 0; L < 3; ++L) af[L] = *reinterpret_cast<const uint4*>(sa + 32 * BM * L + 512 * i);
+            FD_LIMB_MFMA6(acc[i], af, bf);
+        }
+    };
+    if (c_lo < c_hi) {
+        static_for<D>([&](auto j) __attribute__((always_inline)) { load_ab(j, c_lo + decltype(j)::value); });
+        store_a(std::integral_constant<int, 0>{}, 0);
+        __syncthreads();
+        for (int c = c_lo; c < c_hi; c += D) {
+            static_for<D>([&](auto j) __attribute__((always_inline)) {
+                constexpr int J = decltype(j)::value;
+                mfma_chunk(j, J & 1);
+                store_a(std::integral_constant<int, (J + 1) % D>{}, (J & 1) ^ 1);
+                load_ab(j, c + J + D);
+                __syncthreads();
+            });
+        }
+    }
+    // ---- epilogue: affine output map (conv_fast.hip), C/D layout of the 32x32 MFMA
+    const bool final_pass = nsplit == 1;
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(final_pass ? g.Y : g.slabs + (size_t)zs * g.slab_stride);
+    const __amdgpu_buffer_rsrc_t rsAdd = fd_make_rsrc(g.add ? g.add : g.Y);
+    const bool has_add = final_pass && g.add, has_bias = final_pass && g.bias, relu = final_pass && g.act == 1;
+    const unsigned cs4 = 4u * (unsigned)g.out_cs;
+    const long p = p0 + wave * 32 + l31;
+    unsigned pix = FD_OOB;
+    if (p < Np) {
+        const int n = (int)(p / plane);
+        const int rem = (int)(p - (long)n * plane);
+        const int y = rem / g.NX, x = rem - y * g.NX;
+        pix = 4u * (unsigned)((long)n * g.out_ns + (long)(y * g.osy + g.ooy) * g.out_w + (x * g.osx + g.oox));
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            unsigned off[4];
+            float addv[4], bv[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int m = m0 + i * 32 + r4 + 8 * rq + 4 * half;
+                off[r4] = m < g.M ? pix + (unsigned)m * cs4 : FD_OOB;
+                bv[r4] = has_bias ? g.bias[m < g.M ? m : g.M - 1] : 0.f;
+                addv[r4] = has_add ? fd_ldg32(rsAdd, off[r4]) : 0.f;
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float v = acc[i][rq * 4 + r4] + bv[r4];
+                v = relu ? (v > 0.f ? v : 0.f) : v;
+                v += addv[r4];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsY, (int)off[r4], 0, 0);
+            }
+        }
+    }
+}
+
+template <int MB, int D>
+__global__ void __launch_bounds__(256, 2) k_conv_limb(FastGemmArgs g, int ntm, int ntn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int slot = (int)blockIdx.x >> 3;
+    const int tm = slot % ntm, tn = (slot / ntm) * 8 + ((int)blockIdx.x & 7);
+    if (tn >= ntn) return;
+    conv_limb_body<MB, D>(g, smem, tm, tn, (int)blockIdx.y, (int)gridDim.y);
+}
+
+// the output-parity classes of a stride-2 data gradient side by side (conv_fast.hip: k_conv_fast_grp); q.first_bx in units of this
+// kernel's 1-D grid (8 * ceil(pixel tiles / 8) * ntm workgroups per class)
+template <int MB, int D>
+__global__ void __launch_bounds__(256, 2) k_conv_limb_grp(FastGemmArgs g, FastGemmGroup q, int ntm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int j = 0;
+    while (j + 1 < q.n && (int)blockIdx.x >= q.first_bx[j + 1]) ++j;
+    g.A = q.A[j]; g.NY = q.NY[j]; g.NX = q.NX[j]; g.oy = q.oy[j]; g.ox = q.ox[j]; g.ooy = q.ooy[j]; g.oox = q.oox[j];
+    g.T = q.T[j]; g.TB = q.TB[j]; g.K = q.K[j];
+    if (q.own_out) { g.Y += q.y_off[j]; g.out_ns = q.out_ns[j]; g.out_cs = q.out_cs[j]; g.out_w = q.out_w[j]; }
+    const int bx = (int)blockIdx.x - q.first_bx[j];
+    const int ntn = (int)(((long)g.Nb * g.NY * g.NX + 127) / 128);
+    const int slot = bx >> 3;
+    const int tm = slot % ntm, tn = (slot / ntm) * 8 + (bx & 7);
+    if (tn >= ntn) return;
+    conv_limb_body<MB, D>(g, smem, tm, tn, 0, 1);
+}
+
+// A3 of the matrix A[m][kk = t * Cr + c] = W[co][ci][kh0 + dkh a][kw0 + dkw b], t = a * TB + b; mode 0: (m, c) = (co, ci) - forward;
+// mode 1: (m, c) = (ci, co) - data gradient (the stand-alone form of re-layout modes 9 / 10)
+__global__ void __launch_bounds__(256) k_limb_conv_weight_split(const float* __restrict__ W, uint4* __restrict__ A3, int Co, int Ci, int KH, int KW,
+                                                                int TA, int TB, int kh0, int dkh, int kw0, int dkw, int mode) {
+    const int Mr = mode ? Ci : Co, Cr = mode ? Co : Ci;
+    const long K = (long)TA * TB * Cr;
+    const long n = (long)Mr * (K >> 3);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int m = (int)(i % Mr);
+        const long kk = (i / Mr) * 8;
+        const int t = (int)(kk / Cr), c0 = (int)(kk - (long)t * Cr);
+        const int a = t / TB, b = t - a * TB;
+        const int kh = kh0 + dkh * a, kw = kw0 + dkw * b;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = mode ? c0 + e : m, ci = mode ? m : c0 + e;
+            x[e] = W[(((long)co * Ci + ci) * KH + kh) * KW + kw];
+        }
+        uint4 h, md, l;
+        split8(x, h, md, l);
+        A3[a3_piece(kk, 0, m, Mr)] = h;
+        A3[a3_piece(kk, 1, m, Mr)] = md;
+        A3[a3_piece(kk, 2, m, Mr)] = l;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct LimbWgradArgs {
     const float* dY;       // [Nb][M][HW]
@@ -448,6 +662,73 @@ int limb_gemm_launch(const float* wt, const float* x, float* y, const float* bia
     FD_LAUNCH_CHECK("limb gemm");
     if (splits > 1)
         return fast_splitk_finish_launch(ws, y, bias, g.slab_stride, g.slab_stride, splits, HW, M, act, st, add);
+    return 0;
+}
+
+// ---- implicit-GEMM convolutions (k_conv_limb): a problem in conv_fast.h's terms, a.A = the A3 image of [M][(tap, channel)]
+bool limb_conv_problem_ok(int M, int C, int pad_mode, int act) {
+    return fd_tun().limb_conv != 0 && C % 32 == 0 && C >= 64 && M >= 64 && pad_mode == 0 && (act == 0 || act == 1);
+}
+int limb_conv_weight_split_launch(const float* w, float* wt, int Co, int Ci, int KH, int KW, int TA, int TB, int kh0, int dkh, int kw0, int dkw,
+                                  int mode, hipStream_t st) {
+    const long n = (long)(mode ? Ci : Co) * (((long)TA * TB * (mode ? Co : Ci)) >> 3);
+    long b = (n + 255) / 256;
+    b = b > 2048 ? 2048 : b;
+    hipLaunchKernelGGL(k_limb_conv_weight_split, dim3((unsigned)b), dim3(256), 0, st, w, reinterpret_cast<uint4*>(wt), Co, Ci, KH, KW, TA, TB,
+                       kh0, dkh, kw0, dkw, mode);
+    FD_LAUNCH_CHECK("limb conv weight split");
+    return 0;
+}
+int limb_conv_splits(const FastGemmArgs& a) {
+    if (!(a.osy == 1 && a.osx == 1) || a.out_total > (long)fd_tun().limb_split_max_out) return 1;
+    const long tiles = (long)fd_cdiv(a.M, 32 * limb_gemm_mb(a.M)) * fd_cdiv((long)a.Nb * a.NY * a.NX, 128);
+    const int nch = a.T * (a.C >> 4);
+    int sp = limb_splits(tiles, nch, fd_tun().limb_target);
+    while (sp > 1 && (nch % sp != 0 || (nch / sp) % 2 != 0)) --sp;
+    return sp;
+}
+long limb_conv_ws_floats(const FastGemmArgs& a) {
+    const int sp = limb_conv_splits(a);
+    return sp > 1 ? (long)sp * a.out_total : 0;
+}
+int limb_conv_launch(const FastGemmArgs& a, hipStream_t st) {
+    if ((double)a.Nb * a.C * a.Hi * a.Wi * 4.0 >= 2147483648.0 || (double)a.M * a.K * 6.0 >= 2147483648.0 ||
+        (double)a.out_total * 4.0 >= 2147483648.0) {
+        fd_set_error("limb conv: tensor exceeds the 2 GiB addressing range"); return -1;
+    }
+    FD_REQUIRE(a.C % 32 == 0 && a.K == a.T * a.C, "limb conv: channels must be a multiple of 32");
+    const int mb = limb_gemm_mb(a.M);
+    const int ntm = fd_cdiv(a.M, 32 * mb), ntn = fd_cdiv((long)a.Nb * a.NY * a.NX, 128);
+    const int splits = limb_conv_splits(a);
+    FD_REQUIRE(splits == 1 || a.slabs, "limb conv: split-K workspace missing");
+    const dim3 grid(8u * (unsigned)fd_cdiv(ntn, 8) * (unsigned)ntm, (unsigned)splits);
+    const size_t lds = 2 * 96 * (size_t)(32 * mb);
+    if (mb == 2) hipLaunchKernelGGL((k_conv_limb<2, 2>), grid, dim3(256), lds, st, a, ntm, ntn);
+    else hipLaunchKernelGGL((k_conv_limb<4, 2>), grid, dim3(256), lds, st, a, ntm, ntn);
+    FD_LAUNCH_CHECK("limb conv");
+    if (splits > 1)
+        return fast_splitk_finish_launch(a.slabs, a.Y, a.bias, a.out_total, a.slab_stride, splits, a.out_cs, a.M, a.act, st, a.add);
+    return 0;
+}
+int limb_conv_group_launch(const FastGemmArgs& a, const FastGemmGroup& q, hipStream_t st) {
+    if ((double)a.Nb * a.C * a.Hi * a.Wi * 4.0 >= 2147483648.0 || (double)a.out_total * 4.0 >= 2147483648.0) {
+        fd_set_error("limb conv: tensor exceeds the 2 GiB addressing range"); return -1;
+    }
+    FD_REQUIRE(a.C % 32 == 0, "limb conv: channels must be a multiple of 32");
+    const int mb = limb_gemm_mb(a.M);
+    const int ntm = fd_cdiv(a.M, 32 * mb);
+    FastGemmGroup grp = q;
+    int gx = 0;
+    for (int j = 0; j < q.n; ++j) {
+        if ((double)a.M * q.K[j] * 6.0 >= 2147483648.0) { fd_set_error("limb conv: weights exceed the 2 GiB addressing range"); return -1; }
+        grp.first_bx[j] = gx;
+        gx += 8 * fd_cdiv(fd_cdiv((long)a.Nb * q.NY[j] * q.NX[j], 128), 8) * ntm;
+    }
+    grp.first_bx[q.n] = gx;
+    const size_t lds = 2 * 96 * (size_t)(32 * mb);
+    if (mb == 2) hipLaunchKernelGGL((k_conv_limb_grp<2, 2>), dim3((unsigned)gx), dim3(256), lds, st, a, grp, ntm);
+    else hipLaunchKernelGGL((k_conv_limb_grp<4, 2>), dim3((unsigned)gx), dim3(256), lds, st, a, grp, ntm);
+    FD_LAUNCH_CHECK("limb conv (grouped)");
     return 0;
 }
 

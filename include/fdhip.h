@@ -31,8 +31,9 @@ extern "C" {
  *    fd_bn_train_bwd_remask, fd_stack_normalize, fd_conv2d_fwd_bn(_ok), fd_pose_head_fwd / _bwd; fd_tuning grew at its end
  *    (wino_min_cout, wino_wgrad_min_cout, wino_wgrad_xcd_few, wino_fwd_halfm, wino_wgrad_halfm, grp_tile64_below).  Nothing removed, no signature changed.
  * 4: additions only (round 6): fd_replay (+ fd_call_rec, fd_replay_function_count / _name / _signature); fd_tuning grew at its end (limb_1x1,
- *    limb_depth, limb_target, limb_split_max_out, limb_wgrad_target); fd_relayout_job.mode 7 / 8 (weights pre-split into bf16 limbs);
- *    fd_refine_cfg accepts an empty crop window.  Nothing removed, no signature changed. */
+ *    limb_depth, limb_target, limb_split_max_out, limb_wgrad_target, limb_conv); fd_relayout_job.mode 7 / 8 (1x1 weights pre-split into bf16
+ *    limbs) and 9 / 10 (the same for a tap subset of a larger kernel); fd_refine_cfg accepts an empty crop window.  Nothing removed, no
+ *    signature changed. */
 #define FD_ABI_VERSION 4
 
 int fd_abi_version(void);
@@ -86,6 +87,8 @@ typedef struct fd_tuning {
     int limb_target;              /* 256 workgroups a limb forward / data-gradient launch is split-K'd up to ... */
     int limb_split_max_out;       /* 4194304   ... when its output has at most this many floats (a split costs a slab round trip of the output) */
     int limb_wgrad_target;        /* 256 workgroups a limb weight-gradient launch is pixel-sliced up to (x2 for its 4-wave tiles) */
+    int limb_conv;                /* 1   stride-2 convolutions with >= 64 channels on both sides (ResNet layerN.0.conv1 / downsample: no Winograd form), forward
+                                         and data gradient, as split-precision implicit GEMMs (k_conv_limb); 0: the f32-MFMA direct kernels */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);
@@ -319,7 +322,8 @@ typedef struct fd_relayout_job {
     const float* w;
     float* dst;
     int Co, Ci, KH, KW, TA, TB, kh0, dkh, kw0, dkw;
-    int mode;          /* 0 forward [Co][tap][Ci], 1 data-gradient [Ci][tap][Co], 2 generic data-gradient [Ci][Co][tap] */
+    int mode;          /* 0 forward [Co][tap][Ci], 1 data-gradient [Ci][tap][Co], 2 generic data-gradient [Ci][Co][tap]; 3 - 6 Winograd U;
+                          7 / 8 the 1x1 matrix, 9 / 10 the [m][(tap, channel)] matrix of layouts 0 / 1 pre-split into bf16 limbs (csrc/conv_limb.h) */
     int reserved;
     long n;            /* elements */
     long first_block;  /* set by fd_relayout_plan */

@@ -112,3 +112,106 @@ def test_limb_weight_layout_batched_equals_standalone():
         call("fd_relayout_batch", ptr(dev), nj, blocks, stream())
         torch.cuda.synchronize()
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "kind %d" % kind
+
+
+# ---- stride-2 convolutions on the split-precision implicit GEMM (k_conv_limb): ResNet layerN.0.conv1 (3x3) and downsample (1x1) -------------
+# (batch, Cin, Cout, H, W, K): the ResNet-18 shapes of the step (640x192, stacked batch 12 / 24), a split-K shape, channel / pixel tails
+# (the 1x1 downsample layers stay on the f32 kernels - fd_tuning.limb_conv takes kernels with more than one tap - and are here as controls)
+S2_SHAPES = [(4, 64, 128, 48, 160, 3), (4, 64, 128, 48, 160, 1), (6, 128, 256, 24, 80, 3), (12, 256, 512, 12, 40, 3), (12, 256, 512, 12, 40, 1),
+             (3, 96, 160, 11, 38, 3), (2, 64, 96, 10, 14, 3), (1, 128, 64, 7, 9, 1)]
+
+
+def _run_s2(B, ci, co, h, w, k, limb, bias, act, add):
+    tuning.set_lib(limb_conv=limb)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(ci * 5 + co + k)
+        x = torch.randn(B, ci, h, w, device="cuda", generator=g).relu_()
+        wt = torch.randn(co, ci, k, k, device="cuda", generator=g) * (2.0 / (ci * k * k)) ** 0.5
+        pad = k // 2
+        ho, wo = (h + 2 * pad - k) // 2 + 1, (w + 2 * pad - k) // 2 + 1
+        gy = torch.randn(B, co, ho, wo, device="cuda", generator=g)
+        bs = torch.randn(co, device="cuda", generator=g) if bias else None
+        ga = torch.randn(B, ci, h, w, device="cuda", generator=g) if add else None
+        plan = FD._conv_plan(x, wt, 2, pad, 0, act, False)
+        dp = plan.dp
+        y = torch.empty(B, co, ho, wo, device="cuda"); gx = torch.empty_like(x)
+        f_ws = torch.empty(max(plan.fwd_ws, 1), device="cuda"); f_wt = torch.empty(max(plan.fwd_wt, 1), device="cuda")
+        d_ws_n, d_wt_n = plan.data_sizes()
+        d_ws = torch.empty(max(d_ws_n, 1), device="cuda"); d_wt = torch.empty(max(d_wt_n, 1), device="cuda")
+        st = stream()
+        call("fd_conv2d_fwd", dp, ptr(x), ptr(wt), ptr(bs), ptr(y), ptr(f_wt), 0, ptr(f_ws), st)
+        if add:
+            call("fd_conv2d_bwd_data_add", dp, ptr(gy), ptr(wt), ptr(ga), ptr(gx), ptr(d_wt), 0, ptr(d_ws), st)
+        else:
+            call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(wt), ptr(gx), ptr(d_wt), 0, ptr(d_ws), st)
+        torch.cuda.synchronize()
+        return x, wt, gy, bs, ga, y, gx, pad
+    finally:
+        tuning.set_lib(limb_conv=1)
+
+
+@pytest.mark.parametrize("shape", S2_SHAPES, ids=lambda s: "b%d_%d-%d_%dx%d_k%d" % s)
+@pytest.mark.parametrize("bias,act,add", [(False, 0, False), (True, 1, True)], ids=["plain", "bias-relu-add"])
+def test_limb_stride2_conv_keeps_fp32_accuracy(shape, bias, act, add):
+    """forward (+ bias, ReLU) and data gradient (four output-parity classes in one grouped launch, + a second gradient joined in the
+    epilogue) of the stride-2 layers: error against float64 relative to the scale of the result <= 3e-6 and no worse than 2x the
+    f32-MFMA direct kernel's + 1e-7 on the same inputs."""
+    import conftest
+    B, ci, co, h, w, k = shape
+    res = {}
+    for limb in (0, 1):
+        x, wt, gy, bs, ga, y, gx, pad = _run_s2(B, ci, co, h, w, k, limb, bias, act, add)
+        xd = x.double().cpu().requires_grad_(True)
+        ry = torch.nn.functional.conv2d(xd, wt.double().cpu(), bs.double().cpu() if bias else None, stride=2, padding=pad)
+        rgx, = torch.autograd.grad(ry, xd, gy.double().cpu())
+        if act:
+            ry = ry.relu()
+        if add:
+            rgx = rgx + ga.double().cpu()
+        e = lambda a, r: float((a.double().cpu() - r.detach()).abs().max() / r.detach().abs().max())
+        res[limb] = (e(y, ry), e(gx, rgx))
+    for kk, name in enumerate(("forward", "data gradient")):
+        bound = max(3e-6, 2 * res[0][kk] + 1e-7)
+        conftest.report("limb stride-2 %s %s: max |err| / max |ref| vs float64" % ("b%d %d->%d @%dx%d k%d" % shape, name), res[1][kk], bound,
+                        "(f32-MFMA kernel %.1e)" % res[0][kk])
+        assert res[1][kk] <= bound, "%s: limb %.3g, f32 kernel %.3g" % (name, res[1][kk], res[0][kk])
+
+
+def test_limb_stride2_route_is_taken_and_logged(capfd):
+    tuning.set_lib(log=1)
+    try:
+        _run_s2(4, 64, 128, 48, 160, 3, 1, False, 0, False)
+    finally:
+        tuning.set_lib(log=0)
+    err = capfd.readouterr().err
+    assert err.count("limb direct") >= 2, err
+
+
+@pytest.mark.parametrize("k", [3])
+def test_limb_stride2_weight_layout_batched_equals_standalone(k):
+    """re-layout modes 9 / 10 (the taps' matrix pre-split into bf16 limbs, forward and the parity classes of the data gradient) written by
+    the batched launch == the stand-alone split kernel's image, bit for bit"""
+    import ctypes
+    from fusiondepth_amd._lib import RelayoutJob, query
+    co, ci, pad = 160, 96, k // 2
+    x = torch.randn(2, ci, 10, 16, device="cuda")
+    wt = torch.randn(co, ci, k, k, device="cuda")
+    plan = FD._conv_plan(x, wt, 2, pad, 0, 0, False)
+    d_ws_n, d_wt_n = plan.data_sizes()
+    ho, wo = (10 + 2 * pad - k) // 2 + 1, (16 + 2 * pad - k) // 2 + 1
+    for kind, n in ((0, plan.fwd_wt), (1, d_wt_n)):
+        a = torch.zeros(n, device="cuda"); b = torch.zeros(n, device="cuda")
+        y = torch.randn(2, co, ho, wo, device="cuda"); gx = torch.empty_like(x)
+        ws = torch.empty(max(plan.fwd_ws, d_ws_n, 1), device="cuda")
+        if kind == 0:
+            call("fd_conv2d_fwd", plan.dp, ptr(x), ptr(wt), None, ptr(y), ptr(a), 0, ptr(ws), stream())
+        else:
+            call("fd_conv2d_bwd_data", plan.dp, ptr(y), ptr(wt), ptr(gx), ptr(a), 0, ptr(ws), stream())
+        jobs = (RelayoutJob * 4)()
+        nj = query("fd_conv2d_relayout_jobs", plan.dp, kind, ptr(wt), ptr(b), ctypes.addressof(jobs))
+        assert nj == (1 if kind == 0 else 4) and all(jobs[i].mode == (9 if kind == 0 else 10) for i in range(nj))
+        blocks = query("fd_relayout_plan", ctypes.addressof(jobs), nj)
+        dev = torch.frombuffer(bytearray(bytes(memoryview(jobs))[: nj * ctypes.sizeof(RelayoutJob)]), dtype=torch.uint8).cuda()
+        call("fd_relayout_batch", ptr(dev), nj, blocks, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), "kind %d" % kind
