@@ -810,6 +810,10 @@ inline bool limb_conv_fwd_ok(const fd_conv_desc* d) {
 inline bool limb_conv_dgrad_ok(const fd_conv_desc* d) {
     return d->stride == 2 && d->KH * d->KW > 1 && d->pad_mode == 0 && limb_conv_problem_ok(d->Cin, d->Cout, 0, 0);
 }
+inline bool limb_conv_wgrad_ok(const fd_conv_desc* d, const ConvShape& s) {
+    return d->stride == 2 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->pad_mode == 0 && !d->in_norm &&
+           limb_wgrad_s2_shape_ok(d->Cout, d->Cin, d->H, d->W, s.Ho, s.Wo);
+}
 inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && d->Cin >= 64 && !d->in_norm; }   // narrow layers: a (tap, channel) tile would be mostly padding
 
 // fd_tuning.log: one stderr line per convolution call (which kernel family it was routed to) - a tuning aid
@@ -1414,6 +1418,7 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     else if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
     else { const int sp = wgrad_splits(d, s); slabs = sp > 1 ? (long)sp * wsz : 0; }
     if (limb_wgrad_ok(d)) { const long l = limb_wgrad_ws_floats(d->Cout, d->Cin, d->N, d->H * d->W); slabs = l > slabs ? l : slabs; }   // (the direct kernel stays the fallback for unaligned tensors)
+    if (limb_conv_wgrad_ok(d, s)) { const long l = limb_wgrad_s2_ws_floats(d->Cout, d->Cin, d->N, s.Ho * s.Wo); slabs = l > slabs ? l : slabs; }
     const long bias_part = (long)d->Cout * CS_SPLITS;
     if (slabs < wsz) slabs = wsz;                            // accumulate mode stages a single slab
     return slabs > bias_part ? slabs : bias_part;          // the two uses are sequential on the stream
@@ -1430,9 +1435,12 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
     hipStream_t st = (hipStream_t)stream;
     const long Np = (long)d->N * s.Ho * s.Wo;
     const bool limb_w = limb_wgrad_ok(d) && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
-    conv_log("wgrad", limb_w ? "limb 1x1" : narrow_wgrad_ok(d) ? "narrow" : stem_wgrad_ok(d) ? "stem" : wino_use_wgrad(d) ? "wino" : fast_wgrad_ok(d) ? "direct" : "generic", d);
+    const bool limb_w2 = !limb_w && limb_conv_wgrad_ok(d, s) && (((uintptr_t)x | (uintptr_t)gy) & 15) == 0;
+    conv_log("wgrad", limb_w ? "limb 1x1" : limb_w2 ? "limb direct" : narrow_wgrad_ok(d) ? "narrow" : stem_wgrad_ok(d) ? "stem" : wino_use_wgrad(d) ? "wino" : fast_wgrad_ok(d) ? "direct" : "generic", d);
     if (limb_w) {
         if (int rc = limb_wgrad_launch(x, gy, gw, ws, d->Cout, d->Cin, d->N, d->H * d->W, accumulate, st)) return rc;
+    } else if (limb_w2) {
+        if (int rc = limb_wgrad_s2_launch(x, gy, gw, ws, d->Cout, d->Cin, d->N, d->H, d->W, s.Ho, s.Wo, accumulate, st)) return rc;
     } else if (narrow_wgrad_ok(d)) {
         if (int rc = narrow_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
     } else if (stem_wgrad_ok(d)) {

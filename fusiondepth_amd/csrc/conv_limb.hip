@@ -557,6 +557,194 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_limb(LimbWgrad
         }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, 3x3 stride 2
+// dW[m][c][ta][tb] = sum_{n, y, x} dY[n][m][y][x] X[n][c][2y + ta - 1][2x + tb - 1] (zero padding): k_wgrad_limb's arithmetic with one TAP per
+// workgroup (grid x = tap x tile) and a loader built for the stride:
+//   * a K-chunk = 32 consecutive output pixels = 8 groups of 4 (a group never leaves its output row: Wo % 4 == 0); the groups' (image, row,
+//     column) are WAVE-UNIFORM and advance on the scalar unit - no per-lane index arithmetic at all;
+//   * the X operand of a group = input pixels 2x .. 2x+7 of ONE input row (32 contiguous bytes); lanes are (row = lane / 4, kq = lane % 4),
+//     load instruction j of an item reads 16-byte piece 4j + kq of the chunk's 256-byte window, so four adjacent lanes read 64 contiguous
+//     bytes (the first version - a lane reads its own 8 pixels' 64 bytes, adjacent lanes = different channel rows - touched 6x the cache
+//     lines per instruction and ran at 0.6x the f32 kernel: profiles/round6_limb_s2_ab.log).  A piece holds 2 output pixels' inputs: the
+//     even ones for tb = 1, the odd ones for tb = 2, and for tb = 0 the odd ones of the window shifted by 8 bytes (the 16-byte buffer loads
+//     need 4-byte alignment only), the pixel left of the image replaced by 0;
+//   * so a lane's 8 K-values are the pixels {8j + 2kq, 8j + 2kq + 1 : j = 0..3} of the chunk - a permutation of the summation index, applied
+//     to dY (four 8-byte loads per item) and X alike;
+//   * LDS planes are padded by 32 bytes: the 16-byte stores of 8 adjacent lanes (2 rows x 4 kq -> planes 0, 1, 6, 7) fall into 8 distinct
+//     16-byte slots of the 256-byte bank window.
+// Needs W % 8 == 0 (Wo % 4 == 0, aligned pieces) and (Ho Wo) % 8 == 0; other shapes stay on k_wgrad_fast.
+struct LimbWgradS2Args {
+    const float* dY;       // [Nb][M][NY * NX]
+    const float* X;        // [Nb][C][Hi][Wi]
+    float* slabs;          // [splits][M][9][C]
+    int M, C, Nb, Hi, Wi, NY, NX;
+    int ntm, ntn;
+    int chunks_per_split;
+};
+
+template <int WAVES_M, int WAVES_N, int D>
+__global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_limb_s2(LimbWgradS2Args g) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
+    constexpr int BM = 64 * WAVES_M, BN = 32 * WAVES_N;
+    constexpr int PA = 16 * BM + 32, PB = 16 * BN + 32;              // padded plane strides (bytes)
+    constexpr int A_BYTES = 12 * PA;
+    constexpr int NAI = BM * 4 / NT, NBI = BN * 4 / NT;
+    static_assert((BM * 4) % NT == 0 && (BN * 4) % NT == 0, "loader mismatch");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+    const int tiles = g.ntm * g.ntn;
+    const int t = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - t * tiles;
+    const int ta = t / 3, tb = t - 3 * ta;
+    const int tm = tile % g.ntm, tn = tile / g.ntm;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int plane = g.NY * g.NX;
+    const unsigned chw = (unsigned)(g.Hi * g.Wi);
+    const long Kall = (long)g.Nb * plane;
+    const long k_lo = (long)blockIdx.y * g.chunks_per_split * 32;
+    long k_hi = k_lo + (long)g.chunks_per_split * 32;
+    k_hi = k_hi < Kall ? k_hi : Kall;
+
+    const int rl = lane >> 2, kq = lane & 3;
+    // wave-uniform position of the next 4-pixel group to load: flat index kg, (image, output row, output column)
+    long kg = k_lo;
+    int gn = (int)(k_lo / plane);
+    int gy, gx;
+    { const int rem = (int)(k_lo - (long)gn * plane); gy = rem / g.NX; gx = rem - gy * g.NX; }
+    const __amdgpu_buffer_rsrc_t rsA = fd_make_rsrc(g.dY), rsB = fd_make_rsrc(g.X);
+    unsigned a_lane[NAI], b_lane[NBI];
+#pragma unroll
+    for (int i = 0; i < NAI; ++i) {
+        int m = m0 + (wave + (NT / 64) * i) * 16 + rl; m = m < g.M ? m : g.M - 1;
+        a_lane[i] = 4u * (unsigned)m * (unsigned)plane + 8u * (unsigned)kq;
+    }
+    const unsigned tb_shift = tb == 0 ? 8u : 0u;
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        int c = n0 + (wave + (NT / 64) * i) * 16 + rl; c = c < g.C ? c : g.C - 1;
+        b_lane[i] = 4u * (unsigned)c * chw + 16u * (unsigned)(kq & 1);
+    }
+    f32x2_t xa[D][NAI][4];
+    float4 xb[D][NBI][4];
+    unsigned lz[D];                                                  // bit j: piece j of this lane starts at output column 0 (tb = 0: its first value is padding)
+    auto load_chunk = [&](auto slot_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        unsigned zmask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // groups 2j and 2j + 1 (8 output pixels): dY offset of the pair, X offsets of each
+            unsigned ob[2];
+            unsigned oa = FD_OOB;
+            bool x0[2], rok[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool ok = kg < k_hi;
+                const int r = 2 * gy + ta - 1;
+                const bool rowok = ok & ((unsigned)r < (unsigned)g.Hi);
+                const unsigned base = 4u * ((unsigned)gn * (unsigned)g.C * chw + (unsigned)(r * g.Wi + 2 * gx));
+                ob[q] = base; rok[q] = rowok;
+                x0[q] = gx == 0;
+                if (q == 0) oa = ok ? 4u * ((unsigned)gn * (unsigned)g.M * (unsigned)plane + (unsigned)(gy * g.NX + gx)) : FD_OOB;
+                kg += 4; gx += 4;
+                const bool w1 = gx >= g.NX;
+                gx = w1 ? 0 : gx;
+                gy += w1 ? 1 : 0;
+                const bool w2 = gy >= g.NY;
+                gy = w2 ? 0 : gy;
+                gn += w2 ? 1 : 0;
+            }
+            // tb = 0: the window starts 8 bytes earlier (input columns 2x - 2 .. 2x + 1) - except where x = 0: that piece stays where it is
+            // (no bytes in front of the tensor are touched) and its first value is the padding zero
+            const bool zl = ((kq & 2) ? x0[1] : x0[0]) && (kq & 1) == 0;
+            const unsigned obl = ((kq & 2) ? rok[1] : rok[0]) ? ((kq & 2) ? ob[1] : ob[0]) - (zl ? 0u : tb_shift) : FD_OOB;
+            zmask |= zl ? (1u << j) : 0u;
+#pragma unroll
+            for (int i = 0; i < NAI; ++i)
+                xa[S][i][j] = __builtin_bit_cast(f32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rsA, (int)(oa + a_lane[i]), 0, 0));
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) xb[S][i][j] = fd_ldg128(rsB, obl + b_lane[i]);
+        }
+        lz[S] = zmask;
+    };
+    auto split_store = [&](const float (&v)[8], unsigned char* q, int limb_stride) __attribute__((always_inline)) {
+        uint4 h, m, l;
+        split2(v[0], v[1], h.x, m.x, l.x); split2(v[2], v[3], h.y, m.y, l.y);
+        split2(v[4], v[5], h.z, m.z, l.z); split2(v[6], v[7], h.w, m.w, l.w);
+        *reinterpret_cast<uint4*>(q) = h;
+        *reinterpret_cast<uint4*>(q + limb_stride) = m;
+        *reinterpret_cast<uint4*>(q + 2 * limb_stride) = l;
+    };
+    auto store_chunk = [&](auto slot_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        const int s6 = (kq >> 1) * 6 + (kq & 1);
+#pragma unroll
+        for (int i = 0; i < NAI; ++i) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = xa[S][i][j].x; v[2 * j + 1] = xa[S][i][j].y; }
+            split_store(v, smem + s6 * PA + 16 * ((wave + (NT / 64) * i) * 16 + rl), 2 * PA);
+        }
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 f = xb[S][i][j];
+                const bool zl = tb == 0 && ((lz[S] >> j) & 1u);
+                v[2 * j] = zl ? 0.f : (tb == 1 ? f.x : f.y);
+                v[2 * j + 1] = tb == 1 ? f.z : (zl ? f.y : f.w);
+            }
+            split_store(v, smem + A_BYTES + s6 * PB + 16 * ((wave + (NT / 64) * i) * 16 + rl), 2 * PB);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nchunk = (int)((k_hi - k_lo + 31) / 32);
+    if (nchunk > 0) {
+        static_for<D>([&](auto j) __attribute__((always_inline)) { load_chunk(j); });
+        for (int c = 0; c < nchunk; c += D) {
+            static_for<D>([&](auto j) __attribute__((always_inline)) {
+                store_chunk(j);
+                __syncthreads();
+                load_chunk(j);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const unsigned char* sa = smem + (s * 6 + half) * PA + 16 * (wave_m * 64 + l31);
+                    const unsigned char* sb = smem + A_BYTES + (s * 6 + half) * PB + 16 * (wave_n * 32 + l31);
+                    uint4 af[2][3], bf[3];
+#pragma unroll
+                    for (int L = 0; L < 3; ++L) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) af[i][L] = *reinterpret_cast<const uint4*>(sa + 2 * PA * L + 512 * i);
+                        bf[L] = *reinterpret_cast<const uint4*>(sb + 2 * PB * L);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) FD_LIMB_MFMA6(acc[i], af[i], bf);
+                }
+                __syncthreads();
+            });
+        }
+    }
+    // ---- slab [z][m][t][c]
+    float* slab = g.slabs + (size_t)blockIdx.y * (size_t)g.M * 9 * g.C;
+    const int c = n0 + wave_n * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m < g.M && c < g.C) slab[((size_t)m * 9 + t) * g.C + c] = acc[i][r];
+        }
+}
+
 // ------------------------------------------------------------------------------------------------ weight pre-split (stand-alone)
 // A3 piece (m, kk .. kk+7) from W: transposed == 0: A[m][k] = W[m * K + k] (forward: m = Cout, k = Cin);
 // transposed != 0: A[m][k] = W[k * M + m] (data gradient: m = Cin, k = Cout)
@@ -777,4 +965,42 @@ int limb_wgrad_launch(const float* x, const float* gy, float* gw, float* ws, int
     }
     FD_LAUNCH_CHECK("limb wgrad");
     return fast_wgrad_finish_launch(ws, gw, M, C, 1, splits, accumulate, st);
+}
+
+// ---- 3x3 stride-2 weight gradient (k_wgrad_limb_s2)
+bool limb_wgrad_s2_shape_ok(int M, int C, int Hi, int Wi, int NY, int NX) {
+    return fd_tun().limb_conv != 0 && M >= 64 && C >= 64 && C % 32 == 0 && Wi % 8 == 0 && NX * 2 == Wi && NY * 2 >= Hi && NY * 2 <= Hi + 1 &&
+           ((long)NY * NX) % 8 == 0;
+}
+int limb_wgrad_s2_splits(int M, int C, int Nb, int plane, int* chunks_per_split) {
+    const LimbCfg c = limb_wgrad_cfg(M, C);
+    const long tiles = 9L * fd_cdiv(M, 64 * c.wm) * fd_cdiv(C, 32 * c.wn);
+    const long nch = ((long)Nb * plane + 31) / 32;
+    const long target = (long)fd_tun().limb_wgrad_target * (c.wm * c.wn == 8 ? 1 : 2);
+    long want = (target + tiles - 1) / tiles;
+    long maxs = nch / 4;
+    if (maxs < 1) maxs = 1;
+    if (want > maxs) want = maxs;
+    if (want > 512) want = 512;
+    if (want < 1) want = 1;
+    const long per = (nch + want - 1) / want;
+    if (chunks_per_split) *chunks_per_split = (int)per;
+    return (int)((nch + per - 1) / per);
+}
+long limb_wgrad_s2_ws_floats(int M, int C, int Nb, int plane) { return (long)limb_wgrad_s2_splits(M, C, Nb, plane, nullptr) * M * 9 * C; }
+
+int limb_wgrad_s2_launch(const float* x, const float* gy, float* gw, float* ws, int M, int C, int Nb, int Hi, int Wi, int NY, int NX, int accumulate,
+                         hipStream_t st) {
+    const LimbCfg c = limb_wgrad_cfg(M, C);
+    LimbWgradS2Args g = {};
+    g.dY = gy; g.X = x; g.slabs = ws; g.M = M; g.C = C; g.Nb = Nb; g.Hi = Hi; g.Wi = Wi; g.NY = NY; g.NX = NX;
+    g.ntm = fd_cdiv(M, 64 * c.wm); g.ntn = fd_cdiv(C, 32 * c.wn);
+    const int splits = limb_wgrad_s2_splits(M, C, Nb, NY * NX, &g.chunks_per_split);
+    const dim3 grid((unsigned)(9 * g.ntm * g.ntn), (unsigned)splits);
+    const size_t lds = 12 * (size_t)(16 * (64 * c.wm + 32 * c.wn) + 64);
+    if (c.wm == 2 && c.wn == 2) hipLaunchKernelGGL((k_wgrad_limb_s2<2, 2, 2>), grid, dim3(256), lds, st, g);
+    else if (c.wm == 1) hipLaunchKernelGGL((k_wgrad_limb_s2<1, 4, 2>), grid, dim3(256), lds, st, g);
+    else hipLaunchKernelGGL((k_wgrad_limb_s2<2, 4, 2>), grid, dim3(512), lds, st, g);
+    FD_LAUNCH_CHECK("limb wgrad (3x3 stride 2)");
+    return fast_wgrad_finish_launch(ws, gw, M, C, 9, splits, accumulate, st);
 }

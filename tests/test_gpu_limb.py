@@ -118,7 +118,7 @@ def test_limb_weight_layout_batched_equals_standalone():
 # (batch, Cin, Cout, H, W, K): the ResNet-18 shapes of the step (640x192, stacked batch 12 / 24), a split-K shape, channel / pixel tails
 # (the 1x1 downsample layers stay on the f32 kernels - fd_tuning.limb_conv takes kernels with more than one tap - and are here as controls)
 S2_SHAPES = [(4, 64, 128, 48, 160, 3), (4, 64, 128, 48, 160, 1), (6, 128, 256, 24, 80, 3), (12, 256, 512, 12, 40, 3), (12, 256, 512, 12, 40, 1),
-             (3, 96, 160, 11, 38, 3), (2, 64, 96, 10, 14, 3), (1, 128, 64, 7, 9, 1)]
+             (3, 96, 160, 11, 38, 3), (2, 64, 96, 10, 14, 3), (1, 128, 64, 7, 9, 1), (2, 64, 64, 13, 32, 3), (5, 128, 128, 6, 24, 3)]
 
 
 def _run_s2(B, ci, co, h, w, k, limb, bias, act, add):
@@ -135,17 +135,21 @@ def _run_s2(B, ci, co, h, w, k, limb, bias, act, add):
         plan = FD._conv_plan(x, wt, 2, pad, 0, act, False)
         dp = plan.dp
         y = torch.empty(B, co, ho, wo, device="cuda"); gx = torch.empty_like(x)
+        gw0 = torch.randn(co, ci, k, k, device="cuda", generator=g)
+        gw = gw0.clone() if add else torch.empty_like(gw0)
         f_ws = torch.empty(max(plan.fwd_ws, 1), device="cuda"); f_wt = torch.empty(max(plan.fwd_wt, 1), device="cuda")
         d_ws_n, d_wt_n = plan.data_sizes()
         d_ws = torch.empty(max(d_ws_n, 1), device="cuda"); d_wt = torch.empty(max(d_wt_n, 1), device="cuda")
+        w_ws = torch.empty(plan.weight_ws(), device="cuda")
         st = stream()
         call("fd_conv2d_fwd", dp, ptr(x), ptr(wt), ptr(bs), ptr(y), ptr(f_wt), 0, ptr(f_ws), st)
         if add:
             call("fd_conv2d_bwd_data_add", dp, ptr(gy), ptr(wt), ptr(ga), ptr(gx), ptr(d_wt), 0, ptr(d_ws), st)
         else:
             call("fd_conv2d_bwd_data", dp, ptr(gy), ptr(wt), ptr(gx), ptr(d_wt), 0, ptr(d_ws), st)
+        call("fd_conv2d_bwd_weight", dp, ptr(x), ptr(gy), ptr(gw), None, ptr(w_ws), 1 if add else 0, st)      # add: accumulate onto gw0
         torch.cuda.synchronize()
-        return x, wt, gy, bs, ga, y, gx, pad
+        return x, wt, gy, bs, ga, y, gx, pad, gw, (gw0 if add else None)
     finally:
         tuning.set_lib(limb_conv=1)
 
@@ -153,24 +157,27 @@ def _run_s2(B, ci, co, h, w, k, limb, bias, act, add):
 @pytest.mark.parametrize("shape", S2_SHAPES, ids=lambda s: "b%d_%d-%d_%dx%d_k%d" % s)
 @pytest.mark.parametrize("bias,act,add", [(False, 0, False), (True, 1, True)], ids=["plain", "bias-relu-add"])
 def test_limb_stride2_conv_keeps_fp32_accuracy(shape, bias, act, add):
-    """forward (+ bias, ReLU) and data gradient (four output-parity classes in one grouped launch, + a second gradient joined in the
-    epilogue) of the stride-2 layers: error against float64 relative to the scale of the result <= 3e-6 and no worse than 2x the
+    """forward (+ bias, ReLU), data gradient (four output-parity classes in one grouped launch, + a second gradient joined in the
+    epilogue) and weight gradient (one tap per workgroup; + accumulation onto an existing buffer) of the stride-2 layers: error against float64 relative to the scale of the result <= 3e-6 and no worse than 2x the
     f32-MFMA direct kernel's + 1e-7 on the same inputs."""
     import conftest
     B, ci, co, h, w, k = shape
     res = {}
     for limb in (0, 1):
-        x, wt, gy, bs, ga, y, gx, pad = _run_s2(B, ci, co, h, w, k, limb, bias, act, add)
+        x, wt, gy, bs, ga, y, gx, pad, gw, gw0 = _run_s2(B, ci, co, h, w, k, limb, bias, act, add)
         xd = x.double().cpu().requires_grad_(True)
-        ry = torch.nn.functional.conv2d(xd, wt.double().cpu(), bs.double().cpu() if bias else None, stride=2, padding=pad)
-        rgx, = torch.autograd.grad(ry, xd, gy.double().cpu())
+        wd = wt.double().cpu().requires_grad_(True)
+        ry = torch.nn.functional.conv2d(xd, wd, bs.double().cpu() if bias else None, stride=2, padding=pad)
+        rgx, rgw = torch.autograd.grad(ry, (xd, wd), gy.double().cpu())
+        if gw0 is not None:
+            rgw = rgw + gw0.double().cpu()
         if act:
             ry = ry.relu()
         if add:
             rgx = rgx + ga.double().cpu()
         e = lambda a, r: float((a.double().cpu() - r.detach()).abs().max() / r.detach().abs().max())
-        res[limb] = (e(y, ry), e(gx, rgx))
-    for kk, name in enumerate(("forward", "data gradient")):
+        res[limb] = (e(y, ry), e(gx, rgx), e(gw, rgw))
+    for kk, name in enumerate(("forward", "data gradient", "weight gradient")):
         bound = max(3e-6, 2 * res[0][kk] + 1e-7)
         conftest.report("limb stride-2 %s %s: max |err| / max |ref| vs float64" % ("b%d %d->%d @%dx%d k%d" % shape, name), res[1][kk], bound,
                         "(f32-MFMA kernel %.1e)" % res[0][kk])
@@ -184,7 +191,7 @@ def test_limb_stride2_route_is_taken_and_logged(capfd):
     finally:
         tuning.set_lib(log=0)
     err = capfd.readouterr().err
-    assert err.count("limb direct") >= 2, err
+    assert err.count("limb direct") >= 3, err
 
 
 @pytest.mark.parametrize("k", [3])
