@@ -802,17 +802,23 @@ inline long align4(long n) { return (n + 3) / 4 * 4; }
 inline bool fast_fwd_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && !d->in_norm; }
 inline bool fast_dgrad_ok(const fd_conv_desc* d) { return d->Cout % 16 == 0; }
 // the stride-2 layers on the split-precision implicit GEMM (conv_limb.hip: k_conv_limb), forward and data gradient
-// (kernels with more than one tap: the 1x1 stride-2 downsample layers are launch-bound GEMMs with K = Cin only - 11 - 26 us on either
-// arithmetic, and the limb kernel's split-K finish launch makes them slower: profiles/round6_limb_s2_ab.log)
+// (3x3 kernels always; the 1x1 stride-2 downsample layers only where the launch fills the chip without split-K - limb_conv_1x1_worth)
 inline bool limb_conv_fwd_ok(const fd_conv_desc* d) {
-    return d->stride == 2 && d->KH * d->KW > 1 && !d->in_norm && limb_conv_problem_ok(d->Cout, d->Cin, d->pad_mode, d->act);
+    if (!(d->stride == 2 && !d->in_norm && limb_conv_problem_ok(d->Cout, d->Cin, d->pad_mode, d->act))) return false;
+    if (d->KH * d->KW > 1) return true;
+    ConvShape s;
+    return d->pad == 0 && conv_out_shape(d, s) && limb_conv_1x1_worth(d->Cout, (long)d->N * s.Ho * s.Wo);
 }
 inline bool limb_conv_dgrad_ok(const fd_conv_desc* d) {
-    return d->stride == 2 && d->KH * d->KW > 1 && d->pad_mode == 0 && limb_conv_problem_ok(d->Cin, d->Cout, 0, 0);
+    if (!(d->stride == 2 && d->pad_mode == 0 && limb_conv_problem_ok(d->Cin, d->Cout, 0, 0))) return false;
+    if (d->KH * d->KW > 1) return true;
+    ConvShape s;
+    return d->pad == 0 && conv_out_shape(d, s) && limb_conv_1x1_worth(d->Cin, (long)d->N * s.Ho * s.Wo);
 }
 inline bool limb_conv_wgrad_ok(const fd_conv_desc* d, const ConvShape& s) {
-    return d->stride == 2 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->pad_mode == 0 && !d->in_norm &&
-           limb_wgrad_s2_shape_ok(d->Cout, d->Cin, d->H, d->W, s.Ho, s.Wo);
+    if (!(d->stride == 2 && d->pad_mode == 0 && !d->in_norm && limb_wgrad_s2_shape_ok(d->Cout, d->Cin, d->H, d->W, s.Ho, s.Wo))) return false;
+    if (d->KH == 3 && d->KW == 3 && d->pad == 1) return true;
+    return d->KH == 1 && d->KW == 1 && d->pad == 0 && d->Cin >= 256;      // (K = pixels here: the short dimension is Cin x Cout tiles)
 }
 inline bool fast_wgrad_ok(const fd_conv_desc* d) { return d->Cin % 16 == 0 && d->Cin >= 64 && !d->in_norm; }   // narrow layers: a (tap, channel) tile would be mostly padding
 
@@ -1418,7 +1424,7 @@ extern "C" long fd_conv2d_bwd_weight_ws_floats(const fd_conv_desc* d) {
     else if (fast_wgrad_ok(d)) slabs = (long)fast_wgrad_splits(d->Cout, d->Cin, d->KH * d->KW, (long)d->N * s.Ho * s.Wo) * wsz;
     else { const int sp = wgrad_splits(d, s); slabs = sp > 1 ? (long)sp * wsz : 0; }
     if (limb_wgrad_ok(d)) { const long l = limb_wgrad_ws_floats(d->Cout, d->Cin, d->N, d->H * d->W); slabs = l > slabs ? l : slabs; }   // (the direct kernel stays the fallback for unaligned tensors)
-    if (limb_conv_wgrad_ok(d, s)) { const long l = limb_wgrad_s2_ws_floats(d->Cout, d->Cin, d->N, s.Ho * s.Wo); slabs = l > slabs ? l : slabs; }
+    if (limb_conv_wgrad_ok(d, s)) { const long l = limb_wgrad_s2_ws_floats(d->Cout, d->Cin, d->N, s.Ho * s.Wo, d->KH * d->KW); slabs = l > slabs ? l : slabs; }
     const long bias_part = (long)d->Cout * CS_SPLITS;
     if (slabs < wsz) slabs = wsz;                            // accumulate mode stages a single slab
     return slabs > bias_part ? slabs : bias_part;          // the two uses are sequential on the stream
@@ -1440,7 +1446,7 @@ extern "C" int fd_conv2d_bwd_weight(const fd_conv_desc* d, const float* x, const
     if (limb_w) {
         if (int rc = limb_wgrad_launch(x, gy, gw, ws, d->Cout, d->Cin, d->N, d->H * d->W, accumulate, st)) return rc;
     } else if (limb_w2) {
-        if (int rc = limb_wgrad_s2_launch(x, gy, gw, ws, d->Cout, d->Cin, d->N, d->H, d->W, s.Ho, s.Wo, accumulate, st)) return rc;
+        if (int rc = limb_wgrad_s2_launch(x, gy, gw, ws, d->Cout, d->Cin, d->N, d->H, d->W, s.Ho, s.Wo, d->KH * d->KW, accumulate, st)) return rc;
     } else if (narrow_wgrad_ok(d)) {
         if (int rc = narrow_wgrad_launch(d, x, gy, gw, ws, accumulate, st)) return rc;
     } else if (stem_wgrad_ok(d)) {

@@ -116,6 +116,7 @@ int limb_conv_launch(const FastGemmArgs& a, hipStream_t st);
 int limb_conv_group_launch(const FastGemmArgs& a, const FastGemmGroup& q, hipStream_t st);
 // ... and their weight gradient (3x3, stride 2, pad 1, zero padding: k_wgrad_limb_s2)
 bool limb_wgrad_s2_shape_ok(int M, int C, int Hi, int Wi, int NY, int NX);
-long limb_wgrad_s2_ws_floats(int M, int C, int Nb, int plane);
-int limb_wgrad_s2_launch(const float* x, const float* gy, float* gw, float* ws, int M, int C, int Nb, int Hi, int Wi, int NY, int NX, int accumulate,
-                         hipStream_t st);
+long limb_wgrad_s2_ws_floats(int M, int C, int Nb, int plane, int ntaps);
+int limb_wgrad_s2_launch(const float* x, const float* gy, float* gw, float* ws, int M, int C, int Nb, int Hi, int Wi, int NY, int NX, int ntaps,
+                         int accumulate, hipStream_t st);
+bool limb_conv_1x1_worth(int M, long Np);

@@ -580,6 +580,7 @@ struct LimbWgradS2Args {
     int M, C, Nb, Hi, Wi, NY, NX;
     int ntm, ntn;
     int chunks_per_split;
+    int tap0, ntaps;       // 0, 9: the 3x3 kernel; 4, 1: a 1x1 stride-2 kernel without padding = the centre tap alone (slabs [splits][M][1][C])
 };
 
 template <int WAVES_M, int WAVES_N, int D>
@@ -596,7 +597,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_limb_s2(LimbWg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
     const int tiles = g.ntm * g.ntn;
-    const int t = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - t * tiles;
+    const int ts = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - ts * tiles;
+    const int t = g.tap0 + ts;
     const int ta = t / 3, tb = t - 3 * ta;
     const int tm = tile % g.ntm, tn = tile / g.ntm;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -734,14 +736,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) k_wgrad_limb_s2(LimbWg
         }
     }
     // ---- slab [z][m][t][c]
-    float* slab = g.slabs + (size_t)blockIdx.y * (size_t)g.M * 9 * g.C;
+    float* slab = g.slabs + (size_t)blockIdx.y * (size_t)g.M * g.ntaps * g.C;
     const int c = n0 + wave_n * 32 + l31;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wave_m * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m < g.M && c < g.C) slab[((size_t)m * 9 + t) * g.C + c] = acc[i][r];
+            if (m < g.M && c < g.C) slab[((size_t)m * g.ntaps + ts) * g.C + c] = acc[i][r];
         }
 }
 
@@ -972,9 +974,9 @@ bool limb_wgrad_s2_shape_ok(int M, int C, int Hi, int Wi, int NY, int NX) {
     return fd_tun().limb_conv != 0 && M >= 64 && C >= 64 && C % 32 == 0 && Wi % 8 == 0 && NX * 2 == Wi && NY * 2 >= Hi && NY * 2 <= Hi + 1 &&
            ((long)NY * NX) % 8 == 0;
 }
-int limb_wgrad_s2_splits(int M, int C, int Nb, int plane, int* chunks_per_split) {
+int limb_wgrad_s2_splits(int M, int C, int Nb, int plane, int ntaps, int* chunks_per_split) {
     const LimbCfg c = limb_wgrad_cfg(M, C);
-    const long tiles = 9L * fd_cdiv(M, 64 * c.wm) * fd_cdiv(C, 32 * c.wn);
+    const long tiles = (long)ntaps * fd_cdiv(M, 64 * c.wm) * fd_cdiv(C, 32 * c.wn);
     const long nch = ((long)Nb * plane + 31) / 32;
     const long target = (long)fd_tun().limb_wgrad_target * (c.wm * c.wn == 8 ? 1 : 2);
     long want = (target + tiles - 1) / tiles;
@@ -987,20 +989,29 @@ int limb_wgrad_s2_splits(int M, int C, int Nb, int plane, int* chunks_per_split)
     if (chunks_per_split) *chunks_per_split = (int)per;
     return (int)((nch + per - 1) / per);
 }
-long limb_wgrad_s2_ws_floats(int M, int C, int Nb, int plane) { return (long)limb_wgrad_s2_splits(M, C, Nb, plane, nullptr) * M * 9 * C; }
+long limb_wgrad_s2_ws_floats(int M, int C, int Nb, int plane, int ntaps) {
+    return (long)limb_wgrad_s2_splits(M, C, Nb, plane, ntaps, nullptr) * M * ntaps * C;
+}
 
-int limb_wgrad_s2_launch(const float* x, const float* gy, float* gw, float* ws, int M, int C, int Nb, int Hi, int Wi, int NY, int NX, int accumulate,
-                         hipStream_t st) {
+// ntaps = 9: 3x3 kernel with padding 1; ntaps = 1: 1x1 kernel without padding (the centre tap's access pattern)
+int limb_wgrad_s2_launch(const float* x, const float* gy, float* gw, float* ws, int M, int C, int Nb, int Hi, int Wi, int NY, int NX, int ntaps,
+                         int accumulate, hipStream_t st) {
     const LimbCfg c = limb_wgrad_cfg(M, C);
     LimbWgradS2Args g = {};
     g.dY = gy; g.X = x; g.slabs = ws; g.M = M; g.C = C; g.Nb = Nb; g.Hi = Hi; g.Wi = Wi; g.NY = NY; g.NX = NX;
     g.ntm = fd_cdiv(M, 64 * c.wm); g.ntn = fd_cdiv(C, 32 * c.wn);
-    const int splits = limb_wgrad_s2_splits(M, C, Nb, NY * NX, &g.chunks_per_split);
-    const dim3 grid((unsigned)(9 * g.ntm * g.ntn), (unsigned)splits);
+    g.ntaps = ntaps; g.tap0 = ntaps == 9 ? 0 : 4;
+    const int splits = limb_wgrad_s2_splits(M, C, Nb, NY * NX, ntaps, &g.chunks_per_split);
+    const dim3 grid((unsigned)(ntaps * g.ntm * g.ntn), (unsigned)splits);
     const size_t lds = 12 * (size_t)(16 * (64 * c.wm + 32 * c.wn) + 64);
     if (c.wm == 2 && c.wn == 2) hipLaunchKernelGGL((k_wgrad_limb_s2<2, 2, 2>), grid, dim3(256), lds, st, g);
     else if (c.wm == 1) hipLaunchKernelGGL((k_wgrad_limb_s2<1, 4, 2>), grid, dim3(256), lds, st, g);
     else hipLaunchKernelGGL((k_wgrad_limb_s2<2, 4, 2>), grid, dim3(512), lds, st, g);
     FD_LAUNCH_CHECK("limb wgrad (3x3 stride 2)");
-    return fast_wgrad_finish_launch(ws, gw, M, C, 9, splits, accumulate, st);
+    return fast_wgrad_finish_launch(ws, gw, M, C, ntaps, splits, accumulate, st);
 }
+
+// 1x1 stride-2 layers (the downsample branch of layerN.0): launch-bound GEMMs when the plane is small and K = Cin short - the ResNet-18
+// ones at 640x192 are 11 - 26 us on either arithmetic and the limb kernel's split-K finish makes them slower; taken only when the launch
+// fills the chip without a split (ResNet-50's: K = 256 .. 1024 at 2 - 4x the pixels)
+bool limb_conv_1x1_worth(int M, long Np) { return (long)fd_cdiv(M, 32 * limb_gemm_mb(M)) * fd_cdiv(Np, 128) >= 200; }

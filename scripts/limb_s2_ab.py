@@ -9,6 +9,7 @@ from fusiondepth_amd import functional as FD, tuning
 from fusiondepth_amd._lib import call, ptr, stream
 from limb_ab import timed
 
+R50_SHAPES = [(128, 128, 48, 160, 3), (256, 256, 24, 80, 3), (512, 512, 12, 40, 3), (256, 512, 48, 160, 1), (512, 1024, 24, 80, 1), (1024, 2048, 12, 40, 1)]
 SHAPES = [(64, 128, 48, 160, 3), (64, 128, 48, 160, 1), (128, 256, 24, 80, 3), (128, 256, 24, 80, 1), (256, 512, 12, 40, 3), (256, 512, 12, 40, 1)]
 
 
@@ -37,14 +38,18 @@ def run(B, ci, co, h, w, k, limb):
 
 
 def main():
-    out = open(os.path.join(ROOT, "profiles", "round6_limb_s2_ab.log"), "w")
+    out = open(os.path.join(ROOT, "profiles", "round6_limb_s2_ab_r50.log" if "r50" in sys.argv[1:] else "round6_limb_s2_ab.log"), "w")
     def say(s):
         print(s, flush=True); out.write(s + "\n"); out.flush()
     say("stride-2 convolutions of ResNet-18 @640x192: f32-MFMA direct kernels vs split-precision implicit GEMM (k_conv_limb); us per call alone on "
         "the GPU (incl. split-K finish), TFLOP/s of algorithmic flops, max|err|/max|ref| vs float64")
-    for B in ([int(a) for a in sys.argv[1:]] or [12, 24]):
+    args = [a for a in sys.argv[1:] if a != "r50"]
+    shapes = R50_SHAPES if "r50" in sys.argv[1:] else SHAPES
+    if "r50" in sys.argv[1:]:
+        say("(ResNet-50's stride-2 layers: conv2 of layerN.0 and the downsample branch)")
+    for B in ([int(a) for a in args] or [12, 24]):
         tot = {0: [0.0, 0.0, 0.0], 1: [0.0, 0.0, 0.0]}
-        for (ci, co, h, w, k) in SHAPES:
+        for (ci, co, h, w, k) in shapes:
             res = {}
             for limb in (0, 1):
                 t, (x, wt, gy, y, gx, pad, gw) = run(B, ci, co, h, w, k, limb)

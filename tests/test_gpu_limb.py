@@ -116,9 +116,10 @@ def test_limb_weight_layout_batched_equals_standalone():
 
 # ---- stride-2 convolutions on the split-precision implicit GEMM (k_conv_limb): ResNet layerN.0.conv1 (3x3) and downsample (1x1) -------------
 # (batch, Cin, Cout, H, W, K): the ResNet-18 shapes of the step (640x192, stacked batch 12 / 24), a split-K shape, channel / pixel tails
-# (the 1x1 downsample layers stay on the f32 kernels - fd_tuning.limb_conv takes kernels with more than one tap - and are here as controls)
+# (1x1 downsample layers go to the limb kernels only where the launch fills the chip without split-K: the small ones here are controls)
 S2_SHAPES = [(4, 64, 128, 48, 160, 3), (4, 64, 128, 48, 160, 1), (6, 128, 256, 24, 80, 3), (12, 256, 512, 12, 40, 3), (12, 256, 512, 12, 40, 1),
-             (3, 96, 160, 11, 38, 3), (2, 64, 96, 10, 14, 3), (1, 128, 64, 7, 9, 1), (2, 64, 64, 13, 32, 3), (5, 128, 128, 6, 24, 3)]
+             (3, 96, 160, 11, 38, 3), (2, 64, 96, 10, 14, 3), (1, 128, 64, 7, 9, 1), (2, 64, 64, 13, 32, 3), (5, 128, 128, 6, 24, 3),
+             (8, 256, 512, 48, 160, 1), (4, 512, 1024, 24, 80, 1)]       # ResNet-50's downsample layers: large enough for the limb kernels
 
 
 def _run_s2(B, ci, co, h, w, k, limb, bias, act, add):
