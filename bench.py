@@ -37,13 +37,14 @@ LOSS_BYTES_PER_PIXEL = 343.7          # compulsory fwd+bwd HBM traffic of the fu
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 # what the arithmetic is, next to `dtype` (an undisclosed precision change would void the line).  Every tensor is fp32;
 # products and sums are fp32 (v_mfma_f32_32x32x2_f32 / 16x16x4: exact fp32, Winograd transforms in fp32) EXCEPT the convolutions no Winograd
-# form exists for, with >= 64 channels on both sides (csrc/conv_limb.hip): the 1x1 stride-1 layers (ResNet-50 bottlenecks; on the ResNet-18
-# configurations only the PoseDecoder's 512 -> 256 squeeze) in all three directions, and the 3x3 stride-2 layers (layerN.0.conv1 of every
-# ResNet) forward + data gradient: each fp32 operand is split exactly into three bf16 limbs, the product is six bf16 MFMAs accumulated in
-# fp32 - error against float64 equal to the f32 kernels' (tests/test_gpu_limb.py), all float64-anchored parity bounds unchanged.
-ARITH_NOTE = ("fp32 storage, fp32 accumulate; products fp32-exact (f32 MFMA) except 1x1 stride-1 (all directions) and 3x3 stride-2 (forward, "
-              "data gradient) convolutions with >= 64 channels: bf16x3 split, six products, fp32 accumulate (fp32-equal error vs float64; "
-              "fd_tuning.limb_1x1 = limb_conv = 0 restores the f32 kernels)")
+# form exists for, with >= 64 channels on both sides (csrc/conv_limb.hip), in all three directions: the 1x1 stride-1 layers (ResNet-50
+# bottlenecks; on the ResNet-18 configurations only the PoseDecoder's 512 -> 256 squeeze) and the stride-2 layers (3x3 layerN.0 of every
+# ResNet; the 1x1 downsample branch where its launch fills the chip - ResNet-50's).  There each fp32 operand is split exactly into three
+# bf16 limbs and the product is six bf16 MFMAs accumulated in fp32 - error against float64 equal to the f32 kernels' on every shape
+# (tests/test_gpu_limb.py), all float64-anchored parity bounds unchanged.
+ARITH_NOTE = ("fp32 storage, fp32 accumulate; products fp32-exact (f32 MFMA) except the convolutions without a Winograd form with >= 64 channels "
+              "(1x1 stride-1; 3x3 stride-2 and large 1x1 stride-2; forward, data and weight gradient): bf16x3 split, six products, fp32 accumulate "
+              "(fp32-equal error vs float64; fd_tuning.limb_1x1 = limb_conv = 0 restores the f32 kernels)")
 PEAK_HBM_GBS = 8000.0
 
 
