@@ -15,6 +15,7 @@
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include "conv_fast.h"
+#include "conv_limb.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1653,6 +1654,224 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino(WinoWgradArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient, split precision
+// k_wgrad_wino<false, true> (zero padding, transposed F(2x2, 3x3), >= 64 output channels) on the bf16 matrix pipes at fp32 accuracy
+// (conv_limb.h: every fp32 operand = three bf16 limbs, six limb products, fp32 accumulation).  Same grid, slices, loader addressing, row
+// combinations and epilogue; what changes is WHERE the horizontal transforms run and what LDS holds:
+//   * the loader thread of a QUAD of pairs applies the vertical combination (as before), the padding (as before) AND the horizontal transforms
+//     P = (y0, y0+y1, y0-y1, y1), Q = (d0-d2, d1+d2, d2-d1, d1-d3) of its four pairs, splits them into limbs and writes 8-byte pieces:
+//     LDS holds, per operand, [component 4][limb 3][K half 2][row 64] 16-byte MFMA fragments of 8 pairs - the chunk's 16 pairs are ONE
+//     v_mfma_f32_32x32x16_bf16 k-step;
+//   * the matrix loop is 24 fragment reads + 24 MFMAs per chunk and wave (768 matrix-pipe cycles instead of the 2 048 of 32
+//     v_mfma_f32_32x32x2_f32) with no vector arithmetic at all; every value is transformed and split ONCE per workgroup (the f32 kernel
+//     transforms at operand-read time: once per wave that reads it);
+//   * one LDS buffer (51 KB: three workgroups per CU), two barriers per chunk; the next chunk's global loads are issued in front of the
+//     matrix phase and are in flight during it.
+constexpr int WL_HPL = 64 * 16 + 64;              // one K half of a (component, limb) plane: 64 rows x 16 B, padded (bank spread of the two halves)
+constexpr int WL_PLANE = 2 * WL_HPL;
+constexpr int WL_OP = 12 * WL_PLANE;              // one operand: 4 components x 3 limbs
+constexpr int WL_LDS_BYTES = 2 * WL_OP;
+
+#define FD_WLIMB_MFMA6(ACC, AF, BF)                                                                                                   \
+    do {                                                                                                                              \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[2]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[2]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[1]), __builtin_bit_cast(wl_bf16x8, BF[1]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[1]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[1]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
+    } while (0)
+typedef __bf16 wl_bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(WNT) k_wgrad_wino_limb(WinoWgradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* smemb = reinterpret_cast<unsigned char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W2 = g.W >> 1;
+    const int HT = g.H >> 1;
+    constexpr int R = 4;
+    const int plane2 = HT * W2, Np = g.Nb * plane2;
+    const unsigned hw = (unsigned)(g.H * g.W);
+    const int ctiles = (g.C + WBN - 1) / WBN;
+    int bt, bs, by;
+    if (g.slice_major == 2) {                                    // XCD-aware 1-D grid (k_wgrad_wino)
+        const int mtiles = (g.M + WBM - 1) / WBM, nt = R * ctiles * mtiles;
+        const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
+        int t;
+        if (g.xcds_per_slice <= 1) { t = k % nt; bs = (k / nt) * 8 + xcd; }
+        else { const int per = nt / g.xcds_per_slice; bs = xcd / g.xcds_per_slice; t = (xcd % g.xcds_per_slice) * per + k; }
+        by = t / (R * ctiles);
+        bt = t - by * R * ctiles;
+    } else {
+        bt = g.slice_major ? blockIdx.z : blockIdx.x; bs = g.slice_major ? blockIdx.x : blockIdx.z; by = blockIdx.y;
+    }
+    const int ky = bt / ctiles, c0 = (bt - ky * ctiles) * WBN;
+    const int m0 = by * WBM;
+    const int pp_lo = (int)((long)bs * g.pairs_per_split < Np ? (long)bs * g.pairs_per_split : Np);
+    const int pp_hi = (long)pp_lo + g.pairs_per_split < Np ? pp_lo + (int)g.pairs_per_split : Np;
+    const int nchunk = pp_hi > pp_lo ? (pp_hi - pp_lo + WGP - 1) / WGP : 0;
+
+    // ---- loader: thread = (row tid / 4 of both operands, QUAD tid % 4 = four consecutive pairs of the chunk, one tile row: W / 2 % 4 == 0).
+    // Four adjacent lanes read 128 contiguous bytes of a dY row; two pairs of one component make one split2 (a dword = two consecutive K
+    // positions), a quad an 8-byte store into the fragment - the first version (a thread = one pair of four rows, 2-byte stores: 96 LDS
+    // store instructions per thread and chunk) ran at 0.76x the f32 kernel (profiles/round6_wgrad_wino_limb.log).
+    const int q = tid & 3, row = tid >> 2;
+    unsigned a_row, b_row;
+    {
+        int m = m0 + row; m = m < g.M ? m : g.M - 1;
+        int c = c0 + row; c = c < g.C ? c : g.C - 1;
+        a_row = 4u * (unsigned)m * hw; b_row = 4u * (unsigned)c * hw;
+    }
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.dY);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)(4u * (unsigned)g.Nb * (unsigned)g.C * hw), 0x00020000);
+    // (a register ring of two chunks - loads two iterations ahead - measured the same alone and in the step at 196 registers: removed)
+    float4 ya[1][2], yb[1][2];                 // dY: 8 columns of the two tile rows
+    float4 xa[1][2], xb[1][2];                 // X: columns 2j-1 .. 2j+6 (left edge: 2j .. 2j+7) of the two combined rows ...
+    f32x2 xa2[1], xb2[1];                      // ... and 2j+7, 2j+8 (left edge: 2j+8, 2j+9)
+    unsigned a_off = FD_OOB, x_off = FD_OOB, a_off2 = FD_OOB, x_off2 = FD_OOB;
+    const int yr_a = ky == 3 ? 1 : 0;
+    const bool y_two = ky == 1 || ky == 2;
+    const float y_sgn = ky == 2 ? -1.f : 1.f;
+    const int xr_a = ky == 0 ? 0 : (ky == 2 ? 2 : 1), xr_b = ky == 3 ? 3 : (ky == 2 ? 1 : 2);
+    const float x_sgn = ky == 1 ? 1.f : -1.f;
+    int pf = 0, rf = 0;                        // bit 0 / 1: the quad starts / ends an image row
+    int pc = pp_lo;
+    int cn, cy, cj;
+    {
+        const int pq = pp_lo + 4 * q;
+        cn = pq / plane2;
+        const int rem = pq - cn * plane2;
+        cy = rem / W2; cj = rem - cy * W2;
+    }
+    auto prep_chunk = [&](bool live) __attribute__((always_inline)) {
+        const int pg = pc + 4 * q;
+        const bool ok = live & (pg < pp_hi);
+        const int n = cn, y = cy, j = cj;
+        const bool e_left = j == 0, e_right = 2 * j + 8 >= g.W;
+        auto x_row = [&](int r) __attribute__((always_inline)) {
+            const bool okb = ok & ((unsigned)r < (unsigned)g.H);
+            const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(r * g.W + 2 * j));
+            return okb ? (e_left ? base : base - 4u) : FD_OOB;
+        };
+        const unsigned yo = 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)((2 * y + yr_a) * g.W + 2 * j));
+        a_off = ok ? yo : FD_OOB;
+        a_off2 = (ok & y_two) ? yo + 4u * (unsigned)g.W : FD_OOB;
+        x_off = x_row(2 * y - 1 + xr_a);
+        x_off2 = x_row(2 * y - 1 + xr_b);
+        pf = (e_left ? 1 : 0) | (e_right ? 2 : 0);
+        pc += WGP;
+        cj += g.adv_j;
+        const bool c1 = cj >= W2;
+        cj -= c1 ? W2 : 0;
+        cy += g.adv_y + (c1 ? 1 : 0);
+        const bool c2 = cy >= HT;
+        cy -= c2 ? HT : 0;
+        cn += g.adv_n + (c2 ? 1 : 0);
+    };
+    auto load_all = [&](auto slot_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        ya[S][0] = fd_ldg128(rsY, a_off + a_row); ya[S][1] = fd_ldg128(rsY, a_off + a_row + 16u);
+        yb[S][0] = fd_ldg128(rsY, a_off2 + a_row); yb[S][1] = fd_ldg128(rsY, a_off2 + a_row + 16u);
+        xa[S][0] = fd_ldg128(rsX, x_off + b_row); xa[S][1] = fd_ldg128(rsX, x_off + b_row + 16u); xa2[S] = fd_ldg64(rsX, x_off + b_row + 32u);
+        xb[S][0] = fd_ldg128(rsX, x_off2 + b_row); xb[S][1] = fd_ldg128(rsX, x_off2 + b_row + 16u); xb2[S] = fd_ldg64(rsX, x_off2 + b_row + 32u);
+    };
+    // this quad's 8-byte slot inside the fragments of its row: K half q / 2, positions 4 (q % 2) .. + 3
+    unsigned char* const slot = smemb + (q >> 1) * WL_HPL + row * 16 + 8 * (q & 1);
+    auto store_all = [&](auto slot_tag) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value;
+        // vertical combinations (exact products: a +- b)
+        float Y[8], X[10];
+        Y[0] = fmaf(y_sgn, yb[S][0].x, ya[S][0].x); Y[1] = fmaf(y_sgn, yb[S][0].y, ya[S][0].y); Y[2] = fmaf(y_sgn, yb[S][0].z, ya[S][0].z); Y[3] = fmaf(y_sgn, yb[S][0].w, ya[S][0].w);
+        Y[4] = fmaf(y_sgn, yb[S][1].x, ya[S][1].x); Y[5] = fmaf(y_sgn, yb[S][1].y, ya[S][1].y); Y[6] = fmaf(y_sgn, yb[S][1].z, ya[S][1].z); Y[7] = fmaf(y_sgn, yb[S][1].w, ya[S][1].w);
+        float r[10];
+        r[0] = fmaf(x_sgn, xb[S][0].x, xa[S][0].x); r[1] = fmaf(x_sgn, xb[S][0].y, xa[S][0].y); r[2] = fmaf(x_sgn, xb[S][0].z, xa[S][0].z); r[3] = fmaf(x_sgn, xb[S][0].w, xa[S][0].w);
+        r[4] = fmaf(x_sgn, xb[S][1].x, xa[S][1].x); r[5] = fmaf(x_sgn, xb[S][1].y, xa[S][1].y); r[6] = fmaf(x_sgn, xb[S][1].z, xa[S][1].z); r[7] = fmaf(x_sgn, xb[S][1].w, xa[S][1].w);
+        r[8] = fmaf(x_sgn, xb2[S].x, xa2[S].x); r[9] = fmaf(x_sgn, xb2[S].y, xa2[S].y);
+        // columns 2j-1 .. 2j+8; a quad at the left edge was loaded from column 2j on (shift), its column -1 and the right edge's column W are 0
+        const bool L = rf & 1, Rr = rf & 2;
+        X[0] = L ? 0.f : r[0];
+#pragma unroll
+        for (int k = 1; k < 10; ++k) X[k] = L ? r[k - 1] : r[k];
+        X[9] = Rr ? 0.f : X[9];
+        // horizontal transforms of the four pairs, limbs, fragments (component t: planes 3 t .. 3 t + 2 = limbs h, m, l)
+        unsigned char* qa = slot;
+        unsigned char* qb = slot + WL_OP;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float pv[4], qv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float y0 = Y[2 * k], y1 = Y[2 * k + 1];
+                const float d0 = X[2 * k], d1 = X[2 * k + 1], d2 = X[2 * k + 2], d3 = X[2 * k + 3];
+                pv[k] = t == 0 ? y0 : (t == 1 ? y0 + y1 : (t == 2 ? y0 - y1 : y1));
+                qv[k] = t == 0 ? d0 - d2 : (t == 1 ? d1 + d2 : (t == 2 ? d2 - d1 : d1 - d3));
+            }
+            unsigned h0, m0_, l0, h1, m1, l1;
+            fdlimb::split2(pv[0], pv[1], h0, m0_, l0); fdlimb::split2(pv[2], pv[3], h1, m1, l1);
+            *reinterpret_cast<u32x2*>(qa + (3 * t) * WL_PLANE) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(qa + (3 * t + 1) * WL_PLANE) = u32x2{m0_, m1};
+            *reinterpret_cast<u32x2*>(qa + (3 * t + 2) * WL_PLANE) = u32x2{l0, l1};
+            fdlimb::split2(qv[0], qv[1], h0, m0_, l0); fdlimb::split2(qv[2], qv[3], h1, m1, l1);
+            *reinterpret_cast<u32x2*>(qb + (3 * t) * WL_PLANE) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(qb + (3 * t + 1) * WL_PLANE) = u32x2{m0_, m1};
+            *reinterpret_cast<u32x2*>(qb + (3 * t + 2) * WL_PLANE) = u32x2{l0, l1};
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int arow = lane >> 5, acol = lane & 31;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (nchunk > 0) {
+        constexpr std::integral_constant<int, 0> S0{};
+        prep_chunk(true);
+        rf = pf;
+        load_all(S0);
+        prep_chunk(1 < nchunk);
+        const unsigned char* fa = smemb + arow * WL_HPL + (32 * wm + acol) * 16;
+        const unsigned char* fb = smemb + WL_OP + arow * WL_HPL + (32 * wn + acol) * 16;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            store_all(S0);
+            __syncthreads();
+            load_all(S0);                                             // chunk ch + 1: in flight during the matrix phase
+            rf = pf;
+            prep_chunk(ch + 2 < nchunk);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint4 af[3], bf[3];
+#pragma unroll
+                for (int Lm = 0; Lm < 3; ++Lm) {
+                    af[Lm] = *reinterpret_cast<const uint4*>(fa + (t * 3 + Lm) * WL_PLANE);
+                    bf[Lm] = *reinterpret_cast<const uint4*>(fb + (t * 3 + Lm) * WL_PLANE);
+                }
+                FD_WLIMB_MFMA6(acc[t], af, bf);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- epilogue (k_wgrad_wino's): slab[z][m][ri * 3 + kx][c] from the four accumulators
+    const int c = c0 + 32 * wn + acol;
+    const __amdgpu_buffer_rsrc_t rsS = fd_make_rsrc(g.slabs + (size_t)bs * ((size_t)g.M * (3 * R) * g.C));
+    const int mb = m0 + 32 * wm + 4 * arow;
+    const unsigned col = (c < g.C) ? 4u * (unsigned)(ky * 3 * g.C + c) : FD_OOB;
+    const unsigned row_step = 4u * (3u * R) * (unsigned)g.C, kx_step = 4u * (unsigned)g.C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        const unsigned off = (m < g.M) ? col + (unsigned)m * row_step : FD_OOB;
+        const float M0 = acc[0][r], M1 = acc[1][r], M2 = acc[2][r], M3 = acc[3][r];
+        const float hh = 0.5f * (M1 + M2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, M0 + hh), rsS, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 0.5f * (M1 - M2)), rsS, (int)(off + kx_step), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hh - M3), rsS, (int)(off + 2u * kx_step), 0, 0);
+    }
+}
+
 inline int wino_splits(const fd_conv_desc* d, int M, int C) {
     const long tiles = (long)fd_cdiv((long)d->N * d->H * (d->W / 2), WBN) * fd_cdiv(M, WBM);
     const int nchunk = 3 * (C / WBKC);
@@ -1923,7 +2142,11 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
     const dim3 grid = g.slice_major == 2 ? dim3((unsigned)(nt * mt * sp)) : (g.slice_major ? dim3(sp, mt, nt) : dim3(nt, mt, sp));
     const size_t lds = sizeof(float) * WG_LDS_FLOATS;
     const bool halfm = d->Cout <= 32 && fd_tun().wino_wgrad_halfm != 0;   // at most 32 output channels: two waves per K half (k_wgrad_wino<.., HALFM>)
-    if (halfm) {
+    if (fd_tun().wino_wgrad_limb != 0 && twod && d->pad_mode == 0 && d->Cout >= 64 && d->W % 8 == 0) {       // the ResNet trunk's layers: split-precision matrix loop
+        static FdLdsAttrOnce attr_l;
+        if (attr_l.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino_limb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_l.mark(); }
+        hipLaunchKernelGGL(k_wgrad_wino_limb, grid, dim3(WNT), (size_t)WL_LDS_BYTES, st, g);
+    } else if (halfm) {
         static FdLdsAttrOnce attr_h;
         if (attr_h.needed()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -31,7 +31,7 @@ extern "C" {
  *    fd_bn_train_bwd_remask, fd_stack_normalize, fd_conv2d_fwd_bn(_ok), fd_pose_head_fwd / _bwd; fd_tuning grew at its end
  *    (wino_min_cout, wino_wgrad_min_cout, wino_wgrad_xcd_few, wino_fwd_halfm, wino_wgrad_halfm, grp_tile64_below).  Nothing removed, no signature changed.
  * 4: additions only (round 6): fd_replay (+ fd_call_rec, fd_replay_function_count / _name / _signature); fd_tuning grew at its end (limb_1x1,
- *    limb_depth, limb_target, limb_split_max_out, limb_wgrad_target, limb_conv); fd_relayout_job.mode 7 / 8 (1x1 weights pre-split into bf16
+ *    limb_depth, limb_target, limb_split_max_out, limb_wgrad_target, limb_conv, wino_wgrad_limb); fd_relayout_job.mode 7 / 8 (1x1 weights pre-split into bf16
  *    limbs) and 9 / 10 (the same for a tap subset of a larger kernel); fd_refine_cfg accepts an empty crop window.  Nothing removed, no
  *    signature changed. */
 #define FD_ABI_VERSION 4
@@ -89,6 +89,8 @@ typedef struct fd_tuning {
     int limb_wgrad_target;        /* 256 workgroups a limb weight-gradient launch is pixel-sliced up to (x2 for its 4-wave tiles) */
     int limb_conv;                /* 1   stride-2 convolutions with >= 64 channels on both sides (ResNet layerN.0.conv1 / downsample: no Winograd form), forward
                                          and data gradient, as split-precision implicit GEMMs (k_conv_limb); 0: the f32-MFMA direct kernels */
+    int wino_wgrad_limb;          /* 1   the 2-D Winograd weight gradient of zero-padded layers with >= 64 output channels with a split-precision matrix
+                                         loop (k_wgrad_wino_limb: transforms + limb split in the loader, 768 instead of 2 048 matrix cycles per chunk) */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);
