@@ -1683,6 +1683,7 @@ constexpr int WL_LDS_BYTES = 2 * WL_OP;
     } while (0)
 typedef __bf16 wl_bf16x8 __attribute__((ext_vector_type(8)));
 
+template <bool REFL>          // reflection (decoder) or zero (ResNet trunk) padding
 __global__ void __launch_bounds__(WNT) k_wgrad_wino_limb(WinoWgradArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     unsigned char* smemb = reinterpret_cast<unsigned char*>(smem);
@@ -1750,8 +1751,12 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino_limb(WinoWgradArgs g) {
         const int n = cn, y = cy, j = cj;
         const bool e_left = j == 0, e_right = 2 * j + 8 >= g.W;
         auto x_row = [&](int r) __attribute__((always_inline)) {
-            const bool okb = ok & ((unsigned)r < (unsigned)g.H);
-            const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(r * g.W + 2 * j));
+            const bool inb = (unsigned)r < (unsigned)g.H;
+            int rr_ = r < 0 ? -r : r;
+            rr_ = rr_ >= g.H ? 2 * g.H - 2 - rr_ : rr_;
+            const int ruse = REFL ? rr_ : r;
+            const bool okb = ok & (REFL | inb);
+            const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)(ruse * g.W + 2 * j));
             return okb ? (e_left ? base : base - 4u) : FD_OOB;
         };
         const unsigned yo = 4u * ((unsigned)n * (unsigned)g.M * hw + (unsigned)((2 * y + yr_a) * g.W + 2 * j));
@@ -1788,12 +1793,13 @@ __global__ void __launch_bounds__(WNT) k_wgrad_wino_limb(WinoWgradArgs g) {
         r[0] = fmaf(x_sgn, xb[S][0].x, xa[S][0].x); r[1] = fmaf(x_sgn, xb[S][0].y, xa[S][0].y); r[2] = fmaf(x_sgn, xb[S][0].z, xa[S][0].z); r[3] = fmaf(x_sgn, xb[S][0].w, xa[S][0].w);
         r[4] = fmaf(x_sgn, xb[S][1].x, xa[S][1].x); r[5] = fmaf(x_sgn, xb[S][1].y, xa[S][1].y); r[6] = fmaf(x_sgn, xb[S][1].z, xa[S][1].z); r[7] = fmaf(x_sgn, xb[S][1].w, xa[S][1].w);
         r[8] = fmaf(x_sgn, xb2[S].x, xa2[S].x); r[9] = fmaf(x_sgn, xb2[S].y, xa2[S].y);
-        // columns 2j-1 .. 2j+8; a quad at the left edge was loaded from column 2j on (shift), its column -1 and the right edge's column W are 0
+        // columns 2j-1 .. 2j+8; a quad at the left edge was loaded from column 2j on (shift); its column -1 and the right edge's column W
+        // are the padding: 0, or the mirror columns 1 and W - 2
         const bool L = rf & 1, Rr = rf & 2;
-        X[0] = L ? 0.f : r[0];
 #pragma unroll
         for (int k = 1; k < 10; ++k) X[k] = L ? r[k - 1] : r[k];
-        X[9] = Rr ? 0.f : X[9];
+        X[0] = L ? (REFL ? X[2] : 0.f) : r[0];
+        X[9] = Rr ? (REFL ? X[7] : 0.f) : X[9];
         // horizontal transforms of the four pairs, limbs, fragments (component t: planes 3 t .. 3 t + 2 = limbs h, m, l)
         unsigned char* qa = slot;
         unsigned char* qb = slot + WL_OP;
@@ -2142,10 +2148,16 @@ int wino_wgrad_launch(const fd_conv_desc* d, const float* x, const float* gy, fl
     const dim3 grid = g.slice_major == 2 ? dim3((unsigned)(nt * mt * sp)) : (g.slice_major ? dim3(sp, mt, nt) : dim3(nt, mt, sp));
     const size_t lds = sizeof(float) * WG_LDS_FLOATS;
     const bool halfm = d->Cout <= 32 && fd_tun().wino_wgrad_halfm != 0;   // at most 32 output channels: two waves per K half (k_wgrad_wino<.., HALFM>)
-    if (fd_tun().wino_wgrad_limb != 0 && twod && d->pad_mode == 0 && d->Cout >= 64 && d->W % 8 == 0) {       // the ResNet trunk's layers: split-precision matrix loop
+    if (fd_tun().wino_wgrad_limb != 0 && twod && (d->pad_mode == 0 || fd_tun().wino_wgrad_limb >= 2) && d->Cout >= 64 && d->W % 8 == 0) {
+        // split-precision matrix loop: the ResNet trunk's layers (wino_wgrad_limb = 1), the reflect-padded decoder blocks as well (2)
         static FdLdsAttrOnce attr_l;
-        if (attr_l.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino_limb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_l.mark(); }
-        hipLaunchKernelGGL(k_wgrad_wino_limb, grid, dim3(WNT), (size_t)WL_LDS_BYTES, st, g);
+        if (attr_l.needed()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino_limb<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_wino_limb<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_l.mark();
+        }
+        if (d->pad_mode == 1) hipLaunchKernelGGL(k_wgrad_wino_limb<true>, grid, dim3(WNT), (size_t)WL_LDS_BYTES, st, g);
+        else hipLaunchKernelGGL(k_wgrad_wino_limb<false>, grid, dim3(WNT), (size_t)WL_LDS_BYTES, st, g);
     } else if (halfm) {
         static FdLdsAttrOnce attr_h;
         if (attr_h.needed()) {

@@ -89,8 +89,9 @@ typedef struct fd_tuning {
     int limb_wgrad_target;        /* 256 workgroups a limb weight-gradient launch is pixel-sliced up to (x2 for its 4-wave tiles) */
     int limb_conv;                /* 1   stride-2 convolutions with >= 64 channels on both sides (ResNet layerN.0.conv1 / downsample: no Winograd form), forward
                                          and data gradient, as split-precision implicit GEMMs (k_conv_limb); 0: the f32-MFMA direct kernels */
-    int wino_wgrad_limb;          /* 1   the 2-D Winograd weight gradient of zero-padded layers with >= 64 output channels with a split-precision matrix
-                                         loop (k_wgrad_wino_limb: transforms + limb split in the loader, 768 instead of 2 048 matrix cycles per chunk) */
+    int wino_wgrad_limb;          /* 2   the 2-D Winograd weight gradient with >= 64 output channels and W % 8 == 0 with a split-precision matrix loop
+                                         (k_wgrad_wino_limb: transforms + limb split in the loader, 768 instead of 2 048 matrix cycles per chunk): 1 the
+                                         zero-padded layers (ResNet trunk), 2 the reflect-padded decoder blocks as well, 0 the f32 kernel everywhere */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);

@@ -980,9 +980,10 @@ def test_winograd_weight_gradient_vs_float64_reference(N, Ci, Co, H, W, mode, tw
     relclose(cpu(w.grad), cpu(gwd.float() + 1.0), "accumulated dw", rtol=1e-5, arel=3e-6)
 
 
-@pytest.mark.parametrize("N,Ci,Co,H,W", [(1, 80, 64, 4, 6), (2, 64, 64, 24, 80), (1, 96, 80, 8, 10), (2, 64, 64, 2, 4), (5, 64, 64, 48, 160),
-                                         (3, 512, 512, 6, 20), (4, 128, 128, 24, 80), (6, 256, 256, 12, 40), (2, 112, 96, 10, 16)])
-def test_winograd_weight_gradient_split_precision_vs_float64(N, Ci, Co, H, W, fdtune):
+@pytest.mark.parametrize("mode", ["zero", "reflect"])
+@pytest.mark.parametrize("N,Ci,Co,H,W", [(1, 80, 64, 4, 6), (2, 64, 64, 24, 80), (1, 96, 80, 8, 10), (2, 64, 64, 2, 8), (5, 64, 64, 48, 160),
+                                         (3, 512, 512, 6, 20), (4, 128, 128, 24, 80), (6, 256, 256, 12, 40), (2, 112, 96, 10, 16), (2, 272, 128, 24, 80)])
+def test_winograd_weight_gradient_split_precision_vs_float64(N, Ci, Co, H, W, mode, fdtune):
     """k_wgrad_wino_limb (fd_tuning.wino_wgrad_limb: the transposed F(2x2, 3x3) weight gradient of zero-padded layers with the horizontal
     transforms + bf16x3 limb split in the loader and a bf16 matrix loop): error against float64 no worse than 2x the f32 kernel's + 1e-7
     relative to the largest entry, and <= 3e-6; accumulation onto an existing gradient; the route is really taken (log)."""
@@ -992,22 +993,22 @@ def test_winograd_weight_gradient_split_precision_vs_float64(N, Ci, Co, H, W, fd
     x = torch.randn(N, Ci, H, W, device="cuda").relu_()
     w = torch.nn.Parameter(torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05)
     gy = torch.randn(N, Co, H, W, device="cuda")
-    xd = F.pad(x.double(), (1, 1, 1, 1))
+    xd = F.pad(x.double(), (1, 1, 1, 1), mode="reflect" if mode == "reflect" else "constant")
     wd = w.detach().double().requires_grad_(True)
     gwd = torch.autograd.grad(F.conv2d(xd, wd), wd, gy.double())[0]
     err = {}
-    for limb in (0, 1):
+    for limb in (0, 2):                      # 2: zero- and reflect-padded layers
         fdtune.lib(wino_wgrad_limb=limb)
-        y = FD.conv2d(x, w, None, 1, 1, "zero")
+        y = FD.conv2d(x, w, None, 1, 1, mode)
         gw = torch.autograd.grad(y, w, gy)[0]
         err[limb] = float((gw.double() - gwd).abs().max() / gwd.abs().max())
     bound = max(3e-6, 2 * err[0] + 1e-7)
-    conftest.report("Winograd weight gradient, limb matrix loop b%d %d->%d @%dx%d: max |err| / max |ref| vs float64" % (N, Ci, Co, H, W), err[1], bound,
+    conftest.report("Winograd weight gradient, limb matrix loop b%d %d->%d @%dx%d %s: max |err| / max |ref| vs float64" % (N, Ci, Co, H, W, mode), err[2], bound,
                     "(f32 kernel %.1e)" % err[0])
-    assert err[1] <= bound, err
+    assert err[2] <= bound, err
     w.grad = torch.ones_like(w)
     FD.enable_direct_grad([w])
-    FD.conv2d(x, w, None, 1, 1, "zero").backward(gy)
+    FD.conv2d(x, w, None, 1, 1, mode).backward(gy)
     relclose(cpu(w.grad), cpu(gwd.float() + 1.0), "accumulated dw (limb)", rtol=1e-5, arel=3e-6)
 
 
