@@ -240,6 +240,33 @@ def test_round5_tuning_switches_keep_the_results(FD, fdtune, fields):
         relclose(cpu(gw), cpu(gwd.float()), "dw " + what, rtol=1e-4, arel=1e-5)
 
 
+@pytest.mark.parametrize("fields", [dict(limb_conv=0), dict(wino_wgrad_limb=0), dict(wino_wgrad_limb=1), dict(limb_1x1=0), dict(limb_conv=0, wino_wgrad_limb=0, limb_1x1=0)],
+                         ids=lambda f: ",".join("%s=%s" % kv for kv in f.items()))
+def test_round6_tuning_switches_keep_the_results(FD, fdtune, fields):
+    """The split-precision routes of round 6 (fd_tuning.limb_conv / wino_wgrad_limb / limb_1x1) choose between kernels, not between
+    results: a ResNet stage transition (3x3 stride 2 + 1x1 downsample), a large 1x1 stride-2 layer, 3x3 layers whose weight gradient takes
+    the limb matrix loop (zero and reflect padding) and a 1x1 bottleneck layer, all three directions against torch float64 at the bounds
+    of the f32 kernels."""
+    fdtune.lib(**fields)
+    torch.manual_seed(777)
+    cases = [(2, 64, 128, 24, 40, 3, 2, "zero"), (2, 64, 128, 24, 40, 1, 2, "zero"), (8, 256, 512, 24, 80, 1, 2, "zero"), (2, 256, 256, 12, 40, 3, 1, "zero"),
+             (2, 128, 64, 24, 40, 3, 1, "reflect"), (2, 256, 64, 12, 40, 1, 1, "zero")]
+    for N, Ci, Co, H, W, K, stride, mode in cases:
+        x = torch.randn(N, Ci, H, W, device="cuda", requires_grad=True)
+        w = (torch.randn(Co, Ci, K, K, device="cuda") * 0.05).requires_grad_(True)
+        y = FD.conv2d(x, w, None, stride, K // 2, mode, "none")
+        cot = torch.randn_like(y)
+        gx, gw = torch.autograd.grad((y * cot).sum(), [x, w])
+        xd, wd = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+        xp = F.pad(xd, (K // 2,) * 4, mode="reflect" if mode == "reflect" else "constant")
+        yd = F.conv2d(xp, wd, None, stride)
+        gxd, gwd = torch.autograd.grad((yd * cot.double()).sum(), [xd, wd])
+        what = "%dx%d k%d s%d %s" % (Ci, Co, K, stride, mode)
+        relclose(cpu(y), cpu(yd.float()), "y " + what, rtol=1e-5, arel=3e-6)
+        relclose(cpu(gx), cpu(gxd.float()), "dx " + what, rtol=1e-4, arel=1e-5)
+        relclose(cpu(gw), cpu(gwd.float()), "dw " + what, rtol=1e-4, arel=1e-5)
+
+
 @pytest.mark.parametrize("N,C,H,W", [(2, 3, 192, 640), (2, 6, 192, 640), (3, 2, 96, 320), (2, 4, 70, 150), (1, 5, 8, 8), (1, 1, 33, 9)])
 def test_stem_convolution_on_the_patch_kernel(FD, N, C, H, W, fdtune):
     """conv_stem.hip (7x7 stride-2 pad-3 stems, networks/resnet_encoder.py:95) against torch float64 conv2d, and against the generic
