@@ -496,6 +496,36 @@ __global__ void __launch_bounds__(256) k_relayout_batch(const fd_relayout_job* _
                 float* o = dg ? j.dst + ((size_t)(ci0 + c) * 4 + ri) * Co + co0 + r : j.dst + ((size_t)(co0 + r) * 4 + ri) * Ci + ci0 + c;
                 o[0] = v[0]; o[n] = 0.5f * (v[0] + v[1] + v[2]); o[2 * n] = 0.5f * (v[0] - v[1] + v[2]); o[3 * n] = v[2];
             }
+        } else if (j.mode == 11 || j.mode == 12) {       // F(2x2, 3x3): the limb image of U2 (conv_wino.hip: wino_limb_piece); 12: of the flipped kernel, m = ci
+            const bool dg = j.mode == 12;
+            const unsigned nm = dg ? nci : nco, nk8 = (dg ? nco : nci) / 8;
+            const long Mrows = dg ? Ci : Co;
+            const int cpt = (int)((dg ? Co : Ci) >> 4);
+            uint4* A3 = reinterpret_cast<uint4*>(j.dst);
+            for (unsigned i = threadIdx.x; i < nm * 4 * nk8; i += 256) {
+                const unsigned k8 = i % nk8, q = i / nk8, ri = q % 4, mm = q / 4;
+                float u[4][8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned r = dg ? k8 * 8 + e : mm, c = dg ? mm : k8 * 8 + e;      // tile row = co, tile column block = ci
+                    float v[3];
+                    for (unsigned b = 0; b < 3; ++b) {
+                        const unsigned kb = dg ? 2 - b : b;
+                        const float g0 = tile[r][c * 9 + (dg ? 6 : 0) + kb], g1 = tile[r][c * 9 + 3 + kb], g2 = tile[r][c * 9 + (dg ? 0 : 6) + kb];
+                        v[b] = ri == 0 ? g0 : (ri == 3 ? g2 : (ri == 1 ? 0.5f * (g0 + g1 + g2) : 0.5f * (g0 - g1 + g2)));
+                    }
+                    u[0][e] = v[0]; u[1][e] = 0.5f * (v[0] + v[1] + v[2]); u[2][e] = 0.5f * (v[0] - v[1] + v[2]); u[3][e] = v[2];
+                }
+                const long kk = (long)(dg ? co0 : ci0) + k8 * 8, m = (long)(dg ? ci0 : co0) + mm;
+                const long pbase = (long)ri * cpt + (kk >> 4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint4 h, md, l;
+                    fdlimb::split8(u[t], h, md, l);
+                    const long p0 = (((pbase * 4 + t) * 3) * 2 + ((kk >> 3) & 1)) * Mrows + m;
+                    A3[p0] = h; A3[p0 + 2 * Mrows] = md; A3[p0 + 4 * Mrows] = l;
+                }
+            }
         } else if (j.mode == 7 || j.mode == 8) {         // 1x1 weights pre-split into bf16 limbs (conv_limb.h): 7 A[m = co][k = ci], 8 A[m = ci][k = co]
             const bool tr = j.mode == 8;
             const unsigned nm = tr ? nci : nco, nk8 = (tr ? nco : nci) / 8;
@@ -1340,6 +1370,14 @@ int bwd_data_impl(const fd_conv_desc* d, const float* gy, const float* w, float*
 }
 }  // namespace
 
+namespace {
+// re-layout mode of a Winograd layout: `g` = the convolution the kernel computes (for a data gradient: channels already swapped)
+inline int wino_layout_mode(const fd_conv_desc* g, bool dgrad) {
+    if (wino_fwd_limb(g)) return dgrad ? 12 : 11;
+    if (wino_fwd_2d(g)) return dgrad ? 6 : 5;
+    return dgrad ? 4 : 3;
+}
+}  // namespace
 extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const float* w, float* wt, fd_relayout_job* jobs) {
     if (check_desc(d, "fd_conv2d_relayout_jobs") || !w || !wt || !jobs) return 0;
     auto fill = [&](fd_relayout_job& j, float* dst, int TA, int TB, int kh0, int dkh, int kw0, int dkw, int mode) {
@@ -1352,22 +1390,22 @@ extern "C" int fd_conv2d_relayout_jobs(const fd_conv_desc* d, int kind, const fl
     if (kind == 0) {
         if (!fast_fwd_ok(d) || n16_shape_ok(d, d->Cout, d->Cin)) return 0;
         if (limb_fwd_ok(d)) { fill(jobs[0], wt, 1, 1, 0, 1, 0, 1, 7); return 1; }
-        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? (wino_fwd_2d(d) ? 5 : 3) : (limb_conv_fwd_ok(d) ? 9 : 0));
+        fill(jobs[0], wt, d->KH, d->KW, 0, 1, 0, 1, wino_use_fwd(d) ? wino_layout_mode(d, false) : (limb_conv_fwd_ok(d) ? 9 : 0));
         return 1;
     }
     const int KH = d->KH, KW = d->KW;
     if (limb_dgrad_ok(d)) { fill(jobs[0], wt, 1, 1, 0, 1, 0, 1, 8); return 1; }
     {
         fd_conv_desc gd;
-        if (wino_dgrad_desc(d, gd)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, wino_fwd_2d(&gd) ? 6 : 4); return 1; }
+        if (wino_dgrad_desc(d, gd)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, wino_layout_mode(&gd, true)); return 1; }
     }
     const int mode = fast_dgrad_ok(d) ? 1 : 2;
     if (d->stride == 1) {
         fd_conv_desc gz;
-        if (refl_wino_padded(d, gz)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, wino_fwd_2d(&gz) ? 6 : 4); return 1; }
+        if (refl_wino_padded(d, gz)) { fill(jobs[0], wt, KH, KW, 0, 1, 0, 1, wino_layout_mode(&gz, true)); return 1; }
         fill(jobs[0], wt, KH, KW, KH - 1, -1, KW - 1, -1, mode);
         if (refl_wino_interior(d, gz)) {                 // second layout behind the first: U of the interior's Winograd kernel
-            fill(jobs[1], wt + align4((long)d->Cin * d->Cout * KH * KW), KH, KW, 0, 1, 0, 1, wino_fwd_2d(&gz) ? 6 : 4);
+            fill(jobs[1], wt + align4((long)d->Cin * d->Cout * KH * KW), KH, KW, 0, 1, 0, 1, wino_layout_mode(&gz, true));
             return 2;
         }
         return 1;

@@ -63,6 +63,7 @@ int fast_splitk_finish_launch(const float* slabs, float* Y, const float* bias, l
 bool wino_fwd_ok(const fd_conv_desc* d);
 long wino_wt_floats(const fd_conv_desc* d);
 bool wino_fwd_2d(const fd_conv_desc* d);
+bool wino_fwd_limb(const fd_conv_desc* d);      // k_conv_wino2d_limb: the weight layout is the limb image of U2 (re-layout modes 11 / 12)
 long wino_ws_floats(const fd_conv_desc* d);
 int wino_weight_launch(const fd_conv_desc* d, const float* w, float* U, int flip, hipStream_t st);
 // the BatchNorm that follows a slab-route convolution, fused with the slab reduction (norm.hip: k_bn_train_small_slabs)

@@ -106,6 +106,47 @@ __global__ void k_wino_weight2d(const float* __restrict__ w, float* __restrict__
     }
 }
 
+// The same 16 components as the split-precision image k_conv_wino2d_limb reads (conv_limb.h arithmetic): for row component ri, K-chunk
+// (16 input channels), horizontal component t, limb L, K half h and output channel m one 16-byte piece of 8 bf16,
+//   piece index = ((((ri * C/16 + chunk) * 4 + t) * 3 + L) * 2 + h) * M + m
+// - a chunk's 24 planes of M consecutive pieces are what the kernel copies into LDS, a lane's MFMA fragment is one piece.
+__host__ __device__ inline long wino_limb_piece(int ri, int chunk, int t, int L, int h, long m, long M, int cpt) {
+    return ((((long)(ri * cpt + chunk) * 4 + t) * 3 + L) * 2 + h) * M + m;
+}
+__global__ void k_wino_weight2d_limb(const float* __restrict__ w, uint4* __restrict__ A3, int M, int C, int flip) {
+    const int c8n = C >> 3, cpt = C >> 4;
+    const long n = (long)M * 4 * c8n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i % M);
+        const int ri = (int)((i / M) % 4);
+        const int c8 = (int)(i / (4L * M));
+        float u[4][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            float g[3][3];
+            const float* p = flip ? w + ((long)c * M + m) * 9 : w + ((long)m * C + c) * 9;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) g[a][b] = flip ? p[(2 - a) * 3 + (2 - b)] : p[a * 3 + b];
+            float v[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                v[b] = ri == 0 ? g[0][b] : (ri == 3 ? g[2][b] : (ri == 1 ? 0.5f * (g[0][b] + g[1][b] + g[2][b]) : 0.5f * (g[0][b] - g[1][b] + g[2][b])));
+            u[0][e] = v[0]; u[1][e] = 0.5f * (v[0] + v[1] + v[2]); u[2][e] = 0.5f * (v[0] - v[1] + v[2]); u[3][e] = v[2];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint4 h, md, l;
+            fdlimb::split8(u[t], h, md, l);
+            A3[wino_limb_piece(ri, c8 >> 1, t, 0, c8 & 1, m, M, cpt)] = h;
+            A3[wino_limb_piece(ri, c8 >> 1, t, 1, c8 & 1, m, M, cpt)] = md;
+            A3[wino_limb_piece(ri, c8 >> 1, t, 2, c8 & 1, m, M, cpt)] = l;
+        }
+    }
+}
+
 struct WinoArgs {
     const float* U; const float* X; float* Y; const float* bias; float* slabs;
     const float* add;    // optional, laid out like Y: Y = act(conv + bias) + add
@@ -806,6 +847,220 @@ __global__ void __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(2, 2))
             o.y = (acc[b][1][r] - acc[b][2][r]) - acc[b][3][r];
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsY, (int)off, 0, 0);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ F(2x2, 3x3) slabs, split precision
+// k_conv_wino2d_limb: the slab kernel of the deep layers (k_conv_wino2d / _m128: matrix pipes 0.7 busy - matrix-bound, unlike the
+// one-workgroup kernel, whose split-precision form gained nothing: profiles/round6_wino2p_limb.log) with a bf16x3 matrix loop at fp32
+// accuracy (conv_limb.h).  Same grid (pixel tile, 64-channel tile, row component x channel split; XCD-aware), same raw activation DMAs
+// (row component fixed per workgroup), same slabs and finish kernels.  Different:
+//   * the weights arrive PRE-SPLIT (re-layout modes 11 / 12: wino_limb_piece) - a chunk's (16 input channels) 24 planes of 64 fragments
+//     are plain 16-byte copies global -> registers -> LDS;
+//   * the activations are combined, transformed and split ONCE per workgroup by a transform stage between two barriers - thread = (2x2
+//     tile, four channels of the chunk): 24 eight-byte raw reads, 16 fused multiply-adds + 16 transform operations, 8 split2, 12 eight-byte
+//     fragment stores;
+//   * the matrix phase of a chunk is 24 fragment reads + 24 v_mfma_f32_32x32x16_bf16 per wave (768 matrix-pipe cycles; the f32 kernels
+//     spend 2 048 on the same 16 channels x 32 x 32 x 4 components).
+// One raw buffer (consumed before the first barrier, refilled by DMA during the matrix phase), one fragment buffer per operand: 68 KB.
+typedef __bf16 wl_bf16x8 __attribute__((ext_vector_type(8)));
+#define FD_WLIMB_MFMA6(ACC, AF, BF)                                                                                                   \
+    do {                                                                                                                              \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[2]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[2]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[1]), __builtin_bit_cast(wl_bf16x8, BF[1]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[1]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[1]), ACC, 0, 0, 0); \
+        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
+    } while (0)
+constexpr int W2L_HPL = 64 * 16 + 64;                 // one K half of a (component, limb) plane: 64 rows / tiles x 16 B, padded
+constexpr int W2L_PLANE = 2 * W2L_HPL;
+constexpr int W2L_OP = 12 * W2L_PLANE;                // one operand: 4 components x 3 limbs
+constexpr int W2L_RAW_BYTES = 2 * V_RAW_FLOATS * 4;   // two raw row sets of 16 channels
+constexpr int W2L_LDS_BYTES = 2 * W2L_OP + W2L_RAW_BYTES;
+
+__global__ void __launch_bounds__(WNT) k_conv_wino2d_limb(WinoArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* const smA = reinterpret_cast<unsigned char*>(smem);
+    unsigned char* const smB = smA + W2L_OP;
+    float* const raw = reinterpret_cast<float*>(smA + 2 * W2L_OP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W2 = g.W >> 1, HT = g.H >> 1;
+    const int plane2 = HT * W2;
+    const int Np = g.Nb * plane2;
+    const unsigned hw = (unsigned)(g.H * g.W);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z, nz = gridDim.z;
+    if (g.xcd_swizzle == 2) {                                    // all pixel tiles of a (channel tile, row component, split) slice on one XCD
+        const int L = blockIdx.x, xcd = L & 7, k = L >> 3;
+        bx = k % g.gx;
+        const int sl = (k / g.gx) * 8 + xcd;
+        by = sl % g.gy; bz = sl / g.gy; nz = g.gz;
+    } else if (g.xcd_swizzle) { const int per = gridDim.x >> 3; bx = (bx & 7) * per + (bx >> 3); }
+    const int m0 = by * WBM;
+    const int p0 = bx * WBN;
+    const int ri = bz & 3, ks = bz >> 2, nsplit = nz >> 2;
+    const int cpt = g.C / WBKC;
+    const int per_split = (cpt + nsplit - 1) / nsplit;
+    const int ch_lo = ks * per_split;
+    const int ch_hi = ch_lo + per_split < cpt ? ch_lo + per_split : cpt;
+    const int nchunk = ch_hi > ch_lo ? ch_hi - ch_lo : 0;
+    const bool refl = g.pad_mode == 1;
+    const __amdgpu_buffer_rsrc_t rsU = fd_make_rsrc(g.U);
+    const __amdgpu_buffer_rsrc_t rsXd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)(4u * (unsigned)g.Nb * (unsigned)g.C * hw), 0x00020000);
+    // ---- raw activation DMAs: piece L = 64 (wave + 4 q) + lane of the linear raw stream (16 rows x 34 pieces: pixels -4 .. 131 of the tile's
+    //      flat pixel range over (image, tile row, x)); the two input rows of row component ri are fixed for the whole workgroup
+    const int xr[2] = {ri == 0 ? 0 : (ri == 2 ? 2 : 1), ri == 3 ? 3 : (ri == 2 ? 1 : 2)};
+    const int H2m2 = 2 * g.H - 2;
+    unsigned d_row[2][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int L = 64 * (wave + 4 * q) + lane;
+        const int row = L / 34, seg = L - row * 34;
+        const int F = 2 * p0 - 4 + 4 * seg;
+        const bool ok = row < WBKC && F >= 0 && F < g.Nb * HT * g.W;
+        const int Fc = ok ? F : 0;
+        const int nrow = Fc / g.W, x = Fc - nrow * g.W;
+        const int n = nrow / HT, ty = nrow - n * HT;
+        const unsigned base = 4u * ((unsigned)n * (unsigned)g.C * hw + (unsigned)row * hw + (unsigned)x);
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const int r = 2 * ty - 1 + xr[s_];
+            const bool inb = (unsigned)r < (unsigned)g.H;
+            int rr_ = r < 0 ? -r : r;
+            rr_ = rr_ >= g.H ? H2m2 - rr_ : rr_;
+            const int ruse = refl ? rr_ : r;
+            d_row[s_][q] = (ok & (refl | inb)) ? base + (unsigned)(ruse * g.W * 4) : FD_OOB;
+        }
+    }
+    // ---- weight fragments of a chunk: 24 planes x 64 rows = 1 536 pieces, six per thread (piece tid + 256 i: plane (tid + 256 i) / 64)
+    unsigned u_lane[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int q = tid + 256 * i;
+        const int pl = q >> 6, row = q & 63;
+        int m = m0 + row; m = m < g.M ? m : g.M - 1;
+        u_lane[i] = 16u * ((unsigned)pl * (unsigned)g.M + (unsigned)m);
+    }
+    const unsigned u_chunk = 16u * 24u * (unsigned)g.M;               // bytes per chunk of the image
+    int pc = 0;                                                       // chunk (relative to ch_lo) the next fetch takes
+    uint4 ru[6];
+    auto fetch = [&]() __attribute__((always_inline)) {               // weights of chunk pc -> registers, raw rows of chunk pc -> LDS; then advance
+        const bool live = pc < nchunk;
+        const unsigned u_soff = (unsigned)(ri * cpt + ch_lo + (live ? pc : 0)) * u_chunk;
+        const unsigned d_soff = 4u * (unsigned)((ch_lo + pc) * WBKC) * hw;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            ru[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (int)(live ? u_lane[i] : FD_OOB), (int)u_soff, 0));
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (q == 2 && wave != 0) continue;
+                float* dst = raw + s_ * V_RAW_FLOATS + (wave + 4 * q) * 256;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsXd, (__attribute__((address_space(3))) void*)dst, 16, (int)(live ? d_row[s_][q] : FD_OOB), (int)d_soff, 0, 0);
+            }
+        ++pc;
+    };
+    auto store_u = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int q = tid + 256 * i;
+            const int pl = q >> 6, row = q & 63;                      // plane = (t * 3 + L) * 2 + h
+            *reinterpret_cast<uint4*>(smA + (pl >> 1) * W2L_PLANE + (pl & 1) * W2L_HPL + row * 16) = ru[i];
+        }
+    };
+    // ---- transform stage: this thread's 2x2 tile (lane) and channels 4 wave .. 4 wave + 3 of the chunk
+    int t12, t0, t3;
+    float tml, tmr;
+    {
+        const int pp = p0 + lane < Np ? p0 + lane : 0;
+        const int rem = pp % plane2;
+        const int jj = rem % W2;
+        const bool le = jj == 0, re = 2 * jj + 2 >= g.W;
+        t12 = 4 + 2 * lane;
+        t0 = (le && refl) ? t12 : t12 - 2;
+        t3 = (re && refl) ? t12 : t12 + 2;
+        tml = (le && !refl) ? 0.f : 1.f;
+        tmr = (re && !refl) ? 0.f : 1.f;
+    }
+    float sgn = ri == 1 ? 1.f : -1.f;                                 // the row combination: rowA + sgn * rowB
+    asm volatile("" : "+v"(sgn));
+    unsigned char* const bslot = smB + (wave >> 1) * W2L_HPL + lane * 16 + 8 * (wave & 1);
+    auto transform = [&]() __attribute__((always_inline)) {
+        float v[4][4];                                               // [component][channel]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* pr = raw + (4 * wave + i) * LDR;
+            const float* pe = pr + V_RAW_FLOATS;
+            const f32x2 d12 = *reinterpret_cast<const f32x2*>(pr + t12), e12 = *reinterpret_cast<const f32x2*>(pe + t12);
+            const f32x2 dl = *reinterpret_cast<const f32x2*>(pr + t0), dr = *reinterpret_cast<const f32x2*>(pr + t3);
+            const f32x2 el = *reinterpret_cast<const f32x2*>(pe + t0), er = *reinterpret_cast<const f32x2*>(pe + t3);
+            const float c0 = fmaf(sgn, el.y, dl.y), c1 = fmaf(sgn, e12.x, d12.x), c2 = fmaf(sgn, e12.y, d12.y), c3 = fmaf(sgn, er.x, dr.x);
+            v[0][i] = fmaf(c0, tml, -c2); v[1][i] = c1 + c2; v[2][i] = c2 - c1; v[3][i] = fmaf(-c3, tmr, c1);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            fdlimb::split2(v[t][0], v[t][1], h0, m0_, l0); fdlimb::split2(v[t][2], v[t][3], h1, m1, l1);
+            *reinterpret_cast<u32x2*>(bslot + (3 * t) * W2L_PLANE) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(bslot + (3 * t + 1) * W2L_PLANE) = u32x2{m0_, m1};
+            *reinterpret_cast<u32x2*>(bslot + (3 * t + 2) * W2L_PLANE) = u32x2{l0, l1};
+        }
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int arow = lane >> 5, acol = lane & 31;
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    if (nchunk > 0) {
+        fetch();                                                     // chunk 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned char* fa = smA + arow * W2L_HPL + (32 * wm + acol) * 16;
+        const unsigned char* fb = smB + arow * W2L_HPL + (32 * wn + acol) * 16;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            store_u();                                               // weight fragments of chunk ch (in registers since the last matrix phase)
+            transform();                                             // raw rows of chunk ch -> activation fragments
+            __syncthreads();                                         // fragments complete, raw buffer free
+            fetch();                                                 // chunk ch + 1 (past the end: nothing is fetched)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint4 af[3], bf[3];
+#pragma unroll
+                for (int Lm = 0; Lm < 3; ++Lm) {
+                    af[Lm] = *reinterpret_cast<const uint4*>(fa + (t * 3 + Lm) * W2L_PLANE);
+                    bf[Lm] = *reinterpret_cast<const uint4*>(fb + (t * 3 + Lm) * W2L_PLANE);
+                }
+                FD_WLIMB_MFMA6(acc[t], af, bf);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the next chunk's DMAs and weight loads have landed
+            __syncthreads();
+        }
+    }
+    // ---- epilogue (k_conv_wino2d_m128's, one 32-row block per wave): S_ri [N][M][H/2][W] of this (row component, channel split) to slab bz
+    const int po = p0 + 32 * wn + acol;
+    const unsigned hwo = (unsigned)(HT * g.W);
+    unsigned out_base = FD_OOB;
+    if (po < Np) {
+        const int n = po / plane2;
+        const int rem = po - n * plane2;
+        const int yy = rem / W2, jj = rem - yy * W2;
+        out_base = 4u * ((unsigned)n * (unsigned)g.M * hwo + (unsigned)(yy * g.W + 2 * jj));
+    }
+    const __amdgpu_buffer_rsrc_t rsY = fd_make_rsrc(g.slabs + (size_t)bz * g.slab_stride);
+    const int mbase = m0 + 32 * wm + 4 * arow;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        const unsigned off = (m < g.M) ? out_base + 4u * (unsigned)m * hwo : FD_OOB;
+        f32x2 o;
+        o.x = (acc[0][r] + acc[1][r]) + acc[2][r];
+        o.y = (acc[1][r] - acc[2][r]) - acc[3][r];
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsY, (int)off, 0, 0);
     }
 }
 
@@ -1672,16 +1927,6 @@ constexpr int WL_PLANE = 2 * WL_HPL;
 constexpr int WL_OP = 12 * WL_PLANE;              // one operand: 4 components x 3 limbs
 constexpr int WL_LDS_BYTES = 2 * WL_OP;
 
-#define FD_WLIMB_MFMA6(ACC, AF, BF)                                                                                                   \
-    do {                                                                                                                              \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[2]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[2]), ACC, 0, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[1]), __builtin_bit_cast(wl_bf16x8, BF[1]), ACC, 0, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[1]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[1]), ACC, 0, 0, 0); \
-        ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wl_bf16x8, AF[0]), __builtin_bit_cast(wl_bf16x8, BF[0]), ACC, 0, 0, 0); \
-    } while (0)
-typedef __bf16 wl_bf16x8 __attribute__((ext_vector_type(8)));
 
 template <bool REFL>          // reflection (decoder) or zero (ResNet trunk) padding
 __global__ void __launch_bounds__(WNT) k_wgrad_wino_limb(WinoWgradArgs g) {
@@ -1918,6 +2163,10 @@ int wino_fwd_mode(const fd_conv_desc* d) {
     return deep ? 1 : 0;
 }
 bool wino_fwd_2d(const fd_conv_desc* d) { return wino_fwd_mode(d) != 0; }      // the weights are U2[t][m][ri][c] for both 2-D kernels
+// the F(2x2, 3x3) slab kernel with a split-precision matrix loop (k_conv_wino2d_limb): its weights are the limb image of U2
+bool wino_fwd_limb(const fd_conv_desc* d) {
+    return fd_tun().wino_fwd_limb != 0 && wino_fwd_mode(d) == 1 && d->Cout >= 64 && d->W % 4 == 0 && d->Cin % 16 == 0 && d->Cin >= 64;
+}
 // channel splits of the 2-D kernel on top of its four row components
 // channel splits of the 2-D slab kernels on top of their four row components, for workgroup tiles of `bm` output channels
 inline int wino2d_ksplits_bm(const fd_conv_desc* d, int bm) {
@@ -1945,8 +2194,11 @@ inline bool wino2d_m128(const fd_conv_desc* d) {
     // fill = n / (rounds * slots), compared as cross products
     return n128 * (fd_cdiv(n64, s64) * s64) > n64 * (fd_cdiv(n128, s128) * s128);
 }
-inline int wino2d_ksplits(const fd_conv_desc* d) { return wino2d_ksplits_bm(d, wino2d_m128(d) ? M2_BM : WBM); }
-long wino_wt_floats(const fd_conv_desc* d) { return 4L * d->Cout * (wino_fwd_2d(d) ? 4 : 3) * d->Cin; }
+inline int wino2d_ksplits(const fd_conv_desc* d) { return wino2d_ksplits_bm(d, (!wino_fwd_limb(d) && wino2d_m128(d)) ? M2_BM : WBM); }
+long wino_wt_floats(const fd_conv_desc* d) {
+    if (wino_fwd_limb(d)) return 24L * d->Cout * d->Cin;                  // 16 components x 3 bf16 limbs
+    return 4L * d->Cout * (wino_fwd_2d(d) ? 4 : 3) * d->Cin;
+}
 long wino_ws_floats(const fd_conv_desc* d) {
     const int mode = wino_fwd_mode(d);
     if (mode == 2) return 0;
@@ -1958,6 +2210,12 @@ long wino_ws_floats(const fd_conv_desc* d) {
 int wino_weight_launch(const fd_conv_desc* d, const float* w, float* U, int flip, hipStream_t st) {
     const int M = d->Cout, C = d->Cin;
     const bool twod = wino_fwd_2d(d);
+    if (wino_fwd_limb(d)) {
+        const long nl = (long)M * 4 * (C >> 3);
+        hipLaunchKernelGGL(k_wino_weight2d_limb, dim3(fd_cdiv(nl, 256) > 4096 ? 4096 : fd_cdiv(nl, 256)), dim3(256), 0, st, w, reinterpret_cast<uint4*>(U), M, C, flip);
+        FD_LAUNCH_CHECK("wino weight transform (limbs)");
+        return 0;
+    }
     const long n = (long)M * (twod ? 4 : 3) * C;
     const dim3 grid(fd_cdiv(n, 256) > 4096 ? 4096 : fd_cdiv(n, 256));
     if (twod) hipLaunchKernelGGL(k_wino_weight2d, grid, dim3(256), 0, st, w, U, M, C, flip);
@@ -2039,13 +2297,20 @@ int wino_conv_launch(const fd_conv_desc* d, const float* x, const float* U, cons
         const int HT = d->H / 2;
         const int gx2 = fd_cdiv((long)d->N * HT * (d->W / 2), WBN);
         g.slab_stride = out_total / 2;                                     // S_ri: [N][M][H/2][W]
-        const bool m128 = wino2d_m128(d) && ((uintptr_t)x & 15) == 0;      // (unaligned x: k_conv_wino2d with the same split count)
+        const bool limb2d = wino_fwd_limb(d);                              // the weights are the limb image: only k_conv_wino2d_limb reads it
+        if (limb2d && ((uintptr_t)x & 15) != 0) { fd_set_error("wino conv: the split-precision slab kernel needs a 16-byte aligned input"); return -1; }
+        const bool m128 = !limb2d && wino2d_m128(d) && ((uintptr_t)x & 15) == 0;      // (unaligned x: k_conv_wino2d with the same split count)
         const int gy2 = fd_cdiv(d->Cout, m128 ? M2_BM : WBM);
         const int xmap = 1;        // XCD-aware 1-D grid (plain 3-D grid: layer4 162 instead of 79 MB of HBM traffic per launch, -0.35 % in the step)
         g.xcd_swizzle = (gx2 % 8 == 0 && gx2 >= 16) ? 1 : 0;
         dim3 grid(gx2, gy2, sp);
         if (xmap && (gy2 * sp) % 8 == 0) { g.xcd_swizzle = 2; g.gx = gx2; g.gy = gy2; g.gz = sp; grid = dim3((unsigned)(gx2 * gy2 * sp)); }
-        if (m128) hipLaunchKernelGGL(k_conv_wino2d_m128, grid, dim3(WNT), sizeof(float) * M2_LDS_FLOATS, st, g);
+        if (limb2d) {
+            static FdLdsAttrOnce attr_l;
+            if (attr_l.needed()) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wino2d_limb), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_l.mark(); }
+            hipLaunchKernelGGL(k_conv_wino2d_limb, grid, dim3(WNT), (size_t)W2L_LDS_BYTES, st, g);
+        }
+        else if (m128) hipLaunchKernelGGL(k_conv_wino2d_m128, grid, dim3(WNT), sizeof(float) * M2_LDS_FLOATS, st, g);
         else hipLaunchKernelGGL(k_conv_wino2d, grid, dim3(WNT), sizeof(float) * W_LDS_FLOATS, st, g);
         FD_LAUNCH_CHECK("k_conv_wino2d");
         if (bn)             // the slab reduction + vertical output transform inside the small-plane BatchNorm kernel that follows (round 5)

@@ -25,7 +25,7 @@ class Tuning(ctypes.Structure):
         "size", "wino_fwd", "wino_wgrad", "wino_fwd_2d_min", "wino_fwd_2dp_min_wgs", "wino_fwd_2dp_dma", "wino_fwd_2dp_deep", "wino_wgrad_2d", "wino_target", "wino_wgrad_target", "conv_target",
         "wgrad_target", "conv_c1", "conv_n16_min_pixels", "reflect_ring", "reflect_wino", "reflect_wino_min_pixels",
         "reflect_wino_padded_max", "force_cfg", "force_splits", "stem7", "log", "wino_fwd_2d_m128", "wino_min_cout", "wino_wgrad_min_cout", "wino_wgrad_xcd_few", "wino_fwd_halfm", "wino_wgrad_halfm",
-        "grp_tile64_below", "limb_1x1", "limb_depth", "limb_target", "limb_split_max_out", "limb_wgrad_target", "limb_conv", "wino_wgrad_limb")]
+        "grp_tile64_below", "limb_1x1", "limb_depth", "limb_target", "limb_split_max_out", "limb_wgrad_target", "limb_conv", "wino_wgrad_limb", "wino_fwd_limb")]
 
 
 LIB_FIELDS = tuple(n for n, _ in Tuning._fields_ if n != "size")
@@ -128,7 +128,7 @@ _ENV_LIB = {
     "FD_CONV_C1": ("conv_c1", int), "FD_CONV_N16_MIN": ("conv_n16_min_pixels", int), "FD_REFLECT_RING": ("reflect_ring", int),
     "FD_REFLECT_WINO": ("reflect_wino", int), "FD_REFLECT_WINO_MIN": ("reflect_wino_min_pixels", int),
     "FD_REFLECT_WINO_PADDED_MAX": ("reflect_wino_padded_max", int), "FD_STEM7": ("stem7", int), "FD_CONV_LOG": ("log", int), "FD_WINO_FWD_2D_M128": ("wino_fwd_2d_m128", int),
-    "FD_WINO_MIN_COUT": ("wino_min_cout", int), "FD_WINO_WGRAD_MIN_COUT": ("wino_wgrad_min_cout", int), "FD_GRP_TILE64_BELOW": ("grp_tile64_below", int), "FD_LIMB_1X1": ("limb_1x1", int), "FD_LIMB_DEPTH": ("limb_depth", int), "FD_LIMB_TARGET": ("limb_target", int), "FD_LIMB_SPLIT_MAX_OUT": ("limb_split_max_out", int), "FD_LIMB_WGRAD_TARGET": ("limb_wgrad_target", int), "FD_LIMB_CONV": ("limb_conv", int), "FD_WINO_WGRAD_LIMB": ("wino_wgrad_limb", int), "FD_WINO_WGRAD_XCD_FEW": ("wino_wgrad_xcd_few", int), "FD_WINO_WGRAD_HALFM": ("wino_wgrad_halfm", int), "FD_WINO_FWD_HALFM": ("wino_fwd_halfm", int),
+    "FD_WINO_MIN_COUT": ("wino_min_cout", int), "FD_WINO_WGRAD_MIN_COUT": ("wino_wgrad_min_cout", int), "FD_GRP_TILE64_BELOW": ("grp_tile64_below", int), "FD_LIMB_1X1": ("limb_1x1", int), "FD_LIMB_DEPTH": ("limb_depth", int), "FD_LIMB_TARGET": ("limb_target", int), "FD_LIMB_SPLIT_MAX_OUT": ("limb_split_max_out", int), "FD_LIMB_WGRAD_TARGET": ("limb_wgrad_target", int), "FD_LIMB_CONV": ("limb_conv", int), "FD_WINO_WGRAD_LIMB": ("wino_wgrad_limb", int), "FD_WINO_FWD_LIMB": ("wino_fwd_limb", int), "FD_WINO_WGRAD_XCD_FEW": ("wino_wgrad_xcd_few", int), "FD_WINO_WGRAD_HALFM": ("wino_wgrad_halfm", int), "FD_WINO_FWD_HALFM": ("wino_fwd_halfm", int),
 }
 _ENV_HOST = {
     "FD_LATE_RELAYOUT": ("late_relayout", lambda v: v != "0"), "FD_POSE_STREAM": ("pose_stream", lambda v: v != "0"),

@@ -31,7 +31,7 @@ extern "C" {
  *    fd_bn_train_bwd_remask, fd_stack_normalize, fd_conv2d_fwd_bn(_ok), fd_pose_head_fwd / _bwd; fd_tuning grew at its end
  *    (wino_min_cout, wino_wgrad_min_cout, wino_wgrad_xcd_few, wino_fwd_halfm, wino_wgrad_halfm, grp_tile64_below).  Nothing removed, no signature changed.
  * 4: additions only (round 6): fd_replay (+ fd_call_rec, fd_replay_function_count / _name / _signature); fd_tuning grew at its end (limb_1x1,
- *    limb_depth, limb_target, limb_split_max_out, limb_wgrad_target, limb_conv, wino_wgrad_limb); fd_relayout_job.mode 7 / 8 (1x1 weights pre-split into bf16
+ *    limb_depth, limb_target, limb_split_max_out, limb_wgrad_target, limb_conv, wino_wgrad_limb, wino_fwd_limb); fd_relayout_job.mode 7 / 8 (1x1 weights pre-split into bf16
  *    limbs) and 9 / 10 (the same for a tap subset of a larger kernel); fd_refine_cfg accepts an empty crop window.  Nothing removed, no
  *    signature changed. */
 #define FD_ABI_VERSION 4
@@ -92,6 +92,8 @@ typedef struct fd_tuning {
     int wino_wgrad_limb;          /* 2   the 2-D Winograd weight gradient with >= 64 output channels and W % 8 == 0 with a split-precision matrix loop
                                          (k_wgrad_wino_limb: transforms + limb split in the loader, 768 instead of 2 048 matrix cycles per chunk): 1 the
                                          zero-padded layers (ResNet trunk), 2 the reflect-padded decoder blocks as well, 0 the f32 kernel everywhere */
+    int wino_fwd_limb;            /* 1   the F(2x2, 3x3) slab kernel of the deep layers (forward / data gradient, >= 64 channels on both sides, W % 4 == 0) with
+                                         pre-split weights and a split-precision matrix loop (k_conv_wino2d_limb); 0: k_conv_wino2d(_m128) */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);
@@ -326,7 +328,7 @@ typedef struct fd_relayout_job {
     float* dst;
     int Co, Ci, KH, KW, TA, TB, kh0, dkh, kw0, dkw;
     int mode;          /* 0 forward [Co][tap][Ci], 1 data-gradient [Ci][tap][Co], 2 generic data-gradient [Ci][Co][tap]; 3 - 6 Winograd U;
-                          7 / 8 the 1x1 matrix, 9 / 10 the [m][(tap, channel)] matrix of layouts 0 / 1 pre-split into bf16 limbs (csrc/conv_limb.h) */
+                          7 / 8 the 1x1 matrix, 9 / 10 the [m][(tap, channel)] matrix of layouts 0 / 1 pre-split into bf16 limbs (csrc/conv_limb.h); 11 / 12 the limb image of layouts 5 / 6 */
     int reserved;
     long n;            /* elements */
     long first_block;  /* set by fd_relayout_plan */

@@ -1039,6 +1039,36 @@ def test_winograd_weight_gradient_split_precision_vs_float64(N, Ci, Co, H, W, mo
     relclose(cpu(w.grad), cpu(gwd.float() + 1.0), "accumulated dw (limb)", rtol=1e-5, arel=3e-6)
 
 
+@pytest.mark.parametrize("N,Ci,Co,H,W,mode", [(12, 256, 256, 12, 40, "zero"), (6, 512, 512, 6, 20, "zero"), (2, 128, 256, 24, 80, "reflect"), (2, 256, 128, 24, 80, "reflect"),
+                                              (1, 272, 272, 24, 80, "reflect"), (3, 256, 320, 4, 8, "zero"), (2, 512, 256, 12, 40, "reflect")])
+def test_winograd_slab_kernel_split_precision_vs_float64(N, Ci, Co, H, W, mode, FD, fdtune):
+    """k_conv_wino2d_limb (fd_tuning.wino_fwd_limb: the F(2x2, 3x3) slab kernel of the deep layers with pre-split weights, a
+    once-per-workgroup transform + limb-split stage and a bf16 matrix loop), forward (+ bias, ELU) and data gradient (the same kernel on dY
+    with the flipped kernel's image), zero and reflect padding, channel splits, partial channel tiles: error against float64 no worse than
+    2x the f32 kernels' + 1e-7 relative to the largest entry and <= 3e-6 / 1e-5; the route is taken (log)."""
+    import conftest
+    torch.manual_seed(Ci * 3 + Co)
+    x = torch.randn(N, Ci, H, W, device="cuda", requires_grad=True)
+    w = (torch.randn(Co, Ci, 3, 3, device="cuda") * 0.03).requires_grad_(True)
+    b = torch.randn(Co, device="cuda")
+    cot = torch.randn(N, Co, H, W, device="cuda")
+    xd, wd = x.detach().double().requires_grad_(True), w.detach().double()
+    xp = F.pad(xd, (1, 1, 1, 1), mode="reflect" if mode == "reflect" else "constant")
+    yd = F.elu(F.conv2d(xp, wd, b.double()))
+    gxd, = torch.autograd.grad((yd * cot.double()).sum(), [xd])
+    err = {}
+    for limb in (0, 1):
+        fdtune.lib(wino_fwd_limb=limb)
+        y = FD.conv2d(x, w, b, 1, 1, mode, "elu")
+        gx, = torch.autograd.grad((y * cot).sum(), [x])
+        err[limb] = (float((y.detach().double() - yd.detach()).abs().max() / yd.detach().abs().max()), float((gx.double() - gxd).abs().max() / gxd.abs().max()))
+    for k, name, floor in ((0, "forward", 3e-6), (1, "data gradient", 1e-5)):
+        bound = max(floor, 2 * err[0][k] + 1e-7)
+        conftest.report("Winograd slab kernel, limb matrix loop b%d %d->%d @%dx%d %s %s: max |err| / max |ref| vs float64" % (N, Ci, Co, H, W, mode, name),
+                        err[1][k], bound, "(f32 kernel %.1e)" % err[0][k])
+        assert err[1][k] <= bound, (name, err)
+
+
 def test_interleaved_encoders_equal_sequential_passes():
     """networks.interleaved_forward (four encoders advanced block by block in turns, each on its own stream) returns exactly what
     four sequential forward calls return, and autograd through it gives the same parameter gradients."""
