@@ -37,20 +37,18 @@ LOSS_BYTES_PER_PIXEL = 343.7          # compulsory fwd+bwd HBM traffic of the fu
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 # what the arithmetic is, next to `dtype` (an undisclosed precision change would void the line).  Every tensor is fp32;
 # products and sums are fp32 (v_mfma_f32_32x32x2_f32 / 16x16x4: exact fp32, Winograd transforms in fp32) EXCEPT, for layers with >= 64
-# channels on both sides, the MATRIX-BOUND kernels: (i) the convolutions no Winograd form exists for (csrc/conv_limb.hip), in all three
-# directions - the 1x1 stride-1 layers (ResNet-50 bottlenecks; on the ResNet-18 configurations only the PoseDecoder's 512 -> 256
-# squeeze) and the stride-2 layers (3x3 layerN.0 of every ResNet; the 1x1 downsample branch where its launch fills the chip); (ii) the
-# Winograd WEIGHT gradient of the 3x3 stride-1 layers (k_wgrad_wino_limb); (iii) the Winograd slab kernel of the deep 3x3 layers,
-# forward and data gradient (k_conv_wino2d_limb: ResNet layer3 / layer4, the decoder's wide blocks).  In (ii) and (iii) the Winograd
-# transforms stay fp32; then, as in (i), each fp32 operand is split exactly into three bf16 limbs and the product is six bf16 MFMAs
-# accumulated in fp32 - error against float64 equal to the f32 kernels' on every shape (tests/test_gpu_limb.py,
-# test_winograd_*_split_precision_vs_float64), all float64-anchored parity bounds unchanged.  The one-workgroup Winograd kernel of
-# layer1 / layer2 (the roofline probe) is fp32 throughout.
-ARITH_NOTE = ("fp32 storage, fp32 accumulate; products fp32-exact (f32 MFMA) except, with >= 64 channels, the matrix-bound kernels: convolutions "
-              "without a Winograd form (1x1 stride-1; 3x3 stride-2 and large 1x1 stride-2; forward, data and weight gradient), the Winograd "
-              "weight gradient of the 3x3 layers and the Winograd slab kernel of the deep 3x3 layers (forward, data gradient): bf16x3 split, six "
-              "products, fp32 accumulate (fp32-equal error vs float64; fd_tuning.limb_1x1 = limb_conv = wino_wgrad_limb = wino_fwd_limb = 0 "
-              "restores the f32 kernels)")
+# channels on both sides: (i) the convolutions no Winograd form exists for (csrc/conv_limb.hip), in all three directions - the 1x1
+# stride-1 layers (ResNet-50 bottlenecks; on the ResNet-18 configurations only the PoseDecoder's 512 -> 256 squeeze) and the stride-2
+# layers (3x3 layerN.0 of every ResNet; the 1x1 downsample branch where its launch fills the chip); (ii) the Winograd WEIGHT gradient
+# of the 3x3 stride-1 layers (k_wgrad_wino_limb: transforms in fp32, then the matrix loop).  There each fp32 operand is split exactly
+# into three bf16 limbs and the product is six bf16 MFMAs accumulated in fp32 - error against float64 equal to the f32 kernels' on every
+# shape (tests/test_gpu_limb.py, test_winograd_weight_gradient_split_precision_vs_float64), all float64-anchored parity bounds
+# unchanged.  Every Winograd forward / data-gradient kernel (the roofline probe among them) is fp32 throughout: the split-precision slab
+# kernel (fd_tuning.wino_fwd_limb) is off by default because one full-size backward bound does not hold with it.
+ARITH_NOTE = ("fp32 storage, fp32 accumulate; products fp32-exact (f32 MFMA) except, with >= 64 channels: convolutions without a Winograd form "
+              "(1x1 stride-1; 3x3 stride-2 and large 1x1 stride-2; forward, data and weight gradient) and the Winograd weight gradient of "
+              "the 3x3 layers: bf16x3 split, six products, fp32 accumulate (fp32-equal error vs float64; fd_tuning.limb_1x1 = "
+              "limb_conv = wino_wgrad_limb = 0 restores the f32 kernels)")
 PEAK_HBM_GBS = 8000.0
 
 

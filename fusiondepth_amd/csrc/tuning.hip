@@ -23,7 +23,7 @@ fd_tuning make_defaults() {
     t.grp_tile64_below = 0;
     t.wino_wgrad_xcd_few = 1; t.wino_fwd_halfm = 1; t.wino_wgrad_halfm = 1;
     t.limb_1x1 = 1; t.limb_depth = 2; t.limb_target = 256; t.limb_split_max_out = 4194304; t.limb_wgrad_target = 256;
-    t.limb_conv = 1; t.wino_wgrad_limb = 2; t.wino_fwd_limb = 1;
+    t.limb_conv = 1; t.wino_wgrad_limb = 2; t.wino_fwd_limb = 0;
     t.wino_min_cout = 32; t.wino_wgrad_min_cout = 32;     // the decoder's 32-channel blocks with half a tile idle: profiles/round5_decoder_m32_time.log
     return t;
 }

@@ -92,8 +92,10 @@ typedef struct fd_tuning {
     int wino_wgrad_limb;          /* 2   the 2-D Winograd weight gradient with >= 64 output channels and W % 8 == 0 with a split-precision matrix loop
                                          (k_wgrad_wino_limb: transforms + limb split in the loader, 768 instead of 2 048 matrix cycles per chunk): 1 the
                                          zero-padded layers (ResNet trunk), 2 the reflect-padded decoder blocks as well, 0 the f32 kernel everywhere */
-    int wino_fwd_limb;            /* 1   the F(2x2, 3x3) slab kernel of the deep layers (forward / data gradient, >= 64 channels on both sides, W % 4 == 0) with
-                                         pre-split weights and a split-precision matrix loop (k_conv_wino2d_limb); 0: k_conv_wino2d(_m128) */
+    int wino_fwd_limb;            /* 0   1: the F(2x2, 3x3) slab kernel of the deep layers (forward / data gradient, >= 64 channels on both sides, W % 4 == 0)
+                                         with pre-split weights and a split-precision matrix loop (k_conv_wino2d_limb) instead of k_conv_wino2d(_m128).
+                                         Per-kernel error vs float64 equal to the f32 kernels' and +0.2 ... +0.8 % in the step, but OFF: with it one bound
+                                         of the full-size backward test at 1024x320 is exceeded (depth-decoder gradient norm 1.81e-3 against 1.65e-3) */
 } fd_tuning;
 void fd_tuning_defaults(fd_tuning* t);
 int fd_set_tuning(const fd_tuning* t);

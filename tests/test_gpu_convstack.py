@@ -240,7 +240,8 @@ def test_round5_tuning_switches_keep_the_results(FD, fdtune, fields):
         relclose(cpu(gw), cpu(gwd.float()), "dw " + what, rtol=1e-4, arel=1e-5)
 
 
-@pytest.mark.parametrize("fields", [dict(limb_conv=0), dict(wino_wgrad_limb=0), dict(wino_wgrad_limb=1), dict(limb_1x1=0), dict(limb_conv=0, wino_wgrad_limb=0, limb_1x1=0)],
+@pytest.mark.parametrize("fields", [dict(limb_conv=0), dict(wino_wgrad_limb=0), dict(wino_wgrad_limb=1), dict(limb_1x1=0), dict(limb_conv=0, wino_wgrad_limb=0, limb_1x1=0),
+                                    dict(wino_fwd_limb=1)],
                          ids=lambda f: ",".join("%s=%s" % kv for kv in f.items()))
 def test_round6_tuning_switches_keep_the_results(FD, fdtune, fields):
     """The split-precision routes of round 6 (fd_tuning.limb_conv / wino_wgrad_limb / limb_1x1) choose between kernels, not between
