@@ -1,23 +1,24 @@
-// Split-precision ("3 x bf16 limbs, six products, fp32 accumulate") GEMM kernels for the 1x1 stride-1 convolutions - the
-// bottleneck blocks of a ResNet-50 (torchvision Bottleneck conv1 / conv3 / downsample: networks/resnet_encoder.py:62-74), the
-// PoseDecoder's squeeze layer (networks/pose_decoder.py:20) - forward, data gradient and weight gradient.
+// Split-precision ("3 x bf16 limbs, six products, fp32 accumulate") kernels for the convolutions that have no Winograd form:
+//   * 1x1 stride-1 - the bottleneck blocks of a ResNet-50 (torchvision Bottleneck conv1 / conv3 / downsample: networks/resnet_encoder.py:62-74),
+//     the PoseDecoder's squeeze layer (networks/pose_decoder.py:20): k_gemm_limb (forward, data gradient), k_wgrad_limb;
+//   * stride 2 - layerN.0.conv1 (BasicBlock) / conv2 (Bottleneck) 3x3 and the large 1x1 downsample layers of every ResNet: k_conv_limb
+//     (forward), k_conv_limb_grp (the four output-parity classes of the data gradient in one launch), k_wgrad_limb_s2.
 //
-// Why: a 1x1 convolution is a plain GEMM (no taps for Winograd to save); on v_mfma_f32_32x32x2_f32 it runs at the fp32 VECTOR
-// rate (157 TFLOP/s peak, 58 - 100 measured on these shapes).  v_mfma_f32_32x32x16_bf16 is 16x faster per instruction; with every
-// fp32 operand split into three bf16 limbs (conv_limb.h) six of them reproduce the fp32 product: 2.7x the fp32 matrix peak at
-// fp32 accuracy.
+// Why: such a convolution is a plain (implicit) GEMM; on v_mfma_f32_32x32x2_f32 it runs at the fp32 matrix rate (157 TFLOP/s peak, 58 - 100
+// measured on these shapes).  v_mfma_f32_32x32x16_bf16 is 16x faster per instruction; with every fp32 operand split into three bf16 limbs
+// (conv_limb.h) six of them reproduce the fp32 product: 2.7x the fp32 matrix peak at fp32 accuracy.  Inside the training step, where four
+// streams share the matrix pipes, the matrix cycles saved count even where a kernel's stand-alone time does not move
+// (profiles/round6_experiments.md section 3).
 //
 // Shape of the kernels (CDNA4: 64-lane waves, 4 SIMDs per CU, 160 KB LDS):
 //   * forward / data gradient  Y[n][m][p] = sum_k A[m][k] X[n][k][p]:  A = the weights, PRE-SPLIT once per optimiser step into the
-//     LDS image of a K-chunk (conv_limb.h) -> plain 16-byte copies global -> LDS, no arithmetic; X is read as fp32 (coalesced along
-//     the pixels), a thread owns one pixel x 8 consecutive channels, splits them in registers (52 vector instructions) and writes the
-//     three 16-byte MFMA operand pieces; LDS holds K-contiguous pieces in "lane order" (piece of row r at slot r), so every operand
-//     fragment is ONE conflict-free ds_read_b128 and every store one ds_write_b128.
+//     LDS image of a K-chunk (conv_limb.h; K = channel for the 1x1 layers, (tap, channel) for k_conv_limb) -> plain 16-byte copies
+//     global -> LDS, no arithmetic; X is read as fp32 (coalesced along the pixels): lane l of a wave loads 8 consecutive channels of
+//     its pixel, splits them in registers (52 vector instructions) and HAS its three MFMA B fragments - no LDS round trip for X;
 //   * weight gradient  dW[m][c] = sum_{n,p} dY[n][m][p] X[n][c][p]:  both operands are K(= pixel)-contiguous fp32 rows; a thread
-//     owns 8 consecutive pixels of a row (two 16-byte loads), same split, same LDS image.  Split over K into slabs, reduced by the
-//     existing fixed-order finish kernel (deterministic, no atomics).
-//   * a wave owns 64 x 64 outputs (2 x 2 blocks of 32 x 32: 64 accumulator registers), a workgroup 4 waves; per K-step of 16 a wave
-//     reads 12 pieces and issues 24 MFMAs (768 matrix-pipe cycles).
+//     owns 8 pixels of a row, same split, 16-byte LDS stores.  Split over K into slabs, reduced by the existing fixed-order finish
+//     kernel (deterministic, no atomics); the stride-2 form takes one tap per workgroup (see k_wgrad_limb_s2);
+//   * per K-step of 16 a wave reads 3 fragments per 32 x 32 block and operand and issues 6 MFMAs per block (192 matrix-pipe cycles).
 #include "../../include/fdhip.h"
 #include "fd_common.h"
 #include "conv_fast.h"
